@@ -1,0 +1,219 @@
+#!/usr/bin/env python3
+"""bench.py -- headline metric of BASELINE.json: Mrays/s at 1920x1080, 8 spp, 4 bounces.
+
+One "step" = one full render of the workload (accumulation reset, `spp` frames of the path-tracing
+kernels + accumulation, and -- for N > 1 -- the RCCL gather of the float4 pieces to rank 0 and their
+assembly).  Scene, camera and RNG streams are synthetic and deterministic (gdpathtracing_amd/scenes.py);
+the scene is resident in HBM before the timed region starts.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line.  `value` = ray segments actually traced by all ranks / max-over-ranks time.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+# bytes one event touches in the flattened layout (DESIGN.md "Algorithmic bytes")
+WIDE_BYTES = dict(blas_expand=64, tri_tests=48, tlas_expand=64, inst_visits=64, shaded_hits=80 + 176 + 64)
+# the same events priced in the reference layout
+REF_BYTES = dict(blas_expand=96, tri_tests=48, tlas_expand=64, inst_visits=224, shaded_hits=320)
+
+
+def algorithmic_bytes(stats, n_pixels, n_frames, table):
+    b = sum(stats[k] * v for k, v in table.items())
+    # framebuffer: per pixel one float4 accumulation write + one rgba8 + one depth write per launch
+    return b + n_pixels * (16 + 4 + 4)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--spp", type=int, default=8)
+    ap.add_argument("--bounces", type=int, default=4)
+    ap.add_argument("--tris", type=int, default=51200)
+    ap.add_argument("--scene", default="demo", choices=["demo", "cornell", "inst"])
+    ap.add_argument("--builder", default="sah", choices=["sah", "exact"])
+    ap.add_argument("--accum", default="ldr8", choices=["ldr8", "hdr"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", default="480x270")
+    args = ap.parse_args()
+
+    import torch
+    from gdpathtracing_amd import capi, host, scenes
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    if args.scene == "demo":
+        sc = scenes.demo_scene(args.tris)
+    elif args.scene == "cornell":
+        sc = scenes.cornell_scene()
+    else:
+        sc = scenes.instanced_scene()
+    W, H, spp, bounces = args.width, args.height, args.spp, args.bounces
+    cam = scenes.camera_block(sc.camera, W, H)
+    accum_mode = capi.ACCUM_REF_LDR8 if args.accum == "ldr8" else capi.ACCUM_HDR_F32
+
+    ctx = host.Context(local_rank)
+    t0 = time.time()
+    ctx.build_scene(sc, capi.BUILD_SAH if args.builder == "sah" else capi.BUILD_REFERENCE_EXACT)
+    build_s = time.time() - t0
+    ctx.set_partition(rank, world)
+    ctx.set_params(W, H, bounces, accum_mode)
+    ctx.set_camera(cam)
+    stream = torch.cuda.current_stream()
+    ctx.set_stream(stream.cuda_stream)
+
+    # gather plumbing (N > 1): the local float4 piece viewed as a torch tensor, no copy
+    piece = gathered = None
+    if world > 1:
+        ptr, nbytes = ctx.device_accum()
+
+        class _View:
+            __cuda_array_interface__ = {"shape": (nbytes // 4,), "typestr": "<f4", "data": (ptr, False), "version": 2}
+
+        piece = torch.as_tensor(_View(), device=torch.device("cuda", local_rank))
+        if rank == 0:
+            gathered = torch.empty((world, nbytes // 4), dtype=torch.float32, device=piece.device)
+
+    def step():
+        ctx.accum_reset()
+        ctx.render(spp, 1, asynchronous=True)
+        if world > 1:
+            # direct point-to-point gather: every peer sends its piece over its own xGMI link
+            dist.gather(piece, list(gathered.unbind(0)) if rank == 0 else None, dst=0)
+            if rank == 0:
+                ctx.assemble_from_ranks(gathered.data_ptr(), world)
+
+    # exact event counts of one step (deterministic), outside the timed region
+    ctx.accum_reset()
+    ctx.render(spp, 1, counted=True)
+    st = ctx.stats()
+    counts = torch.tensor([st[k] for k in ("rays", "blas_expand", "tri_tests", "tlas_expand", "inst_visits", "shaded_hits")],
+                          dtype=torch.int64, device="cuda")
+    if world > 1:
+        dist.all_reduce(counts)
+    rays, blas_expand, tri_tests, tlas_expand, inst_visits, shaded_hits = [int(x) for x in counts.tolist()]
+    total = dict(rays=rays, blas_expand=blas_expand, tri_tests=tri_tests, tlas_expand=tlas_expand,
+                 inst_visits=inst_visits, shaded_hits=shaded_hits)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    # the dominant kernel's duration: HIP events on the stream the kernels run on
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        ctx.accum_reset()
+        ev[i][0].record(stream)
+        ctx.render(spp, 1, asynchronous=True)
+        ev[i][1].record(stream)
+        if world > 1:
+            dist.gather(piece, list(gathered.unbind(0)) if rank == 0 else None, dst=0)
+            if rank == 0:
+                ctx.assemble_from_ranks(gathered.data_ptr(), world)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))  # per step: all trace launches of one render
+
+    if rank == 0:
+        n_pixels = W * H
+        ms_per_step = elapsed / args.steps * 1e3
+        mrays = rays * args.steps / elapsed / 1e6
+        # roofline of the dominant kernel (this rank's share of the events ~ total / world)
+        alg = algorithmic_bytes(total, n_pixels, spp, WIDE_BYTES) / world
+        alg_ref = algorithmic_bytes(total, n_pixels, spp, REF_BYTES) / world
+        achieved = alg / (kernel_ms * 1e-3) / 1e9
+        out = {
+            "metric": "Mrays/sec at 1920x1080, 8 spp, 4 bounces",
+            "value": round(mrays, 3),
+            "unit": "Mrays/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": "C3: S-demo (open Cornell cube + light + 2 instances of a %d-tri procedural mesh), %dx%d, %d spp, "
+                            "%d bounces, accum=%s, builder=%s" % (args.tris, W, H, spp, bounces, args.accum, args.builder)
+                if args.scene == "demo" else "%s %dx%d %d spp %d bounces" % (sc.name, W, H, spp, bounces),
+                "unique_tris": sc.n_unique_tris, "instances": len(sc.instances),
+                "rays_per_step": rays, "nominal_rays_per_step": n_pixels * spp * (bounces + 1),
+                "parallelism": "screen strips x%d" % world,
+                "scene_build_s": round(build_s, 4),
+            },
+            "roofline": {
+                "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                "kernel": "path-trace launches of one render (%d frames)" % spp,
+                "kernel_ms": round(kernel_ms, 4),
+                "algorithmic_bytes": int(alg),
+                "ref_layout_algorithmic_bytes": int(alg_ref),
+                "ref_layout_achieved": round(alg_ref / (kernel_ms * 1e-3) / 1e9, 2),
+                "note": "scene is L2/Infinity-Cache resident; bytes are cache-served requests, not HBM traffic",
+            },
+            "counters": total,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle import binding as ob
+            sw, sh = (int(x) for x in args.cpu_sample.split("x"))
+            ref = ob.build_scene(sc)
+            scam = scenes.camera_block(sc.camera, sw, sh)
+            t0 = time.perf_counter()
+            _, _, _, cnt, used = ob.render(ref, scam, sw, sh, bounces, spp, 1, accum_mode)
+            dt = time.perf_counter() - t0
+            out["cpu_baseline"] = {
+                "value": round(cnt["rays"] / dt / 1e6, 3), "unit": "Mrays/s", "cores": used, "kind": "port",
+                "sample": "same scene/camera/seeds at %dx%d, %d spp, %d bounces (%.1f s, %d rays); oracle = C restatement "
+                          "of main.glsl over the reference-layout BVH, pthreads" % (sw, sh, spp, bounces, dt, cnt["rays"]),
+            }
+        print(json.dumps(out))
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

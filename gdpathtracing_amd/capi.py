@@ -1,0 +1,112 @@
+"""ctypes loader for libjpt_hip.so (the C ABI of include/jpt.h).
+
+There is no CPU fallback: if the HIP library is missing or no GPU is present, calls fail loudly.
+`build()` compiles the library in-tree with hipcc for gfx950.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libjpt_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+OK = 0
+ACCUM_REF_LDR8, ACCUM_HDR_F32 = 0, 1
+BUILD_REFERENCE_EXACT, BUILD_SAH = 0, 1
+BUF_TRI_GEOMETRY, BUF_TRI_DATA, BUF_MATERIALS, BUF_BVH_NODES, BUF_INSTANCES, BUF_TLAS_NODES, BUF_TRIANGLES = range(7)
+
+# every symbol include/jpt.h declares
+SYMBOLS = [
+    "jpt_abi_version", "jpt_create", "jpt_destroy", "jpt_last_error", "jpt_set_stream",
+    "jpt_scene_upload_reference_layout", "jpt_scene_begin", "jpt_scene_add_mesh", "jpt_scene_add_instance",
+    "jpt_scene_set_materials", "jpt_scene_set_textures", "jpt_scene_commit", "jpt_scene_get_reference_buffer",
+    "jpt_set_params", "jpt_set_partition", "jpt_set_camera", "jpt_render", "jpt_render_counted", "jpt_render_async",
+    "jpt_sync", "jpt_accum_reset", "jpt_read_ldr_rgba8", "jpt_read_accum_f32", "jpt_read_depth_f32",
+    "jpt_device_accum", "jpt_assemble_from_ranks", "jpt_local_rows", "jpt_get_stats",
+]
+
+
+class JptError(RuntimeError):
+    pass
+
+
+class Surface(C.Structure):
+    _fields_ = [("vertices", C.c_void_p), ("normals", C.c_void_p), ("uvs", C.c_void_p), ("indices", C.c_void_p),
+                ("n_vertices", C.c_int32), ("n_indices", C.c_int32)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("rays", C.c_uint64), ("frames", C.c_uint64), ("blas_expand", C.c_uint64), ("tri_tests", C.c_uint64),
+                ("tlas_expand", C.c_uint64), ("inst_visits", C.c_uint64), ("shaded_hits", C.c_uint64),
+                ("last_render_ms", C.c_double), ("last_trace_ms", C.c_double), ("last_build_ms", C.c_double)]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile libjpt_hip.so in-tree (hipcc --offload-arch=gfx950)."""
+    cmd = ["make", "-C", CSRC, "-j4"] + (["-B"] if force else [])
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if verbose or res.returncode:
+        print(res.stdout)
+    if res.returncode:
+        raise JptError("building libjpt_hip.so failed")
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    """Load the HIP library; raises JptError when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise JptError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                       "(there is no CPU fallback for the HIP path)" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, i32, u32 = C.c_void_p, C.c_int32, C.c_uint32
+    L.jpt_abi_version.restype = C.c_int
+    L.jpt_create.argtypes = [C.c_int, C.POINTER(vp)]
+    L.jpt_destroy.argtypes = [vp]
+    L.jpt_destroy.restype = None
+    L.jpt_last_error.argtypes = [vp]
+    L.jpt_last_error.restype = C.c_char_p
+    L.jpt_set_stream.argtypes = [vp, vp]
+    L.jpt_scene_upload_reference_layout.argtypes = [vp, vp, u32, vp, vp, u32, vp, u32, vp, u32, vp, u32, vp, i32, i32]
+    L.jpt_scene_begin.argtypes = [vp]
+    L.jpt_scene_add_mesh.argtypes = [vp, C.POINTER(Surface), i32, C.POINTER(u32)]
+    L.jpt_scene_add_instance.argtypes = [vp, u32, vp, vp, i32]
+    L.jpt_scene_set_materials.argtypes = [vp, vp, u32]
+    L.jpt_scene_set_textures.argtypes = [vp, vp, i32, i32]
+    L.jpt_scene_commit.argtypes = [vp, i32]
+    L.jpt_scene_get_reference_buffer.argtypes = [vp, i32, vp, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.jpt_set_params.argtypes = [vp, i32, i32, i32, i32, i32]
+    L.jpt_set_partition.argtypes = [vp, i32, i32]
+    L.jpt_set_camera.argtypes = [vp, vp]
+    for n in ("jpt_render", "jpt_render_counted", "jpt_render_async"):
+        getattr(L, n).argtypes = [vp, i32, u32]
+    L.jpt_sync.argtypes = [vp]
+    L.jpt_accum_reset.argtypes = [vp]
+    L.jpt_read_ldr_rgba8.argtypes = [vp, vp]
+    L.jpt_read_accum_f32.argtypes = [vp, vp]
+    L.jpt_read_depth_f32.argtypes = [vp, vp]
+    L.jpt_device_accum.argtypes = [vp, C.POINTER(C.c_size_t)]
+    L.jpt_device_accum.restype = vp
+    L.jpt_assemble_from_ranks.argtypes = [vp, vp, i32]
+    L.jpt_local_rows.argtypes = [vp]
+    L.jpt_local_rows.restype = i32
+    L.jpt_get_stats.argtypes = [vp, C.POINTER(Stats)]
+    _lib = L
+    return L
+
+
+def check(ctx, rc: int, what: str):
+    if rc != OK:
+        msg = lib().jpt_last_error(ctx)
+        raise JptError("%s failed (%d): %s" % (what, rc, msg.decode() if msg else "?"))

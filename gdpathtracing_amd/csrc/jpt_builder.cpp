@@ -1,0 +1,753 @@
+// jpt_builder.cpp -- see jpt_builder.h.  Host C++ only (no device code).
+#include "jpt_builder.h"
+
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstring>
+#include <numeric>
+
+namespace jpt {
+
+void RefScene::clear()
+{
+    triangles.clear();
+    tri_geom.clear();
+    tri_data.clear();
+    bvh_nodes.clear();
+    instances.clear();
+    tlas_nodes.clear();
+    mesh_roots.clear();
+}
+
+// ------------------------------------------------------------------------------------------------
+// small vec4 helpers with the reference's semantics: std::min/std::max per component INCLUDING w
+// (vec.h:78-86), arithmetic on w as well (vec.h:53-71).
+namespace {
+
+inline float lo_(float a, float b) { return (b < a) ? b : a; }  // std::min
+inline float hi_(float a, float b) { return (a < b) ? b : a; }  // std::max
+inline float comp(const Vec4& v, int axis) { return axis == 0 ? v.x : axis == 1 ? v.y : axis == 2 ? v.z : axis == 3 ? v.w : v.x; }
+
+struct Box4 {
+    Vec4 lo, hi;
+    // bvh.cpp:6-10: `vec4(FLT_MAX)` / `vec4(FLT_MIN)` only set x (vec.h:49) -> y = z = 0, w = 1.
+    static Box4 reference_default() { return Box4{{FLT_MAX, 0.0f, 0.0f, 1.0f}, {FLT_MIN, 0.0f, 0.0f, 1.0f}}; }
+    void grow(const Vec4& p)  // bvh.cpp:12-16
+    {
+        lo = Vec4{lo_(lo.x, p.x), lo_(lo.y, p.y), lo_(lo.z, p.z), lo_(lo.w, p.w)};
+        hi = Vec4{hi_(hi.x, p.x), hi_(hi.y, p.y), hi_(hi.z, p.z), hi_(hi.w, p.w)};
+    }
+    float half_area() const  // bvh.h:39-43
+    {
+        const float dx = hi.x - lo.x, dy = hi.y - lo.y, dz = hi.z - lo.z;
+        return dx * dy + dy * dz + dz * dx;
+    }
+};
+
+// ---- reference-exact BLAS build (bvh.cpp:39-185) ------------------------------------------------
+
+struct ExactBlasBuilder {
+    std::vector<RefBvhNode>& nodes;
+    std::vector<RefTriangle>& tris;
+
+    // EvaluateSAH (bvh.cpp:39-106): 8 bins over the node's VERTEX box, triangles binned by centroid
+    float sweep_axis(const RefBvhNode& node, int axis, float& split_out) const
+    {
+        constexpr int kBins = 8;
+        Box4 bin_box[kBins];
+        int bin_n[kBins];
+        for (int i = 0; i < kBins; i++) {
+            bin_box[i] = Box4::reference_default();
+            bin_n[i] = 0;
+        }
+        const float lo = comp(node.aabbMin, axis), hi = comp(node.aabbMax, axis);
+        const float range = hi - lo;
+        if (range < 1e-6f) return 1e+30f;
+        const float inv_range = 1.0f / range;
+        for (uint32_t i = 0; i < node.tri_count; i++) {
+            const RefTriangle& t = tris[node.first_tri_index + i];
+            const int b = std::clamp(int(float(kBins) * (comp(t.centroid, axis) - lo) * inv_range), 0, kBins - 1);
+            bin_n[b]++;
+            bin_box[b].grow(t.vertices[0]);
+            bin_box[b].grow(t.vertices[1]);
+            bin_box[b].grow(t.vertices[2]);
+        }
+        Box4 prefix_box[kBins];
+        int prefix_n[kBins];
+        Box4 acc = Box4::reference_default();
+        int n = 0;
+        for (int i = 0; i < kBins - 1; i++) {
+            acc.grow(bin_box[i].lo);
+            acc.grow(bin_box[i].hi);
+            n += bin_n[i];
+            prefix_box[i] = acc;
+            prefix_n[i] = n;
+        }
+        float best = 1e+30f;
+        acc = Box4::reference_default();
+        n = 0;
+        for (int i = kBins - 1; i > 0; i--) {
+            acc.grow(bin_box[i].lo);
+            acc.grow(bin_box[i].hi);
+            n += bin_n[i];
+            const float cost = prefix_box[i - 1].half_area() * float(prefix_n[i - 1]) + acc.half_area() * float(n);
+            if (cost < best) {
+                best = cost;
+                split_out = lo + (float(i) / float(kBins)) * range;
+            }
+        }
+        return best;
+    }
+
+    // build_recursive (bvh.cpp:108-185): pre-order numbering, left child = parent + 1
+    uint32_t build(int start, int end)
+    {
+        if (start >= end) return 0;
+        const uint32_t self = (uint32_t)nodes.size();
+        nodes.emplace_back();
+        {
+            Box4 box = Box4::reference_default();
+            for (int i = start; i < end; i++)
+                for (int j = 0; j < 3; j++) box.grow(tris[i].vertices[j]);
+            RefBvhNode& n = nodes[self];
+            n.aabbMin = box.lo;
+            n.aabbMax = box.hi;
+            n.left_child = n.right_child = 0;
+            n.first_tri_index = (uint32_t)start;
+            n.tri_count = (uint32_t)(end - start);
+        }
+        const RefBvhNode node = nodes[self];
+        if (node.tri_count <= 4) return self;
+
+        float best_split = 0.0f, best_cost = 1e30f;
+        int best_axis = -1;
+        for (int axis = 0; axis < 3; axis++) {
+            float split = 0.0f;
+            const float cost = sweep_axis(node, axis, split);
+            if (cost < best_cost) {
+                best_cost = cost;
+                best_split = split;
+                best_axis = axis;
+            }
+        }
+        const float ex = node.aabbMax.x - node.aabbMin.x, ey = node.aabbMax.y - node.aabbMin.y,
+                    ez = node.aabbMax.z - node.aabbMin.z;
+        const float parent_cost = float(node.tri_count) * (ex * ey + ey * ez + ez * ex);
+        if (best_cost * 0.8f >= parent_cost) return self;
+
+        int i = start, j = end - 1;
+        while (i <= j) {
+            if (comp(tris[i].centroid, best_axis) < best_split) i++;
+            else std::swap(tris[i], tris[j--]);
+        }
+        const int left_count = i - start;
+        if (left_count == 0 || left_count == (int)node.tri_count) {
+            const int mid = start + (end - start) / 2;
+            // libstdc++'s element order (the reference on Linux); other STLs order ties differently
+            std::nth_element(tris.begin() + start, tris.begin() + mid, tris.begin() + end,
+                             [best_axis](const RefTriangle& a, const RefTriangle& b) {
+                                 return comp(a.centroid, best_axis) < comp(b.centroid, best_axis);
+                             });
+            i = mid;
+        }
+        const uint32_t l = build(start, i);
+        nodes[self].left_child = l;
+        const uint32_t r = build(i, end);
+        nodes[self].right_child = r;
+        nodes[self].tri_count = 0;
+        return self;
+    }
+};
+
+// ---- native binned-SAH BLAS build -----------------------------------------------------------------
+
+struct Box3 {
+    float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+    void grow(const float* p)
+    {
+        for (int k = 0; k < 3; k++) {
+            lo[k] = std::min(lo[k], p[k]);
+            hi[k] = std::max(hi[k], p[k]);
+        }
+    }
+    void grow(const Box3& b)
+    {
+        for (int k = 0; k < 3; k++) {
+            lo[k] = std::min(lo[k], b.lo[k]);
+            hi[k] = std::max(hi[k], b.hi[k]);
+        }
+    }
+    float half_area() const
+    {
+        const float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+        return dx * dy + dy * dz + dz * dx;
+    }
+};
+
+struct SahBlasBuilder {
+    std::vector<RefBvhNode>& nodes;
+    std::vector<RefTriangle>& tris;  // permuted in place, like the reference
+    int base;                        // first triangle of this mesh in `tris`
+    std::vector<Box3> tri_box;       // per triangle (mesh-local index)
+    std::vector<float> centroid;     // 3 per triangle
+    std::vector<uint32_t> order;     // permutation being built
+    float pad = 0.0f;
+
+    static constexpr int kBins = 16;
+    static constexpr int kMaxLeaf = 4;
+
+    void prepare(int start, int end)
+    {
+        base = start;
+        const int n = end - start;
+        tri_box.resize(n);
+        centroid.resize((size_t)n * 3);
+        order.resize(n);
+        Box3 all;
+        for (int i = 0; i < n; i++) {
+            const RefTriangle& t = tris[start + i];
+            Box3 b;
+            for (int j = 0; j < 3; j++) b.grow(&t.vertices[j].x);
+            tri_box[i] = b;
+            all.grow(b);
+            for (int k = 0; k < 3; k++) centroid[(size_t)i * 3 + k] = 0.5f * (b.lo[k] + b.hi[k]);
+            order[i] = (uint32_t)i;
+        }
+        // boxes are padded so every Moller-Trumbore-accepted hit also passes the slab test in float
+        float m = 0.0f;
+        for (int k = 0; k < 3; k++) m = std::max(m, std::max(std::fabs(all.lo[k]), std::fabs(all.hi[k])));
+        pad = m * 2e-6f + 1e-30f;
+    }
+
+    uint32_t build(int lo, int hi)  // range in `order`
+    {
+        const uint32_t self = (uint32_t)nodes.size();
+        nodes.emplace_back();
+        Box3 box, cbox;
+        for (int i = lo; i < hi; i++) {
+            box.grow(tri_box[order[i]]);
+            cbox.grow(&centroid[(size_t)order[i] * 3]);
+        }
+        {
+            RefBvhNode& n = nodes[self];
+            n.aabbMin = Vec4{box.lo[0] - pad, box.lo[1] - pad, box.lo[2] - pad, 1.0f};
+            n.aabbMax = Vec4{box.hi[0] + pad, box.hi[1] + pad, box.hi[2] + pad, 1.0f};
+            n.left_child = n.right_child = 0;
+            n.first_tri_index = (uint32_t)(base + lo);
+            n.tri_count = (uint32_t)(hi - lo);
+        }
+        const int count = hi - lo;
+        if (count <= 1) return self;
+
+        int best_axis = -1, best_bin = -1;
+        float best_cost = FLT_MAX;
+        for (int axis = 0; axis < 3; axis++) {
+            const float c0 = cbox.lo[axis], c1 = cbox.hi[axis];
+            if (!(c1 > c0)) continue;
+            const float scale = float(kBins) / (c1 - c0);
+            Box3 bb[kBins];
+            int bn[kBins] = {0};
+            for (int i = lo; i < hi; i++) {
+                const uint32_t t = order[i];
+                int b = (int)((centroid[(size_t)t * 3 + axis] - c0) * scale);
+                b = b < 0 ? 0 : (b >= kBins ? kBins - 1 : b);
+                bb[b].grow(tri_box[t]);
+                bn[b]++;
+            }
+            float right_area[kBins];
+            int right_n[kBins];
+            Box3 acc;
+            int n = 0;
+            for (int b = kBins - 1; b > 0; b--) {
+                acc.grow(bb[b]);
+                n += bn[b];
+                right_area[b] = n ? acc.half_area() : 0.0f;
+                right_n[b] = n;
+            }
+            acc = Box3();
+            n = 0;
+            for (int b = 0; b < kBins - 1; b++) {
+                acc.grow(bb[b]);
+                n += bn[b];
+                if (n == 0 || right_n[b + 1] == 0) continue;
+                const float cost = acc.half_area() * float(n) + right_area[b + 1] * float(right_n[b + 1]);
+                if (cost < best_cost) {
+                    best_cost = cost;
+                    best_axis = axis;
+                    best_bin = b;
+                }
+            }
+        }
+        const float leaf_cost = float(count) * box.half_area();
+        // traversal step ~ 1.2 triangle tests
+        const bool split_pays = best_axis >= 0 && (best_cost + 1.2f * box.half_area()) < leaf_cost;
+        if (count <= kMaxLeaf && !split_pays) return self;
+
+        int mid;
+        if (best_axis >= 0) {
+            const float c0 = cbox.lo[best_axis], c1 = cbox.hi[best_axis];
+            const float scale = float(kBins) / (c1 - c0);
+            auto it = std::partition(order.begin() + lo, order.begin() + hi, [&](uint32_t t) {
+                int b = (int)((centroid[(size_t)t * 3 + best_axis] - c0) * scale);
+                b = b < 0 ? 0 : (b >= kBins ? kBins - 1 : b);
+                return b <= best_bin;
+            });
+            mid = (int)(it - order.begin());
+        } else {
+            mid = lo;
+        }
+        if (mid == lo || mid == hi) {  // all centroids coincide: split by index
+            mid = lo + count / 2;
+        }
+        const uint32_t l = build(lo, mid);
+        nodes[self].left_child = l;
+        const uint32_t r = build(mid, hi);
+        nodes[self].right_child = r;
+        nodes[self].tri_count = 0;
+        return self;
+    }
+
+    void apply_order(int start, int end)
+    {
+        std::vector<RefTriangle> tmp(tris.begin() + start, tris.begin() + end);
+        for (int i = 0; i < end - start; i++) tris[start + i] = tmp[order[i]];
+    }
+};
+
+// Utils::transform_to_float (utils.h:15-37)
+void transform12_to_mat16(const float* t, float* m)
+{
+    for (int c = 0; c < 3; c++) {
+        m[c * 4 + 0] = t[0 * 3 + c];
+        m[c * 4 + 1] = t[1 * 3 + c];
+        m[c * 4 + 2] = t[2 * 3 + c];
+        m[c * 4 + 3] = 0.0f;
+    }
+    m[12] = t[9];
+    m[13] = t[10];
+    m[14] = t[11];
+    m[15] = 1.0f;
+}
+
+// TLAS::FindBestMatch (bvh.cpp:319-340)
+int nearest_partner(const std::vector<RefTlasNode>& nodes, const std::vector<int>& list, int n, int a)
+{
+    float smallest = 1e30f;
+    int best = -1;
+    const RefTlasNode& na = nodes[list[a]];
+    for (int b = 0; b < n; b++) {
+        if (b == a) continue;
+        const RefTlasNode& nb = nodes[list[b]];
+        const float ex = hi_(na.aabbMax[0], nb.aabbMax[0]) - lo_(na.aabbMin[0], nb.aabbMin[0]);
+        const float ey = hi_(na.aabbMax[1], nb.aabbMax[1]) - lo_(na.aabbMin[1], nb.aabbMin[1]);
+        const float ez = hi_(na.aabbMax[2], nb.aabbMax[2]) - lo_(na.aabbMin[2], nb.aabbMin[2]);
+        const float area = ex * ey + ey * ez + ez * ex;
+        if (area < smallest) {
+            smallest = area;
+            best = b;
+        }
+    }
+    return best;
+}
+
+// TLAS::build (bvh.cpp:264-317): agglomerative clustering, 2N nodes, root copied to slot 0
+bool build_tlas(const std::vector<RefInstance>& inst, std::vector<RefTlasNode>& out, std::string& err)
+{
+    int count = (int)inst.size();
+    out.clear();
+    out.emplace_back();  // slot 0 = root
+    std::memset(&out[0], 0, sizeof(RefTlasNode));
+    if (count == 0) return true;
+    if (count * 2 > 65535) {  // 16-bit child indices (bvh.h:59, bvh.cpp:300)
+        err = "TLAS: more than 32767 instances do not fit the reference's 16-bit child indices";
+        return false;
+    }
+    std::vector<int> live;
+    live.reserve(count);
+    for (int i = 0; i < count; i++) {
+        RefTlasNode n;
+        std::memset(&n, 0, sizeof n);
+        n.aabbMin[0] = inst[i].aabbMin.x; n.aabbMin[1] = inst[i].aabbMin.y; n.aabbMin[2] = inst[i].aabbMin.z;
+        n.aabbMax[0] = inst[i].aabbMax.x; n.aabbMax[1] = inst[i].aabbMax.y; n.aabbMax[2] = inst[i].aabbMax.z;
+        n.blas = (uint32_t)i;
+        n.leftRight = 0;
+        live.push_back((int)out.size());
+        out.push_back(n);
+    }
+    int a = 0, b = nearest_partner(out, live, count, a);
+    while (count > 1) {
+        const int c = nearest_partner(out, live, count, b);
+        if (a == c) {
+            const int ia = live[a], ib = live[b];
+            RefTlasNode n;
+            std::memset(&n, 0, sizeof n);  // .blas of internal nodes is uninitialised in the reference
+            n.leftRight = (uint32_t)ia + ((uint32_t)ib << 16);
+            for (int k = 0; k < 3; k++) {
+                n.aabbMin[k] = lo_(out[ia].aabbMin[k], out[ib].aabbMin[k]);
+                n.aabbMax[k] = hi_(out[ia].aabbMax[k], out[ib].aabbMax[k]);
+            }
+            live[a] = (int)out.size();
+            out.push_back(n);
+            live[b] = live[--count];
+            b = nearest_partner(out, live, count, a);
+        } else {
+            a = b;
+            b = c;
+        }
+    }
+    out[0] = out[live[a]];
+    return true;
+}
+
+}  // namespace
+
+// godot Basis::invert (cofactors) + Transform3D::affine_inverse, float.  godot-cpp (branch 4.3) is an
+// absent submodule; this is its published algorithm.  Runs before the path: it only fills the matrices
+// of the BLASInstance record.
+void affine_inverse12(const float* t, float* o)
+{
+    auto R = [&](int r, int c) { return t[r * 3 + c]; };
+    auto cof = [&](int r1, int c1, int r2, int c2) { return R(r1, c1) * R(r2, c2) - R(r1, c2) * R(r2, c1); };
+    const float co0 = cof(1, 1, 2, 2), co1 = cof(1, 2, 2, 0), co2 = cof(1, 0, 2, 1);
+    const float det = R(0, 0) * co0 + R(0, 1) * co1 + R(0, 2) * co2;
+    const float s = 1.0f / det;
+    float m[9];
+    m[0] = co0 * s; m[1] = cof(0, 2, 2, 1) * s; m[2] = cof(0, 1, 1, 2) * s;
+    m[3] = co1 * s; m[4] = cof(0, 0, 2, 2) * s; m[5] = cof(0, 2, 1, 0) * s;
+    m[6] = co2 * s; m[7] = cof(0, 1, 2, 0) * s; m[8] = cof(0, 0, 1, 1) * s;
+    for (int k = 0; k < 9; k++) o[k] = m[k];
+    const float nx = -t[9], ny = -t[10], nz = -t[11];
+    o[9] = m[0] * nx + m[1] * ny + m[2] * nz;
+    o[10] = m[3] * nx + m[4] * ny + m[5] * nz;
+    o[11] = m[6] * nx + m[7] * ny + m[8] * nz;
+}
+
+void SceneBuilder::begin()
+{
+    meshes_.clear();
+    instances_.clear();
+}
+
+uint32_t SceneBuilder::add_mesh(const SurfaceView* surfaces, int32_t n_surfaces)
+{
+    // the de-indexing half of BuildBVH (bvh.cpp:192-213)
+    PendingMesh pm;
+    for (int32_t l = 0; l < n_surfaces; l++) {
+        const SurfaceView& s = surfaces[l];
+        for (int32_t i = 0; i + 2 < s.n_indices; i += 3) {
+            RefTriangle t;
+            std::memset(&t, 0, sizeof t);
+            for (int j = 0; j < 3; j++) {
+                const int32_t k = s.indices[i + j];
+                t.vertices[j] = Vec4{s.vertices[k * 3], s.vertices[k * 3 + 1], s.vertices[k * 3 + 2], 1.0f};
+                t.normals[j] = Vec4{s.normals[k * 3], s.normals[k * 3 + 1], s.normals[k * 3 + 2], 1.0f};
+                t.uvs[j][0] = s.uvs[k * 2];
+                t.uvs[j][1] = s.uvs[k * 2 + 1];
+            }
+            t.materialIndex = (uint32_t)l;
+            // (v0 + v1 + v2) * 0.33333333f on all four components (bvh.cpp:210, vec.h:53-66)
+            const Vec4 &a = t.vertices[0], &b = t.vertices[1], &c = t.vertices[2];
+            t.centroid = Vec4{((a.x + b.x) + c.x) * 0.33333333f, ((a.y + b.y) + c.y) * 0.33333333f,
+                              ((a.z + b.z) + c.z) * 0.33333333f, ((a.w + b.w) + c.w) * 0.33333333f};
+            pm.tris.push_back(t);
+        }
+    }
+    meshes_.push_back(std::move(pm));
+    return (uint32_t)meshes_.size() - 1;
+}
+
+bool SceneBuilder::add_instance(uint32_t mesh_id, const float* t12, const int32_t* material_ids, int32_t n_ids)
+{
+    if (mesh_id >= meshes_.size()) return false;
+    PendingInstance pi;
+    pi.mesh = mesh_id;
+    std::memcpy(pi.t12, t12, sizeof pi.t12);
+    pi.mats[0] = pi.mats[1] = pi.mats[2] = 0;  // the reference leaves unset slots uninitialised (bvh.h:73-79)
+    for (int i = 0; i < std::min(n_ids, 3); i++) pi.mats[i] = (uint32_t)material_ids[i];
+    instances_.push_back(pi);
+    return true;
+}
+
+bool SceneBuilder::commit(BuildMode mode, RefScene& out, std::string& err)
+{
+    out.clear();
+    // per unique mesh: append triangles, build its BLAS into the shared node array (geometry_group3d.cpp:308-313)
+    for (const PendingMesh& pm : meshes_) {
+        const int start = (int)out.triangles.size();
+        out.triangles.insert(out.triangles.end(), pm.tris.begin(), pm.tris.end());
+        const int end = (int)out.triangles.size();
+        uint32_t root = 0;
+        if (end > start) {
+            if (mode == BuildMode::ReferenceExact) {
+                ExactBlasBuilder b{out.bvh_nodes, out.triangles};
+                root = b.build(start, end);
+            } else {
+                SahBlasBuilder b{out.bvh_nodes, out.triangles};
+                b.prepare(start, end);
+                root = b.build(0, end - start);
+                b.apply_order(start, end);
+            }
+        } else {
+            // BuildBVH on an empty mesh returns 0 (bvh.cpp:111-112); keep a valid empty leaf instead
+            root = (uint32_t)out.bvh_nodes.size();
+            RefBvhNode n;
+            std::memset(&n, 0, sizeof n);
+            out.bvh_nodes.push_back(n);
+        }
+        out.mesh_roots.push_back(root);
+    }
+    // instances (geometry_group3d.cpp:322-341)
+    for (const PendingInstance& pi : instances_) {
+        RefInstance inst;
+        std::memset(&inst, 0, sizeof inst);
+        inst.blas_index = out.mesh_roots[pi.mesh];
+        for (int k = 0; k < 3; k++) inst.material[k] = pi.mats[k];
+        float inv12[12];
+        affine_inverse12(pi.t12, inv12);
+        transform12_to_mat16(pi.t12, inst.transform);
+        transform12_to_mat16(inv12, inst.inverse_transform);
+        // BLASInstance::update_aabb (bvh.h:90-115)
+        const RefBvhNode& root = out.bvh_nodes[inst.blas_index];
+        inst.aabbMin = Vec4{1e34f, 1e34f, 1e34f, 1.0f};
+        inst.aabbMax = Vec4{-1e34f, -1e34f, -1e34f, 1.0f};
+        for (int i = 0; i < 8; i++) {
+            const float corner[4] = {(i & 1) ? root.aabbMax.x : root.aabbMin.x, (i & 2) ? root.aabbMax.y : root.aabbMin.y,
+                                     (i & 4) ? root.aabbMax.z : root.aabbMin.z, 1.0f};
+            float tc[4] = {0.0f, 0.0f, 0.0f, 1.0f};
+            for (int j = 0; j < 4; j++)
+                for (int k = 0; k < 4; k++) tc[j] += inst.transform[k * 4 + j] * corner[k];
+            const float s = 2.0f / tc[3];
+            const Vec4 c{tc[0] * s, tc[1] * s, tc[2] * s, tc[3] * s};
+            inst.aabbMin = Vec4{lo_(inst.aabbMin.x, c.x), lo_(inst.aabbMin.y, c.y), lo_(inst.aabbMin.z, c.z), lo_(inst.aabbMin.w, c.w)};
+            inst.aabbMax = Vec4{hi_(inst.aabbMax.x, c.x), hi_(inst.aabbMax.y, c.y), hi_(inst.aabbMax.z, c.z), hi_(inst.aabbMax.w, c.w)};
+        }
+        if (mode == BuildMode::Sah) {
+            // pad the world box like the BLAS boxes (the affine map of the corners rounds)
+            float m = 0.0f;
+            const float* lo = &inst.aabbMin.x;
+            const float* hi = &inst.aabbMax.x;
+            for (int k = 0; k < 3; k++) m = std::max(m, std::max(std::fabs(lo[k]), std::fabs(hi[k])));
+            const float pad = m * 2e-6f;
+            inst.aabbMin = Vec4{lo[0] - pad, lo[1] - pad, lo[2] - pad, 1.0f};
+            inst.aabbMax = Vec4{hi[0] + pad, hi[1] + pad, hi[2] + pad, 1.0f};
+        }
+        out.instances.push_back(inst);
+    }
+    if (!build_tlas(out.instances, out.tlas_nodes, err)) return false;
+    // Triangle -> GpuTriangleGeometry / GpuTriangleData (geometry_group3d.cpp:356-365)
+    out.tri_geom.resize(out.triangles.size());
+    out.tri_data.resize(out.triangles.size());
+    for (size_t i = 0; i < out.triangles.size(); i++) {
+        const RefTriangle& t = out.triangles[i];
+        for (int k = 0; k < 3; k++) out.tri_geom[i].vertices[k] = t.vertices[k];
+        RefTriData& d = out.tri_data[i];
+        std::memset(&d, 0, sizeof d);
+        d.n0[0] = t.normals[0].x; d.n0[1] = t.normals[0].y; d.n0[2] = t.normals[0].z;
+        d.material_index = t.materialIndex;
+        d.n1 = t.normals[1];
+        d.n2 = t.normals[2];
+        for (int k = 0; k < 3; k++) {
+            d.uvs[k][0] = t.uvs[k][0];
+            d.uvs[k][1] = t.uvs[k][1];
+        }
+    }
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------------
+// flatten: reference layout -> 64-byte two-child records
+
+namespace {
+
+struct Flattener {
+    const RefScene& ref;
+    WideScene& out;
+    std::vector<int32_t> blas_ref_of_node;  // child reference for each reference BVH node (lazy)
+    std::string err;
+
+    int32_t leaf_ref(uint32_t first, uint32_t count) { return ~(int32_t)((first & kLeafFirstMask) | ((count - 1) << kLeafCountShift)); }
+
+    // returns the child reference that stands for reference node `ni`
+    int32_t blas_child(uint32_t ni, uint32_t depth)
+    {
+        if (ni >= ref.bvh_nodes.size()) {
+            err = "BVH child index out of range";
+            return ~0;
+        }
+        out.max_blas_depth = std::max(out.max_blas_depth, depth);
+        const RefBvhNode& n = ref.bvh_nodes[ni];
+        if (n.tri_count > 0 || (n.left_child == 0 && n.right_child == 0)) {
+            uint32_t first = n.first_tri_index, count = n.tri_count;
+            if (count == 0) return make_empty_leaf();
+            if (first + count > kLeafFirstMask) {
+                err = "too many triangles for the 25-bit leaf reference";
+                return ~0;
+            }
+            if (count <= (uint32_t)kMaxLeafTris) return leaf_ref(first, count);
+            // oversized leaf (the reference makes them when all three SAH axes are rejected): chain of
+            // records whose two boxes both equal the leaf box
+            const int32_t self = (int32_t)out.blas_nodes.size();
+            out.blas_nodes.emplace_back();
+            WideNode w;
+            std::memset(&w, 0, sizeof w);
+            set_box(w.lmin, w.lmax, n);
+            set_box(w.rmin, w.rmax, n);
+            w.left = leaf_ref(first, kMaxLeafTris);
+            RefBvhNode rest = n;
+            rest.first_tri_index = first + kMaxLeafTris;
+            rest.tri_count = count - kMaxLeafTris;
+            w.right = oversized_rest(rest);
+            out.blas_nodes[self] = w;
+            return self;
+        }
+        const int32_t self = (int32_t)out.blas_nodes.size();
+        out.blas_nodes.emplace_back();
+        WideNode w;
+        std::memset(&w, 0, sizeof w);
+        if (n.left_child >= ref.bvh_nodes.size() || n.right_child >= ref.bvh_nodes.size()) {
+            err = "BVH child index out of range";
+            return ~0;
+        }
+        set_box(w.lmin, w.lmax, ref.bvh_nodes[n.left_child]);
+        set_box(w.rmin, w.rmax, ref.bvh_nodes[n.right_child]);
+        w.left = blas_child(n.left_child, depth + 1);
+        w.right = blas_child(n.right_child, depth + 1);
+        out.blas_nodes[self] = w;
+        return self;
+    }
+
+    int32_t make_empty_leaf()
+    {
+        // a leaf with no triangles: reference it as an internal record whose boxes never hit
+        const int32_t self = (int32_t)out.blas_nodes.size();
+        WideNode w;
+        std::memset(&w, 0, sizeof w);
+        for (int k = 0; k < 3; k++) {
+            w.lmin[k] = w.rmin[k] = FLT_MAX;
+            w.lmax[k] = w.rmax[k] = -FLT_MAX;
+        }
+        w.left = w.right = self;
+        out.blas_nodes.push_back(w);
+        return self;
+    }
+
+    int32_t oversized_rest(const RefBvhNode& n)
+    {
+        if (n.tri_count <= (uint32_t)kMaxLeafTris) return leaf_ref(n.first_tri_index, n.tri_count);
+        const int32_t self = (int32_t)out.blas_nodes.size();
+        out.blas_nodes.emplace_back();
+        WideNode w;
+        std::memset(&w, 0, sizeof w);
+        set_box(w.lmin, w.lmax, n);
+        set_box(w.rmin, w.rmax, n);
+        w.left = leaf_ref(n.first_tri_index, kMaxLeafTris);
+        RefBvhNode rest = n;
+        rest.first_tri_index += kMaxLeafTris;
+        rest.tri_count -= kMaxLeafTris;
+        w.right = oversized_rest(rest);
+        out.blas_nodes[self] = w;
+        return self;
+    }
+
+    static void set_box(float* lo, float* hi, const RefBvhNode& n)
+    {
+        lo[0] = n.aabbMin.x; lo[1] = n.aabbMin.y; lo[2] = n.aabbMin.z;
+        hi[0] = n.aabbMax.x; hi[1] = n.aabbMax.y; hi[2] = n.aabbMax.z;
+    }
+
+    int32_t tlas_child(uint32_t ni, uint32_t depth)
+    {
+        if (ni >= ref.tlas_nodes.size() || depth > 70000) {
+            err = "TLAS child index out of range";
+            return ~0;
+        }
+        out.max_tlas_depth = std::max(out.max_tlas_depth, depth);
+        const RefTlasNode& n = ref.tlas_nodes[ni];
+        if (n.leftRight == 0) {
+            if (n.blas >= ref.instances.size()) {
+                err = "TLAS leaf names an instance that does not exist";
+                return ~0;
+            }
+            return ~(int32_t)n.blas;
+        }
+        const uint32_t l = n.leftRight & 0xFFFFu, r = n.leftRight >> 16;
+        if (l >= ref.tlas_nodes.size() || r >= ref.tlas_nodes.size()) {
+            err = "TLAS child index out of range";
+            return ~0;
+        }
+        const int32_t self = (int32_t)out.tlas_nodes.size();
+        out.tlas_nodes.emplace_back();
+        WideNode w;
+        std::memset(&w, 0, sizeof w);
+        for (int k = 0; k < 3; k++) {
+            w.lmin[k] = ref.tlas_nodes[l].aabbMin[k];
+            w.lmax[k] = ref.tlas_nodes[l].aabbMax[k];
+            w.rmin[k] = ref.tlas_nodes[r].aabbMin[k];
+            w.rmax[k] = ref.tlas_nodes[r].aabbMax[k];
+        }
+        w.left = tlas_child(l, depth + 1);
+        w.right = tlas_child(r, depth + 1);
+        out.tlas_nodes[self] = w;
+        return self;
+    }
+};
+
+}  // namespace
+
+bool flatten(const RefScene& ref, WideScene& out, std::string& err)
+{
+    out = WideScene();
+    Flattener f{ref, out, {}, {}};
+    // triangles: v0 + the two Moller-Trumbore edges (same subtractions as main.glsl:231-232)
+    out.tris.resize(ref.tri_geom.size());
+    for (size_t i = 0; i < ref.tri_geom.size(); i++) {
+        const RefTriGeometry& g = ref.tri_geom[i];
+        WideTri& t = out.tris[i];
+        std::memset(&t, 0, sizeof t);
+        t.v0[0] = g.vertices[0].x; t.v0[1] = g.vertices[0].y; t.v0[2] = g.vertices[0].z;
+        t.e1[0] = g.vertices[1].x - g.vertices[0].x; t.e1[1] = g.vertices[1].y - g.vertices[0].y; t.e1[2] = g.vertices[1].z - g.vertices[0].z;
+        t.e2[0] = g.vertices[2].x - g.vertices[0].x; t.e2[1] = g.vertices[2].y - g.vertices[0].y; t.e2[2] = g.vertices[2].z - g.vertices[0].z;
+        t.src_index = (uint32_t)i;
+    }
+    // one BLAS tree per distinct root referenced by an instance
+    std::vector<std::pair<uint32_t, int32_t>> root_refs;
+    out.instances.resize(ref.instances.size());
+    for (size_t i = 0; i < ref.instances.size(); i++) {
+        const RefInstance& ri = ref.instances[i];
+        int32_t rr = 0;
+        bool found = false;
+        for (auto& p : root_refs)
+            if (p.first == ri.blas_index) {
+                rr = p.second;
+                found = true;
+                break;
+            }
+        if (!found) {
+            rr = f.blas_child(ri.blas_index, 1);
+            if (!f.err.empty()) {
+                err = f.err;
+                return false;
+            }
+            root_refs.emplace_back(ri.blas_index, rr);
+        }
+        WideInstance& wi = out.instances[i];
+        std::memset(&wi, 0, sizeof wi);
+        const float* m = ri.inverse_transform;
+        for (int c = 0; c < 4; c++)
+            for (int r = 0; r < 3; r++) wi.inv[c * 3 + r] = m[c * 4 + r];
+        wi.root = rr;
+    }
+    if (ref.tlas_nodes.empty() || ref.instances.empty()) {
+        out.tlas_root = 0;
+        return true;
+    }
+    out.tlas_root = f.tlas_child(0, 1);
+    if (!f.err.empty()) {
+        err = f.err;
+        return false;
+    }
+    return true;
+}
+
+}  // namespace jpt

@@ -1,0 +1,81 @@
+// jpt_builder.h -- host-side acceleration-structure builder of libjpt_hip.so.
+//
+// Replaces src/bvh/bvh.{h,cpp} of the reference (BVHBuilder::BuildBVH, BLASInstance::set_*,
+// TLAS::build) and the packing tail of GeometryGroup3D::build (geometry_group3d.cpp:305-365).
+// Two modes:
+//   reference-exact  the reference's algorithm restated (same split decisions, same pre-order node
+//                    numbering, same default-box quirk), so the arrays equal what the addon's own
+//                    builder emits and the kernels walk the same tree in the same order;
+//   SAH              a binned-SAH builder over centroid bounds with tight boxes (fast path).
+// Either way `flatten()` re-lays the tree out as 64-byte two-child records for the kernels.
+#pragma once
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "jpt_types.h"
+
+namespace jpt {
+
+struct SurfaceView {  // one ArrayMesh surface (bvh.cpp:192-198)
+    const float* vertices;
+    const float* normals;
+    const float* uvs;
+    const int32_t* indices;
+    int32_t n_vertices, n_indices;
+};
+
+// Scene in the reference layout: exactly the vectors GeometryGroup3D keeps (geometry_group3d.h:40-60).
+struct RefScene {
+    std::vector<RefTriangle> triangles;       // builder-internal (empty after a reference-layout upload)
+    std::vector<RefTriGeometry> tri_geom;
+    std::vector<RefTriData> tri_data;
+    std::vector<RefMaterial> materials;
+    std::vector<RefBvhNode> bvh_nodes;
+    std::vector<RefInstance> instances;
+    std::vector<RefTlasNode> tlas_nodes;
+    std::vector<uint8_t> textures;
+    int32_t tex_res = 0, n_layers = 0;
+    std::vector<uint32_t> mesh_roots;         // BuildBVH return values, one per unique mesh
+    void clear();
+};
+
+// Scene in the flattened device layout.
+struct WideScene {
+    std::vector<WideNode> blas_nodes;
+    std::vector<WideTri> tris;
+    std::vector<WideNode> tlas_nodes;
+    std::vector<WideInstance> instances;
+    int32_t tlas_root = 0;
+    uint32_t max_blas_depth = 0, max_tlas_depth = 0;
+};
+
+enum class BuildMode { ReferenceExact = 0, Sah = 1 };
+
+class SceneBuilder {
+  public:
+    void begin();
+    // BVHBuilder::BuildBVH (bvh.cpp:187-223); returns mesh id
+    uint32_t add_mesh(const SurfaceView* surfaces, int32_t n_surfaces);
+    // BLASInstance::set_materials + set_transform (bvh.h:73-115)
+    bool add_instance(uint32_t mesh_id, const float* transform12, const int32_t* material_ids, int32_t n_ids);
+    // runs the per-mesh builds, instance AABBs, TLAS::build (bvh.cpp:264-317) and the GpuTriangle split
+    // (geometry_group3d.cpp:356-365); fills `out`
+    bool commit(BuildMode mode, RefScene& out, std::string& err);
+
+  private:
+    struct PendingMesh { std::vector<RefTriangle> tris; };
+    struct PendingInstance { uint32_t mesh; float t12[12]; uint32_t mats[3]; };
+    std::vector<PendingMesh> meshes_;
+    std::vector<PendingInstance> instances_;
+};
+
+// godot Transform3D::affine_inverse restated in float (godot-cpp is absent; published algorithm)
+void affine_inverse12(const float* t12, float* out12);
+
+// Reference layout -> flattened layout.  Keeps topology, boxes and child order, so traversal visits the
+// same nodes in the same order as main.glsl:270-350 does on the reference arrays.
+bool flatten(const RefScene& ref, WideScene& out, std::string& err);
+
+}  // namespace jpt

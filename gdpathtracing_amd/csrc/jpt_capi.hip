@@ -1,0 +1,667 @@
+// jpt_capi.hip -- the C ABI of include/jpt.h over the HIP kernels and the host builder.
+#include "../../include/jpt.h"
+
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "jpt_builder.h"
+#include "jpt_kernels.h"
+
+using namespace jpt;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+template <typename T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    ~DevBuf() { release(); }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+    hipError_t resize(size_t count)
+    {
+        if (count == n && (p || count == 0)) return hipSuccess;
+        release();
+        if (count == 0) return hipSuccess;
+        hipError_t e = hipMalloc((void**)&p, count * sizeof(T));
+        if (e == hipSuccess) n = count;
+        return e;
+    }
+    hipError_t upload(const std::vector<T>& v, hipStream_t s)
+    {
+        hipError_t e = resize(v.size());
+        if (e != hipSuccess || v.empty()) return e;
+        return hipMemcpyAsync(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, s);
+    }
+};
+
+}  // namespace
+
+struct jpt_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::string error;
+
+    // host scene
+    SceneBuilder builder;
+    RefScene ref;
+    WideScene wide;
+    bool building = false, scene_ready = false, ref_is_exact = false;
+    std::vector<RefMaterial> pending_materials;
+    std::vector<uint8_t> pending_tex;
+    int32_t pending_tex_res = 0, pending_layers = 0;
+
+    // device scene
+    DevBuf<RefTriGeometry> d_tri_geom;
+    DevBuf<RefTriData> d_tri_data;
+    DevBuf<RefMaterial> d_materials;
+    DevBuf<RefBvhNode> d_bvh;
+    DevBuf<RefInstance> d_instances;
+    DevBuf<RefTlasNode> d_tlas;
+    DevBuf<uint8_t> d_tex;
+    DevBuf<WideNode> d_wblas, d_wtlas;
+    DevBuf<WideTri> d_wtris;
+    DevBuf<WideInstance> d_winst;
+    DeviceScene ds;
+
+    // per-render state
+    bool params_set = false, camera_set = false;
+    int32_t width = 0, height = 0, max_bounces = 4, accum_mode = 0, sampler_mode = 0;
+    int32_t rank = 0, world = 1, local_rows = 0;
+    RefCamera camera;
+    uint32_t frame_count = 0;  // frames accumulated since reset
+    int32_t kernel_variant = 0;
+
+    // framebuffers (local rows of this partition)
+    DevBuf<float4> d_accum;
+    DevBuf<uint32_t> d_ldr;
+    DevBuf<float> d_depth;
+    DevBuf<DevCounters> d_counters;
+    // assembled full image on the gathering rank
+    DevBuf<float4> d_full_accum;
+    DevBuf<uint32_t> d_full_ldr;
+    bool assembled = false;
+
+    jpt_stats stats;
+};
+
+namespace {
+
+int fail(jpt_ctx* c, int code, const std::string& msg)
+{
+    if (c) c->error = msg;
+    return code;
+}
+
+int hip_fail(jpt_ctx* c, hipError_t e, const char* what)
+{
+    return fail(c, JPT_E_DEVICE, std::string(what) + ": " + hipGetErrorString(e));
+}
+
+#define HIP_TRY(c, expr)                                          \
+    do {                                                          \
+        hipError_t e_ = (expr);                                   \
+        if (e_ != hipSuccess) return hip_fail((c), e_, #expr);    \
+    } while (0)
+
+int32_t rows_of_rank(int32_t height, int32_t rank, int32_t world)
+{
+    const int32_t n_strips = (height + kStripRows - 1) / kStripRows;
+    int32_t rows = 0;
+    for (int32_t s = rank; s < n_strips; s += world) {
+        const int32_t y0 = s * kStripRows;
+        rows += (y0 + kStripRows <= height) ? kStripRows : (height - y0);
+    }
+    return rows;
+}
+
+int32_t max_rows_of_any_rank(int32_t height, int32_t world)
+{
+    int32_t m = 0;
+    for (int32_t r = 0; r < world; r++) m = std::max(m, rows_of_rank(height, r, world));
+    return m;
+}
+
+int alloc_framebuffers(jpt_ctx* c)
+{
+    c->local_rows = rows_of_rank(c->height, c->rank, c->world);
+    // every rank allocates the same (maximum) size so a gather sees equal-sized pieces
+    const size_t npx = (size_t)max_rows_of_any_rank(c->height, c->world) * c->width;
+    HIP_TRY(c, c->d_accum.resize(npx));
+    HIP_TRY(c, c->d_ldr.resize(npx));
+    HIP_TRY(c, c->d_depth.resize(npx));
+    HIP_TRY(c, c->d_counters.resize(1));
+    if (npx) {
+        HIP_TRY(c, hipMemsetAsync(c->d_accum.p, 0, npx * sizeof(float4), c->stream));
+        HIP_TRY(c, hipMemsetAsync(c->d_ldr.p, 0, npx * sizeof(uint32_t), c->stream));
+        HIP_TRY(c, hipMemsetAsync(c->d_depth.p, 0, npx * sizeof(float), c->stream));
+    }
+    c->frame_count = 0;
+    c->assembled = false;
+    return JPT_OK;
+}
+
+// host RefScene (+ flatten) -> device
+int upload_scene(jpt_ctx* c)
+{
+    std::string err;
+    if (!flatten(c->ref, c->wide, err)) return fail(c, JPT_E_INVALID, "flatten: " + err);
+    if (c->device < 0) return JPT_OK;  // host-only context: arrays stay on the host, nothing can be rendered
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    HIP_TRY(c, c->d_tri_geom.upload(c->ref.tri_geom, s));
+    HIP_TRY(c, c->d_tri_data.upload(c->ref.tri_data, s));
+    HIP_TRY(c, c->d_materials.upload(c->ref.materials, s));
+    HIP_TRY(c, c->d_bvh.upload(c->ref.bvh_nodes, s));
+    HIP_TRY(c, c->d_instances.upload(c->ref.instances, s));
+    HIP_TRY(c, c->d_tlas.upload(c->ref.tlas_nodes, s));
+    HIP_TRY(c, c->d_tex.upload(c->ref.textures, s));
+    HIP_TRY(c, c->d_wblas.upload(c->wide.blas_nodes, s));
+    HIP_TRY(c, c->d_wtlas.upload(c->wide.tlas_nodes, s));
+    HIP_TRY(c, c->d_wtris.upload(c->wide.tris, s));
+    HIP_TRY(c, c->d_winst.upload(c->wide.instances, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    DeviceScene& d = c->ds;
+    d.ref_tri_geom = c->d_tri_geom.p;
+    d.ref_tri_data = c->d_tri_data.p;
+    d.ref_materials = c->d_materials.p;
+    d.ref_bvh = c->d_bvh.p;
+    d.ref_instances = c->d_instances.p;
+    d.ref_tlas = c->d_tlas.p;
+    d.tex = c->d_tex.p;
+    d.n_tris = (uint32_t)c->ref.tri_geom.size();
+    d.n_materials = (uint32_t)c->ref.materials.size();
+    d.n_ref_bvh = (uint32_t)c->ref.bvh_nodes.size();
+    d.n_instances = (uint32_t)c->ref.instances.size();
+    d.n_ref_tlas = (uint32_t)c->ref.tlas_nodes.size();
+    d.tex_res = c->ref.tex_res;
+    d.n_layers = c->ref.n_layers;
+    d.blas_nodes = c->d_wblas.p;
+    d.wide_tris = c->d_wtris.p;
+    d.tlas_nodes = c->d_wtlas.p;
+    d.wide_instances = c->d_winst.p;
+    d.tlas_root = c->wide.tlas_root;
+    d.n_blas_nodes = (uint32_t)c->wide.blas_nodes.size();
+    d.n_tlas_nodes = (uint32_t)c->wide.tlas_nodes.size();
+    c->scene_ready = true;
+    return JPT_OK;
+}
+
+int validate_ref_scene(jpt_ctx* c)
+{
+    const RefScene& r = c->ref;
+    if (r.tri_geom.size() != r.tri_data.size()) return fail(c, JPT_E_INVALID, "triangle geometry/data counts differ");
+    if (r.materials.empty()) return fail(c, JPT_E_INVALID, "material table is empty (entry 0 is the default material)");
+    for (const RefInstance& i : r.instances)
+        if (i.blas_index >= r.bvh_nodes.size()) return fail(c, JPT_E_INVALID, "instance root index out of range");
+    for (const RefBvhNode& n : r.bvh_nodes) {
+        if (n.tri_count > 0) {
+            if ((size_t)n.first_tri_index + n.tri_count > r.tri_geom.size())
+                return fail(c, JPT_E_INVALID, "BVH leaf triangle range out of bounds");
+        } else if (n.left_child >= r.bvh_nodes.size() || n.right_child >= r.bvh_nodes.size()) {
+            return fail(c, JPT_E_INVALID, "BVH child index out of range");
+        }
+    }
+    return JPT_OK;
+}
+
+int do_render(jpt_ctx* c, int32_t n_frames, uint32_t first_frame_index, bool counted, bool blocking)
+{
+    if (!c) return JPT_E_INVALID;
+    if (c->device < 0) return fail(c, JPT_E_DEVICE, "host-only context (JPT_DEVICE_HOST_ONLY) cannot render: there is no CPU fallback");
+    if (!c->scene_ready) return fail(c, JPT_E_STATE, "no scene: call jpt_scene_upload_reference_layout or jpt_scene_commit first");
+    if (!c->params_set) return fail(c, JPT_E_STATE, "jpt_set_params not called");
+    if (!c->camera_set) return fail(c, JPT_E_STATE, "jpt_set_camera not called");
+    if (n_frames < 0) return fail(c, JPT_E_INVALID, "n_frames < 0");
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    c->assembled = false;
+    DevCounters* cnt = nullptr;
+    if (counted) {
+        cnt = c->d_counters.p;
+        HIP_TRY(c, hipMemsetAsync(cnt, 0, sizeof(DevCounters), s));
+    }
+    HIP_TRY(c, hipEventRecord(c->ev0, s));
+    if (c->local_rows > 0 && c->width > 0) {
+        for (int32_t f = 0; f < n_frames; f++) {
+            FrameParams fp;
+            fp.width = c->width;
+            fp.height = c->height;
+            fp.local_rows = c->local_rows;
+            fp.rank = c->rank;
+            fp.world = c->world;
+            fp.max_bounces = c->max_bounces;
+            fp.accum_mode = c->accum_mode;
+            fp.frame_index = first_frame_index + (uint32_t)f;
+            fp.frame_count = c->frame_count + (uint32_t)f + 1;
+            fp.n_frames = 1;
+            launch_ref_frame(s, c->ds, fp, c->camera, c->d_accum.p, c->d_ldr.p, c->d_depth.p, cnt);
+        }
+        HIP_TRY(c, hipGetLastError());
+    }
+    HIP_TRY(c, hipEventRecord(c->ev1, s));
+    c->frame_count += (uint32_t)n_frames;
+    c->stats.frames = c->frame_count;
+    if (blocking || counted) {
+        HIP_TRY(c, hipEventSynchronize(c->ev1));
+        float ms = 0.0f;
+        HIP_TRY(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+        c->stats.last_render_ms = ms;
+        c->stats.last_trace_ms = ms;
+        if (counted) {
+            DevCounters h;
+            HIP_TRY(c, hipMemcpy(&h, cnt, sizeof h, hipMemcpyDeviceToHost));
+            c->stats.rays = h.rays;
+            c->stats.blas_expand = h.blas_expand;
+            c->stats.tri_tests = h.tri_tests;
+            c->stats.tlas_expand = h.tlas_expand;
+            c->stats.inst_visits = h.inst_visits;
+            c->stats.shaded_hits = h.shaded_hits;
+        }
+    }
+    return JPT_OK;
+}
+
+// local strip-major rows -> full image rows, on the host
+template <typename T>
+void scatter_rows(const std::vector<T>& local, T* out, int32_t width, int32_t height, int32_t rank, int32_t world, int comps)
+{
+    const int32_t n_strips = (height + kStripRows - 1) / kStripRows;
+    int32_t ly = 0;
+    for (int32_t s = rank; s < n_strips; s += world) {
+        for (int32_t r = 0; r < kStripRows; r++) {
+            const int32_t y = s * kStripRows + r;
+            if (y >= height) break;
+            std::memcpy(out + (size_t)y * width * comps, local.data() + (size_t)ly * width * comps, (size_t)width * comps * sizeof(T));
+            ly++;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int jpt_abi_version(void) { return JPT_ABI_VERSION; }
+
+int jpt_create(int device_id, jpt_ctx** out)
+{
+    if (!out) return JPT_E_INVALID;
+    *out = nullptr;
+    if (device_id == JPT_DEVICE_HOST_ONLY) {  // builder-only context: no device is touched
+        jpt_ctx* c = new (std::nothrow) jpt_ctx();
+        if (!c) return JPT_E_DEVICE;
+        c->device = -1;
+        std::memset(&c->stats, 0, sizeof c->stats);
+        std::memset(&c->camera, 0, sizeof c->camera);
+        *out = c;
+        return JPT_OK;
+    }
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        g_create_error = std::string("no HIP device: ") + (e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
+        return JPT_E_DEVICE;
+    }
+    if (device_id < 0 || device_id >= n) {
+        g_create_error = "device id out of range";
+        return JPT_E_INVALID;
+    }
+    jpt_ctx* c = new (std::nothrow) jpt_ctx();
+    if (!c) return JPT_E_DEVICE;
+    c->device = device_id;
+    std::memset(&c->stats, 0, sizeof c->stats);
+    std::memset(&c->camera, 0, sizeof c->camera);
+    if ((e = hipSetDevice(device_id)) != hipSuccess || (e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)) != hipSuccess ||
+        (e = hipEventCreate(&c->ev0)) != hipSuccess || (e = hipEventCreate(&c->ev1)) != hipSuccess) {
+        g_create_error = std::string("HIP init: ") + hipGetErrorString(e);
+        delete c;
+        return JPT_E_DEVICE;
+    }
+    c->stream = c->own_stream;
+    *out = c;
+    return JPT_OK;
+}
+
+void jpt_destroy(jpt_ctx* c)
+{
+    if (!c) return;
+    if (c->device < 0) {
+        delete c;
+        return;
+    }
+    (void)hipSetDevice(c->device);
+    if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+}
+
+const char* jpt_last_error(const jpt_ctx* c) { return c ? c->error.c_str() : g_create_error.c_str(); }
+
+int jpt_set_stream(jpt_ctx* c, void* hip_stream)
+{
+    if (!c || c->device < 0) return JPT_E_INVALID;
+    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    return JPT_OK;
+}
+
+int jpt_scene_upload_reference_layout(jpt_ctx* c, const void* tri_geometry, uint32_t n_triangles, const void* tri_data,
+                                      const void* materials, uint32_t n_materials, const void* bvh_nodes, uint32_t n_bvh_nodes,
+                                      const void* blas_instances, uint32_t n_instances, const void* tlas_nodes,
+                                      uint32_t n_tlas_nodes, const uint8_t* tex_rgba8, int32_t tex_res, int32_t n_layers)
+{
+    if (!c) return JPT_E_INVALID;
+    if ((n_triangles && (!tri_geometry || !tri_data)) || (n_materials && !materials) || (n_bvh_nodes && !bvh_nodes) ||
+        (n_instances && !blas_instances) || (n_tlas_nodes && !tlas_nodes))
+        return fail(c, JPT_E_INVALID, "null buffer with non-zero count");
+    if (n_tlas_nodes > 65536) return fail(c, JPT_E_LIMIT, "TLAS has more nodes than 16-bit child indices address (bvh.h:59)");
+    const auto t0 = std::chrono::steady_clock::now();
+    c->scene_ready = false;
+    RefScene& r = c->ref;
+    r.clear();
+    auto put = [](auto& vec, const void* src, uint32_t n) {
+        using T = typename std::remove_reference<decltype(vec)>::type::value_type;
+        vec.resize(n);
+        if (n) std::memcpy(vec.data(), src, (size_t)n * sizeof(T));
+    };
+    put(r.tri_geom, tri_geometry, n_triangles);
+    put(r.tri_data, tri_data, n_triangles);
+    put(r.materials, materials, n_materials);
+    put(r.bvh_nodes, bvh_nodes, n_bvh_nodes);
+    put(r.instances, blas_instances, n_instances);
+    put(r.tlas_nodes, tlas_nodes, n_tlas_nodes);
+    r.textures.clear();
+    r.tex_res = r.n_layers = 0;
+    if (tex_rgba8 && tex_res > 0 && n_layers > 0) {
+        r.textures.assign(tex_rgba8, tex_rgba8 + (size_t)tex_res * tex_res * 4 * n_layers);
+        r.tex_res = tex_res;
+        r.n_layers = n_layers;
+    }
+    c->ref_is_exact = false;
+    int rc = validate_ref_scene(c);
+    if (rc != JPT_OK) return rc;
+    rc = upload_scene(c);
+    c->stats.last_build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return rc;
+}
+
+int jpt_scene_begin(jpt_ctx* c)
+{
+    if (!c) return JPT_E_INVALID;
+    c->builder.begin();
+    c->pending_materials.clear();
+    c->pending_tex.clear();
+    c->pending_tex_res = c->pending_layers = 0;
+    c->building = true;
+    return JPT_OK;
+}
+
+int jpt_scene_add_mesh(jpt_ctx* c, const jpt_surface* surfaces, int32_t n_surfaces, uint32_t* mesh_id_out)
+{
+    if (!c || !c->building) return fail(c, JPT_E_STATE, "jpt_scene_begin not called");
+    if (n_surfaces < 0 || (n_surfaces && !surfaces)) return fail(c, JPT_E_INVALID, "bad surface array");
+    std::vector<SurfaceView> sv((size_t)n_surfaces);
+    for (int32_t i = 0; i < n_surfaces; i++) {
+        const jpt_surface& s = surfaces[i];
+        if (s.n_indices < 0 || s.n_vertices < 0 || (s.n_indices && (!s.indices || !s.vertices || !s.normals || !s.uvs)))
+            return fail(c, JPT_E_INVALID, "surface needs vertex, normal, uv and index arrays (bvh.cpp:195-198)");
+        if (s.n_indices % 3) return fail(c, JPT_E_INVALID, "index count is not a multiple of 3");
+        for (int32_t k = 0; k < s.n_indices; k++)
+            if (s.indices[k] < 0 || s.indices[k] >= s.n_vertices) return fail(c, JPT_E_INVALID, "vertex index out of range");
+        sv[i] = SurfaceView{s.vertices, s.normals, s.uvs, s.indices, s.n_vertices, s.n_indices};
+    }
+    const uint32_t id = c->builder.add_mesh(sv.data(), n_surfaces);
+    if (mesh_id_out) *mesh_id_out = id;
+    return JPT_OK;
+}
+
+int jpt_scene_add_instance(jpt_ctx* c, uint32_t mesh_id, const float* transform12, const int32_t* material_ids, int32_t n_ids)
+{
+    if (!c || !c->building) return fail(c, JPT_E_STATE, "jpt_scene_begin not called");
+    if (!transform12 || n_ids < 0 || (n_ids && !material_ids)) return fail(c, JPT_E_INVALID, "bad instance arguments");
+    if (!c->builder.add_instance(mesh_id, transform12, material_ids, n_ids)) return fail(c, JPT_E_INVALID, "unknown mesh id");
+    return JPT_OK;
+}
+
+int jpt_scene_set_materials(jpt_ctx* c, const void* materials, uint32_t n_materials)
+{
+    if (!c || !c->building) return fail(c, JPT_E_STATE, "jpt_scene_begin not called");
+    if (n_materials && !materials) return fail(c, JPT_E_INVALID, "null materials");
+    c->pending_materials.resize(n_materials);
+    if (n_materials) std::memcpy(c->pending_materials.data(), materials, (size_t)n_materials * sizeof(RefMaterial));
+    return JPT_OK;
+}
+
+int jpt_scene_set_textures(jpt_ctx* c, const uint8_t* tex, int32_t tex_res, int32_t n_layers)
+{
+    if (!c || !c->building) return fail(c, JPT_E_STATE, "jpt_scene_begin not called");
+    c->pending_tex.clear();
+    c->pending_tex_res = c->pending_layers = 0;
+    if (tex && tex_res > 0 && n_layers > 0) {
+        c->pending_tex.assign(tex, tex + (size_t)tex_res * tex_res * 4 * n_layers);
+        c->pending_tex_res = tex_res;
+        c->pending_layers = n_layers;
+    }
+    return JPT_OK;
+}
+
+int jpt_scene_commit(jpt_ctx* c, int32_t builder)
+{
+    if (!c || !c->building) return fail(c, JPT_E_STATE, "jpt_scene_begin not called");
+    if (builder != JPT_BUILD_REFERENCE_EXACT && builder != JPT_BUILD_SAH) return fail(c, JPT_E_INVALID, "unknown builder");
+    const auto t0 = std::chrono::steady_clock::now();
+    c->scene_ready = false;
+    std::string err;
+    if (!c->builder.commit(builder == JPT_BUILD_SAH ? BuildMode::Sah : BuildMode::ReferenceExact, c->ref, err))
+        return fail(c, JPT_E_LIMIT, err);
+    c->ref.materials = c->pending_materials;
+    c->ref.textures = c->pending_tex;
+    c->ref.tex_res = c->pending_tex_res;
+    c->ref.n_layers = c->pending_layers;
+    c->ref_is_exact = (builder == JPT_BUILD_REFERENCE_EXACT);
+    int rc = validate_ref_scene(c);
+    if (rc != JPT_OK) return rc;
+    rc = upload_scene(c);
+    c->building = false;
+    c->stats.last_build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return rc;
+}
+
+int jpt_scene_get_reference_buffer(jpt_ctx* c, int32_t which, void* out, size_t capacity, size_t* size_out)
+{
+    if (!c) return JPT_E_INVALID;
+    const void* src = nullptr;
+    size_t bytes = 0;
+    const RefScene& r = c->ref;
+    switch (which) {
+        case JPT_BUF_TRI_GEOMETRY: src = r.tri_geom.data(); bytes = r.tri_geom.size() * sizeof(RefTriGeometry); break;
+        case JPT_BUF_TRI_DATA: src = r.tri_data.data(); bytes = r.tri_data.size() * sizeof(RefTriData); break;
+        case JPT_BUF_MATERIALS: src = r.materials.data(); bytes = r.materials.size() * sizeof(RefMaterial); break;
+        case JPT_BUF_BVH_NODES: src = r.bvh_nodes.data(); bytes = r.bvh_nodes.size() * sizeof(RefBvhNode); break;
+        case JPT_BUF_INSTANCES: src = r.instances.data(); bytes = r.instances.size() * sizeof(RefInstance); break;
+        case JPT_BUF_TLAS_NODES: src = r.tlas_nodes.data(); bytes = r.tlas_nodes.size() * sizeof(RefTlasNode); break;
+        case JPT_BUF_TRIANGLES: src = r.triangles.data(); bytes = r.triangles.size() * sizeof(RefTriangle); break;
+        default: return fail(c, JPT_E_INVALID, "unknown buffer id");
+    }
+    if (size_out) *size_out = bytes;
+    if (out) {
+        if (capacity < bytes) return fail(c, JPT_E_INVALID, "buffer too small");
+        if (bytes) std::memcpy(out, src, bytes);
+    }
+    return JPT_OK;
+}
+
+int jpt_set_params(jpt_ctx* c, int32_t width, int32_t height, int32_t max_bounces, int32_t accum_mode, int32_t sampler_mode)
+{
+    if (!c) return JPT_E_INVALID;
+    if (width < 0 || height < 0 || width > 65536 || height > 65536) return fail(c, JPT_E_INVALID, "bad resolution");
+    if (max_bounces < 0 || max_bounces > 64) return fail(c, JPT_E_INVALID, "max_bounces must be in [0,64]");
+    if (accum_mode != JPT_ACCUM_REF_LDR8 && accum_mode != JPT_ACCUM_HDR_F32) return fail(c, JPT_E_INVALID, "unknown accum_mode");
+    if (sampler_mode != JPT_SAMPLER_NEAREST_CLAMP) return fail(c, JPT_E_INVALID, "unknown sampler_mode");
+    if (c->device < 0) return fail(c, JPT_E_DEVICE, "host-only context has no framebuffers");
+    HIP_TRY(c, hipSetDevice(c->device));
+    c->width = width;
+    c->height = height;
+    c->max_bounces = max_bounces;
+    c->accum_mode = accum_mode;
+    c->sampler_mode = sampler_mode;
+    c->params_set = true;
+    return alloc_framebuffers(c);
+}
+
+int jpt_set_partition(jpt_ctx* c, int32_t rank, int32_t world)
+{
+    if (!c) return JPT_E_INVALID;
+    if (world < 1 || rank < 0 || rank >= world) return fail(c, JPT_E_INVALID, "need 0 <= rank < world");
+    c->rank = rank;
+    c->world = world;
+    if (c->params_set && c->device >= 0) {
+        HIP_TRY(c, hipSetDevice(c->device));
+        return alloc_framebuffers(c);
+    }
+    return JPT_OK;
+}
+
+int jpt_set_camera(jpt_ctx* c, const void* camera160)
+{
+    if (!c || !camera160) return fail(c, JPT_E_INVALID, "null camera");
+    std::memcpy(&c->camera, camera160, sizeof(RefCamera));
+    c->camera_set = true;
+    return JPT_OK;
+}
+
+int jpt_render(jpt_ctx* c, int32_t n_frames, uint32_t first_frame_index) { return do_render(c, n_frames, first_frame_index, false, true); }
+int jpt_render_counted(jpt_ctx* c, int32_t n_frames, uint32_t first_frame_index) { return do_render(c, n_frames, first_frame_index, true, true); }
+int jpt_render_async(jpt_ctx* c, int32_t n_frames, uint32_t first_frame_index) { return do_render(c, n_frames, first_frame_index, false, false); }
+
+int jpt_sync(jpt_ctx* c)
+{
+    if (!c || c->device < 0) return JPT_E_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    float ms = 0.0f;
+    if (hipEventElapsedTime(&ms, c->ev0, c->ev1) == hipSuccess) c->stats.last_render_ms = c->stats.last_trace_ms = ms;
+    return JPT_OK;
+}
+
+int jpt_accum_reset(jpt_ctx* c)
+{
+    if (!c) return JPT_E_INVALID;
+    c->frame_count = 0;  // frame_count == 1 on the next frame overwrites the sum (progressive_rendering.glsl:34)
+    c->stats.frames = 0;
+    c->assembled = false;
+    return JPT_OK;
+}
+
+static int read_common(jpt_ctx* c, void* out)
+{
+    if (!c || !out) return fail(c, JPT_E_INVALID, "null output");
+    if (!c->params_set) return fail(c, JPT_E_STATE, "jpt_set_params not called");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return JPT_OK;
+}
+
+int jpt_read_ldr_rgba8(jpt_ctx* c, uint8_t* out)
+{
+    int rc = read_common(c, out);
+    if (rc) return rc;
+    const size_t full = (size_t)c->width * c->height;
+    if (c->assembled) {
+        HIP_TRY(c, hipMemcpy(out, c->d_full_ldr.p, full * 4, hipMemcpyDeviceToHost));
+        return JPT_OK;
+    }
+    std::vector<uint32_t> local((size_t)c->local_rows * c->width);
+    if (!local.empty()) HIP_TRY(c, hipMemcpy(local.data(), c->d_ldr.p, local.size() * 4, hipMemcpyDeviceToHost));
+    if (c->world == 1) std::memcpy(out, local.data(), local.size() * 4);
+    else {
+        std::memset(out, 0, full * 4);
+        scatter_rows(local, reinterpret_cast<uint32_t*>(out), c->width, c->height, c->rank, c->world, 1);
+    }
+    return JPT_OK;
+}
+
+int jpt_read_accum_f32(jpt_ctx* c, float* out)
+{
+    int rc = read_common(c, out);
+    if (rc) return rc;
+    const size_t full = (size_t)c->width * c->height;
+    if (c->assembled) {
+        HIP_TRY(c, hipMemcpy(out, c->d_full_accum.p, full * sizeof(float4), hipMemcpyDeviceToHost));
+        return JPT_OK;
+    }
+    std::vector<float> local((size_t)c->local_rows * c->width * 4);
+    if (!local.empty()) HIP_TRY(c, hipMemcpy(local.data(), c->d_accum.p, local.size() * 4, hipMemcpyDeviceToHost));
+    if (c->world == 1) std::memcpy(out, local.data(), local.size() * 4);
+    else {
+        std::memset(out, 0, full * 16);
+        scatter_rows(local, out, c->width, c->height, c->rank, c->world, 4);
+    }
+    return JPT_OK;
+}
+
+int jpt_read_depth_f32(jpt_ctx* c, float* out)
+{
+    int rc = read_common(c, out);
+    if (rc) return rc;
+    const size_t full = (size_t)c->width * c->height;
+    std::vector<float> local((size_t)c->local_rows * c->width);
+    if (!local.empty()) HIP_TRY(c, hipMemcpy(local.data(), c->d_depth.p, local.size() * 4, hipMemcpyDeviceToHost));
+    if (c->world == 1) std::memcpy(out, local.data(), local.size() * 4);
+    else {
+        std::memset(out, 0, full * 4);
+        scatter_rows(local, out, c->width, c->height, c->rank, c->world, 1);
+    }
+    return JPT_OK;
+}
+
+void* jpt_device_accum(jpt_ctx* c, size_t* bytes_out)
+{
+    if (!c) return nullptr;
+    if (bytes_out) *bytes_out = c->d_accum.n * sizeof(float4);
+    return c->d_accum.p;
+}
+
+int32_t jpt_local_rows(jpt_ctx* c) { return c ? c->local_rows : 0; }
+
+int jpt_assemble_from_ranks(jpt_ctx* c, const void* device_gathered, int32_t world)
+{
+    if (!c || !device_gathered) return fail(c, JPT_E_INVALID, "null gathered buffer");
+    if (c->device < 0) return fail(c, JPT_E_DEVICE, "host-only context");
+    if (!c->params_set) return fail(c, JPT_E_STATE, "jpt_set_params not called");
+    if (world != c->world) return fail(c, JPT_E_INVALID, "world differs from jpt_set_partition");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t full = (size_t)c->width * c->height;
+    HIP_TRY(c, c->d_full_accum.resize(full));
+    HIP_TRY(c, c->d_full_ldr.resize(full));
+    launch_assemble(c->stream, (const float4*)device_gathered, world, c->width, c->height,
+                    max_rows_of_any_rank(c->height, world), c->d_full_accum.p, c->d_full_ldr.p, c->frame_count);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->assembled = true;
+    return JPT_OK;
+}
+
+int jpt_get_stats(jpt_ctx* c, jpt_stats* out)
+{
+    if (!c || !out) return JPT_E_INVALID;
+    *out = c->stats;
+    return JPT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,110 @@
+// jpt_kernels.h -- what the host layer (jpt_capi.hip) sees of the device code.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "jpt_shade.h"
+#include "jpt_types.h"
+
+namespace jpt {
+
+constexpr int kStripRows = 8;  // screen partition granule (jpt_set_partition)
+
+struct DevCounters {  // SURVEY.md 8(d) event counters
+    unsigned long long rays, blas_expand, tri_tests, tlas_expand, inst_visits, shaded_hits;
+};
+
+struct FrameParams {
+    int32_t width, height;      // full image (Params.width/height, main.glsl:103-104)
+    int32_t local_rows;         // rows this context renders
+    int32_t rank, world;        // 8-row strips s with s % world == rank
+    int32_t max_bounces;        // main.glsl:377 literal 5 == max_bounces + 1
+    int32_t accum_mode;         // JPT_ACCUM_*
+    uint32_t frame_index;       // camera.frame_index of this frame (main.glsl:409)
+    uint32_t frame_count;       // ProgressiveRendering frame_count of this frame (progressive_rendering.cpp:53-60)
+    int32_t n_frames;           // frames rendered by one launch (wide kernels)
+};
+
+// All device-resident scene data of a context.
+struct DeviceScene {
+    // reference layout (drop-in route + cold shading data)
+    const RefTriGeometry* ref_tri_geom = nullptr;
+    const RefTriData* ref_tri_data = nullptr;
+    const RefMaterial* ref_materials = nullptr;
+    const RefBvhNode* ref_bvh = nullptr;
+    const RefInstance* ref_instances = nullptr;
+    const RefTlasNode* ref_tlas = nullptr;
+    const uint8_t* tex = nullptr;
+    uint32_t n_tris = 0, n_materials = 0, n_ref_bvh = 0, n_instances = 0, n_ref_tlas = 0;
+    int32_t tex_res = 0, n_layers = 0;
+    // flattened layout (native route)
+    const WideNode* blas_nodes = nullptr;
+    const WideTri* wide_tris = nullptr;
+    const WideNode* tlas_nodes = nullptr;
+    const WideInstance* wide_instances = nullptr;
+    int32_t tlas_root = 0;  // child reference of the TLAS root
+    uint32_t n_blas_nodes = 0, n_tlas_nodes = 0;
+
+    SceneShading shading() const
+    {
+        SceneShading s;
+        s.tri_data = ref_tri_data;
+        s.instances = ref_instances;
+        s.materials = ref_materials;
+        s.tex = tex;
+        s.n_materials = n_materials;
+        s.tex_res = tex_res;
+        s.n_layers = n_layers;
+        return s;
+    }
+};
+
+#if defined(__HIPCC__)
+// local row -> image row for the strip-interleaved partition
+__device__ __forceinline__ int local_to_global_row(int ly, const FrameParams& fp)
+{
+    const int strip = ly / kStripRows;
+    return (strip * fp.world + fp.rank) * kStripRows + (ly - strip * kStripRows);
+}
+
+// progressive_rendering.glsl:28-46 for one pixel, preceded by the rgba8 store of main.glsl:434 in
+// REF_LDR8 mode.  accum: rgba32f frameBuffer; ldr: the rgba8 screen after ACES.
+__device__ __forceinline__ void accumulate_pixel(const FrameParams& fp, size_t idx, f3 radiance, float4* __restrict__ accum,
+                                                 uint32_t* __restrict__ ldr)
+{
+    f3 cur = radiance;
+    if (fp.accum_mode == 0) {
+        cur = mk3(from_unorm8(unorm8(radiance.x)), from_unorm8(unorm8(radiance.y)), from_unorm8(unorm8(radiance.z)));
+    }
+    f3 sum = cur;
+    if (fp.frame_count > 1) {
+        const float4 prev = accum[idx];
+        sum = mk3(cur.x + prev.x, cur.y + prev.y, cur.z + prev.z);
+    }
+    accum[idx] = make_float4(sum.x, sum.y, sum.z, 1.0f);
+    const float fc = (float)fp.frame_count;
+    const f3 col = aces_film(mk3(sum.x / fc, sum.y / fc, sum.z / fc) * 1.0f);
+    ldr[idx] = unorm8(col.x) | (unorm8(col.y) << 8) | (unorm8(col.z) << 16) | 0xFF000000u;
+}
+
+__device__ __forceinline__ void flush_counters(const DevCounters& c, DevCounters* __restrict__ out)
+{
+    if (c.rays) atomicAdd(&out->rays, c.rays);
+    if (c.blas_expand) atomicAdd(&out->blas_expand, c.blas_expand);
+    if (c.tri_tests) atomicAdd(&out->tri_tests, c.tri_tests);
+    if (c.tlas_expand) atomicAdd(&out->tlas_expand, c.tlas_expand);
+    if (c.inst_visits) atomicAdd(&out->inst_visits, c.inst_visits);
+    if (c.shaded_hits) atomicAdd(&out->shaded_hits, c.shaded_hits);
+}
+#endif
+
+// one frame over the reference layout (jpt_kernels_ref.hip); counters may be null
+void launch_ref_frame(hipStream_t stream, const DeviceScene& ds, const FrameParams& fp, const RefCamera& cam, float4* accum,
+                      uint32_t* ldr, float* depth, DevCounters* counters);
+
+// rank-major gathered strips -> full framebuffer (multi-GPU assemble)
+void launch_assemble(hipStream_t stream, const float4* gathered, int world, int width, int height, int max_local_rows,
+                     float4* accum_full, uint32_t* ldr_full, uint32_t frame_count);
+
+}  // namespace jpt

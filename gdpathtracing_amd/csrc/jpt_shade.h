@@ -1,0 +1,292 @@
+// jpt_shade.h -- per-path device code shared by every tracing kernel: RNG, primary-ray generation,
+// shading-record fetch, the diffuse + GGX mixture BRDF with VNDF sampling, and the path update.
+// Replaces main.glsl:163-222,372-421 and brdfs.glsl:1-138 of the reference
+// (project/addons/jar_path_tracing/src/shaders/).
+#pragma once
+
+#include "jpt_device_math.h"
+#include "jpt_types.h"
+
+namespace jpt {
+
+#define JPT_PI 3.141592653589793238462643f  // brdfs.glsl:1
+
+struct Ray {  // main.glsl:26-30
+    f3 o, d, rD;
+};
+
+struct Hit {  // the fields of HitInfo (main.glsl:62-71) that survive traversal
+    float t;
+    float u, v;
+    uint32_t tri;   // index into the reference-order triangle arrays
+    uint32_t inst;  // BLAS instance id
+    f3 lo, ld;      // ray origin / direction in the hit instance's local space (position = lo + t*ld)
+};
+
+struct Shading {  // main.glsl:73-82
+    f3 position, normal, out_dir;
+    float lambert_out;
+    f3 emission, diffuse_albedo, fresnel_0;
+    float roughness;
+};
+
+struct SceneShading {  // cold, once-per-hit data: kept in the reference layout
+    const RefTriData* __restrict__ tri_data;
+    const RefInstance* __restrict__ instances;
+    const RefMaterial* __restrict__ materials;
+    const uint8_t* __restrict__ tex;
+    uint32_t n_materials;
+    int32_t tex_res, n_layers;
+};
+
+// ---- RNG (main.glsl:163-181) -----------------------------------------------------------------
+
+__device__ __forceinline__ void pcg2d(uint32_t& sx, uint32_t& sy, float& rx, float& ry)
+{
+    uint32_t x = 1664525u * sx + 1013904223u;
+    uint32_t y = 1664525u * sy + 1013904223u;
+    x += 1664525u * y;
+    y += 1664525u * x;
+    x ^= x >> 16;
+    y ^= y >> 16;
+    x += 1664525u * y;
+    y += 1664525u * x;
+    x ^= x >> 16;
+    y ^= y >> 16;
+    sx = x;
+    sy = y;
+    rx = (float)x * 2.32830643654e-10f;
+    ry = (float)y * 2.32830643654e-10f;
+}
+
+__device__ __forceinline__ void prng_seed(uint32_t px, uint32_t py, uint32_t frame, uint32_t& sx, uint32_t& sy)
+{
+    uint32_t x = px * 0x9e3779b9u + frame;
+    uint32_t y = py * 0x9e3779b9u + frame;
+    x ^= x >> 16;
+    y ^= y >> 16;
+    sx = x * 0x9e3779b9u;
+    sy = y * 0x9e3779b9u;
+}
+
+// ---- primary ray (main.glsl:405-421, box_muller :183-187) -------------------------------------
+
+__device__ __forceinline__ Ray primary_ray(const RefCamera& cam, int width, int height, int px, int py, uint32_t frame,
+                                           uint32_t& sx, uint32_t& sy)
+{
+    prng_seed((uint32_t)px, (uint32_t)py, frame, sx, sy);
+    float r0, r1;
+    pcg2d(sx, sy, r0, r1);
+    r1 = r1 * 0.25f;
+    // box_muller: R = sqrt(-2 log(r0)) is dead code in the reference; only theta is used
+    float js, jc;
+    sincos_(6.2831853f * r1, js, jc);
+    const float scx = ((float)px + jc) / (float)width * 2.0f - 1.0f;
+    const float scy = ((float)py + js) / (float)height * 2.0f - 1.0f;
+    const float nx = scx, ny = -scy;
+    const float* m = cam.ivp;
+    float wx = m[0] * nx + m[4] * ny + m[8] + m[12];
+    float wy = m[1] * nx + m[5] * ny + m[9] + m[13];
+    float wz = m[2] * nx + m[6] * ny + m[10] + m[14];
+    const float ww = m[3] * nx + m[7] * ny + m[11] + m[15];
+    wx = wx / ww;
+    wy = wy / ww;
+    wz = wz / ww;
+    Ray ray;
+    ray.o = mk3(cam.position.x, cam.position.y, cam.position.z);
+    ray.d = normalize3(mk3(wx, wy, wz) - ray.o);
+    ray.rD = rcp3(ray.d);
+    return ray;
+}
+
+__device__ __forceinline__ f3 sample_sky(f3 d)  // main.glsl:189-192
+{
+    const float t = 0.5f * (d.y + 1.0f);
+    return mk3(mix_(0.95f, 0.9f, t) * 1.0f, mix_(0.95f, 0.94f, t) * 1.0f, mix_(0.95f, 1.0f, t) * 1.0f);
+}
+
+// texture(textureArray, vec3(uv, layer)) (main.glsl:214): nearest + clamp-to-edge
+__device__ __forceinline__ f3 sample_texture(const SceneShading& sc, float u, float v, int layer)
+{
+    if (!sc.tex || sc.n_layers <= 0 || sc.tex_res <= 0) return mk3(0.0f, 0.0f, 0.0f);
+    if (layer >= sc.n_layers) layer = sc.n_layers - 1;
+    const int res = sc.tex_res;
+    const float fx = __builtin_floorf(u * (float)res), fy = __builtin_floorf(v * (float)res);
+    const int ix = (fx < 0.0f || fx != fx) ? 0 : (fx > (float)(res - 1) ? res - 1 : (int)fx);
+    const int iy = (fy < 0.0f || fy != fy) ? 0 : (fy > (float)(res - 1) ? res - 1 : (int)fy);
+    const uint8_t* p = sc.tex + (((size_t)layer * res + iy) * res + ix) * 4;
+    return mk3(from_unorm8(p[0]), from_unorm8(p[1]), from_unorm8(p[2]));
+}
+
+// ---- shading record (main.glsl:194-222) -------------------------------------------------------
+
+__device__ __forceinline__ Shading get_shading_data(const SceneShading& sc, const Hit& h, bool front)
+{
+    Shading s;
+    const RefTriData& tri = sc.tri_data[h.tri];
+    const RefInstance& b = sc.instances[h.inst];
+    const uint32_t slot = tri.material_index;
+    // b.materials[tri.materialIndex] is unchecked in the reference (main.glsl:198): slots past 2 read on
+    uint32_t mat_id = (slot < 3) ? b.material[slot] : reinterpret_cast<const uint32_t*>(&b + 1)[slot - 3];
+    if (mat_id >= sc.n_materials) mat_id = 0;
+    const RefMaterial& material = sc.materials[mat_id];
+
+    const f3 lpos = h.lo + h.ld * h.t;  // hitInfo.position = ray.o + t * ray.d (main.glsl:249)
+    s.position = xform_point(b.transform, lpos);
+    s.out_dir = normalize3(xform_dir(b.transform, -h.ld));
+    const float u = h.u, v = h.v;
+    const float w0 = 1.0f - u - v;
+    const float uvx = tri.uvs[0][0] * w0 + tri.uvs[1][0] * u + tri.uvs[2][0] * v;
+    const float uvy = tri.uvs[0][1] * w0 + tri.uvs[1][1] * u + tri.uvs[2][1] * v;
+    f3 n = mk3(tri.n0[0], tri.n0[1], tri.n0[2]) * w0 + mk3(tri.n1.x, tri.n1.y, tri.n1.z) * u +
+           mk3(tri.n2.x, tri.n2.y, tri.n2.z) * v;
+    n = normalize3(xform_dir(b.transform, n));
+    s.normal = front ? n : -n;
+
+    s.lambert_out = dot3(s.normal, s.out_dir);
+    const float em = fmax_(0.0f, material.emission.w);
+    s.emission = mk3(material.emission.x * em, material.emission.y * em, material.emission.z * em);
+    f3 albedo = mk3(material.albedo.x, material.albedo.y, material.albedo.z);
+    if (material.albedo_texture_index >= 0) albedo = albedo * sample_texture(sc, uvx, uvy, material.albedo_texture_index);
+
+    const float metalicity = material.metallic;
+    s.fresnel_0 = mk3(mix_(0.02f, albedo.x, metalicity), mix_(0.02f, albedo.y, metalicity), mix_(0.02f, albedo.z, metalicity));
+    s.diffuse_albedo = albedo - albedo * metalicity;
+    s.roughness = fmax_(0.006f, material.roughness);
+    return s;
+}
+
+// ---- BRDF (brdfs.glsl) ------------------------------------------------------------------------
+
+__device__ __forceinline__ float schlick_factor(float cosine_theta)  // brdfs.glsl:4-6
+{
+    const float factor = 1.0f - cosine_theta;
+    const float factor_squared = factor * factor;
+    return factor_squared * factor_squared * factor;
+}
+
+__device__ __forceinline__ f3 brdf_eval(const Shading& sh, f3 l)  // brdfs.glsl:10-38
+{
+    const float n_dot_light = dot3(sh.normal, l);
+    const float n_dot_view = sh.lambert_out;
+    if (fmin_(n_dot_light, n_dot_view) < 0.0f) return mk3(0.0f, 0.0f, 0.0f);
+
+    const f3 half_vector = normalize3(l + sh.out_dir);
+    const float half_dot_view = dot3(half_vector, sh.out_dir);
+
+    const float f90 = (half_dot_view * half_dot_view) * (2.0f * sh.roughness) + 0.5f;
+    const float diffuse_fresnel = mix_(1.0f, f90, schlick_factor(n_dot_view)) * mix_(1.0f, f90, schlick_factor(n_dot_light));
+    f3 r = mk3(diffuse_fresnel * sh.diffuse_albedo.x, diffuse_fresnel * sh.diffuse_albedo.y,
+               diffuse_fresnel * sh.diffuse_albedo.z);
+
+    const float half_dot_normal = dot3(half_vector, sh.normal);
+    const float roughness_sq = sh.roughness * sh.roughness;
+    const float denominator = half_dot_normal * (roughness_sq - 1.0f) + 1.0f;  // un-squared n.h, as the reference
+    const float distribution = roughness_sq / (denominator * denominator);
+
+    const float masking = n_dot_light * __builtin_sqrtf((n_dot_view - roughness_sq * n_dot_view) * n_dot_view + roughness_sq);
+    const float shadowing =
+        n_dot_view * __builtin_sqrtf((n_dot_light - roughness_sq * n_dot_light) * n_dot_light + roughness_sq);
+    const float geometry = 0.5f / (masking + shadowing);
+
+    const float ff = schlick_factor(fmax_(0.0f, half_dot_view));
+    const f3 spec_f = mk3(mix_(sh.fresnel_0.x, 1.0f, ff), mix_(sh.fresnel_0.y, 1.0f, ff), mix_(sh.fresnel_0.z, 1.0f, ff));
+    const float dg = distribution * geometry;
+    r = r + mk3(dg * spec_f.x, dg * spec_f.y, dg * spec_f.z);
+    return r / JPT_PI;
+}
+
+__device__ __forceinline__ float diffuse_probability(const Shading& sh)  // brdfs.glsl:107-110
+{
+    return fmin_(0.5f, dot3(sh.diffuse_albedo, mk3(0.2126f, 0.7152f, 0.0722f)));
+}
+
+__device__ __forceinline__ f3 sample_brdf(const Shading& sh, float xi0, float xi1)  // brdfs.glsl:112-128
+{
+    // get_shading_space (brdfs.glsl:83-93)
+    const f3 nrm = sh.normal;
+    const float sign = nrm.z > 0.0f ? 1.0f : -1.0f;
+    const float a = -1.0f / (sign + nrm.z);
+    const float b = nrm.x * nrm.y * a;
+    const f3 c0 = mk3(1.0f + sign * nrm.x * nrm.x * a, sign * b, -sign * nrm.x);
+    const f3 c1 = mk3(b, sign + nrm.y * nrm.y * a, -nrm.y);
+    const f3 c2 = nrm;
+
+    const float diffuse_prob = diffuse_probability(sh);
+    f3 local;
+    if (xi0 < diffuse_prob) {
+        xi0 = xi0 / diffuse_prob;
+        // sample_hemisphere_psa (brdfs.glsl:95-101)
+        float sp, cp;
+        sincos_((2.0f * JPT_PI) * xi0, sp, cp);
+        const float radius = __builtin_sqrtf(xi1);
+        const float z = __builtin_sqrtf(1.0f - radius * radius);
+        local = mk3(radius * cp, radius * sp, z);
+    } else {
+        xi0 = (xi0 - diffuse_prob) / (1.0f - diffuse_prob);
+        const f3 view = mk3(dot3(c0, sh.out_dir), dot3(c1, sh.out_dir), dot3(c2, sh.out_dir));
+        // sample_ggx_vndf (brdfs.glsl:40-54), roughness = vec2(r)
+        const float rg = sh.roughness;
+        const f3 tv = normalize3(mk3(view.x * rg, view.y * rg, view.z));
+        float sp, cp;
+        sincos_((2.0f * JPT_PI) * xi0, sp, cp);
+        const float z = 1.0f - xi1 * (1.0f + tv.z);
+        const float sin_theta = __builtin_sqrtf(fmax_(0.0f, 1.0f - z * z));
+        const f3 hs = mk3(sin_theta * cp, sin_theta * sp, z);
+        const f3 sum = hs + tv;
+        const f3 h = normalize3(mk3(sum.x * rg, sum.y * rg, sum.z));
+        // sample_ggx_in_dir: -reflect(view, h) (brdfs.glsl:69-72)
+        const float k = 2.0f * dot3(h, view);
+        local = -(view - h * k);
+    }
+    return mk3(c0.x * local.x + c1.x * local.y + c2.x * local.z, c0.y * local.x + c1.y * local.y + c2.y * local.z,
+               c0.z * local.x + c1.z * local.y + c2.z * local.z);
+}
+
+__device__ __forceinline__ float brdf_density(const Shading& sh, f3 l)  // brdfs.glsl:130-138, :74-81, :56-67, :103-105
+{
+    const float diffuse_prob = diffuse_probability(sh);
+    const f3 half_vector = normalize3(l + sh.out_dir);
+    const float half_dot_view = dot3(half_vector, sh.out_dir);
+    const float half_dot_normal = dot3(half_vector, sh.normal);
+    float vndf = 0.0f;
+    if (!(half_dot_normal < 0.0f)) {
+        const float n_dot_view = sh.lambert_out;
+        const float roughness_sq = sh.roughness * sh.roughness;
+        const float inv_roughness_sq = 1.0f - roughness_sq;
+        const float denominator = n_dot_view + __builtin_sqrtf(roughness_sq + inv_roughness_sq * n_dot_view * n_dot_view);
+        const float d_vis = fmax_(0.0f, half_dot_view) * (2.0f / JPT_PI) / denominator;
+        const float m_sq_term = 1.0f - inv_roughness_sq * half_dot_normal * half_dot_normal;
+        vndf = d_vis * roughness_sq / (m_sq_term * m_sq_term);
+    }
+    const float specular_density = vndf / (4.0f * half_dot_view);
+    const float diffuse_density = fmax_(0.0f, dot3(sh.normal, l)) / JPT_PI;
+    return mix_(specular_density, diffuse_density, diffuse_prob);
+}
+
+// One path vertex after a hit (main.glsl:381-394).  Returns false when the path ends
+// (lambert_in <= 0); otherwise `ray` is the next segment and `throughput` is updated.
+__device__ __forceinline__ bool bounce(const Shading& s, uint32_t& sx, uint32_t& sy, Ray& ray, f3& throughput)
+{
+    ray.o = s.position + s.normal * 0.001f;
+    float xi0, xi1;
+    pcg2d(sx, sy, xi0, xi1);
+    ray.d = sample_brdf(s, xi0, xi1);
+    ray.rD = rcp3(ray.d);
+    const float density = brdf_density(s, ray.d);
+    const float lambert_in = dot3(s.normal, ray.d);
+    if (lambert_in <= 0.0f) return false;
+    const f3 f = (brdf_eval(s, ray.d) * lambert_in) / density;
+    throughput = throughput * f;
+    return true;
+}
+
+__device__ __forceinline__ f3 aces_film(f3 x)  // progressive_rendering.glsl:19-26
+{
+    const float a = 2.51f, b = 0.03f, c = 2.43f, d = 0.59f, e = 0.14f;
+    return mk3(clamp_((x.x * (a * x.x + b)) / (x.x * (c * x.x + d) + e), 0.0f, 1.0f),
+               clamp_((x.y * (a * x.y + b)) / (x.y * (c * x.y + d) + e), 0.0f, 1.0f),
+               clamp_((x.z * (a * x.z + b)) / (x.z * (c * x.z + d) + e), 0.0f, 1.0f));
+}
+
+}  // namespace jpt

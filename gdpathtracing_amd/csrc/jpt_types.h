@@ -1,0 +1,132 @@
+// jpt_types.h -- wire formats at the boundary (byte-compatible with the reference)
+// and the flattened device layout the native kernels traverse.
+#pragma once
+
+#include <stdint.h>
+
+namespace jpt {
+
+// ---- reference wire formats -------------------------------------------------------------------
+
+struct Vec4 {  // BVH::vec4, src/bvh/vec.h:45-51
+    float x, y, z, w;
+};
+
+struct RefTriangle {  // BVH::Triangle, src/bvh/bvh.h:22-29 (builder-internal)
+    Vec4 vertices[3];
+    Vec4 centroid;
+    Vec4 normals[3];
+    float uvs[3][2];
+    uint32_t materialIndex;
+    uint32_t _pad;
+};
+
+struct RefBvhNode {  // BVH::BVHNode, src/bvh/bvh.h:46-54 == main.glsl:45-52
+    Vec4 aabbMin;
+    Vec4 aabbMax;
+    uint32_t left_child;
+    uint32_t right_child;
+    uint32_t first_tri_index;
+    uint32_t tri_count;
+};
+
+struct RefTlasNode {  // BVH::TLASNode, src/bvh/bvh.h:56-62 == main.glsl:54-60
+    float aabbMin[3];
+    uint32_t leftRight;  // lo16 = left, hi16 = right, 0 => leaf
+    float aabbMax[3];
+    uint32_t blas;
+};
+
+struct RefInstance {  // BVH::BLASInstance, src/bvh/bvh.h:64-72 == main.glsl:84-93
+    float transform[16];
+    float inverse_transform[16];
+    Vec4 aabbMin;
+    Vec4 aabbMax;
+    uint32_t blas_index;
+    uint32_t material[3];
+};
+
+struct RefTriGeometry {  // GpuTriangleGeometry, render_parameters.h:59-62 == main.glsl:14-16
+    Vec4 vertices[3];
+};
+
+struct RefTriData {  // GpuTriangleData, render_parameters.h:64-71 == main.glsl:18-24
+    float n0[3];
+    uint32_t material_index;
+    Vec4 n1;
+    Vec4 n2;
+    float uvs[3][2];
+    uint32_t _pad[2];
+};
+
+struct RefMaterial {  // GpuMaterial, render_parameters.h:49-57 == main.glsl:32-43
+    Vec4 albedo;
+    Vec4 emission;  // rgb colour, w = energy multiplier
+    float metallic;
+    float roughness;
+    int32_t albedo_texture_index;
+    float padding[5];
+};
+
+struct RefCamera {  // Camera, render_parameters.h:14-21 == main.glsl:110-117
+    float vp[16];
+    float ivp[16];
+    Vec4 position;
+    uint32_t frame_index;
+    float near_;
+    float far_;
+    uint32_t _pad;
+};
+
+static_assert(sizeof(RefTriangle) == 144, "Triangle");
+static_assert(sizeof(RefBvhNode) == 48, "BVHNode");
+static_assert(sizeof(RefTlasNode) == 32, "TLASNode");
+static_assert(sizeof(RefInstance) == 176, "BLASInstance");
+static_assert(sizeof(RefTriGeometry) == 48, "GpuTriangleGeometry");
+static_assert(sizeof(RefTriData) == 80, "GpuTriangleData");
+static_assert(sizeof(RefMaterial) == 64, "GpuMaterial");
+static_assert(sizeof(RefCamera) == 160, "Camera");
+
+// ---- flattened device layout (native kernels) -------------------------------------------------
+//
+// One 64-byte record per internal node carrying BOTH children's boxes and references, so one
+// expansion is a single aligned 64-B fetch (4 x dwordx4 per lane) instead of the reference's three
+// 48-B node reads (main.glsl:277,286-287).  The same record serves BLAS and TLAS levels.
+//
+// Child reference encoding (int32):
+//   ref >= 0          internal node, index into the node array of its level
+//   ref <  0, BLAS    leaf: first triangle = ~ref (bits 0..24), count - 1 in bits 25..30
+//   ref <  0, TLAS    leaf: instance id = ~ref
+struct alignas(64) WideNode {
+    float lmin[3], lmax[3];
+    float rmin[3], rmax[3];
+    int32_t left, right;
+    uint32_t _pad[2];
+};
+static_assert(sizeof(WideNode) == 64, "WideNode");
+
+// 48-byte triangle record: v0 and the two Moller-Trumbore edges, precomputed with the same float
+// subtractions intersectTriangle performs (main.glsl:231-232), so t,u,v are bit-identical.
+struct alignas(16) WideTri {
+    float v0[3];
+    uint32_t src_index;  // index into the reference-order shading arrays (tri_data)
+    float e1[3];
+    uint32_t _p1;
+    float e2[3];
+    uint32_t _p2;
+};
+static_assert(sizeof(WideTri) == 48, "WideTri");
+
+// 64-byte hot instance record (traversal): rows of the 3x4 inverse transform + BLAS root reference.
+struct alignas(64) WideInstance {
+    float inv[12];   // column-major 3x4: c0.xyz, c1.xyz, c2.xyz, c3.xyz
+    int32_t root;    // child reference of the BLAS root (may be a leaf)
+    uint32_t _pad[3];
+};
+static_assert(sizeof(WideInstance) == 64, "WideInstance");
+
+constexpr int kLeafCountShift = 25;
+constexpr uint32_t kLeafFirstMask = (1u << kLeafCountShift) - 1u;
+constexpr int kMaxLeafTris = 64;
+
+}  // namespace jpt

@@ -1,0 +1,232 @@
+"""Host-side mirror of the reference's interface for this path, over the C ABI (include/jpt.h).
+
+Same names and meaning as the reference's C++ classes, minus the Godot scene tree:
+
+  GeometryGroup3D      src/path_tracing/geometry_group3d.{h,cpp}   build(), get_*_buffer(), counts
+  PathTracingCamera    src/path_tracing/path_tracing_camera.{h,cpp} init(), render(), denoising_mode
+  ProgressiveRendering src/path_tracing/post_processing/progressive_rendering.{h,cpp}  frame_count logic
+
+This is plumbing (ctypes + numpy); the product is libjpt_hip.so.  The C++ form of the same adapter, for
+linking into the addon, is described in INTEGRATION.md.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import numpy as np
+
+from . import capi, scenes, wire
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+class Context:
+    """One jpt_ctx (one GPU).  Thin, explicit wrapper: every method is one C-ABI call."""
+
+    def __init__(self, device: int = 0):
+        self._lib = capi.lib()
+        h = C.c_void_p()
+        rc = self._lib.jpt_create(device, C.byref(h))
+        if rc != capi.OK:
+            msg = self._lib.jpt_last_error(None)
+            raise capi.JptError("jpt_create failed (%d): %s" % (rc, msg.decode() if msg else "?"))
+        self.h = h
+        self.width = self.height = 0
+        self._keep = []
+
+    def close(self):
+        if getattr(self, "h", None):
+            self._lib.jpt_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc, what):
+        capi.check(self.h, rc, what)
+
+    # ---- scene
+    def upload_reference_layout(self, tri_geom, tri_data, materials, bvh_nodes, instances, tlas_nodes, textures=None):
+        arrs = [np.ascontiguousarray(a) for a in (tri_geom, tri_data, materials, bvh_nodes, instances, tlas_nodes)]
+        tex = None if textures is None else np.ascontiguousarray(textures, dtype=np.uint8)
+        self._ck(self._lib.jpt_scene_upload_reference_layout(
+            self.h, _ptr(arrs[0]), len(arrs[0]), _ptr(arrs[1]), _ptr(arrs[2]), len(arrs[2]), _ptr(arrs[3]), len(arrs[3]),
+            _ptr(arrs[4]), len(arrs[4]), _ptr(arrs[5]), len(arrs[5]), _ptr(tex),
+            0 if tex is None else tex.shape[1], 0 if tex is None else tex.shape[0]), "jpt_scene_upload_reference_layout")
+
+    def build_scene(self, scene: scenes.Scene, builder: int = capi.BUILD_SAH):
+        L = self._lib
+        self._ck(L.jpt_scene_begin(self.h), "jpt_scene_begin")
+        ids = []
+        for mesh in scene.meshes:
+            arr = (capi.Surface * len(mesh.surfaces))()
+            for i, s in enumerate(mesh.surfaces):
+                arr[i].vertices, arr[i].normals, arr[i].uvs, arr[i].indices = map(_ptr, (s.vertices, s.normals, s.uvs, s.indices))
+                arr[i].n_vertices, arr[i].n_indices = len(s.vertices), len(s.indices)
+            mid = C.c_uint32()
+            self._ck(L.jpt_scene_add_mesh(self.h, arr, len(mesh.surfaces), C.byref(mid)), "jpt_scene_add_mesh")
+            ids.append(mid.value)
+        for inst in scene.instances:
+            t = np.ascontiguousarray(inst.transform, dtype=np.float32)
+            m = np.ascontiguousarray(inst.material_ids, dtype=np.int32)
+            self._ck(L.jpt_scene_add_instance(self.h, ids[inst.mesh], _ptr(t), _ptr(m), len(m)), "jpt_scene_add_instance")
+        mats = np.ascontiguousarray(scene.materials, dtype=wire.MATERIAL)
+        self._ck(L.jpt_scene_set_materials(self.h, _ptr(mats), len(mats)), "jpt_scene_set_materials")
+        if scene.textures is not None:
+            tex = np.ascontiguousarray(scene.textures, dtype=np.uint8)
+            self._ck(L.jpt_scene_set_textures(self.h, _ptr(tex), tex.shape[1], tex.shape[0]), "jpt_scene_set_textures")
+        self._ck(L.jpt_scene_commit(self.h, builder), "jpt_scene_commit")
+
+    def reference_buffer(self, which: int, dtype) -> np.ndarray:
+        n = C.c_size_t()
+        self._ck(self._lib.jpt_scene_get_reference_buffer(self.h, which, None, 0, C.byref(n)), "jpt_scene_get_reference_buffer")
+        out = np.zeros(n.value // np.dtype(dtype).itemsize, dtype=dtype)
+        self._ck(self._lib.jpt_scene_get_reference_buffer(self.h, which, _ptr(out), out.nbytes, C.byref(n)),
+                 "jpt_scene_get_reference_buffer")
+        return out
+
+    # ---- per-render state
+    def set_params(self, width, height, max_bounces=4, accum_mode=capi.ACCUM_REF_LDR8, sampler_mode=0):
+        self._ck(self._lib.jpt_set_params(self.h, width, height, max_bounces, accum_mode, sampler_mode), "jpt_set_params")
+        self.width, self.height = width, height
+
+    def set_partition(self, rank, world):
+        self._ck(self._lib.jpt_set_partition(self.h, rank, world), "jpt_set_partition")
+
+    def set_camera(self, camera_block: np.ndarray):
+        cam = np.ascontiguousarray(camera_block, dtype=wire.CAMERA).reshape(1)
+        self._ck(self._lib.jpt_set_camera(self.h, _ptr(cam)), "jpt_set_camera")
+
+    def set_stream(self, hip_stream: Optional[int]):
+        self._ck(self._lib.jpt_set_stream(self.h, hip_stream), "jpt_set_stream")
+
+    def render(self, n_frames=1, first_frame_index=1, counted=False, asynchronous=False):
+        fn = self._lib.jpt_render_counted if counted else (self._lib.jpt_render_async if asynchronous else self._lib.jpt_render)
+        self._ck(fn(self.h, n_frames, first_frame_index), "jpt_render")
+
+    def sync(self):
+        self._ck(self._lib.jpt_sync(self.h), "jpt_sync")
+
+    def accum_reset(self):
+        self._ck(self._lib.jpt_accum_reset(self.h), "jpt_accum_reset")
+
+    # ---- outputs
+    def read_ldr(self) -> np.ndarray:
+        out = np.zeros((self.height, self.width, 4), dtype=np.uint8)
+        self._ck(self._lib.jpt_read_ldr_rgba8(self.h, _ptr(out)), "jpt_read_ldr_rgba8")
+        return out
+
+    def read_accum(self) -> np.ndarray:
+        out = np.zeros((self.height, self.width, 4), dtype=np.float32)
+        self._ck(self._lib.jpt_read_accum_f32(self.h, _ptr(out)), "jpt_read_accum_f32")
+        return out
+
+    def read_depth(self) -> np.ndarray:
+        out = np.zeros((self.height, self.width), dtype=np.float32)
+        self._ck(self._lib.jpt_read_depth_f32(self.h, _ptr(out)), "jpt_read_depth_f32")
+        return out
+
+    def device_accum(self):
+        n = C.c_size_t()
+        p = self._lib.jpt_device_accum(self.h, C.byref(n))
+        return p, n.value
+
+    def local_rows(self) -> int:
+        return self._lib.jpt_local_rows(self.h)
+
+    def assemble_from_ranks(self, device_ptr: int, world: int):
+        self._ck(self._lib.jpt_assemble_from_ranks(self.h, device_ptr, world), "jpt_assemble_from_ranks")
+
+    def stats(self) -> dict:
+        s = capi.Stats()
+        self._ck(self._lib.jpt_get_stats(self.h, C.byref(s)), "jpt_get_stats")
+        return s.as_dict()
+
+
+class GeometryGroup3D:
+    """geometry_group3d.h:17-95.  `build()` runs the builder + upload; the get_*_buffer() getters return
+    the reference-layout byte buffers (valid after a REFERENCE_EXACT build)."""
+
+    def __init__(self, scene: scenes.Scene, builder: int = capi.BUILD_SAH):
+        self.scene = scene
+        self.builder = builder
+        self.ctx: Optional[Context] = None
+
+    def build(self, ctx: Context):                      # geometry_group3d.cpp:228
+        self.ctx = ctx
+        ctx.build_scene(self.scene, self.builder)
+
+    def get_triangles_geometry_buffer(self):            # geometry_group3d.cpp:40
+        return self.ctx.reference_buffer(capi.BUF_TRI_GEOMETRY, wire.TRI_GEOMETRY)
+
+    def get_triangles_data_buffer(self):                # :45
+        return self.ctx.reference_buffer(capi.BUF_TRI_DATA, wire.TRI_DATA)
+
+    def get_materials_buffer(self):                     # :50
+        return self.ctx.reference_buffer(capi.BUF_MATERIALS, wire.MATERIAL)
+
+    def get_bvh_buffer(self):                           # :55
+        return self.ctx.reference_buffer(capi.BUF_BVH_NODES, wire.BVH_NODE)
+
+    def get_blas_buffer(self):                          # :60
+        return self.ctx.reference_buffer(capi.BUF_INSTANCES, wire.BLAS_INSTANCE)
+
+    def get_tlas_buffer(self):                          # :65
+        return self.ctx.reference_buffer(capi.BUF_TLAS_NODES, wire.TLAS_NODE)
+
+    def get_triangle_count(self):                       # :17
+        return len(self.get_triangles_geometry_buffer())
+
+    def get_blas_count(self):                           # :7
+        return len(self.get_blas_buffer())
+
+    def get_bvh_node_count(self):                       # :22
+        return len(self.get_bvh_buffer())
+
+    def get_tlas_node_count(self):                      # :27
+        return len(self.get_tlas_buffer())
+
+
+class PathTracingCamera:
+    """path_tracing_camera.h:25-112: init() creates the device state, render() advances one frame
+    (frame_index pre-incremented, path_tracing_camera.cpp:199) and accumulates progressively; the
+    accumulation restarts when the camera transform changes (progressive_rendering.cpp:53-60)."""
+
+    PROGRESSIVE_RENDERING, TEMPORAL_REPROJECTION, NONE = 0, 1, 2   # path_tracing_camera.h:30-34
+
+    def __init__(self, geometry_group: GeometryGroup3D, device: int = 0, max_bounces: int = 4,
+                 accum_mode: int = capi.ACCUM_REF_LDR8):
+        self.geometry_group = geometry_group
+        self.camera_desc = geometry_group.scene.camera
+        self.max_bounces = max_bounces
+        self.accum_mode = accum_mode
+        self.denoising_mode = self.PROGRESSIVE_RENDERING
+        self.frame_index = 0          # the reference never initialises it (render_parameters.h:19); 0 here
+        self.ctx = Context(device)
+        self._prev_transform = None
+        self.width = self.height = 0
+
+    def init(self, width: int, height: int):                        # path_tracing_camera.cpp:111-187
+        self.width, self.height = width, height
+        self.geometry_group.build(self.ctx)
+        self.ctx.set_params(width, height, self.max_bounces, self.accum_mode)
+
+    def render(self, n_frames: int = 1):                            # path_tracing_camera.cpp:193-232
+        if self.denoising_mode == self.TEMPORAL_REPROJECTION:
+            raise NotImplementedError("temporal reprojection is out of scope (SURVEY.md 8(f)-4)")
+        t = np.asarray(self.camera_desc.transform, dtype=np.float32)
+        moved = self._prev_transform is None or not np.allclose(self._prev_transform, t, rtol=0, atol=1e-5)
+        self._prev_transform = t.copy()
+        if moved or self.denoising_mode == self.NONE:
+            self.ctx.accum_reset()                                  # frame_count = 1 (progressive_rendering.cpp:56-57)
+        self.ctx.set_camera(scenes.camera_block(self.camera_desc, self.width, self.height))
+        first = self.frame_index + 1                                # camera.frame_index++ before the dispatch
+        self.ctx.render(n_frames, first)
+        self.frame_index += n_frames
+        return self.ctx.read_ldr()                                  # get_image_uniform_buffer (:228-229)

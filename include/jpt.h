@@ -1,0 +1,192 @@
+/*
+ * jpt.h -- C ABI of libjpt_hip.so, the MI355X (gfx950) back end for the GDPathTracing hot path.
+ *
+ * This is the drop-in boundary.  In the reference the path sits behind the
+ * `gdcs::ComputeShader` object (absent submodule src/gdcs) that PathTracingCamera and
+ * ProgressiveRendering drive, plus the CPU builder in src/bvh that GeometryGroup3D::build calls.
+ * Each entry point below names the reference call(s) it replaces (paths relative to the reference
+ * repository).  Plain pointers and sizes only; caller-owned host memory, library-owned device memory;
+ * every function returns 0 on success or a negative JPT_E_* code and records a message readable with
+ * jpt_last_error().  One context per GPU and per host thread; calls are blocking unless noted.
+ *
+ * All matrices are column-major float[16] as src/utils.h:15-49 writes them; all structs are the
+ * little-endian wire formats of SURVEY.md 8(a) T-3..T-11 (gdpathtracing_amd/csrc/jpt_types.h).
+ */
+#ifndef JPT_H
+#define JPT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define JPT_ABI_VERSION 1
+
+typedef struct jpt_ctx jpt_ctx;
+
+enum {
+    JPT_OK = 0,
+    JPT_E_INVALID = -1,      /* bad argument / call order */
+    JPT_E_DEVICE = -2,       /* HIP error (no GPU, launch failure, out of memory) */
+    JPT_E_LIMIT = -3,        /* scene exceeds a format limit (e.g. 16-bit TLAS child index, bvh.h:59) */
+    JPT_E_STATE = -4         /* scene / params / camera not set */
+};
+
+/* accumulation modes */
+enum {
+    JPT_ACCUM_REF_LDR8 = 0,  /* per frame: clamp01 + 8-bit quantise, then float sum (what the reference does:
+                                main.glsl:98,434 -> progressive_rendering.glsl:33-37) */
+    JPT_ACCUM_HDR_F32 = 1    /* pure float sum of radiance */
+};
+
+/* texture sampler (state lives in absent gdcs; parity unpinned) */
+enum { JPT_SAMPLER_NEAREST_CLAMP = 0 };
+
+/* BVH builders */
+enum {
+    JPT_BUILD_REFERENCE_EXACT = 0, /* reproduces src/bvh/bvh.cpp node-for-node (incl. its default-box quirk);
+                                      kernels traverse the same tree in the same order */
+    JPT_BUILD_SAH = 1              /* native binned-SAH builder, flattened wide-fetch layout (fast path) */
+};
+
+/* which reference-layout buffer (GeometryGroup3D::get_*_buffer, geometry_group3d.cpp:40-68) */
+enum {
+    JPT_BUF_TRI_GEOMETRY = 0, /* GpuTriangleGeometry[]  48 B */
+    JPT_BUF_TRI_DATA = 1,     /* GpuTriangleData[]      80 B */
+    JPT_BUF_MATERIALS = 2,    /* GpuMaterial[]          64 B */
+    JPT_BUF_BVH_NODES = 3,    /* BVH::BVHNode[]         48 B */
+    JPT_BUF_INSTANCES = 4,    /* BVH::BLASInstance[]   176 B */
+    JPT_BUF_TLAS_NODES = 5,   /* BVH::TLASNode[]        32 B */
+    JPT_BUF_TRIANGLES = 6     /* BVH::Triangle[]       144 B (builder-internal, bvh.h:22-29) */
+};
+
+/* One ArrayMesh surface as BVHBuilder::BuildBVH reads it (bvh.cpp:192-198). */
+typedef struct {
+    const float   *vertices;   /* n_vertices * 3   Mesh::ARRAY_VERTEX  */
+    const float   *normals;    /* n_vertices * 3   Mesh::ARRAY_NORMAL  */
+    const float   *uvs;        /* n_vertices * 2   Mesh::ARRAY_TEX_UV  */
+    const int32_t *indices;    /* n_indices        Mesh::ARRAY_INDEX   */
+    int32_t n_vertices;
+    int32_t n_indices;
+} jpt_surface;
+
+typedef struct {
+    uint64_t rays;             /* ray segments traced = ray_trace() invocations (main.glsl:352) */
+    uint64_t frames;           /* frames rendered since jpt_accum_reset */
+    uint64_t blas_expand;      /* node expansions / tests, only filled by counting renders (jpt_render_counted) */
+    uint64_t tri_tests;
+    uint64_t tlas_expand;
+    uint64_t inst_visits;
+    uint64_t shaded_hits;
+    double   last_render_ms;   /* device time of the last jpt_render (HIP events on the ctx stream) */
+    double   last_trace_ms;    /* of which: the path-tracing kernel(s) */
+    double   last_build_ms;    /* host time of the last scene commit (builder + flatten + upload) */
+} jpt_stats;
+
+/* ---- lifetime --------------------------------------------------------------------------------- */
+
+/* replaces: RenderingServer::create_local_rendering_device() + new ComputeShader(...)
+ * (path_tracing_camera.cpp:114,139; progressive_rendering.cpp:25).
+ * device_id = JPT_DEVICE_HOST_ONLY makes a builder-only context: the jpt_scene_* calls and
+ * jpt_scene_get_reference_buffer work without a GPU; everything that renders returns JPT_E_DEVICE
+ * (there is no CPU fallback). */
+#define JPT_DEVICE_HOST_ONLY (-1)
+int jpt_create(int device_id, jpt_ctx **out);
+void jpt_destroy(jpt_ctx *ctx);
+const char *jpt_last_error(const jpt_ctx *ctx);   /* ctx may be NULL: error of the last failed jpt_create */
+int jpt_abi_version(void);
+
+/* Run all work of this ctx on an existing HIP stream (hipStream_t as void*), e.g. torch's current
+ * stream.  NULL restores the context's own stream.  No reference counterpart. */
+int jpt_set_stream(jpt_ctx *ctx, void *hip_stream);
+
+/* ---- scene ingest, route (i): reference layout ------------------------------------------------ */
+
+/* replaces: the six cs->create_storage_buffer_uniform(geometry_group->get_*_buffer(), b, 1) calls and
+ * cs->create_layered_image_uniform(textures, ...) (path_tracing_camera.cpp:170-175,178-184).  Buffers are
+ * byte-for-byte what GeometryGroup3D emits; they are re-flattened on upload.  tex_rgba8 may be NULL. */
+int jpt_scene_upload_reference_layout(jpt_ctx *ctx,
+                                      const void *tri_geometry, uint32_t n_triangles,
+                                      const void *tri_data,
+                                      const void *materials, uint32_t n_materials,
+                                      const void *bvh_nodes, uint32_t n_bvh_nodes,
+                                      const void *blas_instances, uint32_t n_instances,
+                                      const void *tlas_nodes, uint32_t n_tlas_nodes,
+                                      const uint8_t *tex_rgba8, int32_t tex_res, int32_t n_layers);
+
+/* ---- scene ingest, route (ii): native build --------------------------------------------------- */
+
+/* replaces GeometryGroup3D::build's tail (geometry_group3d.cpp:305-365): */
+int jpt_scene_begin(jpt_ctx *ctx);
+/*   BVHBuilder::BuildBVH(bvh_nodes, triangles, mesh)                 geometry_group3d.cpp:311, bvh.cpp:187-223 */
+int jpt_scene_add_mesh(jpt_ctx *ctx, const jpt_surface *surfaces, int32_t n_surfaces, uint32_t *mesh_id_out);
+/*   BLASInstance::{set_materials,set_transform}                      geometry_group3d.cpp:328-333, bvh.h:73-115
+ *   transform12 = godot Transform3D: basis rows (xx xy xz yx yy yz zx zy zz) then origin (x y z). */
+int jpt_scene_add_instance(jpt_ctx *ctx, uint32_t mesh_id, const float *transform12,
+                           const int32_t *material_ids, int32_t n_material_ids);
+/*   materials.push_back(gpu_material) / textures                     geometry_group3d.cpp:271-304 */
+int jpt_scene_set_materials(jpt_ctx *ctx, const void *materials, uint32_t n_materials);
+int jpt_scene_set_textures(jpt_ctx *ctx, const uint8_t *tex_rgba8, int32_t tex_res, int32_t n_layers);
+/*   TLAS::build + Triangle -> GpuTriangle split + upload             geometry_group3d.cpp:350-365 */
+int jpt_scene_commit(jpt_ctx *ctx, int32_t builder);
+/* GeometryGroup3D::get_*_buffer() (geometry_group3d.cpp:40-68): valid after a REFERENCE_EXACT commit.
+ * out may be NULL to query the size. */
+int jpt_scene_get_reference_buffer(jpt_ctx *ctx, int32_t which, void *out, size_t capacity, size_t *size_out);
+
+/* ---- per-render state ------------------------------------------------------------------------- */
+
+/* replaces: Params upload (RenderParameters, path_tracing_camera.cpp:129-133,142; only width/height are
+ * read by the shader, main.glsl:407,411), the literal 5 of main.glsl:377 (= max_bounces + 1), and the
+ * rgba8 / r32f / rgba32f image creation (path_tracing_camera.cpp:148-165, progressive_rendering.cpp:35-39). */
+int jpt_set_params(jpt_ctx *ctx, int32_t width, int32_t height, int32_t max_bounces,
+                   int32_t accum_mode, int32_t sampler_mode);
+
+/* Multi-GPU screen partition (no reference counterpart): this context renders the
+ * 8-row strips s with s % world == rank.  Default rank 0 of 1 = whole image. */
+int jpt_set_partition(jpt_ctx *ctx, int32_t rank, int32_t world);
+
+/* replaces: cs->update_storage_buffer_uniform(camera_rid, camera.to_packed_byte_array())
+ * (path_tracing_camera.cpp:198-200).  camera160 = struct Camera (render_parameters.h:14-21); its
+ * frame_index field is ignored -- jpt_render takes the frame index explicitly. */
+int jpt_set_camera(jpt_ctx *ctx, const void *camera160);
+
+/* replaces n_frames iterations of PathTracingCamera::render's GPU work: cs->compute(main.glsl)
+ * + ProgressiveRendering::render (path_tracing_camera.cpp:199-214, progressive_rendering.cpp:53-65).
+ * Frame f uses camera.frame_index = first_frame_index + f and continues the accumulation
+ * (frame_count = frames since jpt_accum_reset).  Blocking; device time in jpt_stats. */
+int jpt_render(jpt_ctx *ctx, int32_t n_frames, uint32_t first_frame_index);
+/* Same result, kernels compiled with event counters; fills the jpt_stats counter fields. */
+int jpt_render_counted(jpt_ctx *ctx, int32_t n_frames, uint32_t first_frame_index);
+/* Asynchronous form: enqueue on the ctx stream and return; jpt_sync() or a jpt_read_* waits. */
+int jpt_render_async(jpt_ctx *ctx, int32_t n_frames, uint32_t first_frame_index);
+int jpt_sync(jpt_ctx *ctx);
+
+/* replaces: camera_moved -> frame_count = 1 (progressive_rendering.cpp:53-57) */
+int jpt_accum_reset(jpt_ctx *ctx);
+
+/* ---- outputs ---------------------------------------------------------------------------------- */
+
+/* replaces: cs->get_image_uniform_buffer(output_texture_rid) (path_tracing_camera.cpp:228-229):
+ * W*H*4 bytes, the screen image after ACES(sum / frame_count) (progressive_rendering.glsl:39-45). */
+int jpt_read_ldr_rgba8(jpt_ctx *ctx, uint8_t *out);
+/* the rgba32f frameBuffer (progressive_rendering.glsl:10,37): W*H*4 floats */
+int jpt_read_accum_f32(jpt_ctx *ctx, float *out);
+/* the r32f depthBuffer (main.glsl:99,435), last frame: W*H floats */
+int jpt_read_depth_f32(jpt_ctx *ctx, float *out);
+
+/* Device pointers of this context's LOCAL framebuffers (its partition's rows, strip-major), for
+ * plumbing (RCCL gather through torch): float4 accumulation, and its size in bytes. */
+void *jpt_device_accum(jpt_ctx *ctx, size_t *bytes_out);
+/* Rank 0 after the gather: scatter `world` rank-major local buffers (device pointer) into this context's
+ * full W*H framebuffers so jpt_read_* return the assembled image. */
+int jpt_assemble_from_ranks(jpt_ctx *ctx, const void *device_gathered, int32_t world);
+int32_t jpt_local_rows(jpt_ctx *ctx);
+
+int jpt_get_stats(jpt_ctx *ctx, jpt_stats *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* JPT_H */
