@@ -50,8 +50,9 @@ def main():
     ap.add_argument("--scene", default="demo", choices=["demo", "cornell", "inst"])
     ap.add_argument("--builder", default="sah", choices=["sah", "exact"])
     ap.add_argument("--accum", default="ldr8", choices=["ldr8", "hdr"])
+    ap.add_argument("--kernel", default="wavefront", choices=["wavefront", "ref"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", default="480x270")
+    ap.add_argument("--cpu-sample", default="auto")
     args = ap.parse_args()
 
     import torch
@@ -89,7 +90,10 @@ def main():
     ctx.set_partition(rank, world)
     ctx.set_params(W, H, bounces, accum_mode)
     ctx.set_camera(cam)
-    stream = torch.cuda.current_stream()
+    ctx.set_kernel(capi.KERNEL_WAVEFRONT if args.kernel == "wavefront" else capi.KERNEL_REFERENCE_LAYOUT)
+    # one explicit (non-null) stream carries the kernels, the timing events and the collective
+    stream = torch.cuda.Stream()
+    torch.cuda.set_stream(stream)
     ctx.set_stream(stream.cuda_stream)
 
     # gather plumbing (N > 1): the local float4 piece viewed as a torch tensor, no copy
@@ -177,7 +181,7 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": "C3: S-demo (open Cornell cube + light + 2 instances of a %d-tri procedural mesh), %dx%d, %d spp, "
-                            "%d bounces, accum=%s, builder=%s" % (args.tris, W, H, spp, bounces, args.accum, args.builder)
+                            "%d bounces, accum=%s, builder=%s, kernel=%s" % (args.tris, W, H, spp, bounces, args.accum, args.builder, args.kernel)
                 if args.scene == "demo" else "%s %dx%d %d spp %d bounces" % (sc.name, W, H, spp, bounces),
                 "unique_tris": sc.n_unique_tris, "instances": len(sc.instances),
                 "rays_per_step": rays, "nominal_rays_per_step": n_pixels * spp * (bounces + 1),
@@ -198,8 +202,20 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             from oracle import binding as ob
-            sw, sh = (int(x) for x in args.cpu_sample.split("x"))
             ref = ob.build_scene(sc)
+            # probe the host's rate on a small image, then size the sample for ~5-20 s of wall time
+            # (the whole workload if the host is fast enough)
+            pw, ph = 240, 135
+            t0 = time.perf_counter()
+            _, _, _, pc, used = ob.render(ref, scenes.camera_block(sc.camera, pw, ph), pw, ph, bounces, spp, 1, accum_mode)
+            probe_rate = pc["rays"] / max(time.perf_counter() - t0, 1e-6)
+            if args.cpu_sample != "auto":
+                sw, sh = (int(x) for x in args.cpu_sample.split("x"))
+            else:
+                scale = min(1.0, (probe_rate * 15.0 / max(rays, 1)) ** 0.5)
+                sw, sh = max(16, int(W * scale) // 16 * 16), max(9, int(H * scale) // 9 * 9)
+                if scale >= 1.0:
+                    sw, sh = W, H
             scam = scenes.camera_block(sc.camera, sw, sh)
             t0 = time.perf_counter()
             _, _, _, cnt, used = ob.render(ref, scam, sw, sh, bounces, spp, 1, accum_mode)

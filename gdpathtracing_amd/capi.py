@@ -16,6 +16,7 @@ CSRC = os.path.join(_HERE, "csrc")
 OK = 0
 ACCUM_REF_LDR8, ACCUM_HDR_F32 = 0, 1
 BUILD_REFERENCE_EXACT, BUILD_SAH = 0, 1
+KERNEL_WAVEFRONT, KERNEL_REFERENCE_LAYOUT = 0, 1
 BUF_TRI_GEOMETRY, BUF_TRI_DATA, BUF_MATERIALS, BUF_BVH_NODES, BUF_INSTANCES, BUF_TLAS_NODES, BUF_TRIANGLES = range(7)
 
 # every symbol include/jpt.h declares
@@ -23,7 +24,7 @@ SYMBOLS = [
     "jpt_abi_version", "jpt_create", "jpt_destroy", "jpt_last_error", "jpt_set_stream",
     "jpt_scene_upload_reference_layout", "jpt_scene_begin", "jpt_scene_add_mesh", "jpt_scene_add_instance",
     "jpt_scene_set_materials", "jpt_scene_set_textures", "jpt_scene_commit", "jpt_scene_get_reference_buffer",
-    "jpt_set_params", "jpt_set_partition", "jpt_set_camera", "jpt_render", "jpt_render_counted", "jpt_render_async",
+    "jpt_set_params", "jpt_set_kernel", "jpt_set_partition", "jpt_set_camera", "jpt_render", "jpt_render_counted", "jpt_render_async",
     "jpt_sync", "jpt_accum_reset", "jpt_read_ldr_rgba8", "jpt_read_accum_f32", "jpt_read_depth_f32",
     "jpt_device_accum", "jpt_assemble_from_ranks", "jpt_local_rows", "jpt_get_stats",
 ]
@@ -88,6 +89,7 @@ def lib():
     L.jpt_scene_get_reference_buffer.argtypes = [vp, i32, vp, C.c_size_t, C.POINTER(C.c_size_t)]
     L.jpt_set_params.argtypes = [vp, i32, i32, i32, i32, i32]
     L.jpt_set_partition.argtypes = [vp, i32, i32]
+    L.jpt_set_kernel.argtypes = [vp, i32]
     L.jpt_set_camera.argtypes = [vp, vp]
     for n in ("jpt_render", "jpt_render_counted", "jpt_render_async"):
         getattr(L, n).argtypes = [vp, i32, u32]

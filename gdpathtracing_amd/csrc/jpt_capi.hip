@@ -83,7 +83,9 @@ struct jpt_ctx {
     int32_t rank = 0, world = 1, local_rows = 0;
     RefCamera camera;
     uint32_t frame_count = 0;  // frames accumulated since reset
-    int32_t kernel_variant = 0;
+    int32_t kernel_variant = JPT_KERNEL_WAVEFRONT;
+    DevBuf<char> d_workspace;
+    std::vector<uint32_t> h_qcount;  // per-bounce queue sizes of the last wavefront render
 
     // framebuffers (local rows of this partition)
     DevBuf<float4> d_accum;
@@ -234,21 +236,37 @@ int do_render(jpt_ctx* c, int32_t n_frames, uint32_t first_frame_index, bool cou
         cnt = c->d_counters.p;
         HIP_TRY(c, hipMemsetAsync(cnt, 0, sizeof(DevCounters), s));
     }
+    const bool wavefront = c->kernel_variant == JPT_KERNEL_WAVEFRONT;
+    const int nq = c->max_bounces + 2;
+    if (wavefront && c->local_rows > 0 && c->width > 0 && n_frames > 0) {
+        const size_t need = wide_workspace_bytes(c->width, c->local_rows, n_frames, c->max_bounces);
+        if (c->d_workspace.n < need) {
+            HIP_TRY(c, hipStreamSynchronize(s));
+            HIP_TRY(c, c->d_workspace.resize(need));
+        }
+    }
     HIP_TRY(c, hipEventRecord(c->ev0, s));
-    if (c->local_rows > 0 && c->width > 0) {
-        for (int32_t f = 0; f < n_frames; f++) {
-            FrameParams fp;
-            fp.width = c->width;
-            fp.height = c->height;
-            fp.local_rows = c->local_rows;
-            fp.rank = c->rank;
-            fp.world = c->world;
-            fp.max_bounces = c->max_bounces;
-            fp.accum_mode = c->accum_mode;
-            fp.frame_index = first_frame_index + (uint32_t)f;
-            fp.frame_count = c->frame_count + (uint32_t)f + 1;
-            fp.n_frames = 1;
-            launch_ref_frame(s, c->ds, fp, c->camera, c->d_accum.p, c->d_ldr.p, c->d_depth.p, cnt);
+    if (c->local_rows > 0 && c->width > 0 && n_frames > 0) {
+        FrameParams fp;
+        fp.width = c->width;
+        fp.height = c->height;
+        fp.local_rows = c->local_rows;
+        fp.rank = c->rank;
+        fp.world = c->world;
+        fp.max_bounces = c->max_bounces;
+        fp.accum_mode = c->accum_mode;
+        if (wavefront) {
+            fp.frame_index = first_frame_index;
+            fp.frame_count = c->frame_count + 1;
+            fp.n_frames = n_frames;
+            launch_wide_render(s, c->ds, fp, c->camera, c->d_workspace.p, c->d_accum.p, c->d_ldr.p, c->d_depth.p, cnt);
+        } else {
+            for (int32_t f = 0; f < n_frames; f++) {
+                fp.frame_index = first_frame_index + (uint32_t)f;
+                fp.frame_count = c->frame_count + (uint32_t)f + 1;
+                fp.n_frames = 1;
+                launch_ref_frame(s, c->ds, fp, c->camera, c->d_accum.p, c->d_ldr.p, c->d_depth.p, cnt);
+            }
         }
         HIP_TRY(c, hipGetLastError());
     }
@@ -261,6 +279,14 @@ int do_render(jpt_ctx* c, int32_t n_frames, uint32_t first_frame_index, bool cou
         HIP_TRY(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
         c->stats.last_render_ms = ms;
         c->stats.last_trace_ms = ms;
+        if (wavefront && c->d_workspace.p && n_frames > 0 && c->local_rows > 0) {
+            // ray segments traced = sum of the per-bounce queue sizes (always available on this route)
+            c->h_qcount.assign((size_t)nq, 0u);
+            HIP_TRY(c, hipMemcpy(c->h_qcount.data(), c->d_workspace.p, (size_t)nq * sizeof(uint32_t), hipMemcpyDeviceToHost));
+            uint64_t rays = 0;
+            for (int b = 0; b <= c->max_bounces; b++) rays += c->h_qcount[(size_t)b];
+            c->stats.rays = rays;
+        }
         if (counted) {
             DevCounters h;
             HIP_TRY(c, hipMemcpy(&h, cnt, sizeof h, hipMemcpyDeviceToHost));
@@ -556,6 +582,14 @@ int jpt_sync(jpt_ctx* c)
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     float ms = 0.0f;
     if (hipEventElapsedTime(&ms, c->ev0, c->ev1) == hipSuccess) c->stats.last_render_ms = c->stats.last_trace_ms = ms;
+    return JPT_OK;
+}
+
+int jpt_set_kernel(jpt_ctx* c, int32_t variant)
+{
+    if (!c) return JPT_E_INVALID;
+    if (variant != JPT_KERNEL_WAVEFRONT && variant != JPT_KERNEL_REFERENCE_LAYOUT) return fail(c, JPT_E_INVALID, "unknown kernel variant");
+    c->kernel_variant = variant;
     return JPT_OK;
 }
 

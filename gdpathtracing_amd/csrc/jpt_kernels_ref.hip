@@ -192,7 +192,7 @@ __global__ __launch_bounds__(256) void ref_frame_kernel(RefSceneDev sc, SceneSha
             const Shading s = get_shading_data(sh, h, hit.front);
             radiance = radiance + throughput * s.emission;
             if (i == 0) depth = length3(s.position - ray.o);
-            if (!bounce(s, sx, sy, ray, throughput)) break;
+            if (!bounce_step(s, sx, sy, ray, throughput)) break;
         }
         depth = cam.far_ / (cam.far_ - cam.near_) * (1.0f - cam.near_ / depth);
         const size_t idx = (size_t)ly * fp.width + px;

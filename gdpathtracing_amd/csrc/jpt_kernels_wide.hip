@@ -1,0 +1,460 @@
+// jpt_kernels_wide.hip -- the native (fast) route: a wavefront path tracer over the flattened layout.
+//
+// All `n_frames` frames of a render are in flight at once as independent paths (pixel x frame); the
+// per-pixel RNG streams of the reference (main.glsl:409, :386) are kept, so results do not depend on
+// the schedule.  Per bounce, two kernels exchange compact queues in HBM:
+//
+//   wf_trace   persistent waves pull 64 rays at a time from the bounce's queue and walk the two-level
+//              BVH: one 64-byte record per expansion (both children's boxes), per-lane stacks staged in
+//              LDS, Moller-Trumbore on precomputed-edge triangles.  Writes one 32-byte hit record per ray.
+//   wf_shade   shading fetch, BRDF sample / pdf / eval (brdfs.glsl), emission accumulation, and the next
+//              segment's ray, packed to the front of the next queue with a wave ballot + mbcnt prefix and
+//              one atomic per wave (active-ray compaction).
+//
+// wf_generate builds bounce 0's queue; wf_accumulate replays the frames IN ORDER per pixel so the float sum
+// is the same sequence of additions as the reference's frame-by-frame accumulation
+// (progressive_rendering.glsl:33-37).  Replaces main.glsl:270-436 + progressive_rendering.glsl.
+#include "jpt_kernels.h"
+#include "jpt_shade.h"
+
+namespace jpt {
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kStackLds = 24;       // per-lane entries kept in LDS
+constexpr int kStackSpill = 72;     // deeper entries go to scratch (rare)
+constexpr int32_t kSentinel = 0x7fffffff;  // "leave the instance" marker on the stack
+
+struct WideSceneDev {
+    const WideNode* __restrict__ blas_nodes;
+    const WideTri* __restrict__ tris;
+    const WideNode* __restrict__ tlas_nodes;
+    const WideInstance* __restrict__ instances;
+    int32_t tlas_root;
+    uint32_t n_instances;
+};
+
+__device__ __forceinline__ float4 ld4(const void* p) { return *reinterpret_cast<const float4*>(p); }
+
+// slab test of main.glsl:259-268 on one child box
+__device__ __forceinline__ float slab(const f3& o, const f3& rD, float mnx, float mny, float mnz, float mxx, float mxy, float mxz)
+{
+    const float tx1 = (mnx - o.x) * rD.x, tx2 = (mxx - o.x) * rD.x;
+    float tmin = fmin_(tx1, tx2), tmax = fmax_(tx1, tx2);
+    const float ty1 = (mny - o.y) * rD.y, ty2 = (mxy - o.y) * rD.y;
+    tmin = fmax_(tmin, fmin_(ty1, ty2)), tmax = fmin_(tmax, fmax_(ty1, ty2));
+    const float tz1 = (mnz - o.z) * rD.z, tz2 = (mxz - o.z) * rD.z;
+    tmin = fmax_(tmin, fmin_(tz1, tz2)), tmax = fmin_(tmax, fmax_(tz1, tz2));
+    return (tmax >= tmin && tmax > 0.0f) ? tmin : 1e30f;
+}
+
+struct TraceHit {
+    float t, u, v;
+    uint32_t tri, inst;
+    bool front;
+};
+
+// Closest hit of one ray over the flattened two-level BVH.  Visit order, box tests and the triangle
+// test are those of ray_trace_tlas / ray_trace_blas / intersectTriangle (main.glsl:224-350).
+template <bool COUNT>
+__device__ __forceinline__ void trace_ray(const WideSceneDev& sc, const f3 wo, const f3 wd, const f3 wrD, TraceHit& hit,
+                                          int32_t* __restrict__ lds_stack /* [kStackLds][kBlock] slice of this lane */,
+                                          DevCounters& cnt)
+{
+    int32_t spill[kStackSpill];
+    int sp = 0;
+    auto push = [&](int32_t v) {
+        if (sp < kStackLds) lds_stack[sp * kBlock] = v;
+        else if (sp < kStackLds + kStackSpill) spill[sp - kStackLds] = v;
+        sp++;
+    };
+    auto pop = [&]() -> int32_t {
+        sp--;
+        if (sp < kStackLds) return lds_stack[sp * kBlock];
+        if (sp < kStackLds + kStackSpill) return spill[sp - kStackLds];
+        return kSentinel;
+    };
+
+    hit.t = 1e9f;  // main.glsl:354
+    hit.tri = 0;
+    hit.inst = 0;
+    hit.u = hit.v = 0.0f;
+    hit.front = false;
+    if (sc.n_instances == 0) return;
+
+    f3 o = wo, d = wd, rD = wrD;  // current-level ray (world at TLAS level, instance-local below)
+    bool in_blas = false;
+    uint32_t cur_inst = 0;
+    int32_t cur = sc.tlas_root;
+    bool have = true;
+
+    while (true) {
+        if (!have) {
+            if (sp == 0) break;
+            cur = pop();
+            if (cur == kSentinel) {  // back to the TLAS level
+                o = wo;
+                d = wd;
+                rD = wrD;
+                in_blas = false;
+                continue;
+            }
+        }
+        have = false;
+        if (cur >= 0) {
+            // ---- internal record: both children's boxes in one 64-byte fetch
+            const WideNode* n = (in_blas ? sc.blas_nodes : sc.tlas_nodes) + cur;
+            const float4 a = ld4(&n->lmin[0]);   // lmin.xyz lmax.x
+            const float4 b = ld4(&n->lmax[1]);   // lmax.yz rmin.xy
+            const float4 c = ld4(&n->rmin[2]);   // rmin.z rmax.xyz
+            const float4 e = ld4(&n->left);      // left right pad pad
+            if (COUNT) { if (in_blas) cnt.blas_expand++; else cnt.tlas_expand++; }
+            const float d1 = slab(o, rD, a.x, a.y, a.z, a.w, b.x, b.y);
+            const float d2 = slab(o, rD, b.z, b.w, c.x, c.y, c.z, c.w);
+            const int32_t left = __float_as_int(e.x), right = __float_as_int(e.y);
+            const bool lv = d1 < hit.t, rv = d2 < hit.t;
+            // `if (d1 < d2) {push right; push left} else {push left; push right}` then pop (main.glsl:293-299)
+            const bool left_first = d1 < d2;
+            const int32_t near_ref = left_first ? left : right, far_ref = left_first ? right : left;
+            const bool near_v = left_first ? lv : rv, far_v = left_first ? rv : lv;
+            if (near_v) {
+                if (far_v) push(far_ref);
+                cur = near_ref;
+                have = true;
+            } else if (far_v) {
+                cur = far_ref;
+                have = true;
+            }
+        } else if (in_blas) {
+            // ---- triangle leaf (main.glsl:280-283)
+            const uint32_t bits = (uint32_t)~cur;
+            const uint32_t first = bits & kLeafFirstMask;
+            const uint32_t count = (bits >> kLeafCountShift) + 1u;
+            for (uint32_t i = 0; i < count; i++) {
+                const uint32_t ti = first + i;
+                const WideTri* tp = sc.tris + ti;
+                const float4 q0 = ld4(&tp->v0[0]);
+                const float4 q1 = ld4(&tp->e1[0]);
+                const float4 q2 = ld4(&tp->e2[0]);
+                if (COUNT) cnt.tri_tests++;
+                const f3 v0 = mk3(q0.x, q0.y, q0.z), edge1 = mk3(q1.x, q1.y, q1.z), edge2 = mk3(q2.x, q2.y, q2.z);
+                const f3 pvec = cross3(d, edge2);
+                const float det = dot3(edge1, pvec);
+                if (__builtin_fabsf(det) < 1e-5f) continue;
+                const float invDet = 1.0f / det;
+                const f3 tvec = o - v0;
+                const float u = dot3(tvec, pvec) * invDet;
+                if (u < 0.0f || u > 1.0f) continue;
+                const f3 qvec = cross3(tvec, edge1);
+                const float v = dot3(d, qvec) * invDet;
+                if (v < 0.0f || u + v > 1.0f) continue;
+                const float t = dot3(edge2, qvec) * invDet;
+                if (t < 0.0f || t > hit.t) continue;
+                hit.t = t;
+                hit.u = u;
+                hit.v = v;
+                hit.tri = ti;
+                hit.inst = cur_inst;
+                hit.front = dot3(cross3(edge1, edge2), d) > 0.0f;
+            }
+        } else {
+            // ---- TLAS leaf: enter the instance (main.glsl:316-322)
+            cur_inst = (uint32_t)~cur;
+            const WideInstance* ip = sc.instances + cur_inst;
+            const float4 m0 = ld4(&ip->inv[0]);
+            const float4 m1 = ld4(&ip->inv[4]);
+            const float4 m2 = ld4(&ip->inv[8]);
+            const int32_t root = ip->root;
+            if (COUNT) cnt.inst_visits++;
+            // columns c0 = (m0.x m0.y m0.z) c1 = (m0.w m1.x m1.y) c2 = (m1.z m1.w m2.x) c3 = (m2.y m2.z m2.w)
+            o = mk3(m0.x * wo.x + m0.w * wo.y + m1.z * wo.z + m2.y, m0.y * wo.x + m1.x * wo.y + m1.w * wo.z + m2.z,
+                    m0.z * wo.x + m1.y * wo.y + m2.x * wo.z + m2.w);
+            d = mk3(m0.x * wd.x + m0.w * wd.y + m1.z * wd.z, m0.y * wd.x + m1.x * wd.y + m1.w * wd.z,
+                    m0.z * wd.x + m1.y * wd.y + m2.x * wd.z);
+            rD = rcp3(d);
+            in_blas = true;
+            push(kSentinel);
+            cur = root;
+            have = true;
+        }
+    }
+}
+
+// ---- path / queue storage -----------------------------------------------------------------------
+
+struct WfBuffers {
+    float4* ray_o[2];     // queue entry: origin.xyz, w unused
+    float4* ray_d[2];     // direction.xyz, w = path id bits
+    float4* hit_a;        // t, u, v, tri bits
+    uint32_t* hit_b;      // inst | front << 31
+    float4* thr;          // per path: throughput.xyz, w = seed.x bits
+    float4* rad;          // per path: radiance.xyz,   w = seed.y bits   ([frame][slot]: also the per-frame output)
+    float* first_depth;   // per slot of the LAST frame: distance of the first hit (or far)
+    uint32_t* qcount;     // [max_bounces + 2] queue sizes
+    uint32_t* cursor;     // [max_bounces + 2] fetch cursors of wf_trace
+};
+
+struct WfDims {
+    int32_t tiles_x, tiles_y;
+    uint32_t slots_per_frame;  // tiles_x * tiles_y * 64
+    uint32_t n_paths;          // slots_per_frame * n_frames
+};
+
+__device__ __forceinline__ void slot_to_pixel(uint32_t slot, const WfDims& dm, int& px, int& ly)
+{
+    const uint32_t tile = slot >> 6, lane = slot & 63u;
+    const uint32_t ty = tile / (uint32_t)dm.tiles_x, tx = tile - ty * (uint32_t)dm.tiles_x;
+    px = (int)(tx * 8u + (lane & 7u));
+    ly = (int)(ty * 8u + (lane >> 3));
+}
+
+// bounce 0 queue: one primary ray per (pixel, frame) (main.glsl:405-421)
+__global__ __launch_bounds__(kBlock) void wf_generate(WfBuffers wb, WfDims dm, FrameParams fp, RefCamera cam)
+{
+    const uint32_t p = blockIdx.x * kBlock + threadIdx.x;
+    bool active = false;
+    float4 ro, rd, thr, rad;
+    if (p < dm.n_paths) {
+        const uint32_t f = p / dm.slots_per_frame, slot = p - f * dm.slots_per_frame;
+        int px, ly;
+        slot_to_pixel(slot, dm, px, ly);
+        if (px < fp.width && ly < fp.local_rows) {
+            const int py = local_to_global_row(ly, fp);
+            uint32_t sx, sy;
+            const Ray ray = primary_ray(cam, fp.width, fp.height, px, py, fp.frame_index + f, sx, sy);
+            ro = make_float4(ray.o.x, ray.o.y, ray.o.z, 0.0f);
+            rd = make_float4(ray.d.x, ray.d.y, ray.d.z, __uint_as_float(p));
+            thr = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(sx));
+            rad = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(sy));
+            active = true;
+        }
+    }
+    // compaction: only in-bounds paths enter the queue
+    const unsigned long long m = __ballot(active);
+    const int lane = threadIdx.x & 63;
+    uint32_t base = 0;
+    if (lane == 0 && m) base = atomicAdd(&wb.qcount[0], (uint32_t)__popcll(m));
+    base = __shfl(base, 0);
+    if (active) {
+        const uint32_t i = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        wb.ray_o[0][i] = ro;
+        wb.ray_d[0][i] = rd;
+        wb.thr[p] = thr;
+        wb.rad[p] = rad;
+    }
+}
+
+template <bool COUNT>
+__global__ __launch_bounds__(kBlock) void wf_trace(WideSceneDev sc, WfBuffers wb, int bounce, DevCounters* __restrict__ counters)
+{
+    __shared__ int32_t stack[kStackLds * kBlock];
+    const int lane = threadIdx.x & 63;
+    const uint32_t n = wb.qcount[bounce];
+    const float4* __restrict__ qo = wb.ray_o[bounce & 1];
+    const float4* __restrict__ qd = wb.ray_d[bounce & 1];
+    DevCounters cnt = {};
+    while (true) {
+        // each wave pulls the next 64 rays of the queue
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(&wb.cursor[bounce], 64u);
+        base = __shfl(base, 0);
+        if (base >= n) break;
+        const uint32_t i = base + (uint32_t)lane;
+        if (i < n) {
+            const float4 ro = qo[i], rd = qd[i];
+            const f3 o = mk3(ro.x, ro.y, ro.z), d = mk3(rd.x, rd.y, rd.z);
+            TraceHit hit;
+            trace_ray<COUNT>(sc, o, d, rcp3(d), hit, &stack[threadIdx.x], cnt);
+            wb.hit_a[i] = make_float4(hit.t, hit.u, hit.v, __uint_as_float(hit.tri));
+            wb.hit_b[i] = hit.inst | (hit.front ? 0x80000000u : 0u);
+        }
+    }
+    if (COUNT) flush_counters(cnt, counters);
+}
+
+// one path vertex per queue entry (main.glsl:378-397); survivors are packed into the next queue
+template <bool COUNT>
+__global__ __launch_bounds__(kBlock) void wf_shade(SceneShading sh, WfBuffers wb, WfDims dm, FrameParams fp, RefCamera cam,
+                                                   int bounce, DevCounters* __restrict__ counters)
+{
+    const uint32_t n = wb.qcount[bounce];
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    if ((i & ~63u) >= n) return;  // whole wave past the end
+    bool alive = false;
+    float4 no, nd;
+    DevCounters cnt = {};
+    if (i < n) {
+        const int in = bounce & 1;
+        const float4 ro = wb.ray_o[in][i], rd = wb.ray_d[in][i];
+        const uint32_t p = __float_as_uint(rd.w);
+        const float4 ha = wb.hit_a[i];
+        float4 t4 = wb.thr[p], r4 = wb.rad[p];
+        f3 throughput = mk3(t4.x, t4.y, t4.z), radiance = mk3(r4.x, r4.y, r4.z);
+        uint32_t sx = __float_as_uint(t4.w), sy = __float_as_uint(r4.w);
+        Ray ray;
+        ray.o = mk3(ro.x, ro.y, ro.z);
+        ray.d = mk3(rd.x, rd.y, rd.z);
+        const bool is_hit = ha.x < 1e9f;  // main.glsl:349
+        float first_dist = cam.far_;
+        if (COUNT) cnt.rays++;
+        if (!is_hit) {
+            radiance = radiance + throughput * sample_sky(ray.d);
+        } else {
+            if (COUNT) cnt.shaded_hits++;
+            const uint32_t hb = wb.hit_b[i];
+            Hit h;
+            h.t = ha.x;
+            h.u = ha.y;
+            h.v = ha.z;
+            h.tri = __float_as_uint(ha.w);
+            h.inst = hb & 0x7fffffffu;
+            // the hit instance's local ray: same expression ray_trace_tlas evaluates (main.glsl:319-320)
+            const RefInstance& b = sh.instances[h.inst];
+            h.lo = xform_point(b.inverse_transform, ray.o);
+            h.ld = xform_dir(b.inverse_transform, ray.d);
+            const Shading s = get_shading_data(sh, h, (hb >> 31) != 0u);
+            radiance = radiance + throughput * s.emission;
+            if (bounce == 0) first_dist = length3(s.position - ray.o);
+            if (bounce < fp.max_bounces) alive = bounce_step(s, sx, sy, ray, throughput);
+        }
+        if (bounce == 0) {
+            const uint32_t f = p / dm.slots_per_frame;
+            if ((int)f == fp.n_frames - 1) wb.first_depth[p - f * dm.slots_per_frame] = first_dist;
+        }
+        wb.rad[p] = make_float4(radiance.x, radiance.y, radiance.z, __uint_as_float(sy));
+        if (alive) {
+            wb.thr[p] = make_float4(throughput.x, throughput.y, throughput.z, __uint_as_float(sx));
+            no = make_float4(ray.o.x, ray.o.y, ray.o.z, 0.0f);
+            nd = make_float4(ray.d.x, ray.d.y, ray.d.z, __uint_as_float(p));
+        }
+    }
+    // active-ray packing: ballot + prefix count, one atomic per wave
+    const unsigned long long m = __ballot(alive);
+    if (m) {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(&wb.qcount[bounce + 1], (uint32_t)__popcll(m));
+        base = __shfl(base, 0);
+        if (alive) {
+            const uint32_t j = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            const int out = (bounce + 1) & 1;
+            wb.ray_o[out][j] = no;
+            wb.ray_d[out][j] = nd;
+        }
+    }
+    if (COUNT) flush_counters(cnt, counters);
+}
+
+// per pixel: frames in order -> accumulation buffer, display image, depth
+__global__ __launch_bounds__(kBlock) void wf_accumulate(WfBuffers wb, WfDims dm, FrameParams fp, RefCamera cam,
+                                                        float4* __restrict__ accum, uint32_t* __restrict__ ldr,
+                                                        float* __restrict__ depth_out)
+{
+    const uint32_t slot = blockIdx.x * kBlock + threadIdx.x;
+    if (slot >= dm.slots_per_frame) return;
+    int px, ly;
+    slot_to_pixel(slot, dm, px, ly);
+    if (px >= fp.width || ly >= fp.local_rows) return;
+    const size_t idx = (size_t)ly * fp.width + px;
+    // fp.frame_count = ProgressiveRendering frame_count of the FIRST frame of this render
+    f3 sum = mk3(0.0f, 0.0f, 0.0f);
+    bool have_prev = fp.frame_count > 1;
+    if (have_prev) {
+        const float4 prev = accum[idx];
+        sum = mk3(prev.x, prev.y, prev.z);
+    }
+    for (int f = 0; f < fp.n_frames; f++) {
+        const float4 r = wb.rad[(size_t)f * dm.slots_per_frame + slot];
+        f3 cur = mk3(r.x, r.y, r.z);
+        if (fp.accum_mode == 0)  // rgba8 store of main.glsl:434, load of progressive_rendering.glsl:33
+            cur = mk3(from_unorm8(unorm8(cur.x)), from_unorm8(unorm8(cur.y)), from_unorm8(unorm8(cur.z)));
+        sum = have_prev ? cur + sum : cur;  // progressive_rendering.glsl:34-36
+        have_prev = true;
+    }
+    if (fp.n_frames > 0) {
+        accum[idx] = make_float4(sum.x, sum.y, sum.z, 1.0f);
+        const float fc = (float)(fp.frame_count + (uint32_t)fp.n_frames - 1u);
+        const f3 col = aces_film(mk3(sum.x / fc, sum.y / fc, sum.z / fc) * 1.0f);
+        ldr[idx] = unorm8(col.x) | (unorm8(col.y) << 8) | (unorm8(col.z) << 16) | 0xFF000000u;
+    }
+    if (depth_out && fp.n_frames > 0) {
+        const float dist = wb.first_depth[slot];
+        depth_out[idx] = cam.far_ / (cam.far_ - cam.near_) * (1.0f - cam.near_ / dist);  // main.glsl:432
+    }
+}
+
+}  // namespace
+
+size_t wide_workspace_bytes(int width, int local_rows, int n_frames, int max_bounces)
+{
+    const size_t tiles_x = (width + 7) / 8, tiles_y = (local_rows + 7) / 8;
+    const size_t slots = tiles_x * tiles_y * 64, paths = slots * (size_t)n_frames;
+    size_t b = 0;
+    b += paths * sizeof(float4) * 4;   // two ray queues
+    b += paths * sizeof(float4);       // hit_a
+    b += paths * sizeof(uint32_t);     // hit_b
+    b += paths * sizeof(float4) * 2;   // thr, rad
+    b += slots * sizeof(float);        // first_depth
+    b += (size_t)(max_bounces + 2) * 2 * sizeof(uint32_t);
+    return b + 4096;
+}
+
+void launch_wide_render(hipStream_t stream, const DeviceScene& ds, const FrameParams& fp, const RefCamera& cam, void* workspace,
+                        float4* accum, uint32_t* ldr, float* depth, DevCounters* counters)
+{
+    WfDims dm;
+    dm.tiles_x = (fp.width + 7) / 8;
+    dm.tiles_y = (fp.local_rows + 7) / 8;
+    dm.slots_per_frame = (uint32_t)dm.tiles_x * (uint32_t)dm.tiles_y * 64u;
+    dm.n_paths = dm.slots_per_frame * (uint32_t)fp.n_frames;
+    if (dm.n_paths == 0) return;
+    const size_t P = dm.n_paths;
+    char* w = reinterpret_cast<char*>(workspace);
+    auto carve = [&](size_t bytes) {
+        void* p = w;
+        w += (bytes + 255) & ~(size_t)255;
+        return p;
+    };
+    WfBuffers wb;
+    const int nq = fp.max_bounces + 2;
+    wb.qcount = (uint32_t*)carve((size_t)nq * 2 * sizeof(uint32_t));
+    wb.cursor = wb.qcount + nq;
+    wb.ray_o[0] = (float4*)carve(P * sizeof(float4));
+    wb.ray_o[1] = (float4*)carve(P * sizeof(float4));
+    wb.ray_d[0] = (float4*)carve(P * sizeof(float4));
+    wb.ray_d[1] = (float4*)carve(P * sizeof(float4));
+    wb.hit_a = (float4*)carve(P * sizeof(float4));
+    wb.hit_b = (uint32_t*)carve(P * sizeof(uint32_t));
+    wb.thr = (float4*)carve(P * sizeof(float4));
+    wb.rad = (float4*)carve(P * sizeof(float4));
+    wb.first_depth = (float*)carve((size_t)dm.slots_per_frame * sizeof(float));
+
+    WideSceneDev sc;
+    sc.blas_nodes = ds.blas_nodes;
+    sc.tris = ds.wide_tris;
+    sc.tlas_nodes = ds.tlas_nodes;
+    sc.instances = ds.wide_instances;
+    sc.tlas_root = ds.tlas_root;
+    sc.n_instances = ds.n_instances;
+    const SceneShading sh = ds.shading();
+
+    (void)hipMemsetAsync(wb.qcount, 0, (size_t)nq * 2 * sizeof(uint32_t), stream);
+    const uint32_t blocks = (uint32_t)((P + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL(wf_generate, dim3(blocks), dim3(kBlock), 0, stream, wb, dm, fp, cam);
+    // persistent trace grid: enough waves to fill every CU at the kernel's occupancy
+    const uint32_t trace_blocks = 256u * 6u;
+    for (int b = 0; b <= fp.max_bounces; b++) {
+        if (counters) {
+            hipLaunchKernelGGL(wf_trace<true>, dim3(trace_blocks), dim3(kBlock), 0, stream, sc, wb, b, counters);
+            hipLaunchKernelGGL(wf_shade<true>, dim3(blocks), dim3(kBlock), 0, stream, sh, wb, dm, fp, cam, b, counters);
+        } else {
+            hipLaunchKernelGGL(wf_trace<false>, dim3(trace_blocks), dim3(kBlock), 0, stream, sc, wb, b, counters);
+            hipLaunchKernelGGL(wf_shade<false>, dim3(blocks), dim3(kBlock), 0, stream, sh, wb, dm, fp, cam, b, counters);
+        }
+    }
+    const uint32_t ablocks = (dm.slots_per_frame + kBlock - 1) / kBlock;
+    hipLaunchKernelGGL(wf_accumulate, dim3(ablocks), dim3(kBlock), 0, stream, wb, dm, fp, cam, accum, ldr, depth);
+}
+
+}  // namespace jpt

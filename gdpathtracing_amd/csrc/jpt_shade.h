@@ -266,7 +266,7 @@ __device__ __forceinline__ float brdf_density(const Shading& sh, f3 l)  // brdfs
 
 // One path vertex after a hit (main.glsl:381-394).  Returns false when the path ends
 // (lambert_in <= 0); otherwise `ray` is the next segment and `throughput` is updated.
-__device__ __forceinline__ bool bounce(const Shading& s, uint32_t& sx, uint32_t& sy, Ray& ray, f3& throughput)
+__device__ __forceinline__ bool bounce_step(const Shading& s, uint32_t& sx, uint32_t& sy, Ray& ray, f3& throughput)
 {
     ray.o = s.position + s.normal * 0.001f;
     float xi0, xi1;

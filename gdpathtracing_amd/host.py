@@ -96,6 +96,9 @@ class Context:
         self._ck(self._lib.jpt_set_params(self.h, width, height, max_bounces, accum_mode, sampler_mode), "jpt_set_params")
         self.width, self.height = width, height
 
+    def set_kernel(self, variant):
+        self._ck(self._lib.jpt_set_kernel(self.h, variant), "jpt_set_kernel")
+
     def set_partition(self, rank, world):
         self._ck(self._lib.jpt_set_partition(self.h, rank, world), "jpt_set_partition")
 

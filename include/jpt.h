@@ -143,6 +143,13 @@ int jpt_scene_get_reference_buffer(jpt_ctx *ctx, int32_t which, void *out, size_
 int jpt_set_params(jpt_ctx *ctx, int32_t width, int32_t height, int32_t max_bounces,
                    int32_t accum_mode, int32_t sampler_mode);
 
+/* Which device pipeline renders (no reference counterpart; both give the same image):
+ *   WAVEFRONT          queue-based path tracer over the flattened 64-byte-node layout (default, fast);
+ *   REFERENCE_LAYOUT   one thread per pixel straight over the six reference-layout buffers, node for node
+ *                      as main.glsl:270-350 (audit route). */
+enum { JPT_KERNEL_WAVEFRONT = 0, JPT_KERNEL_REFERENCE_LAYOUT = 1 };
+int jpt_set_kernel(jpt_ctx *ctx, int32_t variant);
+
 /* Multi-GPU screen partition (no reference counterpart): this context renders the
  * 8-row strips s with s % world == rank.  Default rank 0 of 1 = whole image. */
 int jpt_set_partition(jpt_ctx *ctx, int32_t rank, int32_t world);
