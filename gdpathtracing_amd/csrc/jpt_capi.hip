@@ -283,8 +283,9 @@ int do_render(jpt_ctx* c, int32_t n_frames, uint32_t first_frame_index, bool cou
             // ray segments traced = sum of the per-bounce queue sizes (always available on this route)
             c->h_qcount.assign((size_t)nq, 0u);
             HIP_TRY(c, hipMemcpy(c->h_qcount.data(), c->d_workspace.p, (size_t)nq * sizeof(uint32_t), hipMemcpyDeviceToHost));
-            uint64_t rays = 0;
-            for (int b = 0; b <= c->max_bounces; b++) rays += c->h_qcount[(size_t)b];
+            // bounce 0's queue is indexed by path id (padding lanes included): count its in-image entries
+            uint64_t rays = (uint64_t)c->width * (uint64_t)c->local_rows * (uint64_t)n_frames;
+            for (int b = 1; b <= c->max_bounces; b++) rays += c->h_qcount[(size_t)b];
             c->stats.rays = rays;
         }
         if (counted) {

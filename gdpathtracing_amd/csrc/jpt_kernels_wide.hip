@@ -25,6 +25,8 @@ constexpr int kBlock = 256;
 constexpr int kStackLds = 24;       // per-lane entries kept in LDS
 constexpr int kStackSpill = 72;     // deeper entries go to scratch (rare)
 constexpr int32_t kSentinel = 0x7fffffff;  // "leave the instance" marker on the stack
+constexpr uint32_t kInactive = 0xffffffffu;  // path id of a padding queue entry
+constexpr int kShadeBlock = 1024;
 
 struct WideSceneDev {
     const WideNode* __restrict__ blas_nodes;
@@ -230,19 +232,18 @@ __global__ __launch_bounds__(kBlock) void wf_generate(WfBuffers wb, WfDims dm, F
             active = true;
         }
     }
-    // compaction: only in-bounds paths enter the queue
-    const unsigned long long m = __ballot(active);
-    const int lane = threadIdx.x & 63;
-    uint32_t base = 0;
-    if (lane == 0 && m) base = atomicAdd(&wb.qcount[0], (uint32_t)__popcll(m));
-    base = __shfl(base, 0);
-    if (active) {
-        const uint32_t i = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-        wb.ray_o[0][i] = ro;
-        wb.ray_d[0][i] = rd;
-        wb.thr[p] = thr;
-        wb.rad[p] = rad;
+    // bounce 0's queue is indexed by path id; out-of-image padding lanes are marked inactive (d.w = ~0)
+    if (p < dm.n_paths) {
+        if (active) {
+            wb.ray_o[0][p] = ro;
+            wb.ray_d[0][p] = rd;
+            wb.thr[p] = thr;
+            wb.rad[p] = rad;
+        } else {
+            wb.ray_d[0][p] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(kInactive));
+        }
     }
+    if (p == 0) wb.qcount[0] = dm.n_paths;
 }
 
 template <bool COUNT>
@@ -254,15 +255,15 @@ __global__ __launch_bounds__(kBlock) void wf_trace(WideSceneDev sc, WfBuffers wb
     const float4* __restrict__ qo = wb.ray_o[bounce & 1];
     const float4* __restrict__ qd = wb.ray_d[bounce & 1];
     DevCounters cnt = {};
-    while (true) {
-        // each wave pulls the next 64 rays of the queue
-        uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(&wb.cursor[bounce], 64u);
-        base = __shfl(base, 0);
-        if (base >= n) break;
+    // waves stride over 64-ray chunks of the queue (no shared cursor: a single-address atomic caps at
+    // ~88 M/s on this chip, which is slower than the tracing itself)
+    const uint32_t wave_id = (blockIdx.x * kBlock + threadIdx.x) >> 6, n_waves = (gridDim.x * kBlock) >> 6;
+    for (uint32_t base = wave_id * 64u; base < n; base += n_waves * 64u) {
         const uint32_t i = base + (uint32_t)lane;
         if (i < n) {
-            const float4 ro = qo[i], rd = qd[i];
+            const float4 rd = qd[i];
+            if (__float_as_uint(rd.w) == kInactive) continue;
+            const float4 ro = qo[i];
             const f3 o = mk3(ro.x, ro.y, ro.z), d = mk3(rd.x, rd.y, rd.z);
             TraceHit hit;
             trace_ray<COUNT>(sc, o, d, rcp3(d), hit, &stack[threadIdx.x], cnt);
@@ -275,20 +276,24 @@ __global__ __launch_bounds__(kBlock) void wf_trace(WideSceneDev sc, WfBuffers wb
 
 // one path vertex per queue entry (main.glsl:378-397); survivors are packed into the next queue
 template <bool COUNT>
-__global__ __launch_bounds__(kBlock) void wf_shade(SceneShading sh, WfBuffers wb, WfDims dm, FrameParams fp, RefCamera cam,
+__global__ __launch_bounds__(kShadeBlock) void wf_shade(SceneShading sh, WfBuffers wb, WfDims dm, FrameParams fp, RefCamera cam,
                                                    int bounce, DevCounters* __restrict__ counters)
 {
+    __shared__ uint32_t wave_alive[kShadeBlock / 64];
+    __shared__ uint32_t block_base;
     const uint32_t n = wb.qcount[bounce];
-    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-    const int lane = threadIdx.x & 63;
-    if ((i & ~63u) >= n) return;  // whole wave past the end
+    const uint32_t i = blockIdx.x * kShadeBlock + threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (blockIdx.x * kShadeBlock >= n) return;  // whole block past the end
     bool alive = false;
     float4 no, nd;
     DevCounters cnt = {};
     if (i < n) {
         const int in = bounce & 1;
-        const float4 ro = wb.ray_o[in][i], rd = wb.ray_d[in][i];
+        const float4 rd = wb.ray_d[in][i];
         const uint32_t p = __float_as_uint(rd.w);
+        if (p != kInactive) {
+        const float4 ro = wb.ray_o[in][i];
         const float4 ha = wb.hit_a[i];
         float4 t4 = wb.thr[p], r4 = wb.rad[p];
         f3 throughput = mk3(t4.x, t4.y, t4.z), radiance = mk3(r4.x, r4.y, r4.z);
@@ -329,19 +334,27 @@ __global__ __launch_bounds__(kBlock) void wf_shade(SceneShading sh, WfBuffers wb
             no = make_float4(ray.o.x, ray.o.y, ray.o.z, 0.0f);
             nd = make_float4(ray.d.x, ray.d.y, ray.d.z, __uint_as_float(p));
         }
-    }
-    // active-ray packing: ballot + prefix count, one atomic per wave
-    const unsigned long long m = __ballot(alive);
-    if (m) {
-        uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(&wb.qcount[bounce + 1], (uint32_t)__popcll(m));
-        base = __shfl(base, 0);
-        if (alive) {
-            const uint32_t j = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-            const int out = (bounce + 1) & 1;
-            wb.ray_o[out][j] = no;
-            wb.ray_d[out][j] = nd;
         }
+    }
+    // active-ray packing: wave ballot + prefix count, wave totals combined in LDS, ONE atomic per block
+    const unsigned long long m = __ballot(alive);
+    if (lane == 0) wave_alive[wave] = (uint32_t)__popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t tot = 0;
+        for (int w = 0; w < kShadeBlock / 64; w++) {
+            const uint32_t c = wave_alive[w];
+            wave_alive[w] = tot;
+            tot += c;
+        }
+        block_base = tot ? atomicAdd(&wb.qcount[bounce + 1], tot) : 0u;
+    }
+    __syncthreads();
+    if (alive) {
+        const uint32_t j = block_base + wave_alive[wave] + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        const int out = (bounce + 1) & 1;
+        wb.ray_o[out][j] = no;
+        wb.ray_d[out][j] = nd;
     }
     if (COUNT) flush_counters(cnt, counters);
 }
@@ -441,16 +454,17 @@ void launch_wide_render(hipStream_t stream, const DeviceScene& ds, const FramePa
 
     (void)hipMemsetAsync(wb.qcount, 0, (size_t)nq * 2 * sizeof(uint32_t), stream);
     const uint32_t blocks = (uint32_t)((P + kBlock - 1) / kBlock);
+    const uint32_t sblocks = (uint32_t)((P + kShadeBlock - 1) / kShadeBlock);
     hipLaunchKernelGGL(wf_generate, dim3(blocks), dim3(kBlock), 0, stream, wb, dm, fp, cam);
     // persistent trace grid: enough waves to fill every CU at the kernel's occupancy
     const uint32_t trace_blocks = 256u * 6u;
     for (int b = 0; b <= fp.max_bounces; b++) {
         if (counters) {
             hipLaunchKernelGGL(wf_trace<true>, dim3(trace_blocks), dim3(kBlock), 0, stream, sc, wb, b, counters);
-            hipLaunchKernelGGL(wf_shade<true>, dim3(blocks), dim3(kBlock), 0, stream, sh, wb, dm, fp, cam, b, counters);
+            hipLaunchKernelGGL(wf_shade<true>, dim3(sblocks), dim3(kShadeBlock), 0, stream, sh, wb, dm, fp, cam, b, counters);
         } else {
             hipLaunchKernelGGL(wf_trace<false>, dim3(trace_blocks), dim3(kBlock), 0, stream, sc, wb, b, counters);
-            hipLaunchKernelGGL(wf_shade<false>, dim3(blocks), dim3(kBlock), 0, stream, sh, wb, dm, fp, cam, b, counters);
+            hipLaunchKernelGGL(wf_shade<false>, dim3(sblocks), dim3(kShadeBlock), 0, stream, sh, wb, dm, fp, cam, b, counters);
         }
     }
     const uint32_t ablocks = (dm.slots_per_frame + kBlock - 1) / kBlock;
