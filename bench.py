@@ -56,7 +56,7 @@ def main():
     args = ap.parse_args()
 
     import torch
-    from gdpathtracing_amd import capi, host, scenes
+    from gdpathtracing_amd import capi, host, partition, scenes
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -113,7 +113,7 @@ def main():
         ctx.render(spp, 1, asynchronous=True)
         if world > 1:
             # direct point-to-point gather: every peer sends its piece over its own xGMI link
-            dist.gather(piece, list(gathered.unbind(0)) if rank == 0 else None, dst=0)
+            partition.gather_to_rank0(piece, dist, rank, world, gathered)
             if rank == 0:
                 ctx.assemble_from_ranks(gathered.data_ptr(), world)
 
@@ -147,7 +147,7 @@ def main():
         ctx.render(spp, 1, asynchronous=True)
         ev[i][1].record(stream)
         if world > 1:
-            dist.gather(piece, list(gathered.unbind(0)) if rank == 0 else None, dst=0)
+            partition.gather_to_rank0(piece, dist, rank, world, gathered)
             if rank == 0:
                 ctx.assemble_from_ranks(gathered.data_ptr(), world)
     barrier()
