@@ -1,0 +1,15 @@
+#!/bin/bash
+# Collects the rocprofv3 evidence for bench.py's headline run on the GPU box (run through gpurun):
+#   1. kernel trace + stats                     -> gpurun_out/prof/trace
+#   2. PMC pass FETCH_SIZE                      -> gpurun_out/prof/pmc_fetch   (separate passes: TCC slots)
+#   3. PMC pass WRITE_SIZE                      -> gpurun_out/prof/pmc_write
+# (--pmc is never combined with tracing domains other than --kernel-trace.)
+cd /tmp && export TMPDIR=/tmp
+cd "$GRAFT_REPO_ROOT"
+ARGS="bench.py --steps 5 --warmup 2 --no-cpu-baseline $*"
+mkdir -p gpurun_out/prof
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof/trace -- python3 $ARGS > gpurun_out/prof/trace.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/prof/pmc_fetch -- python3 $ARGS > gpurun_out/prof/pmc_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/prof/pmc_write -- python3 $ARGS > gpurun_out/prof/pmc_write.log 2>&1
+grep '^{' gpurun_out/prof/trace.log | tail -1 > gpurun_out/prof/bench.json
+ls -R gpurun_out/prof | head -40
