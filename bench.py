@@ -26,15 +26,15 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 # bytes one event touches in the flattened layout (DESIGN.md "Algorithmic bytes")
-WIDE_BYTES = dict(blas_expand=64, tri_tests=48, tlas_expand=64, inst_visits=64, shaded_hits=80 + 176 + 64)
+WIDE_BYTES = dict(blas_expand=64, tri_tests=48, tlas_expand=64, inst_visits=64, rays=32 + 20)
 # the same events priced in the reference layout
 REF_BYTES = dict(blas_expand=96, tri_tests=48, tlas_expand=64, inst_visits=224, shaded_hits=320)
 
 
-def algorithmic_bytes(stats, n_pixels, n_frames, table):
-    b = sum(stats[k] * v for k, v in table.items())
-    # framebuffer: per pixel one float4 accumulation write + one rgba8 + one depth write per launch
-    return b + n_pixels * (16 + 4 + 4)
+def algorithmic_bytes(stats, table):
+    """Bytes the traversal kernel asks for, from exact event counts: one 64-B record per BLAS/TLAS expansion,
+    48 B per triangle test, 64 B per instance visit, a 32-B ray in and a 20-B hit out per ray."""
+    return sum(stats[k] * v for k, v in table.items())
 
 
 def main():
@@ -53,6 +53,8 @@ def main():
     ap.add_argument("--kernel", default="wavefront", choices=["wavefront", "ref"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", default="auto")
+    ap.add_argument("--pmc-json", default=os.path.join(ROOT, "profiles", "current_pmc.json"),
+                    help="per-launch HBM bytes of each kernel from the committed rocprofv3 --pmc passes (tools/pmc.sh)")
     args = ap.parse_args()
 
     import torch
@@ -138,34 +140,51 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
-    # the dominant kernel's duration: HIP events on the stream the kernels run on
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    # Timed region.  Every step ends with jpt_sync (the reference reads the image back after every render,
+    # path_tracing_camera.cpp:228-229); the library brackets each wf_trace launch with HIP events on the
+    # stream it launches on, so the dominant kernel's duration is measured live, per step.
+    render_ms, trace_ms = [], []
     t0 = time.perf_counter()
     for i in range(args.steps):
         ctx.accum_reset()
-        ev[i][0].record(stream)
         ctx.render(spp, 1, asynchronous=True)
-        ev[i][1].record(stream)
         if world > 1:
             partition.gather_to_rank0(piece, dist, rank, world, gathered)
             if rank == 0:
                 ctx.assemble_from_ranks(gathered.data_ptr(), world)
+        ctx.sync()
+        st = ctx.stats()
+        render_ms.append(st["last_render_ms"])
+        trace_ms.append(st["last_trace_ms"])
     barrier()
     elapsed = time.perf_counter() - t0
     t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
-    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))  # per step: all trace launches of one render
+    n_trace_launches = (bounces + 1) if args.kernel == "wavefront" else spp
+    kernel_ms = float(np.mean(trace_ms)) / n_trace_launches   # average duration of ONE launch of the dominant kernel
 
     if rank == 0:
         n_pixels = W * H
         ms_per_step = elapsed / args.steps * 1e3
         mrays = rays * args.steps / elapsed / 1e6
         # roofline of the dominant kernel (this rank's share of the events ~ total / world)
-        alg = algorithmic_bytes(total, n_pixels, spp, WIDE_BYTES) / world
-        alg_ref = algorithmic_bytes(total, n_pixels, spp, REF_BYTES) / world
+        alg = algorithmic_bytes(total, WIDE_BYTES) / world / n_trace_launches          # per launch
+        alg_ref = (algorithmic_bytes(total, REF_BYTES) + n_pixels * spp * 48) / world / n_trace_launches
         achieved = alg / (kernel_ms * 1e-3) / 1e9
+        # HBM traffic of the dominant kernel: PMC counters cannot be read from inside the process, so the
+        # per-launch figure comes from the committed rocprofv3 passes of this same command (profiles/)
+        traffic, traffic_src = None, None
+        dom = "wf_trace" if args.kernel == "wavefront" else "ref_frame_kernel"
+        default_run = (W, H, spp, bounces, args.tris, args.scene, args.builder, world) == (1920, 1080, 8, 4, 51200, "demo", "sah", 1)
+        if default_run and os.path.exists(args.pmc_json):
+            try:
+                pj = json.load(open(args.pmc_json))
+                traffic = pj[dom]["hbm_bytes_per_launch"]
+                traffic_src = os.path.relpath(args.pmc_json, ROOT) + ": (2*FETCH_SIZE + WRITE_SIZE) KiB per launch, separate --pmc passes"
+            except Exception:
+                traffic = None
         out = {
             "metric": "Mrays/sec at 1920x1080, 8 spp, 4 bounces",
             "value": round(mrays, 3),
@@ -190,9 +209,11 @@ def main():
             },
             "roofline": {
                 "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-                "kernel": "path-trace launches of one render (%d frames)" % spp,
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
+                "kernel": "wf_trace (one launch per bounce, %d per render)" % n_trace_launches if args.kernel == "wavefront"
+                else "ref_frame_kernel (one launch per frame)",
                 "kernel_ms": round(kernel_ms, 4),
+                "render_ms": round(float(np.mean(render_ms)), 4),
                 "algorithmic_bytes": int(alg),
                 "ref_layout_algorithmic_bytes": int(alg_ref),
                 "ref_layout_achieved": round(alg_ref / (kernel_ms * 1e-3) / 1e9, 2),

@@ -86,6 +86,8 @@ struct jpt_ctx {
     int32_t kernel_variant = JPT_KERNEL_WAVEFRONT;
     DevBuf<char> d_workspace;
     std::vector<uint32_t> h_qcount;  // per-bounce queue sizes of the last wavefront render
+    std::vector<hipEvent_t> trace_events;  // pairs around each wf_trace launch of the last render
+    int32_t trace_events_used = 0;
 
     // framebuffers (local rows of this partition)
     DevBuf<float4> d_accum;
@@ -259,7 +261,15 @@ int do_render(jpt_ctx* c, int32_t n_frames, uint32_t first_frame_index, bool cou
             fp.frame_index = first_frame_index;
             fp.frame_count = c->frame_count + 1;
             fp.n_frames = n_frames;
-            launch_wide_render(s, c->ds, fp, c->camera, c->d_workspace.p, c->d_accum.p, c->d_ldr.p, c->d_depth.p, cnt);
+            const size_t need_ev = 2 * (size_t)(c->max_bounces + 1);
+            while (c->trace_events.size() < need_ev) {
+                hipEvent_t e;
+                HIP_TRY(c, hipEventCreate(&e));
+                c->trace_events.push_back(e);
+            }
+            c->trace_events_used = (int32_t)need_ev;
+            launch_wide_render(s, c->ds, fp, c->camera, c->d_workspace.p, c->d_accum.p, c->d_ldr.p, c->d_depth.p, cnt,
+                               c->trace_events.data());
         } else {
             for (int32_t f = 0; f < n_frames; f++) {
                 fp.frame_index = first_frame_index + (uint32_t)f;
@@ -279,6 +289,14 @@ int do_render(jpt_ctx* c, int32_t n_frames, uint32_t first_frame_index, bool cou
         HIP_TRY(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
         c->stats.last_render_ms = ms;
         c->stats.last_trace_ms = ms;
+        if (wavefront && c->trace_events_used > 0 && n_frames > 0 && c->local_rows > 0) {
+            double tms = 0.0;
+            for (int32_t k = 0; k + 1 < c->trace_events_used; k += 2) {
+                float t = 0.0f;
+                if (hipEventElapsedTime(&t, c->trace_events[(size_t)k], c->trace_events[(size_t)k + 1]) == hipSuccess) tms += t;
+            }
+            c->stats.last_trace_ms = tms;
+        }
         if (wavefront && c->d_workspace.p && n_frames > 0 && c->local_rows > 0) {
             // ray segments traced = sum of the per-bounce queue sizes (always available on this route)
             c->h_qcount.assign((size_t)nq, 0u);
@@ -374,6 +392,7 @@ void jpt_destroy(jpt_ctx* c)
     if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
+    for (hipEvent_t e : c->trace_events) (void)hipEventDestroy(e);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -583,6 +602,14 @@ int jpt_sync(jpt_ctx* c)
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     float ms = 0.0f;
     if (hipEventElapsedTime(&ms, c->ev0, c->ev1) == hipSuccess) c->stats.last_render_ms = c->stats.last_trace_ms = ms;
+    if (c->kernel_variant == JPT_KERNEL_WAVEFRONT && c->trace_events_used > 0) {
+        double tms = 0.0;
+        for (int32_t k = 0; k + 1 < c->trace_events_used; k += 2) {
+            float t = 0.0f;
+            if (hipEventElapsedTime(&t, c->trace_events[(size_t)k], c->trace_events[(size_t)k + 1]) == hipSuccess) tms += t;
+        }
+        c->stats.last_trace_ms = tms;
+    }
     return JPT_OK;
 }
 

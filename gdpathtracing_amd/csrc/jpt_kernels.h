@@ -105,10 +105,11 @@ void launch_ref_frame(hipStream_t stream, const DeviceScene& ds, const FramePara
 
 // one render of fp.n_frames frames over the flattened layout (jpt_kernels_wide.hip).  fp.frame_index /
 // fp.frame_count are those of the FIRST frame.  The first (max_bounces + 2) u32 of `workspace` are the
-// per-bounce queue sizes afterwards (their sum = ray segments traced).
+// per-bounce queue sizes afterwards (their sum = ray segments traced).  trace_events (may be null):
+// 2 * (max_bounces + 1) events recorded around each wf_trace launch.
 size_t wide_workspace_bytes(int width, int local_rows, int n_frames, int max_bounces);
 void launch_wide_render(hipStream_t stream, const DeviceScene& ds, const FrameParams& fp, const RefCamera& cam, void* workspace,
-                        float4* accum, uint32_t* ldr, float* depth, DevCounters* counters);
+                        float4* accum, uint32_t* ldr, float* depth, DevCounters* counters, hipEvent_t* trace_events);
 
 // rank-major gathered strips -> full framebuffer (multi-GPU assemble)
 void launch_assemble(hipStream_t stream, const float4* gathered, int world, int width, int height, int max_local_rows,

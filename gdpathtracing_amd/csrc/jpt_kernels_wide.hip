@@ -414,7 +414,7 @@ size_t wide_workspace_bytes(int width, int local_rows, int n_frames, int max_bou
 }
 
 void launch_wide_render(hipStream_t stream, const DeviceScene& ds, const FrameParams& fp, const RefCamera& cam, void* workspace,
-                        float4* accum, uint32_t* ldr, float* depth, DevCounters* counters)
+                        float4* accum, uint32_t* ldr, float* depth, DevCounters* counters, hipEvent_t* trace_events)
 {
     WfDims dm;
     dm.tiles_x = (fp.width + 7) / 8;
@@ -459,11 +459,13 @@ void launch_wide_render(hipStream_t stream, const DeviceScene& ds, const FramePa
     // persistent trace grid: enough waves to fill every CU at the kernel's occupancy
     const uint32_t trace_blocks = 256u * 6u;
     for (int b = 0; b <= fp.max_bounces; b++) {
+        if (trace_events) (void)hipEventRecord(trace_events[2 * b], stream);
+        if (counters) hipLaunchKernelGGL(wf_trace<true>, dim3(trace_blocks), dim3(kBlock), 0, stream, sc, wb, b, counters);
+        else hipLaunchKernelGGL(wf_trace<false>, dim3(trace_blocks), dim3(kBlock), 0, stream, sc, wb, b, counters);
+        if (trace_events) (void)hipEventRecord(trace_events[2 * b + 1], stream);
         if (counters) {
-            hipLaunchKernelGGL(wf_trace<true>, dim3(trace_blocks), dim3(kBlock), 0, stream, sc, wb, b, counters);
             hipLaunchKernelGGL(wf_shade<true>, dim3(sblocks), dim3(kShadeBlock), 0, stream, sh, wb, dm, fp, cam, b, counters);
         } else {
-            hipLaunchKernelGGL(wf_trace<false>, dim3(trace_blocks), dim3(kBlock), 0, stream, sc, wb, b, counters);
             hipLaunchKernelGGL(wf_shade<false>, dim3(sblocks), dim3(kShadeBlock), 0, stream, sh, wb, dm, fp, cam, b, counters);
         }
     }
