@@ -67,6 +67,14 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
+    # torch bundles its own libamdhip64 (same SONAME as /opt/rocm's).  If this library pulled the system
+    # runtime in first, a later `import torch` in the same process finds no GPU; loading torch's first
+    # works for both.  Only relevant where torch is used next to the library (tests, bench: plumbing).
+    try:
+        import torch
+        torch.cuda.is_available()
+    except Exception:
+        pass
     if not os.path.exists(LIB_PATH):
         raise JptError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                        "(there is no CPU fallback for the HIP path)" % LIB_PATH)

@@ -682,7 +682,7 @@ int32_t jpto_render(const jpto_scene_view *scene, const jpto_camera *camera, int
         n_threads = n > 0 ? (int32_t)n : 1;
     }
     /* rows are dealt in small interleaved strips so threads get similar work */
-    const int32_t strip = 4;
+    const int32_t strip = 1;
     int32_t n_strips = (height + strip - 1) / strip;
     if (n_threads > n_strips) n_threads = n_strips > 0 ? n_strips : 1;
     job_t *jobs = (job_t *)calloc((size_t)n_strips, sizeof(job_t));

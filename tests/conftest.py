@@ -8,6 +8,15 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+# torch's bundled HIP runtime must be the first one loaded in a process that also uses torch.cuda
+# (see gdpathtracing_amd/capi.py); harmless on the CPU-only box.
+try:
+    import torch
+    torch.cuda.is_available()
+except Exception:
+    pass
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
