@@ -50,7 +50,7 @@ def main():
     ap.add_argument("--scene", default="demo", choices=["demo", "cornell", "inst"])
     ap.add_argument("--builder", default="sah", choices=["sah", "exact"])
     ap.add_argument("--accum", default="ldr8", choices=["ldr8", "hdr"])
-    ap.add_argument("--kernel", default="wavefront", choices=["wavefront", "ref"])
+    ap.add_argument("--kernel", default="wavefront", choices=["wavefront", "ref", "wavefront_v1"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", default="auto")
     ap.add_argument("--pmc-json", default=os.path.join(ROOT, "profiles", "current_pmc.json"),
@@ -92,7 +92,7 @@ def main():
     ctx.set_partition(rank, world)
     ctx.set_params(W, H, bounces, accum_mode)
     ctx.set_camera(cam)
-    ctx.set_kernel(capi.KERNEL_WAVEFRONT if args.kernel == "wavefront" else capi.KERNEL_REFERENCE_LAYOUT)
+    ctx.set_kernel({"wavefront": capi.KERNEL_WAVEFRONT, "ref": capi.KERNEL_REFERENCE_LAYOUT, "wavefront_v1": capi.KERNEL_WAVEFRONT_V1}[args.kernel])
     # one explicit (non-null) stream carries the kernels, the timing events and the collective
     stream = torch.cuda.Stream()
     torch.cuda.set_stream(stream)
@@ -162,7 +162,7 @@ def main():
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
-    n_trace_launches = (bounces + 1) if args.kernel == "wavefront" else spp
+    n_trace_launches = (bounces + 1) if args.kernel != "ref" else spp
     kernel_ms = float(np.mean(trace_ms)) / n_trace_launches   # average duration of ONE launch of the dominant kernel
 
     if rank == 0:
@@ -176,7 +176,7 @@ def main():
         # HBM traffic of the dominant kernel: PMC counters cannot be read from inside the process, so the
         # per-launch figure comes from the committed rocprofv3 passes of this same command (profiles/)
         traffic, traffic_src = None, None
-        dom = "wf_trace" if args.kernel == "wavefront" else "ref_frame_kernel"
+        dom = "wf2_trace" if args.kernel == "wavefront" else "ref_frame_kernel"
         default_run = (W, H, spp, bounces, args.tris, args.scene, args.builder, world) == (1920, 1080, 8, 4, 51200, "demo", "sah", 1)
         if default_run and os.path.exists(args.pmc_json):
             try:
@@ -210,7 +210,7 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
-                "kernel": "wf_trace (one launch per bounce, %d per render)" % n_trace_launches if args.kernel == "wavefront"
+                "kernel": "wf2_primary + wf2_trace (one launch per bounce, %d per render)" % n_trace_launches if args.kernel != "ref"
                 else "ref_frame_kernel (one launch per frame)",
                 "kernel_ms": round(kernel_ms, 4),
                 "render_ms": round(float(np.mean(render_ms)), 4),

@@ -238,10 +238,12 @@ int do_render(jpt_ctx* c, int32_t n_frames, uint32_t first_frame_index, bool cou
         cnt = c->d_counters.p;
         HIP_TRY(c, hipMemsetAsync(cnt, 0, sizeof(DevCounters), s));
     }
-    const bool wavefront = c->kernel_variant == JPT_KERNEL_WAVEFRONT;
+    const bool wavefront = c->kernel_variant == JPT_KERNEL_WAVEFRONT || c->kernel_variant == JPT_KERNEL_WAVEFRONT_V1;
+    const bool wf2 = c->kernel_variant == JPT_KERNEL_WAVEFRONT;
     const int nq = c->max_bounces + 2;
     if (wavefront && c->local_rows > 0 && c->width > 0 && n_frames > 0) {
-        const size_t need = wide_workspace_bytes(c->width, c->local_rows, n_frames, c->max_bounces);
+        const size_t need = wf2 ? wf2_workspace_bytes(c->width, c->local_rows, n_frames, c->max_bounces)
+                                : wide_workspace_bytes(c->width, c->local_rows, n_frames, c->max_bounces);
         if (c->d_workspace.n < need) {
             HIP_TRY(c, hipStreamSynchronize(s));
             HIP_TRY(c, c->d_workspace.resize(need));
@@ -268,8 +270,12 @@ int do_render(jpt_ctx* c, int32_t n_frames, uint32_t first_frame_index, bool cou
                 c->trace_events.push_back(e);
             }
             c->trace_events_used = (int32_t)need_ev;
-            launch_wide_render(s, c->ds, fp, c->camera, c->d_workspace.p, c->d_accum.p, c->d_ldr.p, c->d_depth.p, cnt,
-                               c->trace_events.data());
+            if (wf2)
+                launch_wf2_render(s, c->ds, fp, c->camera, c->d_workspace.p, c->d_accum.p, c->d_ldr.p, c->d_depth.p, cnt,
+                                  c->trace_events.data());
+            else
+                launch_wide_render(s, c->ds, fp, c->camera, c->d_workspace.p, c->d_accum.p, c->d_ldr.p, c->d_depth.p, cnt,
+                                   c->trace_events.data());
         } else {
             for (int32_t f = 0; f < n_frames; f++) {
                 fp.frame_index = first_frame_index + (uint32_t)f;
@@ -299,11 +305,13 @@ int do_render(jpt_ctx* c, int32_t n_frames, uint32_t first_frame_index, bool cou
         }
         if (wavefront && c->d_workspace.p && n_frames > 0 && c->local_rows > 0) {
             // ray segments traced = sum of the per-bounce queue sizes (always available on this route)
-            c->h_qcount.assign((size_t)nq, 0u);
-            HIP_TRY(c, hipMemcpy(c->h_qcount.data(), c->d_workspace.p, (size_t)nq * sizeof(uint32_t), hipMemcpyDeviceToHost));
-            // bounce 0's queue is indexed by path id (padding lanes included): count its in-image entries
+            const size_t per_row = wf2 ? (size_t)wf2_segments() : 1u;
+            c->h_qcount.assign((size_t)nq * per_row, 0u);
+            HIP_TRY(c, hipMemcpy(c->h_qcount.data(), c->d_workspace.p, c->h_qcount.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+            // every in-image (pixel, frame) has one primary segment; rows 1.. hold the later bounces' queue sizes
             uint64_t rays = (uint64_t)c->width * (uint64_t)c->local_rows * (uint64_t)n_frames;
-            for (int b = 1; b <= c->max_bounces; b++) rays += c->h_qcount[(size_t)b];
+            for (int b = 1; b <= c->max_bounces; b++)
+                for (size_t k = 0; k < per_row; k++) rays += c->h_qcount[(size_t)b * per_row + k];
             c->stats.rays = rays;
         }
         if (counted) {
@@ -602,7 +610,7 @@ int jpt_sync(jpt_ctx* c)
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     float ms = 0.0f;
     if (hipEventElapsedTime(&ms, c->ev0, c->ev1) == hipSuccess) c->stats.last_render_ms = c->stats.last_trace_ms = ms;
-    if (c->kernel_variant == JPT_KERNEL_WAVEFRONT && c->trace_events_used > 0) {
+    if (c->kernel_variant != JPT_KERNEL_REFERENCE_LAYOUT && c->trace_events_used > 0) {
         double tms = 0.0;
         for (int32_t k = 0; k + 1 < c->trace_events_used; k += 2) {
             float t = 0.0f;
@@ -616,7 +624,7 @@ int jpt_sync(jpt_ctx* c)
 int jpt_set_kernel(jpt_ctx* c, int32_t variant)
 {
     if (!c) return JPT_E_INVALID;
-    if (variant != JPT_KERNEL_WAVEFRONT && variant != JPT_KERNEL_REFERENCE_LAYOUT) return fail(c, JPT_E_INVALID, "unknown kernel variant");
+    if (variant != JPT_KERNEL_WAVEFRONT && variant != JPT_KERNEL_REFERENCE_LAYOUT && variant != JPT_KERNEL_WAVEFRONT_V1) return fail(c, JPT_E_INVALID, "unknown kernel variant");
     c->kernel_variant = variant;
     return JPT_OK;
 }

@@ -111,6 +111,14 @@ size_t wide_workspace_bytes(int width, int local_rows, int n_frames, int max_bou
 void launch_wide_render(hipStream_t stream, const DeviceScene& ds, const FrameParams& fp, const RefCamera& cam, void* workspace,
                         float4* accum, uint32_t* ldr, float* depth, DevCounters* counters, hipEvent_t* trace_events);
 
+// the persistent-block pipeline (jpt_kernels_wf2.hip): same contract.  The first (max_bounces + 2) *
+// wf2_segments() u32 of `workspace` are per-bounce, per-segment queue sizes afterwards; rows 1..max_bounces
+// sum to the secondary ray segments traced.  trace_events: pairs around wf2_primary and each wf2_trace.
+uint32_t wf2_segments();
+size_t wf2_workspace_bytes(int width, int local_rows, int n_frames, int max_bounces);
+void launch_wf2_render(hipStream_t stream, const DeviceScene& ds, const FrameParams& fp, const RefCamera& cam, void* workspace,
+                       float4* accum, uint32_t* ldr, float* depth, DevCounters* counters, hipEvent_t* trace_events);
+
 // rank-major gathered strips -> full framebuffer (multi-GPU assemble)
 void launch_assemble(hipStream_t stream, const float4* gathered, int world, int width, int height, int max_local_rows,
                      float4* accum_full, uint32_t* ldr_full, uint32_t frame_count);

@@ -1,0 +1,421 @@
+// jpt_kernels_wf2.hip -- the native (fast) route: persistent-block wavefront path tracer.
+//
+// All `n_frames` frames of a render are in flight at once as independent paths (pixel x frame); per-pixel
+// RNG streams (main.glsl:409, :386) are carried with the path, so the schedule cannot change results.
+// The grid is G persistent blocks.  Block s owns SEGMENT s of every queue: the screen's 8x8 tiles (x frames)
+// are dealt round-robin to segments, so each segment is a uniform sample of the image and all hand-offs
+// between kernels stay inside a segment -- no global atomics anywhere on the path.
+//
+//   wf2_primary  bounce 0: generates primary rays (main.glsl:405-421) and traces them.  Sky misses are
+//                finished on the spot; hits are packed into the segment's queue (LDS counter).
+//   wf2_shade    one path vertex per queue entry (main.glsl:378-397 + brdfs.glsl); survivors' next rays are
+//                packed to the front of the segment's next queue (wave ballot + prefix popcount + LDS base).
+//   wf2_trace    bounces >= 1: closest hit of every queued ray.
+//   wf2_accumulate  frames IN ORDER per pixel (progressive_rendering.glsl:33-37), display image, depth.
+//
+// Tracing kernels keep every lane busy: a lane whose ray is finished takes the next ray of the block's
+// segment (cursor in LDS) while its neighbours keep walking -- the wave never waits for its slowest ray.
+// Per-lane traversal stacks live in LDS (24 entries x 256 lanes, deeper levels spill to scratch).
+#include "jpt_trace_core.h"
+
+namespace jpt {
+
+namespace {
+
+constexpr int kBlock = kTraceBlock;
+constexpr uint32_t kSegments = 256u * 6u;  // persistent grid: 6 blocks of 256 threads per CU (24 KiB LDS each)
+constexpr int kRefillIdle = 16;            // refill when at least this many lanes of a wave are idle
+constexpr int kStepsPerRound = 4;          // traversal steps between two refill checks
+
+struct Wf2Buffers {
+    float4* ray_o[2];   // queue entry: origin.xyz
+    float4* ray_d[2];   // direction.xyz, w = path id bits
+    float4* hit_a;      // t, u, v, tri bits          (same index as the ray)
+    uint32_t* hit_b;    // inst | front << 31
+    float4* thr;        // per path: throughput.xyz, w = seed.x bits
+    float4* rad;        // per path: radiance.xyz,   w = seed.y bits  ([frame][slot]: also the per-frame output)
+    float* first_depth; // per slot of the LAST frame: distance of the first hit (or far)
+    uint32_t* qcount;   // [max_bounces + 2][kSegments] queue sizes; row b = rays traced in bounce b (b >= 1)
+};
+
+struct Wf2Dims {
+    int32_t tiles_x, tiles_y;
+    uint32_t tiles_per_frame;
+    uint32_t slots_per_frame;  // tiles_per_frame * 64
+    uint32_t n_chunks;         // tiles_per_frame * n_frames
+    uint32_t seg_cap;          // entries per segment
+};
+
+__device__ __forceinline__ void slot_to_pixel(uint32_t slot, const Wf2Dims& dm, int& px, int& ly)
+{
+    const uint32_t tile = slot >> 6, lane = slot & 63u;
+    const uint32_t ty = tile / (uint32_t)dm.tiles_x, tx = tile - ty * (uint32_t)dm.tiles_x;
+    px = (int)(tx * 8u + (lane & 7u));
+    ly = (int)(ty * 8u + (lane >> 3));
+}
+
+__device__ __forceinline__ uint32_t lanes_below(unsigned long long mask, int lane)
+{
+    return (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+}
+
+// ---- bounce 0: generate + trace ------------------------------------------------------------------------
+
+template <bool COUNT>
+__global__ __launch_bounds__(kBlock) void wf2_primary(WideSceneDev sc, Wf2Buffers wb, Wf2Dims dm, FrameParams fp, RefCamera cam,
+                                                      DevCounters* __restrict__ counters)
+{
+    __shared__ int32_t stack[kStackLds * kBlock];
+    __shared__ uint32_t s_cursor, s_out;
+    const int lane = threadIdx.x & 63;
+    const uint32_t seg = blockIdx.x;
+    // chunks seg, seg + G, seg + 2G, ... belong to this block
+    const uint32_t my_chunks = seg < dm.n_chunks ? (dm.n_chunks - seg + kSegments - 1u) / kSegments : 0u;
+    const uint32_t n = my_chunks * 64u;
+    if (threadIdx.x == 0) {
+        s_cursor = 0;
+        s_out = 0;
+    }
+    __syncthreads();
+    int32_t* my_stack = &stack[threadIdx.x];
+    const size_t seg_base = (size_t)seg * dm.seg_cap;
+    DevCounters cnt = {};
+    Traversal<COUNT> tr;
+    bool active = false, exhausted = false;
+    uint32_t path = 0, sy_keep = 0;
+
+    for (;;) {
+        const unsigned long long idle = __ballot(!active);
+        const int n_idle = __popcll(idle);
+        if (!exhausted && n_idle >= kRefillIdle) {
+            uint32_t start = 0;
+            if (lane == 0) start = atomicAdd(&s_cursor, (uint32_t)n_idle);
+            start = (uint32_t)__builtin_amdgcn_readfirstlane((int)start);
+            if (start + (uint32_t)n_idle >= n) exhausted = true;
+            if (start < n && !active) {
+                const uint32_t idx = start + lanes_below(idle, lane);
+                if (idx < n) {
+                    const uint32_t chunk = seg + (idx >> 6) * kSegments;
+                    const uint32_t f = chunk / dm.tiles_per_frame, tile = chunk - f * dm.tiles_per_frame;
+                    const uint32_t slot = tile * 64u + (idx & 63u);
+                    int px, ly;
+                    slot_to_pixel(slot, dm, px, ly);
+                    if (px < fp.width && ly < fp.local_rows) {
+                        const int py = local_to_global_row(ly, fp);
+                        uint32_t sx, sy;
+                        const Ray ray = primary_ray(cam, fp.width, fp.height, px, py, fp.frame_index + f, sx, sy);
+                        path = f * dm.slots_per_frame + slot;
+                        sy_keep = sy;
+                        tr.begin(sc, ray.o, ray.d);
+                        active = true;
+                        if (COUNT) cnt.rays++;
+                    }
+                }
+            }
+        }
+        if (!__any(active)) {
+            if (exhausted) break;
+            continue;
+        }
+        for (int k = 0; k < kStepsPerRound; k++) {
+            if (active && !tr.step(sc, my_stack, cnt)) {
+                active = false;
+                const uint32_t f = path / dm.slots_per_frame;
+                const bool last_frame = (int)f == fp.n_frames - 1;
+                if (tr.hit.t < 1e9f) {  // main.glsl:349: packed into the segment's bounce-0 queue
+                    const uint32_t j = atomicAdd(&s_out, 1u);
+                    wb.ray_o[0][seg_base + j] = make_float4(tr.wo.x, tr.wo.y, tr.wo.z, 0.0f);
+                    wb.ray_d[0][seg_base + j] = make_float4(tr.wd.x, tr.wd.y, tr.wd.z, __uint_as_float(path));
+                    wb.hit_a[seg_base + j] = make_float4(tr.hit.t, tr.hit.u, tr.hit.v, __uint_as_float(tr.hit.tri));
+                    wb.hit_b[seg_base + j] = tr.hit.inst | (tr.hit.front ? 0x80000000u : 0u);
+                } else {                // sky: radiance += 1 * sampleSky(d), path over (main.glsl:380,395-397)
+                    const f3 sky = mk3(0.0f, 0.0f, 0.0f) + mk3(1.0f, 1.0f, 1.0f) * sample_sky(tr.wd);
+                    wb.rad[path] = make_float4(sky.x, sky.y, sky.z, __uint_as_float(sy_keep));
+                    if (last_frame) wb.first_depth[path - f * dm.slots_per_frame] = cam.far_;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) wb.qcount[0 * kSegments + seg] = s_out;
+    if (COUNT) flush_counters(cnt, counters);
+}
+
+// ---- bounces >= 1: trace the segment's ray queue ----------------------------------------------------------
+
+template <bool COUNT>
+__global__ __launch_bounds__(kBlock) void wf2_trace(WideSceneDev sc, Wf2Buffers wb, Wf2Dims dm, int bounce,
+                                                    DevCounters* __restrict__ counters)
+{
+    __shared__ int32_t stack[kStackLds * kBlock];
+    __shared__ uint32_t s_cursor;
+    const int lane = threadIdx.x & 63;
+    const uint32_t seg = blockIdx.x;
+    const uint32_t n = wb.qcount[(size_t)bounce * kSegments + seg];
+    if (n == 0) return;
+    if (threadIdx.x == 0) s_cursor = 0;
+    __syncthreads();
+    int32_t* my_stack = &stack[threadIdx.x];
+    const size_t seg_base = (size_t)seg * dm.seg_cap;
+    const float4* __restrict__ qo = wb.ray_o[bounce & 1] + seg_base;
+    const float4* __restrict__ qd = wb.ray_d[bounce & 1] + seg_base;
+    DevCounters cnt = {};
+    Traversal<COUNT> tr;
+    bool active = false, exhausted = false;
+    uint32_t my_idx = 0;
+
+    for (;;) {
+        const unsigned long long idle = __ballot(!active);
+        const int n_idle = __popcll(idle);
+        if (!exhausted && n_idle >= kRefillIdle) {
+            uint32_t start = 0;
+            if (lane == 0) start = atomicAdd(&s_cursor, (uint32_t)n_idle);
+            start = (uint32_t)__builtin_amdgcn_readfirstlane((int)start);
+            if (start + (uint32_t)n_idle >= n) exhausted = true;
+            if (start < n && !active) {
+                const uint32_t idx = start + lanes_below(idle, lane);
+                if (idx < n) {
+                    const float4 ro = qo[idx], rd = qd[idx];
+                    tr.begin(sc, mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z));
+                    my_idx = idx;
+                    active = true;
+                }
+            }
+        }
+        if (!__any(active)) {
+            if (exhausted) break;
+            continue;
+        }
+        for (int k = 0; k < kStepsPerRound; k++) {
+            if (active && !tr.step(sc, my_stack, cnt)) {
+                active = false;
+                wb.hit_a[seg_base + my_idx] = make_float4(tr.hit.t, tr.hit.u, tr.hit.v, __uint_as_float(tr.hit.tri));
+                wb.hit_b[seg_base + my_idx] = tr.hit.inst | (tr.hit.front ? 0x80000000u : 0u);
+            }
+        }
+    }
+    if (COUNT) flush_counters(cnt, counters);
+}
+
+// ---- shading: one path vertex per queue entry (main.glsl:378-397) -------------------------------------------
+
+template <bool COUNT>
+__global__ __launch_bounds__(kBlock) void wf2_shade(SceneShading sh, Wf2Buffers wb, Wf2Dims dm, FrameParams fp, RefCamera cam,
+                                                    int bounce, DevCounters* __restrict__ counters)
+{
+    __shared__ uint32_t wave_count[kBlock / 64];
+    __shared__ uint32_t s_out_base;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t seg = blockIdx.x;
+    const uint32_t n = wb.qcount[(size_t)bounce * kSegments + seg];
+    const size_t seg_base = (size_t)seg * dm.seg_cap;
+    const int in = bounce & 1, out = (bounce + 1) & 1;
+    if (threadIdx.x == 0) s_out_base = 0;
+    __syncthreads();
+    DevCounters cnt = {};
+    for (uint32_t base = 0; base < n; base += kBlock) {
+        const uint32_t i = base + threadIdx.x;
+        bool alive = false;
+        float4 no, nd;
+        if (i < n) {
+            const float4 ro = wb.ray_o[in][seg_base + i], rd = wb.ray_d[in][seg_base + i];
+            const uint32_t p = __float_as_uint(rd.w);
+            const float4 ha = wb.hit_a[seg_base + i];
+            const uint32_t hb = wb.hit_b[seg_base + i];
+            f3 throughput, radiance;
+            uint32_t sx, sy;
+            const uint32_t f = p / dm.slots_per_frame, slot = p - f * dm.slots_per_frame;
+            if (bounce == 0) {
+                // fresh path: the seed after the jitter draw (main.glsl:409-411), recomputed from (x, y, frame)
+                int px, ly;
+                slot_to_pixel(slot, dm, px, ly);
+                prng_seed((uint32_t)px, (uint32_t)local_to_global_row(ly, fp), fp.frame_index + f, sx, sy);
+                float r0, r1;
+                pcg2d(sx, sy, r0, r1);
+                throughput = mk3(1.0f, 1.0f, 1.0f);
+                radiance = mk3(0.0f, 0.0f, 0.0f);
+            } else {
+                const float4 t4 = wb.thr[p], r4 = wb.rad[p];
+                throughput = mk3(t4.x, t4.y, t4.z);
+                radiance = mk3(r4.x, r4.y, r4.z);
+                sx = __float_as_uint(t4.w);
+                sy = __float_as_uint(r4.w);
+            }
+            Ray ray;
+            ray.o = mk3(ro.x, ro.y, ro.z);
+            ray.d = mk3(rd.x, rd.y, rd.z);
+            if (COUNT && bounce > 0) cnt.rays++;
+            if (!(ha.x < 1e9f)) {  // main.glsl:349
+                radiance = radiance + throughput * sample_sky(ray.d);
+            } else {
+                if (COUNT) cnt.shaded_hits++;
+                Hit h;
+                h.t = ha.x;
+                h.u = ha.y;
+                h.v = ha.z;
+                h.tri = __float_as_uint(ha.w);
+                h.inst = hb & 0x7fffffffu;
+                // the hit instance's local ray: the expression ray_trace_tlas evaluates (main.glsl:319-320)
+                const RefInstance& b = sh.instances[h.inst];
+                h.lo = xform_point(b.inverse_transform, ray.o);
+                h.ld = xform_dir(b.inverse_transform, ray.d);
+                const Shading s = get_shading_data(sh, h, (hb >> 31) != 0u);
+                radiance = radiance + throughput * s.emission;
+                if (bounce == 0 && (int)f == fp.n_frames - 1) wb.first_depth[slot] = length3(s.position - ray.o);
+                if (bounce < fp.max_bounces) alive = bounce_step(s, sx, sy, ray, throughput);
+            }
+            wb.rad[p] = make_float4(radiance.x, radiance.y, radiance.z, __uint_as_float(sy));
+            if (alive) {
+                wb.thr[p] = make_float4(throughput.x, throughput.y, throughput.z, __uint_as_float(sx));
+                no = make_float4(ray.o.x, ray.o.y, ray.o.z, 0.0f);
+                nd = make_float4(ray.d.x, ray.d.y, ray.d.z, __uint_as_float(p));
+            }
+        }
+        // active-ray packing: wave ballot + prefix popcount; wave totals and the running base in LDS
+        const unsigned long long m = __ballot(alive);
+        if (lane == 0) wave_count[wave] = (uint32_t)__popcll(m);
+        __syncthreads();
+        uint32_t my_base = s_out_base;
+        for (int w = 0; w < wave; w++) my_base += wave_count[w];
+        if (alive) {
+            const size_t j = seg_base + my_base + lanes_below(m, lane);
+            wb.ray_o[out][j] = no;
+            wb.ray_d[out][j] = nd;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t tot = 0;
+            for (int w = 0; w < kBlock / 64; w++) tot += wave_count[w];
+            s_out_base += tot;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) wb.qcount[(size_t)(bounce + 1) * kSegments + seg] = s_out_base;
+    if (COUNT) flush_counters(cnt, counters);
+}
+
+// ---- per pixel: frames in order -> accumulation buffer, display image, depth ----------------------------------
+
+__global__ __launch_bounds__(kBlock) void wf2_accumulate(Wf2Buffers wb, Wf2Dims dm, FrameParams fp, RefCamera cam,
+                                                         float4* __restrict__ accum, uint32_t* __restrict__ ldr,
+                                                         float* __restrict__ depth_out)
+{
+    const uint32_t slot = blockIdx.x * kBlock + threadIdx.x;
+    if (slot >= dm.slots_per_frame) return;
+    int px, ly;
+    slot_to_pixel(slot, dm, px, ly);
+    if (px >= fp.width || ly >= fp.local_rows) return;
+    const size_t idx = (size_t)ly * fp.width + px;
+    // fp.frame_count = ProgressiveRendering frame_count of the FIRST frame of this render
+    f3 sum = mk3(0.0f, 0.0f, 0.0f);
+    bool have_prev = fp.frame_count > 1;
+    if (have_prev) {
+        const float4 prev = accum[idx];
+        sum = mk3(prev.x, prev.y, prev.z);
+    }
+    for (int f = 0; f < fp.n_frames; f++) {
+        const float4 r = wb.rad[(size_t)f * dm.slots_per_frame + slot];
+        f3 cur = mk3(r.x, r.y, r.z);
+        if (fp.accum_mode == 0)  // rgba8 store of main.glsl:434, load of progressive_rendering.glsl:33
+            cur = mk3(from_unorm8(unorm8(cur.x)), from_unorm8(unorm8(cur.y)), from_unorm8(unorm8(cur.z)));
+        sum = have_prev ? cur + sum : cur;  // progressive_rendering.glsl:34-36
+        have_prev = true;
+    }
+    if (fp.n_frames > 0) {
+        accum[idx] = make_float4(sum.x, sum.y, sum.z, 1.0f);
+        const float fc = (float)(fp.frame_count + (uint32_t)fp.n_frames - 1u);
+        const f3 col = aces_film(mk3(sum.x / fc, sum.y / fc, sum.z / fc) * 1.0f);
+        ldr[idx] = unorm8(col.x) | (unorm8(col.y) << 8) | (unorm8(col.z) << 16) | 0xFF000000u;
+        if (depth_out) {
+            const float dist = wb.first_depth[slot];
+            depth_out[idx] = cam.far_ / (cam.far_ - cam.near_) * (1.0f - cam.near_ / dist);  // main.glsl:432
+        }
+    }
+}
+
+Wf2Dims make_dims(int width, int local_rows, int n_frames)
+{
+    Wf2Dims dm;
+    dm.tiles_x = (width + 7) / 8;
+    dm.tiles_y = (local_rows + 7) / 8;
+    dm.tiles_per_frame = (uint32_t)dm.tiles_x * (uint32_t)dm.tiles_y;
+    dm.slots_per_frame = dm.tiles_per_frame * 64u;
+    dm.n_chunks = dm.tiles_per_frame * (uint32_t)n_frames;
+    dm.seg_cap = ((dm.n_chunks + kSegments - 1u) / kSegments) * 64u;
+    return dm;
+}
+
+}  // namespace
+
+uint32_t wf2_segments() { return kSegments; }
+
+size_t wf2_workspace_bytes(int width, int local_rows, int n_frames, int max_bounces)
+{
+    const Wf2Dims dm = make_dims(width, local_rows, n_frames);
+    const size_t q = (size_t)dm.seg_cap * kSegments;                  // queue entries
+    const size_t paths = (size_t)dm.slots_per_frame * (size_t)n_frames;
+    size_t b = 0;
+    b += q * sizeof(float4) * 4;    // two ray queues (o, d)
+    b += q * sizeof(float4);        // hit_a
+    b += q * sizeof(uint32_t);      // hit_b
+    b += paths * sizeof(float4) * 2;  // thr, rad
+    b += (size_t)dm.slots_per_frame * sizeof(float);
+    b += (size_t)(max_bounces + 2) * kSegments * sizeof(uint32_t);
+    return b + 16 * 256;
+}
+
+void launch_wf2_render(hipStream_t stream, const DeviceScene& ds, const FrameParams& fp, const RefCamera& cam, void* workspace,
+                       float4* accum, uint32_t* ldr, float* depth, DevCounters* counters, hipEvent_t* trace_events)
+{
+    const Wf2Dims dm = make_dims(fp.width, fp.local_rows, fp.n_frames);
+    if (dm.n_chunks == 0) return;
+    const size_t q = (size_t)dm.seg_cap * kSegments;
+    const size_t paths = (size_t)dm.slots_per_frame * (size_t)fp.n_frames;
+    char* w = reinterpret_cast<char*>(workspace);
+    auto carve = [&](size_t bytes) {
+        void* p = w;
+        w += (bytes + 255) & ~(size_t)255;
+        return p;
+    };
+    Wf2Buffers wb;
+    const int nq = fp.max_bounces + 2;
+    wb.qcount = (uint32_t*)carve((size_t)nq * kSegments * sizeof(uint32_t));
+    wb.ray_o[0] = (float4*)carve(q * sizeof(float4));
+    wb.ray_o[1] = (float4*)carve(q * sizeof(float4));
+    wb.ray_d[0] = (float4*)carve(q * sizeof(float4));
+    wb.ray_d[1] = (float4*)carve(q * sizeof(float4));
+    wb.hit_a = (float4*)carve(q * sizeof(float4));
+    wb.hit_b = (uint32_t*)carve(q * sizeof(uint32_t));
+    wb.thr = (float4*)carve(paths * sizeof(float4));
+    wb.rad = (float4*)carve(paths * sizeof(float4));
+    wb.first_depth = (float*)carve((size_t)dm.slots_per_frame * sizeof(float));
+
+    WideSceneDev sc;
+    sc.blas_nodes = ds.blas_nodes;
+    sc.tris = ds.wide_tris;
+    sc.tlas_nodes = ds.tlas_nodes;
+    sc.instances = ds.wide_instances;
+    sc.tlas_root = ds.tlas_root;
+    sc.n_instances = ds.n_instances;
+    const SceneShading sh = ds.shading();
+    const dim3 grid(kSegments), block(kBlock);
+
+    // every queue size is written by its producer kernel; no memset needed
+    if (trace_events) (void)hipEventRecord(trace_events[0], stream);
+    if (counters) hipLaunchKernelGGL(wf2_primary<true>, grid, block, 0, stream, sc, wb, dm, fp, cam, counters);
+    else hipLaunchKernelGGL(wf2_primary<false>, grid, block, 0, stream, sc, wb, dm, fp, cam, counters);
+    if (trace_events) (void)hipEventRecord(trace_events[1], stream);
+    for (int b = 0; b <= fp.max_bounces; b++) {
+        if (counters) hipLaunchKernelGGL(wf2_shade<true>, grid, block, 0, stream, sh, wb, dm, fp, cam, b, counters);
+        else hipLaunchKernelGGL(wf2_shade<false>, grid, block, 0, stream, sh, wb, dm, fp, cam, b, counters);
+        if (b == fp.max_bounces) break;
+        if (trace_events) (void)hipEventRecord(trace_events[2 * (b + 1)], stream);
+        if (counters) hipLaunchKernelGGL(wf2_trace<true>, grid, block, 0, stream, sc, wb, dm, b + 1, counters);
+        else hipLaunchKernelGGL(wf2_trace<false>, grid, block, 0, stream, sc, wb, dm, b + 1, counters);
+        if (trace_events) (void)hipEventRecord(trace_events[2 * (b + 1) + 1], stream);
+    }
+    const uint32_t ablocks = (dm.slots_per_frame + kBlock - 1) / kBlock;
+    hipLaunchKernelGGL(wf2_accumulate, dim3(ablocks), block, 0, stream, wb, dm, fp, cam, accum, ldr, depth);
+}
+
+}  // namespace jpt

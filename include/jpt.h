@@ -147,7 +147,8 @@ int jpt_set_params(jpt_ctx *ctx, int32_t width, int32_t height, int32_t max_boun
  *   WAVEFRONT          queue-based path tracer over the flattened 64-byte-node layout (default, fast);
  *   REFERENCE_LAYOUT   one thread per pixel straight over the six reference-layout buffers, node for node
  *                      as main.glsl:270-350 (audit route). */
-enum { JPT_KERNEL_WAVEFRONT = 0, JPT_KERNEL_REFERENCE_LAYOUT = 1 };
+enum { JPT_KERNEL_WAVEFRONT = 0, JPT_KERNEL_REFERENCE_LAYOUT = 1,
+       JPT_KERNEL_WAVEFRONT_V1 = 2 /* earlier wavefront pipeline without lane refill, kept for A/B timing */ };
 int jpt_set_kernel(jpt_ctx *ctx, int32_t variant);
 
 /* Multi-GPU screen partition (no reference counterpart): this context renders the
