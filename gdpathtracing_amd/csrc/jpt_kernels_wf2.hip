@@ -77,7 +77,8 @@ __global__ __launch_bounds__(kBlock) void wf2_primary(WideSceneDev sc, Wf2Buffer
         s_out = 0;
     }
     __syncthreads();
-    int32_t* my_stack = &stack[threadIdx.x];
+    int32_t spill[kStackSpill];
+    const typename Traversal<COUNT>::Stack my_stack{&stack[threadIdx.x], spill};
     const size_t seg_base = (size_t)seg * dm.seg_cap;
     DevCounters cnt = {};
     Traversal<COUNT> tr;
@@ -155,7 +156,8 @@ __global__ __launch_bounds__(kBlock) void wf2_trace(WideSceneDev sc, Wf2Buffers 
     if (n == 0) return;
     if (threadIdx.x == 0) s_cursor = 0;
     __syncthreads();
-    int32_t* my_stack = &stack[threadIdx.x];
+    int32_t spill[kStackSpill];
+    const typename Traversal<COUNT>::Stack my_stack{&stack[threadIdx.x], spill};
     const size_t seg_base = (size_t)seg * dm.seg_cap;
     const float4* __restrict__ qo = wb.ray_o[bounce & 1] + seg_base;
     const float4* __restrict__ qd = wb.ray_d[bounce & 1] + seg_base;

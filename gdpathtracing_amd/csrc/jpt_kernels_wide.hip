@@ -30,9 +30,11 @@ __device__ __forceinline__ void trace_ray(const WideSceneDev& sc, const f3 wo, c
                                           int32_t* __restrict__ lds_stack, DevCounters& cnt)
 {
     (void)wrD;
+    int32_t spill[kStackSpill];
+    const typename Traversal<COUNT>::Stack st{lds_stack, spill};
     Traversal<COUNT> tr;
     tr.begin(sc, wo, wd);
-    while (tr.step(sc, lds_stack, cnt)) {
+    while (tr.step(sc, st, cnt)) {
     }
     hit = tr.hit;
 }

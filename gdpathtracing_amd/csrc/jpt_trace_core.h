@@ -54,19 +54,25 @@ struct Traversal {
     int sp;
     uint32_t cur_inst;
     bool in_blas, have;
-    int32_t spill[kStackSpill];
 
-    __device__ __forceinline__ void push(int32_t* __restrict__ lds, int32_t v)
+    // The stack: entries 0..kStackLds-1 in LDS (`lds` = this lane's column), deeper ones in `spill`, a
+    // per-lane scratch array owned by the kernel (kept OUT of this struct so the struct stays in registers).
+    struct Stack {
+        int32_t* __restrict__ lds;
+        int32_t* __restrict__ spill;
+    };
+
+    __device__ __forceinline__ void push(const Stack& st, int32_t v)
     {
-        if (sp < kStackLds) lds[sp * kTraceBlock] = v;
-        else if (sp < kStackLds + kStackSpill) spill[sp - kStackLds] = v;
+        if (sp < kStackLds) st.lds[sp * kTraceBlock] = v;
+        else if (sp < kStackLds + kStackSpill) st.spill[sp - kStackLds] = v;
         sp++;
     }
-    __device__ __forceinline__ int32_t pop(int32_t* __restrict__ lds)
+    __device__ __forceinline__ int32_t pop(const Stack& st)
     {
         sp--;
-        if (sp < kStackLds) return lds[sp * kTraceBlock];
-        if (sp < kStackLds + kStackSpill) return spill[sp - kStackLds];
+        if (sp < kStackLds) return st.lds[sp * kTraceBlock];
+        if (sp < kStackLds + kStackSpill) return st.spill[sp - kStackLds];
         return kSentinel;
     }
 
@@ -89,7 +95,7 @@ struct Traversal {
     }
 
     // Advances by one record.  Returns false when the walk is complete (hit holds the closest hit or t = 1e9).
-    __device__ __forceinline__ bool step(const WideSceneDev& sc, int32_t* __restrict__ lds, DevCounters& cnt)
+    __device__ __forceinline__ bool step(const WideSceneDev& sc, const Stack& lds, DevCounters& cnt)
     {
         if (!have) {
             if (sp == 0) return false;
