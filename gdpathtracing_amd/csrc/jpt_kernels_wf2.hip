@@ -16,6 +16,8 @@
 // Tracing kernels keep every lane busy: a lane whose ray is finished takes the next ray of the block's
 // segment (cursor in LDS) while its neighbours keep walking -- the wave never waits for its slowest ray.
 // Per-lane traversal stacks live in LDS (24 entries x 256 lanes, deeper levels spill to scratch).
+#include <cstdlib>
+
 #include "jpt_trace_core.h"
 
 namespace jpt {
@@ -24,8 +26,29 @@ namespace {
 
 constexpr int kBlock = kTraceBlock;
 constexpr uint32_t kSegments = 256u * 6u;  // persistent grid: 6 blocks of 256 threads per CU (24 KiB LDS each)
-constexpr int kRefillIdle = 16;            // refill when at least this many lanes of a wave are idle
-constexpr int kStepsPerRound = 4;          // traversal steps between two refill checks
+struct WfTune {
+    int refill_idle;     // refill when at least this many lanes of a wave are idle
+    int node_min_lanes;  // leave the node loop when fewer lanes than this still descend
+};
+
+// One round of the walk for every active lane of the wave, "while-while" style so that lanes in different
+// states do not serialise each other's code: (1) a tight loop of internal-record steps (lanes that reach a
+// leaf wait), (2) triangle leaves, (3) instance entries.  Returns true for lanes whose walk is complete.
+template <bool COUNT>
+__device__ __forceinline__ bool walk_round(Traversal<COUNT>& tr, bool active, const WideSceneDev& sc,
+                                           const typename Traversal<COUNT>::Stack& st, DevCounters& cnt, int kNodeMinLanes)
+{
+    for (int it = 0; it < 64; it++) {
+        if (active && !tr.have && tr.sp > 0) tr.pop_next(st);
+        const bool want = active && tr.wants_node();
+        const unsigned long long m = __ballot(want);
+        if (m == 0 || (it > 0 && __popcll(m) < kNodeMinLanes)) break;
+        if (want) tr.node_step(sc, st, cnt);
+    }
+    if (active && tr.wants_leaf()) tr.leaf_step(sc, cnt);
+    if (active && tr.wants_instance()) tr.instance_step(sc, st, cnt);
+    return active && tr.finished();
+}
 
 struct Wf2Buffers {
     float4* ray_o[2];   // queue entry: origin.xyz
@@ -63,7 +86,7 @@ __device__ __forceinline__ uint32_t lanes_below(unsigned long long mask, int lan
 
 template <bool COUNT>
 __global__ __launch_bounds__(kBlock) void wf2_primary(WideSceneDev sc, Wf2Buffers wb, Wf2Dims dm, FrameParams fp, RefCamera cam,
-                                                      DevCounters* __restrict__ counters)
+                                                      WfTune tune, DevCounters* __restrict__ counters)
 {
     __shared__ int32_t stack[kStackLds * kBlock];
     __shared__ uint32_t s_cursor, s_out;
@@ -88,7 +111,7 @@ __global__ __launch_bounds__(kBlock) void wf2_primary(WideSceneDev sc, Wf2Buffer
     for (;;) {
         const unsigned long long idle = __ballot(!active);
         const int n_idle = __popcll(idle);
-        if (!exhausted && n_idle >= kRefillIdle) {
+        if (!exhausted && n_idle >= tune.refill_idle) {
             uint32_t start = 0;
             if (lane == 0) start = atomicAdd(&s_cursor, (uint32_t)n_idle);
             start = (uint32_t)__builtin_amdgcn_readfirstlane((int)start);
@@ -118,8 +141,8 @@ __global__ __launch_bounds__(kBlock) void wf2_primary(WideSceneDev sc, Wf2Buffer
             if (exhausted) break;
             continue;
         }
-        for (int k = 0; k < kStepsPerRound; k++) {
-            if (active && !tr.step(sc, my_stack, cnt)) {
+        {
+            if (walk_round<COUNT>(tr, active, sc, my_stack, cnt, tune.node_min_lanes)) {
                 active = false;
                 const uint32_t f = path / dm.slots_per_frame;
                 const bool last_frame = (int)f == fp.n_frames - 1;
@@ -145,7 +168,7 @@ __global__ __launch_bounds__(kBlock) void wf2_primary(WideSceneDev sc, Wf2Buffer
 // ---- bounces >= 1: trace the segment's ray queue ----------------------------------------------------------
 
 template <bool COUNT>
-__global__ __launch_bounds__(kBlock) void wf2_trace(WideSceneDev sc, Wf2Buffers wb, Wf2Dims dm, int bounce,
+__global__ __launch_bounds__(kBlock) void wf2_trace(WideSceneDev sc, Wf2Buffers wb, Wf2Dims dm, int bounce, WfTune tune,
                                                     DevCounters* __restrict__ counters)
 {
     __shared__ int32_t stack[kStackLds * kBlock];
@@ -169,7 +192,7 @@ __global__ __launch_bounds__(kBlock) void wf2_trace(WideSceneDev sc, Wf2Buffers 
     for (;;) {
         const unsigned long long idle = __ballot(!active);
         const int n_idle = __popcll(idle);
-        if (!exhausted && n_idle >= kRefillIdle) {
+        if (!exhausted && n_idle >= tune.refill_idle) {
             uint32_t start = 0;
             if (lane == 0) start = atomicAdd(&s_cursor, (uint32_t)n_idle);
             start = (uint32_t)__builtin_amdgcn_readfirstlane((int)start);
@@ -188,8 +211,8 @@ __global__ __launch_bounds__(kBlock) void wf2_trace(WideSceneDev sc, Wf2Buffers 
             if (exhausted) break;
             continue;
         }
-        for (int k = 0; k < kStepsPerRound; k++) {
-            if (active && !tr.step(sc, my_stack, cnt)) {
+        {
+            if (walk_round<COUNT>(tr, active, sc, my_stack, cnt, tune.node_min_lanes)) {
                 active = false;
                 wb.hit_a[seg_base + my_idx] = make_float4(tr.hit.t, tr.hit.u, tr.hit.v, __uint_as_float(tr.hit.tri));
                 wb.hit_b[seg_base + my_idx] = tr.hit.inst | (tr.hit.front ? 0x80000000u : 0u);
@@ -401,19 +424,25 @@ void launch_wf2_render(hipStream_t stream, const DeviceScene& ds, const FramePar
     sc.n_instances = ds.n_instances;
     const SceneShading sh = ds.shading();
     const dim3 grid(kSegments), block(kBlock);
+    static const WfTune tune = [] {
+        WfTune t{16, 12};
+        if (const char* e = getenv("JPT_REFILL_IDLE")) t.refill_idle = atoi(e);
+        if (const char* e = getenv("JPT_NODE_MIN_LANES")) t.node_min_lanes = atoi(e);
+        return t;
+    }();
 
     // every queue size is written by its producer kernel; no memset needed
     if (trace_events) (void)hipEventRecord(trace_events[0], stream);
-    if (counters) hipLaunchKernelGGL(wf2_primary<true>, grid, block, 0, stream, sc, wb, dm, fp, cam, counters);
-    else hipLaunchKernelGGL(wf2_primary<false>, grid, block, 0, stream, sc, wb, dm, fp, cam, counters);
+    if (counters) hipLaunchKernelGGL(wf2_primary<true>, grid, block, 0, stream, sc, wb, dm, fp, cam, tune, counters);
+    else hipLaunchKernelGGL(wf2_primary<false>, grid, block, 0, stream, sc, wb, dm, fp, cam, tune, counters);
     if (trace_events) (void)hipEventRecord(trace_events[1], stream);
     for (int b = 0; b <= fp.max_bounces; b++) {
         if (counters) hipLaunchKernelGGL(wf2_shade<true>, grid, block, 0, stream, sh, wb, dm, fp, cam, b, counters);
         else hipLaunchKernelGGL(wf2_shade<false>, grid, block, 0, stream, sh, wb, dm, fp, cam, b, counters);
         if (b == fp.max_bounces) break;
         if (trace_events) (void)hipEventRecord(trace_events[2 * (b + 1)], stream);
-        if (counters) hipLaunchKernelGGL(wf2_trace<true>, grid, block, 0, stream, sc, wb, dm, b + 1, counters);
-        else hipLaunchKernelGGL(wf2_trace<false>, grid, block, 0, stream, sc, wb, dm, b + 1, counters);
+        if (counters) hipLaunchKernelGGL(wf2_trace<true>, grid, block, 0, stream, sc, wb, dm, b + 1, tune, counters);
+        else hipLaunchKernelGGL(wf2_trace<false>, grid, block, 0, stream, sc, wb, dm, b + 1, tune, counters);
         if (trace_events) (void)hipEventRecord(trace_events[2 * (b + 1) + 1], stream);
     }
     const uint32_t ablocks = (dm.slots_per_frame + kBlock - 1) / kBlock;

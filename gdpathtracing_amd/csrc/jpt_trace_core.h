@@ -94,101 +94,129 @@ struct Traversal {
         have = sc.n_instances != 0;
     }
 
+    // ---- the three kinds of records, as separate pieces so a kernel can run them in phases ----------------
+
+    __device__ __forceinline__ bool wants_node() const { return have && cur >= 0; }
+    __device__ __forceinline__ bool wants_leaf() const { return have && cur < 0 && in_blas; }
+    __device__ __forceinline__ bool wants_instance() const { return have && cur < 0 && !in_blas; }
+    __device__ __forceinline__ bool finished() const { return !have && sp == 0; }
+
+    // internal record: both children's boxes in one 64-byte fetch; descends into the nearer valid child
+    __device__ __forceinline__ void node_step(const WideSceneDev& sc, const Stack& st, DevCounters& cnt)
+    {
+        const WideNode* n = (in_blas ? sc.blas_nodes : sc.tlas_nodes) + cur;
+        const float4 a = ld4(&n->lmin[0]);  // lmin.xyz lmax.x
+        const float4 b = ld4(&n->lmax[1]);  // lmax.yz rmin.xy
+        const float4 c = ld4(&n->rmin[2]);  // rmin.z rmax.xyz
+        const float4 e = ld4(&n->left);     // left right pad pad
+        if (COUNT) {
+            if (in_blas) cnt.blas_expand++;
+            else cnt.tlas_expand++;
+        }
+        const float d1 = slab(o, rD, a.x, a.y, a.z, a.w, b.x, b.y);
+        const float d2 = slab(o, rD, b.z, b.w, c.x, c.y, c.z, c.w);
+        const int32_t left = __float_as_int(e.x), right = __float_as_int(e.y);
+        const bool lv = d1 < hit.t, rv = d2 < hit.t;
+        // `if (d1 < d2) {push right; push left} else {push left; push right}` then pop (main.glsl:293-299)
+        const bool left_first = d1 < d2;
+        const int32_t near_ref = left_first ? left : right, far_ref = left_first ? right : left;
+        const bool near_v = left_first ? lv : rv, far_v = left_first ? rv : lv;
+        have = false;
+        if (near_v) {
+            if (far_v) push(st, far_ref);
+            cur = near_ref;
+            have = true;
+        } else if (far_v) {
+            cur = far_ref;
+            have = true;
+        }
+    }
+
+    // triangle leaf (main.glsl:280-283, intersectTriangle :224-257)
+    __device__ __forceinline__ void leaf_step(const WideSceneDev& sc, DevCounters& cnt)
+    {
+        const uint32_t bits = (uint32_t)~cur;
+        const uint32_t first = bits & kLeafFirstMask;
+        const uint32_t count = (bits >> kLeafCountShift) + 1u;
+        have = false;
+        for (uint32_t i = 0; i < count; i++) {
+            const uint32_t ti = first + i;
+            const WideTri* tp = sc.tris + ti;
+            const float4 q0 = ld4(&tp->v0[0]);
+            const float4 q1 = ld4(&tp->e1[0]);
+            const float4 q2 = ld4(&tp->e2[0]);
+            if (COUNT) cnt.tri_tests++;
+            const f3 v0 = mk3(q0.x, q0.y, q0.z), edge1 = mk3(q1.x, q1.y, q1.z), edge2 = mk3(q2.x, q2.y, q2.z);
+            const f3 pvec = cross3(d, edge2);
+            const float det = dot3(edge1, pvec);
+            if (__builtin_fabsf(det) < 1e-5f) continue;
+            const float invDet = 1.0f / det;
+            const f3 tvec = o - v0;
+            const float u = dot3(tvec, pvec) * invDet;
+            if (u < 0.0f || u > 1.0f) continue;
+            const f3 qvec = cross3(tvec, edge1);
+            const float v = dot3(d, qvec) * invDet;
+            if (v < 0.0f || u + v > 1.0f) continue;
+            const float t = dot3(edge2, qvec) * invDet;
+            if (t < 0.0f || t > hit.t) continue;
+            hit.t = t;
+            hit.u = u;
+            hit.v = v;
+            hit.tri = ti;
+            hit.inst = cur_inst;
+            hit.front = dot3(cross3(edge1, edge2), d) > 0.0f;
+        }
+    }
+
+    // TLAS leaf: enter the instance (main.glsl:316-322)
+    __device__ __forceinline__ void instance_step(const WideSceneDev& sc, const Stack& st, DevCounters& cnt)
+    {
+        cur_inst = (uint32_t)~cur;
+        const WideInstance* ip = sc.instances + cur_inst;
+        const float4 m0 = ld4(&ip->inv[0]);
+        const float4 m1 = ld4(&ip->inv[4]);
+        const float4 m2 = ld4(&ip->inv[8]);
+        const int32_t root = ip->root;
+        if (COUNT) cnt.inst_visits++;
+        // columns c0 = (m0.x m0.y m0.z) c1 = (m0.w m1.x m1.y) c2 = (m1.z m1.w m2.x) c3 = (m2.y m2.z m2.w)
+        o = mk3(m0.x * wo.x + m0.w * wo.y + m1.z * wo.z + m2.y, m0.y * wo.x + m1.x * wo.y + m1.w * wo.z + m2.z,
+                m0.z * wo.x + m1.y * wo.y + m2.x * wo.z + m2.w);
+        d = mk3(m0.x * wd.x + m0.w * wd.y + m1.z * wd.z, m0.y * wd.x + m1.x * wd.y + m1.w * wd.z,
+                m0.z * wd.x + m1.y * wd.y + m2.x * wd.z);
+        rD = rcp3(d);
+        in_blas = true;
+        push(st, kSentinel);
+        cur = root;
+        have = true;
+    }
+
+    // take the next record off the stack (precondition: !have && sp > 0).  Leaving an instance restores
+    // the world ray.  Afterwards either `have` or finished().
+    __device__ __forceinline__ void pop_next(const Stack& st)
+    {
+        cur = pop(st);
+        if (cur == kSentinel) {
+            o = wo;
+            d = wd;
+            rD = rcp3(wd);
+            in_blas = false;
+            if (sp == 0) return;
+            cur = pop(st);
+        }
+        have = true;
+    }
+
     // Advances by one record.  Returns false when the walk is complete (hit holds the closest hit or t = 1e9).
-    __device__ __forceinline__ bool step(const WideSceneDev& sc, const Stack& lds, DevCounters& cnt)
+    __device__ __forceinline__ bool step(const WideSceneDev& sc, const Stack& st, DevCounters& cnt)
     {
         if (!have) {
             if (sp == 0) return false;
-            cur = pop(lds);
-            if (cur == kSentinel) {  // back to the TLAS level
-                o = wo;
-                d = wd;
-                rD = rcp3(wd);
-                in_blas = false;
-                if (sp == 0) return false;
-                cur = pop(lds);
-            }
+            pop_next(st);
+            if (!have) return false;
         }
-        have = false;
-        if (cur >= 0) {
-            // ---- internal record: both children's boxes in one 64-byte fetch
-            const WideNode* n = (in_blas ? sc.blas_nodes : sc.tlas_nodes) + cur;
-            const float4 a = ld4(&n->lmin[0]);  // lmin.xyz lmax.x
-            const float4 b = ld4(&n->lmax[1]);  // lmax.yz rmin.xy
-            const float4 c = ld4(&n->rmin[2]);  // rmin.z rmax.xyz
-            const float4 e = ld4(&n->left);     // left right pad pad
-            if (COUNT) {
-                if (in_blas) cnt.blas_expand++;
-                else cnt.tlas_expand++;
-            }
-            const float d1 = slab(o, rD, a.x, a.y, a.z, a.w, b.x, b.y);
-            const float d2 = slab(o, rD, b.z, b.w, c.x, c.y, c.z, c.w);
-            const int32_t left = __float_as_int(e.x), right = __float_as_int(e.y);
-            const bool lv = d1 < hit.t, rv = d2 < hit.t;
-            // `if (d1 < d2) {push right; push left} else {push left; push right}` then pop (main.glsl:293-299)
-            const bool left_first = d1 < d2;
-            const int32_t near_ref = left_first ? left : right, far_ref = left_first ? right : left;
-            const bool near_v = left_first ? lv : rv, far_v = left_first ? rv : lv;
-            if (near_v) {
-                if (far_v) push(lds, far_ref);
-                cur = near_ref;
-                have = true;
-            } else if (far_v) {
-                cur = far_ref;
-                have = true;
-            }
-        } else if (in_blas) {
-            // ---- triangle leaf (main.glsl:280-283)
-            const uint32_t bits = (uint32_t)~cur;
-            const uint32_t first = bits & kLeafFirstMask;
-            const uint32_t count = (bits >> kLeafCountShift) + 1u;
-            for (uint32_t i = 0; i < count; i++) {
-                const uint32_t ti = first + i;
-                const WideTri* tp = sc.tris + ti;
-                const float4 q0 = ld4(&tp->v0[0]);
-                const float4 q1 = ld4(&tp->e1[0]);
-                const float4 q2 = ld4(&tp->e2[0]);
-                if (COUNT) cnt.tri_tests++;
-                const f3 v0 = mk3(q0.x, q0.y, q0.z), edge1 = mk3(q1.x, q1.y, q1.z), edge2 = mk3(q2.x, q2.y, q2.z);
-                const f3 pvec = cross3(d, edge2);
-                const float det = dot3(edge1, pvec);
-                if (__builtin_fabsf(det) < 1e-5f) continue;
-                const float invDet = 1.0f / det;
-                const f3 tvec = o - v0;
-                const float u = dot3(tvec, pvec) * invDet;
-                if (u < 0.0f || u > 1.0f) continue;
-                const f3 qvec = cross3(tvec, edge1);
-                const float v = dot3(d, qvec) * invDet;
-                if (v < 0.0f || u + v > 1.0f) continue;
-                const float t = dot3(edge2, qvec) * invDet;
-                if (t < 0.0f || t > hit.t) continue;
-                hit.t = t;
-                hit.u = u;
-                hit.v = v;
-                hit.tri = ti;
-                hit.inst = cur_inst;
-                hit.front = dot3(cross3(edge1, edge2), d) > 0.0f;
-            }
-        } else {
-            // ---- TLAS leaf: enter the instance (main.glsl:316-322)
-            cur_inst = (uint32_t)~cur;
-            const WideInstance* ip = sc.instances + cur_inst;
-            const float4 m0 = ld4(&ip->inv[0]);
-            const float4 m1 = ld4(&ip->inv[4]);
-            const float4 m2 = ld4(&ip->inv[8]);
-            const int32_t root = ip->root;
-            if (COUNT) cnt.inst_visits++;
-            // columns c0 = (m0.x m0.y m0.z) c1 = (m0.w m1.x m1.y) c2 = (m1.z m1.w m2.x) c3 = (m2.y m2.z m2.w)
-            o = mk3(m0.x * wo.x + m0.w * wo.y + m1.z * wo.z + m2.y, m0.y * wo.x + m1.x * wo.y + m1.w * wo.z + m2.z,
-                    m0.z * wo.x + m1.y * wo.y + m2.x * wo.z + m2.w);
-            d = mk3(m0.x * wd.x + m0.w * wd.y + m1.z * wd.z, m0.y * wd.x + m1.x * wd.y + m1.w * wd.z,
-                    m0.z * wd.x + m1.y * wd.y + m2.x * wd.z);
-            rD = rcp3(d);
-            in_blas = true;
-            push(lds, kSentinel);
-            cur = root;
-            have = true;
-        }
+        if (cur >= 0) node_step(sc, st, cnt);
+        else if (in_blas) leaf_step(sc, cnt);
+        else instance_step(sc, st, cnt);
         return true;
     }
 };
