@@ -10,7 +10,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libjpt_hip.so")
+LIB_PATH = os.environ.get("JPT_LIB", os.path.join(_HERE, "libjpt_hip.so"))  # JPT_LIB: A/B builds (tools/ab.sh)
 CSRC = os.path.join(_HERE, "csrc")
 
 OK = 0

@@ -25,7 +25,7 @@ namespace jpt {
 namespace {
 
 constexpr int kBlock = kTraceBlock;
-constexpr uint32_t kSegments = 256u * 6u;  // persistent grid: 6 blocks of 256 threads per CU (24 KiB LDS each)
+constexpr uint32_t kSegments = 256u * JPT_WAVES_PER_SIMD;  // persistent grid: one 256-thread block per CU per wave/SIMD
 struct WfTune {
     int refill_idle;     // refill when at least this many lanes of a wave are idle
     int node_min_lanes;  // leave the node loop when fewer lanes than this still descend
@@ -85,7 +85,7 @@ __device__ __forceinline__ uint32_t lanes_below(unsigned long long mask, int lan
 // ---- bounce 0: generate + trace ------------------------------------------------------------------------
 
 template <bool COUNT>
-__global__ __launch_bounds__(kBlock) void wf2_primary(WideSceneDev sc, Wf2Buffers wb, Wf2Dims dm, FrameParams fp, RefCamera cam,
+__global__ __launch_bounds__(kBlock, JPT_WAVES_PER_SIMD) void wf2_primary(WideSceneDev sc, Wf2Buffers wb, Wf2Dims dm, FrameParams fp, RefCamera cam,
                                                       WfTune tune, DevCounters* __restrict__ counters)
 {
     __shared__ int32_t stack[kStackLds * kBlock];
@@ -168,7 +168,7 @@ __global__ __launch_bounds__(kBlock) void wf2_primary(WideSceneDev sc, Wf2Buffer
 // ---- bounces >= 1: trace the segment's ray queue ----------------------------------------------------------
 
 template <bool COUNT>
-__global__ __launch_bounds__(kBlock) void wf2_trace(WideSceneDev sc, Wf2Buffers wb, Wf2Dims dm, int bounce, WfTune tune,
+__global__ __launch_bounds__(kBlock, JPT_WAVES_PER_SIMD) void wf2_trace(WideSceneDev sc, Wf2Buffers wb, Wf2Dims dm, int bounce, WfTune tune,
                                                     DevCounters* __restrict__ counters)
 {
     __shared__ int32_t stack[kStackLds * kBlock];

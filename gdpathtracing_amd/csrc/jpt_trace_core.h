@@ -12,7 +12,13 @@
 namespace jpt {
 
 constexpr int kTraceBlock = 256;
-constexpr int kStackLds = 24;              // per-lane entries kept in LDS ([entry][lane], conflict-free)
+#ifndef JPT_STACK_LDS
+#define JPT_STACK_LDS 24
+#endif
+#ifndef JPT_WAVES_PER_SIMD
+#define JPT_WAVES_PER_SIMD 6
+#endif
+constexpr int kStackLds = JPT_STACK_LDS;              // per-lane entries kept in LDS ([entry][lane], conflict-free)
 constexpr int kStackSpill = 72;            // deeper entries go to scratch (rare)
 constexpr int32_t kSentinel = 0x7fffffff;  // "leave the instance" marker on the stack
 
