@@ -13,13 +13,13 @@ namespace jpt {
 
 constexpr int kTraceBlock = 256;
 #ifndef JPT_STACK_LDS
-#define JPT_STACK_LDS 24
+#define JPT_STACK_LDS 20
 #endif
 #ifndef JPT_WAVES_PER_SIMD
-#define JPT_WAVES_PER_SIMD 6
+#define JPT_WAVES_PER_SIMD 7
 #endif
 constexpr int kStackLds = JPT_STACK_LDS;              // per-lane entries kept in LDS ([entry][lane], conflict-free)
-constexpr int kStackSpill = 72;            // deeper entries go to scratch (rare)
+constexpr int kStackSpill = 76;            // deeper entries go to scratch (rare)
 constexpr int32_t kSentinel = 0x7fffffff;  // "leave the instance" marker on the stack
 
 struct WideSceneDev {

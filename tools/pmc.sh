@@ -8,8 +8,8 @@ cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 ARGS="bench.py --steps 5 --warmup 2 --no-cpu-baseline $*"
 mkdir -p gpurun_out/prof
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof/trace -- python3 $ARGS > gpurun_out/prof/trace.log 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/prof/pmc_fetch -- python3 $ARGS > gpurun_out/prof/pmc_fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/prof/pmc_write -- python3 $ARGS > gpurun_out/prof/pmc_write.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof/trace -- python3 $ARGS > gpurun_out/prof/trace.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/prof/pmc_fetch -- python3 $ARGS > gpurun_out/prof/pmc_fetch.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/prof/pmc_write -- python3 $ARGS > gpurun_out/prof/pmc_write.log 2>&1
 grep '^{' gpurun_out/prof/trace.log | tail -1 > gpurun_out/prof/bench.json
 ls -R gpurun_out/prof | head -40
