@@ -181,7 +181,9 @@ def main():
         if default_run and os.path.exists(args.pmc_json):
             try:
                 pj = json.load(open(args.pmc_json))
-                traffic = pj[dom]["hbm_bytes_per_launch"]
+                doms = ["wf2_primary", "wf2_trace"] if args.kernel == "wavefront" else [dom]
+                traffic = int(sum(pj[k]["hbm_bytes_per_launch"] * pj[k]["launches"] for k in doms) /
+                              sum(pj[k]["launches"] for k in doms))
                 traffic_src = os.path.relpath(args.pmc_json, ROOT) + ": (2*FETCH_SIZE + WRITE_SIZE) KiB per launch, separate --pmc passes"
             except Exception:
                 traffic = None

@@ -665,11 +665,16 @@ static void *job_main(void *arg)
     return NULL;
 }
 
-typedef struct { job_t *jobs; int32_t first, step, n; } worker_t;
+typedef struct { job_t *jobs; int32_t first, step, n; volatile int32_t *next; } worker_t;
 static void *worker_main(void *arg)
 {
     worker_t *w = (worker_t *)arg;
-    for (int32_t s = w->first; s < w->n; s += w->step) job_main(&w->jobs[s]);
+    /* strips are taken from a shared counter: sky strips cost ~100x less than strips through the box */
+    for (;;) {
+        int32_t s = __sync_fetch_and_add(w->next, 1);
+        if (s >= w->n) break;
+        job_main(&w->jobs[s]);
+    }
     return NULL;
 }
 
@@ -682,7 +687,7 @@ int32_t jpto_render(const jpto_scene_view *scene, const jpto_camera *camera, int
         n_threads = n > 0 ? (int32_t)n : 1;
     }
     /* rows are dealt in small interleaved strips so threads get similar work */
-    const int32_t strip = 1;
+    const int32_t strip = 2;
     int32_t n_strips = (height + strip - 1) / strip;
     if (n_threads > n_strips) n_threads = n_strips > 0 ? n_strips : 1;
     job_t *jobs = (job_t *)calloc((size_t)n_strips, sizeof(job_t));
@@ -706,7 +711,9 @@ int32_t jpto_render(const jpto_scene_view *scene, const jpto_camera *camera, int
     /* worker w handles strips w, w+T, w+2T, ... */
     worker_t *ws = (worker_t *)calloc((size_t)n_threads, sizeof(worker_t));
     pthread_t *tids = (pthread_t *)calloc((size_t)n_threads, sizeof(pthread_t));
+    volatile int32_t next_strip = 0;
     for (int32_t w = 0; w < n_threads; w++) {
+        ws[w].next = &next_strip;
         ws[w].jobs = jobs;
         ws[w].first = w;
         ws[w].step = n_threads;
