@@ -42,10 +42,13 @@ class Surface(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("frames", C.c_uint64), ("blas_expand", C.c_uint64), ("tri_tests", C.c_uint64),
                 ("tlas_expand", C.c_uint64), ("inst_visits", C.c_uint64), ("shaded_hits", C.c_uint64),
-                ("last_render_ms", C.c_double), ("last_trace_ms", C.c_double), ("last_build_ms", C.c_double)]
+                ("last_render_ms", C.c_double), ("last_trace_ms", C.c_double), ("last_build_ms", C.c_double),
+                ("phase", C.c_uint64 * 8)]
 
     def as_dict(self):
-        return {n: getattr(self, n) for n, _ in self._fields_}
+        d = {n: getattr(self, n) for n, _ in self._fields_}
+        d["phase"] = list(self.phase)
+        return d
 
 
 def build(force: bool = False, verbose: bool = False) -> str:

@@ -323,6 +323,7 @@ int do_render(jpt_ctx* c, int32_t n_frames, uint32_t first_frame_index, bool cou
             c->stats.tlas_expand = h.tlas_expand;
             c->stats.inst_visits = h.inst_visits;
             c->stats.shaded_hits = h.shaded_hits;
+            for (int k = 0; k < 8; k++) c->stats.phase[k] = h.phase[k];
         }
     }
     return JPT_OK;

@@ -13,6 +13,10 @@ constexpr int kStripRows = 8;  // screen partition granule (jpt_set_partition)
 
 struct DevCounters {  // SURVEY.md 8(d) event counters
     unsigned long long rays, blas_expand, tri_tests, tlas_expand, inst_visits, shaded_hits;
+    // wave-level phase statistics of the tracing kernels (counting builds only): how many times a phase ran
+    // in a wave and how many lanes took part -- [0] rounds, [1] node iterations, [2] lanes in them, [3] leaf
+    // phases, [4] lanes in them, [5] instance phases, [6] lanes in them, [7] refills
+    unsigned long long phase[8];
 };
 
 struct FrameParams {
@@ -96,6 +100,8 @@ __device__ __forceinline__ void flush_counters(const DevCounters& c, DevCounters
     if (c.tlas_expand) atomicAdd(&out->tlas_expand, c.tlas_expand);
     if (c.inst_visits) atomicAdd(&out->inst_visits, c.inst_visits);
     if (c.shaded_hits) atomicAdd(&out->shaded_hits, c.shaded_hits);
+    for (int k = 0; k < 8; k++)
+        if (c.phase[k]) atomicAdd(&out->phase[k], c.phase[k]);
 }
 #endif
 

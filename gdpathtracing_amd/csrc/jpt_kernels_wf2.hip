@@ -38,15 +38,34 @@ template <bool COUNT>
 __device__ __forceinline__ bool walk_round(Traversal<COUNT>& tr, bool active, const WideSceneDev& sc,
                                            const typename Traversal<COUNT>::Stack& st, DevCounters& cnt, int kNodeMinLanes)
 {
+    const bool lane0 = (threadIdx.x & 63) == 0;
+    if (COUNT && lane0) cnt.phase[0]++;
     for (int it = 0; it < 64; it++) {
         if (active && !tr.have && tr.sp > 0) tr.pop_next(st);
         const bool want = active && tr.wants_node();
         const unsigned long long m = __ballot(want);
         if (m == 0 || (it > 0 && __popcll(m) < kNodeMinLanes)) break;
+        if (COUNT && lane0) {
+            cnt.phase[1]++;
+            cnt.phase[2] += (unsigned long long)__popcll(m);
+        }
         if (want) tr.node_step(sc, st, cnt);
     }
-    if (active && tr.wants_leaf()) tr.leaf_step(sc, cnt);
-    if (active && tr.wants_instance()) tr.instance_step(sc, st, cnt);
+    const bool wl = active && tr.wants_leaf();
+    const bool wi = active && tr.wants_instance();
+    if (COUNT) {
+        const unsigned long long ml = __ballot(wl), mi = __ballot(wi);
+        if (lane0 && ml) {
+            cnt.phase[3]++;
+            cnt.phase[4] += (unsigned long long)__popcll(ml);
+        }
+        if (lane0 && mi) {
+            cnt.phase[5]++;
+            cnt.phase[6] += (unsigned long long)__popcll(mi);
+        }
+    }
+    if (wl) tr.leaf_step(sc, cnt);
+    if (wi) tr.instance_step(sc, st, cnt);
     return active && tr.finished();
 }
 

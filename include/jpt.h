@@ -83,6 +83,7 @@ typedef struct {
     double   last_render_ms;   /* device time of the last jpt_render (HIP events on the ctx stream) */
     double   last_trace_ms;    /* of which: the path-tracing kernel(s) */
     double   last_build_ms;    /* host time of the last scene commit (builder + flatten + upload) */
+    uint64_t phase[8];         /* counting renders: wave-level phase statistics of the tracing kernels (diagnostic) */
 } jpt_stats;
 
 /* ---- lifetime --------------------------------------------------------------------------------- */
