@@ -73,6 +73,38 @@ __device__ __forceinline__ bool walk_round(Traversal<COUNT>& tr, bool active, co
     return active && tr.finished();
 }
 
+struct Wf2Buffers {
+    float4* ray_o[2];   // queue entry: origin.xyz
+    float4* ray_d[2];   // direction.xyz, w = path id bits
+    float4* hit_a;      // t, u, v, tri bits          (same index as the ray)
+    uint32_t* hit_b;    // inst | front << 31
+    float4* thr;        // per path: throughput.xyz, w = seed.x bits
+    float4* rad;        // per path: radiance.xyz,   w = seed.y bits  ([frame][slot]: also the per-frame output)
+    float* first_depth; // per slot of the LAST frame: distance of the first hit (or far)
+    uint32_t* qcount;   // [max_bounces + 2][kSegments] queue sizes; row b = rays traced in bounce b (b >= 1)
+};
+
+struct Wf2Dims {
+    int32_t tiles_x, tiles_y;
+    uint32_t tiles_per_frame;
+    uint32_t slots_per_frame;  // tiles_per_frame * 64
+    uint32_t n_chunks;         // tiles_per_frame * n_frames
+    uint32_t seg_cap;          // entries per segment
+};
+
+__device__ __forceinline__ void slot_to_pixel(uint32_t slot, const Wf2Dims& dm, int& px, int& ly)
+{
+    const uint32_t tile = slot >> 6, lane = slot & 63u;
+    const uint32_t ty = tile / (uint32_t)dm.tiles_x, tx = tile - ty * (uint32_t)dm.tiles_x;
+    px = (int)(tx * 8u + (lane & 7u));
+    ly = (int)(ty * 8u + (lane >> 3));
+}
+
+__device__ __forceinline__ uint32_t lanes_below(unsigned long long mask, int lane)
+{
+    return (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+}
+
 // ---- bounce 0: generate + trace ------------------------------------------------------------------------
 
 template <bool COUNT>
