@@ -28,48 +28,44 @@ constexpr int kBlock = kTraceBlock;
 constexpr uint32_t kSegments = 256u * JPT_WAVES_PER_SIMD;  // persistent grid: one 256-thread block per CU per wave/SIMD
 struct WfTune {
     int refill_idle;     // refill when at least this many lanes of a wave are idle
-    int turns;           // scheduling turns per round (between two refill checks)
+    int node_min_lanes;  // leave the node loop when fewer lanes than this still descend
 };
 
-// One scheduling round for a wave.  Lanes are in one of three states -- at an internal record, at a triangle,
-// at an instance entry -- and executing a state's code costs the same whether 3 or 60 lanes need it.  So each
-// turn the wave runs the state that most lanes are waiting in (up to `turns` turns per round); lanes in the
-// other states simply wait and their group grows until it is the popular one.  Every ray still sees its own
-// records in its own order, so results do not depend on the schedule.  Returns true for lanes whose walk is
-// complete.
+// One round of the walk for every active lane of the wave, "while-while" style so that lanes in different
+// states do not serialise each other's code: (1) a tight loop of internal-record steps (lanes that reach a
+// leaf wait), (2) triangle leaves, (3) instance entries.  Returns true for lanes whose walk is complete.
 template <bool COUNT>
 __device__ __forceinline__ bool walk_round(Traversal<COUNT>& tr, bool active, const WideSceneDev& sc,
-                                           const typename Traversal<COUNT>::Stack& st, DevCounters& cnt, int turns)
+                                           const typename Traversal<COUNT>::Stack& st, DevCounters& cnt, int kNodeMinLanes)
 {
     const bool lane0 = (threadIdx.x & 63) == 0;
     if (COUNT && lane0) cnt.phase[0]++;
-    for (int it = 0; it < turns; it++) {
+    for (int it = 0; it < 64; it++) {
         if (active && !tr.have && tr.sp > 0) tr.pop_next(st);
-        const bool wn = active && tr.wants_node();
-        const bool wl = active && tr.wants_leaf();
-        const bool wi = active && tr.wants_instance();
-        const int nn = __popcll(__ballot(wn)), nl = __popcll(__ballot(wl)), ni = __popcll(__ballot(wi));
-        if (nn + nl + ni == 0) break;
-        if (nn >= nl && nn >= ni) {
-            if (COUNT && lane0) {
-                cnt.phase[1]++;
-                cnt.phase[2] += (unsigned long long)nn;
-            }
-            if (wn) tr.node_step(sc, st, cnt);
-        } else if (nl >= ni) {
-            if (COUNT && lane0) {
-                cnt.phase[3]++;
-                cnt.phase[4] += (unsigned long long)nl;
-            }
-            if (wl) tr.leaf_one(sc, cnt);
-        } else {
-            if (COUNT && lane0) {
-                cnt.phase[5]++;
-                cnt.phase[6] += (unsigned long long)ni;
-            }
-            if (wi) tr.instance_step(sc, st, cnt);
+        const bool want = active && tr.wants_node();
+        const unsigned long long m = __ballot(want);
+        if (m == 0 || (it > 0 && __popcll(m) < kNodeMinLanes)) break;
+        if (COUNT && lane0) {
+            cnt.phase[1]++;
+            cnt.phase[2] += (unsigned long long)__popcll(m);
+        }
+        if (want) tr.node_step(sc, st, cnt);
+    }
+    const bool wl = active && tr.wants_leaf();
+    const bool wi = active && tr.wants_instance();
+    if (COUNT) {
+        const unsigned long long ml = __ballot(wl), mi = __ballot(wi);
+        if (lane0 && ml) {
+            cnt.phase[3]++;
+            cnt.phase[4] += (unsigned long long)__popcll(ml);
+        }
+        if (lane0 && mi) {
+            cnt.phase[5]++;
+            cnt.phase[6] += (unsigned long long)__popcll(mi);
         }
     }
+    if (wl) tr.leaf_step(sc, cnt);
+    if (wi) tr.instance_step(sc, st, cnt);
     return active && tr.finished();
 }
 
@@ -165,7 +161,7 @@ __global__ __launch_bounds__(kBlock, JPT_WAVES_PER_SIMD) void wf2_primary(WideSc
             continue;
         }
         {
-            if (walk_round<COUNT>(tr, active, sc, my_stack, cnt, tune.turns)) {
+            if (walk_round<COUNT>(tr, active, sc, my_stack, cnt, tune.node_min_lanes)) {
                 active = false;
                 const uint32_t f = path / dm.slots_per_frame;
                 const bool last_frame = (int)f == fp.n_frames - 1;
@@ -235,7 +231,7 @@ __global__ __launch_bounds__(kBlock, JPT_WAVES_PER_SIMD) void wf2_trace(WideScen
             continue;
         }
         {
-            if (walk_round<COUNT>(tr, active, sc, my_stack, cnt, tune.turns)) {
+            if (walk_round<COUNT>(tr, active, sc, my_stack, cnt, tune.node_min_lanes)) {
                 active = false;
                 wb.hit_a[seg_base + my_idx] = make_float4(tr.hit.t, tr.hit.u, tr.hit.v, __uint_as_float(tr.hit.tri));
                 wb.hit_b[seg_base + my_idx] = tr.hit.inst | (tr.hit.front ? 0x80000000u : 0u);
@@ -448,9 +444,9 @@ void launch_wf2_render(hipStream_t stream, const DeviceScene& ds, const FramePar
     const SceneShading sh = ds.shading();
     const dim3 grid(kSegments), block(kBlock);
     static const WfTune tune = [] {
-        WfTune t{16, 8};
+        WfTune t{16, 12};
         if (const char* e = getenv("JPT_REFILL_IDLE")) t.refill_idle = atoi(e);
-        if (const char* e = getenv("JPT_TURNS")) t.turns = atoi(e);
+        if (const char* e = getenv("JPT_NODE_MIN_LANES")) t.node_min_lanes = atoi(e);
         return t;
     }();
 
