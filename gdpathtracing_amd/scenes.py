@@ -318,3 +318,27 @@ def camera_block(cam: CameraDesc, width: int, height: int, frame_index: int = 0)
     c["near"] = cam.near
     c["far"] = cam.far
     return c
+
+
+def write_scene_file(scene: Scene, path: str) -> None:
+    """Binary scene description read by tests/cpp/host_demo.cpp (the C++ host layer's test driver)."""
+    import struct
+    with open(path, "wb") as f:
+        f.write(struct.pack("<II", 0x5354504A, len(scene.meshes)))
+        for m in scene.meshes:
+            f.write(struct.pack("<I", len(m.surfaces)))
+            for s in m.surfaces:
+                f.write(struct.pack("<II", len(s.vertices), len(s.indices)))
+                f.write(s.vertices.tobytes()); f.write(s.normals.tobytes()); f.write(s.uvs.tobytes()); f.write(s.indices.tobytes())
+        f.write(struct.pack("<I", len(scene.materials)))
+        for m in scene.materials:
+            f.write(struct.pack("<9fi", *m["albedo"][:3], m["metallic"], m["roughness"], *m["emission"][:3], m["emission"][3],
+                                int(m["albedo_texture_index"])))
+        f.write(struct.pack("<I", len(scene.instances)))
+        for i in scene.instances:
+            f.write(struct.pack("<I", i.mesh))
+            f.write(np.asarray(i.transform, dtype=np.float32).tobytes())
+            f.write(struct.pack("<I", len(i.material_ids)))
+            f.write(np.asarray(i.material_ids, dtype=np.int32).tobytes())
+        f.write(np.asarray(scene.camera.transform, dtype=np.float32).tobytes())
+        f.write(struct.pack("<f", scene.camera.fov_deg))

@@ -1,0 +1,394 @@
+// jpt_host.hpp -- C++ host layer over the C ABI (include/jpt.h): the reference's classes for this path with
+// the same names, members and call order, minus the Godot scene tree.
+//
+//   GeometryGroup3D        src/path_tracing/geometry_group3d.{h,cpp}
+//   ProgressiveRendering   src/path_tracing/post_processing/progressive_rendering.{h,cpp}   (frame_count logic)
+//   PathTracingCamera      src/path_tracing/path_tracing_camera.{h,cpp}
+//   Camera                 src/path_tracing/render_parameters.h:14-47
+//
+// godot-cpp (Transform3D, Projection, Ref<>, PackedByteArray, StandardMaterial3D ...) is an absent submodule,
+// so the few value types the path needs are plain structs here; their arithmetic (affine_inverse,
+// create_perspective, Projection * Transform3D, Projection::inverse) restates godot's published algorithms in
+// float.  It runs BEFORE the boundary: it only fills the 160-byte Camera block and the instance transforms.
+// Header-only, C++17, no dependencies besides jpt.h.
+#pragma once
+
+#include <jpt.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace jpt_host {
+
+using PackedByteArray = std::vector<uint8_t>;
+
+struct Vector3 {
+    float x = 0, y = 0, z = 0;
+};
+
+struct Color {
+    float r = 0, g = 0, b = 0, a = 1;
+};
+
+struct Transform3D {  // godot: basis rows + origin
+    float basis[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+    Vector3 origin;
+
+    Transform3D affine_inverse() const
+    {
+        // Basis::invert via cofactors, then origin = basis.xform(-origin)
+        const auto& m = basis;
+        auto cof = [&](int r1, int c1, int r2, int c2) { return m[r1][c1] * m[r2][c2] - m[r1][c2] * m[r2][c1]; };
+        const float co0 = cof(1, 1, 2, 2), co1 = cof(1, 2, 2, 0), co2 = cof(1, 0, 2, 1);
+        const float det = m[0][0] * co0 + m[0][1] * co1 + m[0][2] * co2;
+        const float s = 1.0f / det;
+        Transform3D r;
+        r.basis[0][0] = co0 * s; r.basis[0][1] = cof(0, 2, 2, 1) * s; r.basis[0][2] = cof(0, 1, 1, 2) * s;
+        r.basis[1][0] = co1 * s; r.basis[1][1] = cof(0, 0, 2, 2) * s; r.basis[1][2] = cof(0, 2, 1, 0) * s;
+        r.basis[2][0] = co2 * s; r.basis[2][1] = cof(0, 1, 2, 0) * s; r.basis[2][2] = cof(0, 0, 1, 1) * s;
+        const float nx = -origin.x, ny = -origin.y, nz = -origin.z;
+        r.origin.x = r.basis[0][0] * nx + r.basis[0][1] * ny + r.basis[0][2] * nz;
+        r.origin.y = r.basis[1][0] * nx + r.basis[1][1] * ny + r.basis[1][2] * nz;
+        r.origin.z = r.basis[2][0] * nx + r.basis[2][1] * ny + r.basis[2][2] * nz;
+        return r;
+    }
+    bool is_equal_approx(const Transform3D& o) const  // godot: CMP_EPSILON 1e-5 style comparison
+    {
+        auto eq = [](float a, float b) {
+            if (a == b) return true;
+            const float tol = std::max(1e-5f * std::fabs(a), 1e-5f);
+            return std::fabs(a - b) < tol;
+        };
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++)
+                if (!eq(basis[i][j], o.basis[i][j])) return false;
+        return eq(origin.x, o.origin.x) && eq(origin.y, o.origin.y) && eq(origin.z, o.origin.z);
+    }
+    void to_float12(float* t) const
+    {
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++) t[i * 3 + j] = basis[i][j];
+        t[9] = origin.x; t[10] = origin.y; t[11] = origin.z;
+    }
+};
+
+struct Projection {  // godot: columns[4][4]
+    float columns[4][4] = {{1, 0, 0, 0}, {0, 1, 0, 0}, {0, 0, 1, 0}, {0, 0, 0, 1}};
+
+    static Projection create_perspective(float fovy_degrees, float aspect, float z_near, float z_far, bool /*flip_fov*/ = false)
+    {
+        Projection p;
+        const float radians = (fovy_degrees / 2.0f) * (3.14159265358979323846f / 180.0f);
+        const float delta_z = z_far - z_near;
+        const float sine = std::sin(radians);
+        if (delta_z == 0 || sine == 0 || aspect == 0) return p;
+        const float cotangent = std::cos(radians) / sine;
+        p.columns[0][0] = cotangent / aspect;
+        p.columns[1][1] = cotangent;
+        p.columns[2][2] = -(z_far + z_near) / delta_z;
+        p.columns[2][3] = -1;
+        p.columns[3][2] = -2 * z_near * z_far / delta_z;
+        p.columns[3][3] = 0;
+        return p;
+    }
+    // Projection * Transform3D (the transform promoted to a 4x4 with last row 0 0 0 1)
+    Projection operator*(const Transform3D& t) const
+    {
+        float m[4][4];  // columns of t
+        for (int c = 0; c < 3; c++) {
+            m[c][0] = t.basis[0][c]; m[c][1] = t.basis[1][c]; m[c][2] = t.basis[2][c]; m[c][3] = 0;
+        }
+        m[3][0] = t.origin.x; m[3][1] = t.origin.y; m[3][2] = t.origin.z; m[3][3] = 1;
+        Projection r;
+        for (int j = 0; j < 4; j++)
+            for (int i = 0; i < 4; i++) {
+                float ab = 0;
+                for (int k = 0; k < 4; k++) ab += columns[k][i] * m[j][k];
+                r.columns[j][i] = ab;
+            }
+        return r;
+    }
+    Projection inverse() const  // Gauss-Jordan with partial pivoting, double accumulators
+    {
+        double a[4][8];
+        for (int r = 0; r < 4; r++)
+            for (int c = 0; c < 4; c++) {
+                a[r][c] = columns[c][r];
+                a[r][4 + c] = (r == c) ? 1.0 : 0.0;
+            }
+        for (int col = 0; col < 4; col++) {
+            int piv = col;
+            for (int r = col + 1; r < 4; r++)
+                if (std::fabs(a[r][col]) > std::fabs(a[piv][col])) piv = r;
+            if (piv != col)
+                for (int c = 0; c < 8; c++) std::swap(a[piv][c], a[col][c]);
+            const double d = a[col][col];
+            if (d == 0.0) return Projection();
+            for (int c = 0; c < 8; c++) a[col][c] /= d;
+            for (int r = 0; r < 4; r++)
+                if (r != col) {
+                    const double f = a[r][col];
+                    for (int c = 0; c < 8; c++) a[r][c] -= f * a[col][c];
+                }
+        }
+        Projection out;
+        for (int r = 0; r < 4; r++)
+            for (int c = 0; c < 4; c++) out.columns[c][r] = (float)a[r][4 + c];
+        return out;
+    }
+};
+
+// render_parameters.h:14-47
+struct Camera {
+    float vp[16];
+    float ivp[16];
+    float position[4];
+    unsigned int frame_index = 0;  // the reference never initialises it (render_parameters.h:19)
+    float near_ = 0.01f;
+    float far_ = 1000.0f;
+    unsigned int _pad = 0;
+
+    void set_camera_transform(const Transform3D& model, const Projection& projection)
+    {
+        position[0] = model.origin.x; position[1] = model.origin.y; position[2] = model.origin.z; position[3] = 1.0f;
+        const Projection t = projection * model.affine_inverse();
+        const Projection it = t.inverse();
+        for (int i = 0; i < 4; i++)  // Utils::projection_to_float (utils.h:39-49)
+            for (int j = 0; j < 4; j++) {
+                vp[i * 4 + j] = t.columns[i][j];
+                ivp[i * 4 + j] = it.columns[i][j];
+            }
+    }
+};
+static_assert(sizeof(Camera) == 160, "Camera block");
+
+struct StandardMaterial3D {  // the properties GeometryGroup3D reads (geometry_group3d.cpp:279-290); godot defaults
+    Color albedo{1, 1, 1, 1};
+    float metallic = 0.0f;
+    float roughness = 1.0f;
+    Color emission{0, 0, 0, 1};
+    float emission_energy_multiplier = 1.0f;
+    int albedo_texture = -1;  // index into GeometryGroup3D::textures, -1 = none
+};
+
+struct Surface {
+    std::vector<float> vertices, normals, uvs;  // 3, 3, 2 floats per vertex
+    std::vector<int32_t> indices;
+};
+
+struct ArrayMesh {
+    std::vector<Surface> surfaces;
+    int get_surface_count() const { return (int)surfaces.size(); }
+};
+
+struct MeshInstance3D {
+    const ArrayMesh* mesh = nullptr;
+    Transform3D global_transform;
+    std::vector<const StandardMaterial3D*> surface_override_materials;  // null = default material
+};
+
+struct GpuMaterial {  // render_parameters.h:49-57
+    float albedo[4];
+    float emission[4];
+    float metallic, roughness;
+    int albedo_texture_index;
+    float padding[5];
+};
+static_assert(sizeof(GpuMaterial) == 64, "GpuMaterial");
+
+inline void check(jpt_ctx* ctx, int rc, const char* what)
+{
+    if (rc != JPT_OK) throw std::runtime_error(std::string(what) + ": " + jpt_last_error(ctx));
+}
+
+class GeometryGroup3D {
+  public:
+    StandardMaterial3D default_material{Color{0.5f, 0.5f, 0.5f, 1}, 0.0f, 0.5f};  // geometry_group3d.cpp:239-245
+    bool default_material_set = false;
+    int texture_array_resolution = 1024;                 // geometry_group3d.h:64
+    std::vector<PackedByteArray> textures;               // RGBA8 layers, res x res each
+    int builder = JPT_BUILD_SAH;
+
+    void set_default_material(const StandardMaterial3D& m) { default_material = m; default_material_set = true; }
+    void add_child(const MeshInstance3D& node) { children.push_back(node); }
+
+    // geometry_group3d.cpp:228-366: collect instances, dedup meshes / materials by pointer, convert materials,
+    // then builder + instances + TLAS + upload (the jpt_scene_* calls)
+    void build(jpt_ctx* ctx)
+    {
+        ctx_ = ctx;
+        std::vector<const ArrayMesh*> meshes;
+        std::vector<const StandardMaterial3D*> mats;  // entry 0 = default material
+        mats.push_back(&default_material);
+        struct NodeRef { size_t mesh_id; std::vector<int32_t> material_ids; Transform3D t; };
+        std::vector<NodeRef> nodes;
+        for (const MeshInstance3D& n : children) {  // collect_mesh_instances (:150-214)
+            if (!n.mesh) continue;
+            size_t mid = std::find(meshes.begin(), meshes.end(), n.mesh) - meshes.begin();
+            if (mid == meshes.size()) meshes.push_back(n.mesh);
+            NodeRef r{mid, {}, n.global_transform};
+            for (int s = 0; s < n.mesh->get_surface_count(); s++) {
+                const StandardMaterial3D* m = s < (int)n.surface_override_materials.size() ? n.surface_override_materials[s] : nullptr;
+                int32_t id = 0;  // only override materials are honoured; anything else maps to the default (:186-202)
+                if (m) {
+                    size_t k = std::find(mats.begin(), mats.end(), m) - mats.begin();
+                    if (k == mats.size()) mats.push_back(m);
+                    id = (int32_t)k;
+                }
+                r.material_ids.push_back(id);
+            }
+            nodes.push_back(std::move(r));
+        }
+        materials_.clear();
+        for (const StandardMaterial3D* m : mats) {  // :271-292
+            GpuMaterial g;
+            std::memset(&g, 0, sizeof g);
+            g.albedo[0] = m->albedo.r; g.albedo[1] = m->albedo.g; g.albedo[2] = m->albedo.b; g.albedo[3] = 1.0f;
+            g.metallic = m->metallic;
+            g.roughness = m->roughness;
+            g.emission[0] = m->emission.r; g.emission[1] = m->emission.g; g.emission[2] = m->emission.b;
+            g.emission[3] = m->emission_energy_multiplier;
+            g.albedo_texture_index = m->albedo_texture;
+            materials_.push_back(g);
+        }
+        check(ctx, jpt_scene_begin(ctx), "jpt_scene_begin");
+        std::vector<uint32_t> ids;
+        for (const ArrayMesh* mesh : meshes) {  // :308-313
+            std::vector<jpt_surface> sv;
+            for (const Surface& s : mesh->surfaces)
+                sv.push_back(jpt_surface{s.vertices.data(), s.normals.data(), s.uvs.data(), s.indices.data(),
+                                         (int32_t)(s.vertices.size() / 3), (int32_t)s.indices.size()});
+            uint32_t id = 0;
+            check(ctx, jpt_scene_add_mesh(ctx, sv.data(), (int32_t)sv.size(), &id), "jpt_scene_add_mesh");
+            ids.push_back(id);
+        }
+        for (const NodeRef& r : nodes) {  // :322-341
+            float t12[12];
+            r.t.to_float12(t12);
+            check(ctx, jpt_scene_add_instance(ctx, ids[r.mesh_id], t12, r.material_ids.data(), (int32_t)r.material_ids.size()),
+                  "jpt_scene_add_instance");
+        }
+        check(ctx, jpt_scene_set_materials(ctx, materials_.data(), (uint32_t)materials_.size()), "jpt_scene_set_materials");
+        if (!textures.empty()) {
+            PackedByteArray all;
+            for (const PackedByteArray& t : textures) all.insert(all.end(), t.begin(), t.end());
+            check(ctx, jpt_scene_set_textures(ctx, all.data(), texture_array_resolution, (int32_t)textures.size()), "jpt_scene_set_textures");
+        }
+        check(ctx, jpt_scene_commit(ctx, builder), "jpt_scene_commit");
+    }
+
+    // geometry_group3d.cpp:40-68 (bytes as the reference emits them after a REFERENCE_EXACT build)
+    PackedByteArray get_triangles_geometry_buffer() const { return get_buffer(JPT_BUF_TRI_GEOMETRY); }
+    PackedByteArray get_triangles_data_buffer() const { return get_buffer(JPT_BUF_TRI_DATA); }
+    PackedByteArray get_materials_buffer() const { return get_buffer(JPT_BUF_MATERIALS); }
+    PackedByteArray get_bvh_buffer() const { return get_buffer(JPT_BUF_BVH_NODES); }
+    PackedByteArray get_blas_buffer() const { return get_buffer(JPT_BUF_INSTANCES); }
+    PackedByteArray get_tlas_buffer() const { return get_buffer(JPT_BUF_TLAS_NODES); }
+    int get_triangle_count() const { return (int)(get_triangles_geometry_buffer().size() / 48); }   // :17
+    int get_blas_count() const { return (int)(get_blas_buffer().size() / 176); }                    // :7
+    int get_material_count() const { return (int)materials_.size(); }                               // :12
+    int get_bvh_node_count() const { return (int)(get_bvh_buffer().size() / 48); }                  // :22
+    int get_tlas_node_count() const { return (int)(get_tlas_buffer().size() / 32); }                // :27
+
+  private:
+    PackedByteArray get_buffer(int which) const
+    {
+        size_t n = 0;
+        check(ctx_, jpt_scene_get_reference_buffer(ctx_, which, nullptr, 0, &n), "jpt_scene_get_reference_buffer");
+        PackedByteArray out(n);
+        check(ctx_, jpt_scene_get_reference_buffer(ctx_, which, out.data(), n, &n), "jpt_scene_get_reference_buffer");
+        return out;
+    }
+    std::vector<MeshInstance3D> children;
+    std::vector<GpuMaterial> materials_;
+    jpt_ctx* ctx_ = nullptr;
+};
+
+// progressive_rendering.cpp:47-66: the host half (camera-moved test and frame_count); the device half is fused
+// into jpt_render.
+class ProgressiveRendering {
+  public:
+    unsigned int frame_count = 1;
+    // returns true when the accumulation restarts
+    bool render(const Transform3D& camera_transform)
+    {
+        const bool camera_moved = !previous_transform.is_equal_approx(camera_transform);
+        previous_transform = camera_transform;
+        if (camera_moved) frame_count = 1;
+        else frame_count++;
+        return camera_moved;
+    }
+
+  private:
+    Transform3D previous_transform;  // identity initially (progressive_rendering.h:44)
+};
+
+class PathTracingCamera {
+  public:
+    enum Denoising { PROGRESSIVE_RENDERING, TEMPORAL_REPROJECTION, NONE };  // path_tracing_camera.h:30-34
+
+    explicit PathTracingCamera(int device = 0) { check(nullptr, create(device), "jpt_create"); }
+    ~PathTracingCamera() { jpt_destroy(ctx); }
+    PathTracingCamera(const PathTracingCamera&) = delete;
+    PathTracingCamera& operator=(const PathTracingCamera&) = delete;
+
+    float get_fov() const { return fov; }
+    void set_fov(float v) { fov = v; }
+    void set_geometry_group(GeometryGroup3D* g) { geometry_group = g; }
+    Denoising get_denoising_mode() const { return denoising_mode; }
+    void set_denoising_mode(Denoising m) { denoising_mode = m; }
+    void set_global_transform(const Transform3D& t) { global_transform = t; }
+    jpt_ctx* context() const { return ctx; }
+
+    int max_bounces = 4;                    // the literal 5 of main.glsl:377 is max_bounces + 1
+    int accum_mode = JPT_ACCUM_REF_LDR8;    // what the reference does (rgba8 screen image before the sum)
+
+    // path_tracing_camera.cpp:111-187 (resolution is passed in instead of DisplayServer::window_get_size)
+    void init(int w, int h)
+    {
+        if (!geometry_group) throw std::runtime_error("No geometry group set.");  // :117-121
+        width = w;
+        height = h;
+        geometry_group->build(ctx);                                                // :126
+        projection_matrix = Projection::create_perspective(fov, float(width) / float(height), 0.01f, 1000.0f, false);  // :134
+        check(ctx, jpt_set_params(ctx, width, height, max_bounces, accum_mode, JPT_SAMPLER_NEAREST_CLAMP), "jpt_set_params");
+        ready = true;
+    }
+
+    // path_tracing_camera.cpp:193-232: one frame; returns the RGBA8 screen image (get_image_uniform_buffer)
+    PackedByteArray render()
+    {
+        if (!ready) return {};                                                      // :195
+        if (denoising_mode == TEMPORAL_REPROJECTION) throw std::runtime_error("temporal reprojection is out of scope");
+        camera.set_camera_transform(global_transform, projection_matrix);           // :198
+        camera.frame_index++;                                                       // :199
+        check(ctx, jpt_set_camera(ctx, &camera), "jpt_set_camera");                 // :200
+        const bool restart = progressive_renderer.render(global_transform) || denoising_mode == NONE;   // :208-214
+        if (restart) check(ctx, jpt_accum_reset(ctx), "jpt_accum_reset");
+        check(ctx, jpt_render(ctx, 1, camera.frame_index), "jpt_render");           // :204 + progressive pass
+        PackedByteArray out((size_t)width * height * 4);
+        check(ctx, jpt_read_ldr_rgba8(ctx, out.data()), "jpt_read_ldr_rgba8");      // :228-229
+        return out;
+    }
+
+    Camera camera;
+    ProgressiveRendering progressive_renderer;
+
+  private:
+    int create(int device) { return jpt_create(device, &ctx); }
+    jpt_ctx* ctx = nullptr;
+    GeometryGroup3D* geometry_group = nullptr;
+    Transform3D global_transform;
+    Projection projection_matrix;
+    Denoising denoising_mode = PROGRESSIVE_RENDERING;
+    float fov = 90.0f;  // path_tracing_camera.h:80
+    int width = 0, height = 0;
+    bool ready = false;
+};
+
+}  // namespace jpt_host

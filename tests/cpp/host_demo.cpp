@@ -1,0 +1,133 @@
+// host_demo.cpp -- drives the C++ host layer (include/jpt_host.hpp) the way the addon drives the reference
+// classes: scene nodes -> GeometryGroup3D::build -> PathTracingCamera::init / render() per frame.
+// Used by tests/test_cpp_host.py.  Scene description comes from a small binary file written by the test
+// (gdpathtracing_amd/scenes.py -> write_scene_file), results go to <prefix>_*.bin.
+//
+//   host_demo buffers <scene.bin> <prefix>                      host-only context, REFERENCE_EXACT, dumps get_*_buffer()
+//   host_demo render  <scene.bin> <prefix> <w> <h> <frames> <builder> <accum_mode>   GPU 0
+#include <jpt_host.hpp>
+
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <iostream>
+#include <memory>
+
+using namespace jpt_host;
+
+struct Reader {
+    std::ifstream f;
+    explicit Reader(const char* path) : f(path, std::ios::binary) { if (!f) throw std::runtime_error("cannot open scene file"); }
+    template <typename T> T get() { T v; f.read(reinterpret_cast<char*>(&v), sizeof v); return v; }
+    template <typename T> std::vector<T> vec(size_t n) { std::vector<T> v(n); f.read(reinterpret_cast<char*>(v.data()), (std::streamsize)(n * sizeof(T))); return v; }
+};
+
+static void dump(const std::string& path, const void* p, size_t n)
+{
+    std::ofstream o(path, std::ios::binary);
+    o.write(reinterpret_cast<const char*>(p), (std::streamsize)n);
+}
+
+static Transform3D read_transform(Reader& r)
+{
+    Transform3D t;
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) t.basis[i][j] = r.get<float>();
+    t.origin.x = r.get<float>(); t.origin.y = r.get<float>(); t.origin.z = r.get<float>();
+    return t;
+}
+
+int main(int argc, char** argv)
+{
+    try {
+        if (argc < 4) { std::fprintf(stderr, "usage\n"); return 2; }
+        const std::string mode = argv[1], prefix = argv[3];
+        Reader r(argv[2]);
+        if (r.get<uint32_t>() != 0x5354504au) throw std::runtime_error("bad magic");
+        std::vector<std::unique_ptr<ArrayMesh>> meshes;
+        const uint32_t n_meshes = r.get<uint32_t>();
+        for (uint32_t m = 0; m < n_meshes; m++) {
+            auto mesh = std::make_unique<ArrayMesh>();
+            const uint32_t ns = r.get<uint32_t>();
+            for (uint32_t s = 0; s < ns; s++) {
+                const uint32_t nv = r.get<uint32_t>(), ni = r.get<uint32_t>();
+                Surface su;
+                su.vertices = r.vec<float>(3 * nv);
+                su.normals = r.vec<float>(3 * nv);
+                su.uvs = r.vec<float>(2 * nv);
+                su.indices = r.vec<int32_t>(ni);
+                mesh->surfaces.push_back(std::move(su));
+            }
+            meshes.push_back(std::move(mesh));
+        }
+        std::vector<StandardMaterial3D> mats(r.get<uint32_t>());
+        for (auto& m : mats) {
+            m.albedo.r = r.get<float>(); m.albedo.g = r.get<float>(); m.albedo.b = r.get<float>();
+            m.metallic = r.get<float>(); m.roughness = r.get<float>();
+            m.emission.r = r.get<float>(); m.emission.g = r.get<float>(); m.emission.b = r.get<float>();
+            m.emission_energy_multiplier = r.get<float>();
+            m.albedo_texture = r.get<int32_t>();
+        }
+        GeometryGroup3D group;
+        if (!mats.empty()) group.set_default_material(mats[0]);
+        const uint32_t n_inst = r.get<uint32_t>();
+        for (uint32_t i = 0; i < n_inst; i++) {
+            MeshInstance3D node;
+            node.mesh = meshes.at(r.get<uint32_t>()).get();
+            node.global_transform = read_transform(r);
+            const uint32_t nm = r.get<uint32_t>();
+            for (uint32_t k = 0; k < nm; k++) {
+                const int32_t id = r.get<int32_t>();
+                node.surface_override_materials.push_back(id > 0 ? &mats.at((size_t)id) : nullptr);
+            }
+            group.add_child(node);
+        }
+        const Transform3D cam_t = read_transform(r);
+        const float fov = r.get<float>();
+
+        if (mode == "buffers") {
+            jpt_ctx* ctx = nullptr;
+            check(nullptr, jpt_create(JPT_DEVICE_HOST_ONLY, &ctx), "jpt_create");
+            group.builder = JPT_BUILD_REFERENCE_EXACT;
+            group.build(ctx);
+            const PackedByteArray bufs[6] = {group.get_triangles_geometry_buffer(), group.get_triangles_data_buffer(),
+                                             group.get_materials_buffer(), group.get_bvh_buffer(), group.get_blas_buffer(),
+                                             group.get_tlas_buffer()};
+            for (int k = 0; k < 6; k++) dump(prefix + "_buf" + std::to_string(k) + ".bin", bufs[k].data(), bufs[k].size());
+            std::printf("tris %d blas %d bvh %d tlas %d materials %d\n", group.get_triangle_count(), group.get_blas_count(),
+                        group.get_bvh_node_count(), group.get_tlas_node_count(), group.get_material_count());
+            // the camera block the host layer would upload for a 64x36 view
+            Camera c;
+            c.set_camera_transform(cam_t, Projection::create_perspective(fov, 64.0f / 36.0f, 0.01f, 1000.0f));
+            dump(prefix + "_camera.bin", &c, sizeof c);
+            jpt_destroy(ctx);
+            return 0;
+        }
+        if (mode == "render" && argc >= 9) {
+            const int w = std::atoi(argv[4]), h = std::atoi(argv[5]), frames = std::atoi(argv[6]);
+            PathTracingCamera cam(0);
+            group.builder = std::atoi(argv[7]);
+            cam.accum_mode = std::atoi(argv[8]);
+            cam.set_fov(fov);
+            cam.set_geometry_group(&group);
+            cam.set_global_transform(cam_t);
+            cam.camera.frame_index = 0;
+            cam.init(w, h);
+            PackedByteArray screen;
+            for (int f = 0; f < frames; f++) screen = cam.render();   // one frame per call, like the addon
+            std::vector<float> accum((size_t)w * h * 4);
+            check(cam.context(), jpt_read_accum_f32(cam.context(), accum.data()), "jpt_read_accum_f32");
+            dump(prefix + "_accum.bin", accum.data(), accum.size() * 4);
+            dump(prefix + "_ldr.bin", screen.data(), screen.size());
+            dump(prefix + "_camera.bin", &cam.camera, sizeof(Camera));
+            std::printf("rendered %d frames, frame_index %u, frame_count %u\n", frames, cam.camera.frame_index,
+                        cam.progressive_renderer.frame_count);
+            return 0;
+        }
+        std::fprintf(stderr, "bad mode\n");
+        return 2;
+    } catch (const std::exception& e) {
+        std::fprintf(stderr, "host_demo: %s\n", e.what());
+        return 1;
+    }
+}
