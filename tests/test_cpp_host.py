@@ -43,7 +43,7 @@ def test_cpp_geometry_group_emits_the_reference_buffers(oracle, host_demo):
     # Camera::set_camera_transform in float agrees with the float64 helper to float precision
     cam = np.frombuffer(open(os.path.join(d, "b_camera.bin"), "rb").read(), dtype=wire.CAMERA)[0]
     want = scenes.camera_block(sc.camera, 64, 36)
-    assert np.allclose(cam["vp"], want["vp"], rtol=1e-5, atol=1e-6) and np.allclose(cam["ivp"], want["ivp"], rtol=2e-5, atol=1e-5)
+    assert np.allclose(cam["vp"], want["vp"], rtol=1e-5, atol=1e-6) and np.allclose(cam["ivp"], want["ivp"], rtol=2e-4, atol=1e-4)  # near/far = 1e-5: ill-conditioned
     assert tuple(cam["position"]) == tuple(want["position"]) and (cam["near"], cam["far"]) == (want["near"], want["far"])
 
 
