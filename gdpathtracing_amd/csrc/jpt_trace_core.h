@@ -70,16 +70,24 @@ struct Traversal {
 
     __device__ __forceinline__ void push(const Stack& st, int32_t v)
     {
+#ifdef JPT_NO_SPILL  // experiment only: valid when the scene's stack depth never exceeds kStackLds
+        st.lds[sp * kTraceBlock] = v;
+#else
         if (sp < kStackLds) st.lds[sp * kTraceBlock] = v;
         else if (sp < kStackLds + kStackSpill) st.spill[sp - kStackLds] = v;
+#endif
         sp++;
     }
     __device__ __forceinline__ int32_t pop(const Stack& st)
     {
         sp--;
+#ifdef JPT_NO_SPILL
+        return st.lds[sp * kTraceBlock];
+#else
         if (sp < kStackLds) return st.lds[sp * kTraceBlock];
         if (sp < kStackLds + kStackSpill) return st.spill[sp - kStackLds];
         return kSentinel;
+#endif
     }
 
     __device__ __forceinline__ void begin(const WideSceneDev& sc, f3 ro, f3 rd)
