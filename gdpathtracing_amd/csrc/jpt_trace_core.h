@@ -132,7 +132,7 @@ struct Traversal {
                          : "=&v"(x0), "=&v"(x1), "=&v"(x2), "=&v"(x3)
                          : "v"(n)
                          : "memory");
-            asm volatile("" ::"v"(x0), "v"(x1), "v"(x2), "v"(x3));
+            asm volatile("" ::"v"(x0.x + x0.w), "v"(x1.y + x1.z), "v"(x2.x + x2.w), "v"(x3.y + x3.z));
         }
 #endif
 #ifdef JPT_ABL_EXTRA_VALU  // ablation: ~64 extra dependent-free VALU ops per node step
