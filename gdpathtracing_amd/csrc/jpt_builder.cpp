@@ -750,4 +750,110 @@ bool flatten(const RefScene& ref, WideScene& out, std::string& err)
     return true;
 }
 
+namespace {
+
+struct Child4 {
+    float lo[3], hi[3];
+    int32_t ref;
+    float area() const
+    {
+        const float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+        return dx * dy + dy * dz + dz * dx;
+    }
+};
+
+// collapse the subtree under two-child record `ni` of `src` into `dst`; returns the new record's index
+int32_t collapse4(const std::vector<WideNode>& src, std::vector<WideNode4>& dst, int32_t ni, std::vector<int32_t>& memo)
+{
+    if (memo[(size_t)ni] >= 0) return memo[(size_t)ni];
+    const int32_t self = (int32_t)dst.size();
+    memo[(size_t)ni] = self;
+    dst.emplace_back();
+    auto kids_of = [&](int32_t n, Child4* out) {
+        const WideNode& w = src[(size_t)n];
+        for (int k = 0; k < 3; k++) {
+            out[0].lo[k] = w.lmin[k]; out[0].hi[k] = w.lmax[k];
+            out[1].lo[k] = w.rmin[k]; out[1].hi[k] = w.rmax[k];
+        }
+        out[0].ref = w.left;
+        out[1].ref = w.right;
+    };
+    Child4 c[4];
+    int n = 2;
+    kids_of(ni, c);
+    while (n < 4) {
+        int best = -1;
+        float best_area = -1.0f;
+        for (int i = 0; i < n; i++)
+            if (c[i].ref >= 0 && c[i].ref != ni) {  // internal (a self-reference marks an empty leaf record)
+                const WideNode& w = src[(size_t)c[i].ref];
+                if (w.left == c[i].ref && w.right == c[i].ref) continue;  // empty-leaf record: keep as is
+                const float a = c[i].area();
+                if (a > best_area) {
+                    best_area = a;
+                    best = i;
+                }
+            }
+        if (best < 0) break;
+        Child4 two[2];
+        kids_of(c[best].ref, two);
+        c[best] = two[0];
+        c[n++] = two[1];
+    }
+    WideNode4 w;
+    std::memset(&w, 0, sizeof w);
+    for (int i = 0; i < 4; i++) {
+        if (i < n) {
+            w.lo_x[i] = c[i].lo[0]; w.lo_y[i] = c[i].lo[1]; w.lo_z[i] = c[i].lo[2];
+            w.hi_x[i] = c[i].hi[0]; w.hi_y[i] = c[i].hi[1]; w.hi_z[i] = c[i].hi[2];
+            int32_t r = c[i].ref;
+            if (r >= 0) {
+                const WideNode& s2 = src[(size_t)r];
+                if (s2.left == r && s2.right == r) r = kEmptyChild;  // empty-leaf record: nothing below
+                else r = collapse4(src, dst, r, memo);
+            }
+            w.child[i] = r;
+        } else {
+            w.lo_x[i] = w.lo_y[i] = w.lo_z[i] = FLT_MAX;
+            w.hi_x[i] = w.hi_y[i] = w.hi_z[i] = -FLT_MAX;
+            w.child[i] = kEmptyChild;
+        }
+    }
+    dst[(size_t)self] = w;
+    return self;
+}
+
+int32_t collapse_root(const std::vector<WideNode>& src, std::vector<WideNode4>& dst, int32_t root, std::vector<int32_t>& memo)
+{
+    if (root < 0) return root;  // the whole tree is one leaf
+    const WideNode& w = src[(size_t)root];
+    if (w.left == root && w.right == root) {  // empty mesh: a record whose four slots are empty
+        const int32_t self = (int32_t)dst.size();
+        WideNode4 e;
+        std::memset(&e, 0, sizeof e);
+        for (int i = 0; i < 4; i++) {
+            e.lo_x[i] = e.lo_y[i] = e.lo_z[i] = FLT_MAX;
+            e.hi_x[i] = e.hi_y[i] = e.hi_z[i] = -FLT_MAX;
+            e.child[i] = kEmptyChild;
+        }
+        dst.push_back(e);
+        return self;
+    }
+    return collapse4(src, dst, root, memo);
+}
+
+}  // namespace
+
+void flatten4(WideScene& out)
+{
+    out.blas_nodes4.clear();
+    out.tlas_nodes4.clear();
+    std::vector<int32_t> memo(out.blas_nodes.size(), -1);
+    out.instances4 = out.instances;
+    for (size_t i = 0; i < out.instances.size(); i++)
+        out.instances4[i].root = collapse_root(out.blas_nodes, out.blas_nodes4, out.instances[i].root, memo);
+    std::vector<int32_t> memo_t(out.tlas_nodes.size(), -1);
+    out.tlas_root4 = collapse_root(out.tlas_nodes, out.tlas_nodes4, out.tlas_root, memo_t);
+}
+
 }  // namespace jpt

@@ -49,6 +49,10 @@ struct WideScene {
     std::vector<WideInstance> instances;
     int32_t tlas_root = 0;
     uint32_t max_blas_depth = 0, max_tlas_depth = 0;
+    // 4-wide collapse of the same trees (flatten4); instances4[i].root refers to blas_nodes4
+    std::vector<WideNode4> blas_nodes4, tlas_nodes4;
+    std::vector<WideInstance> instances4;
+    int32_t tlas_root4 = 0;
 };
 
 enum class BuildMode { ReferenceExact = 0, Sah = 1 };
@@ -77,5 +81,10 @@ void affine_inverse12(const float* t12, float* out12);
 // Reference layout -> flattened layout.  Keeps topology, boxes and child order, so traversal visits the
 // same nodes in the same order as main.glsl:270-350 does on the reference arrays.
 bool flatten(const RefScene& ref, WideScene& out, std::string& err);
+
+// Collapses the two-child records of `out` (after flatten) into four-child records: a node's children are
+// replaced, largest box first, by their own children until four slots are used.  Boxes and leaves are kept as
+// they are, so the set of triangles a ray can reach is unchanged; only the visiting order differs.
+void flatten4(WideScene& out);
 
 }  // namespace jpt

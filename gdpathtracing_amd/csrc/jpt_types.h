@@ -105,6 +105,19 @@ struct alignas(64) WideNode {
 };
 static_assert(sizeof(WideNode) == 64, "WideNode");
 
+// 4-wide record of the native route (128 B, one L1 line): up to four children's boxes, struct-of-arrays so
+// the four slab tests read whole float4s, plus four child references (same encoding as WideNode;
+// kEmptyChild marks an unused slot).  Built by collapsing the binary tree (flatten4): a ray makes about half
+// as many dependent fetches as on the two-child records.
+struct alignas(128) WideNode4 {
+    float lo_x[4], lo_y[4], lo_z[4];
+    float hi_x[4], hi_y[4], hi_z[4];
+    int32_t child[4];
+    uint32_t _pad[4];
+};
+static_assert(sizeof(WideNode4) == 128, "WideNode4");
+constexpr int32_t kEmptyChild = (int32_t)0x80000000;  // ~0x7fffffff: never a valid leaf reference
+
 // 48-byte triangle record: v0 and the two Moller-Trumbore edges, precomputed with the same float
 // subtractions intersectTriangle performs (main.glsl:231-232), so t,u,v are bit-identical.
 struct alignas(16) WideTri {
