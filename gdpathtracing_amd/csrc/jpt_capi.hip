@@ -59,7 +59,7 @@ struct jpt_ctx {
     SceneBuilder builder;
     RefScene ref;
     WideScene wide;
-    bool building = false, scene_ready = false, ref_is_exact = false;
+    bool building = false, scene_ready = false, ref_is_exact = false, native_tree = false;
     std::vector<RefMaterial> pending_materials;
     std::vector<uint8_t> pending_tex;
     int32_t pending_tex_res = 0, pending_layers = 0;
@@ -74,7 +74,8 @@ struct jpt_ctx {
     DevBuf<uint8_t> d_tex;
     DevBuf<WideNode> d_wblas, d_wtlas;
     DevBuf<WideTri> d_wtris;
-    DevBuf<WideInstance> d_winst;
+    DevBuf<WideInstance> d_winst, d_winst4;
+    DevBuf<WideNode4> d_wblas4, d_wtlas4;
     DeviceScene ds;
 
     // per-render state
@@ -163,6 +164,15 @@ int upload_scene(jpt_ctx* c)
 {
     std::string err;
     if (!flatten(c->ref, c->wide, err)) return fail(c, JPT_E_INVALID, "flatten: " + err);
+    // the four-child collapse is for the native builder's trees; reference-exact trees keep the two-child
+    // records so the kernels visit them node for node like main.glsl (event counters equal the oracle's)
+    const bool use4 = !c->ref_is_exact && c->native_tree;
+    if (use4) flatten4(c->wide);
+    else {
+        c->wide.blas_nodes4.clear();
+        c->wide.tlas_nodes4.clear();
+        c->wide.instances4.clear();
+    }
     if (c->device < 0) return JPT_OK;  // host-only context: arrays stay on the host, nothing can be rendered
     HIP_TRY(c, hipSetDevice(c->device));
     hipStream_t s = c->stream;
@@ -177,6 +187,9 @@ int upload_scene(jpt_ctx* c)
     HIP_TRY(c, c->d_wtlas.upload(c->wide.tlas_nodes, s));
     HIP_TRY(c, c->d_wtris.upload(c->wide.tris, s));
     HIP_TRY(c, c->d_winst.upload(c->wide.instances, s));
+    HIP_TRY(c, c->d_winst4.upload(c->wide.instances4, s));
+    HIP_TRY(c, c->d_wblas4.upload(c->wide.blas_nodes4, s));
+    HIP_TRY(c, c->d_wtlas4.upload(c->wide.tlas_nodes4, s));
     HIP_TRY(c, hipStreamSynchronize(s));
     DeviceScene& d = c->ds;
     d.ref_tri_geom = c->d_tri_geom.p;
@@ -200,6 +213,11 @@ int upload_scene(jpt_ctx* c)
     d.tlas_root = c->wide.tlas_root;
     d.n_blas_nodes = (uint32_t)c->wide.blas_nodes.size();
     d.n_tlas_nodes = (uint32_t)c->wide.tlas_nodes.size();
+    d.use4 = use4;
+    d.blas_nodes4 = c->d_wblas4.p;
+    d.tlas_nodes4 = c->d_wtlas4.p;
+    d.wide_instances4 = c->d_winst4.p;
+    d.tlas_root4 = c->wide.tlas_root4;
     c->scene_ready = true;
     return JPT_OK;
 }
@@ -448,6 +466,7 @@ int jpt_scene_upload_reference_layout(jpt_ctx* c, const void* tri_geometry, uint
         r.n_layers = n_layers;
     }
     c->ref_is_exact = false;
+    c->native_tree = false;  // uploaded trees are walked as given
     int rc = validate_ref_scene(c);
     if (rc != JPT_OK) return rc;
     rc = upload_scene(c);
@@ -529,6 +548,7 @@ int jpt_scene_commit(jpt_ctx* c, int32_t builder)
     c->ref.tex_res = c->pending_tex_res;
     c->ref.n_layers = c->pending_layers;
     c->ref_is_exact = (builder == JPT_BUILD_REFERENCE_EXACT);
+    c->native_tree = (builder == JPT_BUILD_SAH);
     int rc = validate_ref_scene(c);
     if (rc != JPT_OK) return rc;
     rc = upload_scene(c);

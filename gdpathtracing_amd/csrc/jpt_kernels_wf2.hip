@@ -34,9 +34,9 @@ struct WfTune {
 // One round of the walk for every active lane of the wave, "while-while" style so that lanes in different
 // states do not serialise each other's code: (1) a tight loop of internal-record steps (lanes that reach a
 // leaf wait), (2) triangle leaves, (3) instance entries.  Returns true for lanes whose walk is complete.
-template <bool COUNT>
-__device__ __forceinline__ bool walk_round(Traversal<COUNT>& tr, bool active, const WideSceneDev& sc,
-                                           const typename Traversal<COUNT>::Stack& st, DevCounters& cnt, int kNodeMinLanes)
+template <bool COUNT, bool W4>
+__device__ __forceinline__ bool walk_round(Traversal<COUNT, W4>& tr, bool active, const WideSceneDev& sc,
+                                           const typename Traversal<COUNT, W4>::Stack& st, DevCounters& cnt, int kNodeMinLanes)
 {
     const bool lane0 = (threadIdx.x & 63) == 0;
     if (COUNT && lane0) cnt.phase[0]++;
@@ -103,7 +103,7 @@ __device__ __forceinline__ uint32_t lanes_below(unsigned long long mask, int lan
 
 // ---- bounce 0: generate + trace ------------------------------------------------------------------------
 
-template <bool COUNT>
+template <bool COUNT, bool W4>
 __global__ __launch_bounds__(kBlock, JPT_WAVES_PER_SIMD) void wf2_primary(WideSceneDev sc, Wf2Buffers wb, Wf2Dims dm, FrameParams fp, RefCamera cam,
                                                       WfTune tune, DevCounters* __restrict__ counters)
 {
@@ -120,10 +120,10 @@ __global__ __launch_bounds__(kBlock, JPT_WAVES_PER_SIMD) void wf2_primary(WideSc
     }
     __syncthreads();
     int32_t spill[kStackSpill];
-    const typename Traversal<COUNT>::Stack my_stack{&stack[threadIdx.x], spill};
+    const typename Traversal<COUNT, W4>::Stack my_stack{&stack[threadIdx.x], spill};
     const size_t seg_base = (size_t)seg * dm.seg_cap;
     DevCounters cnt = {};
-    Traversal<COUNT> tr;
+    Traversal<COUNT, W4> tr;
     bool active = false, exhausted = false;
     uint32_t path = 0, sy_keep = 0;
 
@@ -161,7 +161,7 @@ __global__ __launch_bounds__(kBlock, JPT_WAVES_PER_SIMD) void wf2_primary(WideSc
             continue;
         }
         {
-            if (walk_round<COUNT>(tr, active, sc, my_stack, cnt, tune.node_min_lanes)) {
+            if (walk_round<COUNT, W4>(tr, active, sc, my_stack, cnt, tune.node_min_lanes)) {
                 active = false;
                 const uint32_t f = path / dm.slots_per_frame;
                 const bool last_frame = (int)f == fp.n_frames - 1;
@@ -186,7 +186,7 @@ __global__ __launch_bounds__(kBlock, JPT_WAVES_PER_SIMD) void wf2_primary(WideSc
 
 // ---- bounces >= 1: trace the segment's ray queue ----------------------------------------------------------
 
-template <bool COUNT>
+template <bool COUNT, bool W4>
 __global__ __launch_bounds__(kBlock, JPT_WAVES_PER_SIMD) void wf2_trace(WideSceneDev sc, Wf2Buffers wb, Wf2Dims dm, int bounce, WfTune tune,
                                                     DevCounters* __restrict__ counters)
 {
@@ -199,12 +199,12 @@ __global__ __launch_bounds__(kBlock, JPT_WAVES_PER_SIMD) void wf2_trace(WideScen
     if (threadIdx.x == 0) s_cursor = 0;
     __syncthreads();
     int32_t spill[kStackSpill];
-    const typename Traversal<COUNT>::Stack my_stack{&stack[threadIdx.x], spill};
+    const typename Traversal<COUNT, W4>::Stack my_stack{&stack[threadIdx.x], spill};
     const size_t seg_base = (size_t)seg * dm.seg_cap;
     const float4* __restrict__ qo = wb.ray_o[bounce & 1] + seg_base;
     const float4* __restrict__ qd = wb.ray_d[bounce & 1] + seg_base;
     DevCounters cnt = {};
-    Traversal<COUNT> tr;
+    Traversal<COUNT, W4> tr;
     bool active = false, exhausted = false;
     uint32_t my_idx = 0;
 
@@ -231,7 +231,7 @@ __global__ __launch_bounds__(kBlock, JPT_WAVES_PER_SIMD) void wf2_trace(WideScen
             continue;
         }
         {
-            if (walk_round<COUNT>(tr, active, sc, my_stack, cnt, tune.node_min_lanes)) {
+            if (walk_round<COUNT, W4>(tr, active, sc, my_stack, cnt, tune.node_min_lanes)) {
                 active = false;
                 wb.hit_a[seg_base + my_idx] = make_float4(tr.hit.t, tr.hit.u, tr.hit.v, __uint_as_float(tr.hit.tri));
                 wb.hit_b[seg_base + my_idx] = tr.hit.inst | (tr.hit.front ? 0x80000000u : 0u);
@@ -434,12 +434,19 @@ void launch_wf2_render(hipStream_t stream, const DeviceScene& ds, const FramePar
     wb.rad = (float4*)carve(paths * sizeof(float4));
     wb.first_depth = (float*)carve((size_t)dm.slots_per_frame * sizeof(float));
 
+    static const bool allow4 = [] {
+        const char* e = getenv("JPT_BVH_WIDTH");
+        return !(e && atoi(e) == 2);
+    }();
+    const bool w4 = allow4 && ds.use4;
     WideSceneDev sc;
     sc.blas_nodes = ds.blas_nodes;
-    sc.tris = ds.wide_tris;
     sc.tlas_nodes = ds.tlas_nodes;
-    sc.instances = ds.wide_instances;
-    sc.tlas_root = ds.tlas_root;
+    sc.blas_nodes4 = ds.blas_nodes4;
+    sc.tlas_nodes4 = ds.tlas_nodes4;
+    sc.tris = ds.wide_tris;
+    sc.instances = w4 ? ds.wide_instances4 : ds.wide_instances;
+    sc.tlas_root = w4 ? ds.tlas_root4 : ds.tlas_root;
     sc.n_instances = ds.n_instances;
     const SceneShading sh = ds.shading();
     const dim3 grid(kSegments), block(kBlock);
@@ -452,16 +459,26 @@ void launch_wf2_render(hipStream_t stream, const DeviceScene& ds, const FramePar
 
     // every queue size is written by its producer kernel; no memset needed
     if (trace_events) (void)hipEventRecord(trace_events[0], stream);
-    if (counters) hipLaunchKernelGGL(wf2_primary<true>, grid, block, 0, stream, sc, wb, dm, fp, cam, tune, counters);
-    else hipLaunchKernelGGL(wf2_primary<false>, grid, block, 0, stream, sc, wb, dm, fp, cam, tune, counters);
+    if (counters) {
+        if (w4) hipLaunchKernelGGL((wf2_primary<true, true>), grid, block, 0, stream, sc, wb, dm, fp, cam, tune, counters);
+        else hipLaunchKernelGGL((wf2_primary<true, false>), grid, block, 0, stream, sc, wb, dm, fp, cam, tune, counters);
+    } else {
+        if (w4) hipLaunchKernelGGL((wf2_primary<false, true>), grid, block, 0, stream, sc, wb, dm, fp, cam, tune, counters);
+        else hipLaunchKernelGGL((wf2_primary<false, false>), grid, block, 0, stream, sc, wb, dm, fp, cam, tune, counters);
+    }
     if (trace_events) (void)hipEventRecord(trace_events[1], stream);
     for (int b = 0; b <= fp.max_bounces; b++) {
         if (counters) hipLaunchKernelGGL(wf2_shade<true>, grid, block, 0, stream, sh, wb, dm, fp, cam, b, counters);
         else hipLaunchKernelGGL(wf2_shade<false>, grid, block, 0, stream, sh, wb, dm, fp, cam, b, counters);
         if (b == fp.max_bounces) break;
         if (trace_events) (void)hipEventRecord(trace_events[2 * (b + 1)], stream);
-        if (counters) hipLaunchKernelGGL(wf2_trace<true>, grid, block, 0, stream, sc, wb, dm, b + 1, tune, counters);
-        else hipLaunchKernelGGL(wf2_trace<false>, grid, block, 0, stream, sc, wb, dm, b + 1, tune, counters);
+        if (counters) {
+            if (w4) hipLaunchKernelGGL((wf2_trace<true, true>), grid, block, 0, stream, sc, wb, dm, b + 1, tune, counters);
+            else hipLaunchKernelGGL((wf2_trace<true, false>), grid, block, 0, stream, sc, wb, dm, b + 1, tune, counters);
+        } else {
+            if (w4) hipLaunchKernelGGL((wf2_trace<false, true>), grid, block, 0, stream, sc, wb, dm, b + 1, tune, counters);
+            else hipLaunchKernelGGL((wf2_trace<false, false>), grid, block, 0, stream, sc, wb, dm, b + 1, tune, counters);
+        }
         if (trace_events) (void)hipEventRecord(trace_events[2 * (b + 1) + 1], stream);
     }
     const uint32_t ablocks = (dm.slots_per_frame + kBlock - 1) / kBlock;

@@ -23,10 +23,12 @@ constexpr int kStackSpill = 76;            // deeper entries go to scratch (rare
 constexpr int32_t kSentinel = 0x7fffffff;  // "leave the instance" marker on the stack
 
 struct WideSceneDev {
-    const WideNode* __restrict__ blas_nodes;
-    const WideTri* __restrict__ tris;
+    const WideNode* __restrict__ blas_nodes;   // two-child records (W4 = false)
     const WideNode* __restrict__ tlas_nodes;
-    const WideInstance* __restrict__ instances;
+    const WideNode4* __restrict__ blas_nodes4; // four-child records (W4 = true)
+    const WideNode4* __restrict__ tlas_nodes4;
+    const WideTri* __restrict__ tris;
+    const WideInstance* __restrict__ instances;  // roots refer to the record kind in use
     int32_t tlas_root;
     uint32_t n_instances;
 };
@@ -51,7 +53,7 @@ struct TraceHit {
     bool front;
 };
 
-template <bool COUNT>
+template <bool COUNT, bool W4 = false>
 struct Traversal {
     f3 wo, wd;        // world ray
     f3 o, d, rD;      // current-level ray (world at TLAS level, instance-local below)
@@ -115,9 +117,63 @@ struct Traversal {
     __device__ __forceinline__ bool wants_instance() const { return have && cur < 0 && !in_blas; }
     __device__ __forceinline__ bool finished() const { return !have && sp == 0; }
 
+    // four-child record (128 B = one L1 line): four slab tests, children visited nearest first.  The order
+    // among children is a performance choice only (the closest hit does not depend on it).
+    __device__ __forceinline__ void node_step4(const WideSceneDev& sc, const Stack& st, DevCounters& cnt)
+    {
+        const WideNode4* n = (in_blas ? sc.blas_nodes4 : sc.tlas_nodes4) + cur;
+        const float4 lx = ld4(&n->lo_x[0]), ly = ld4(&n->lo_y[0]), lz = ld4(&n->lo_z[0]);
+        const float4 hx = ld4(&n->hi_x[0]), hy = ld4(&n->hi_y[0]), hz = ld4(&n->hi_z[0]);
+        const float4 cf = ld4(&n->child[0]);
+        if (COUNT) {
+            if (in_blas) cnt.blas_expand++;
+            else cnt.tlas_expand++;
+        }
+        const int32_t c0 = __float_as_int(cf.x), c1 = __float_as_int(cf.y), c2 = __float_as_int(cf.z), c3 = __float_as_int(cf.w);
+        const float d0 = slab(o, rD, lx.x, ly.x, lz.x, hx.x, hy.x, hz.x);
+        const float d1 = slab(o, rD, lx.y, ly.y, lz.y, hx.y, hy.y, hz.y);
+        const float d2 = slab(o, rD, lx.z, ly.z, lz.z, hx.z, hy.z, hz.z);
+        const float d3 = slab(o, rD, lx.w, ly.w, lz.w, hx.w, hy.w, hz.w);
+        // sort keys: distance clamped to >= 0 (so the bit pattern orders like the value), child slot in the two
+        // low mantissa bits; unusable children (empty slot, or not closer than the current hit) sort last
+        constexpr uint32_t kInvalid = 0x7f800000u;
+        auto key = [&](float d, int32_t c, uint32_t slot) -> uint32_t {
+            const bool ok = (c != kEmptyChild) && (d < hit.t);
+            const uint32_t bits = (__float_as_uint(fmax_(d, 0.0f)) & ~3u) | slot;
+            return ok ? bits : (kInvalid | slot);
+        };
+        uint32_t k0 = key(d0, c0, 0u), k1 = key(d1, c1, 1u), k2 = key(d2, c2, 2u), k3 = key(d3, c3, 3u);
+        auto cswap = [](uint32_t& a, uint32_t& b) {
+            const uint32_t lo = a < b ? a : b, hi = a < b ? b : a;
+            a = lo;
+            b = hi;
+        };
+        cswap(k0, k1);
+        cswap(k2, k3);
+        cswap(k0, k2);
+        cswap(k1, k3);
+        cswap(k1, k2);
+        auto ref_of = [&](uint32_t k) -> int32_t {
+            const uint32_t slot = k & 3u;
+            return slot == 0u ? c0 : slot == 1u ? c1 : slot == 2u ? c2 : c3;
+        };
+        have = false;
+        if (k0 < kInvalid) {
+            if (k3 < kInvalid) push(st, ref_of(k3));
+            if (k2 < kInvalid) push(st, ref_of(k2));
+            if (k1 < kInvalid) push(st, ref_of(k1));
+            cur = ref_of(k0);
+            have = true;
+        }
+    }
+
     // internal record: both children's boxes in one 64-byte fetch; descends into the nearer valid child
     __device__ __forceinline__ void node_step(const WideSceneDev& sc, const Stack& st, DevCounters& cnt)
     {
+        if (W4) {
+            node_step4(sc, st, cnt);
+            return;
+        }
         const WideNode* n = (in_blas ? sc.blas_nodes : sc.tlas_nodes) + cur;
         const float4 a = ld4(&n->lmin[0]);  // lmin.xyz lmax.x
         const float4 b = ld4(&n->lmax[1]);  // lmax.yz rmin.xy
