@@ -826,6 +826,7 @@ int32_t collapse4(const std::vector<WideNode>& src, std::vector<WideNode4>& dst,
 int32_t collapse_root(const std::vector<WideNode>& src, std::vector<WideNode4>& dst, int32_t root, std::vector<int32_t>& memo)
 {
     if (root < 0) return root;  // the whole tree is one leaf
+    if ((size_t)root >= src.size()) return root;  // no tree at all (empty scene)
     const WideNode& w = src[(size_t)root];
     if (w.left == root && w.right == root) {  // empty mesh: a record whose four slots are empty
         const int32_t self = (int32_t)dst.size();
