@@ -55,7 +55,7 @@ struct TraceHit {
 
 template <bool COUNT, bool W4 = false>
 struct Traversal {
-    f3 wo, wd;        // world ray
+    f3 wo, wd, wrD;   // world ray and its reciprocal direction (kept so leaving an instance costs no divisions)
     f3 o, d, rD;      // current-level ray (world at TLAS level, instance-local below)
     TraceHit hit;
     int32_t cur;
@@ -99,6 +99,7 @@ struct Traversal {
         o = ro;
         d = rd;
         rD = rcp3(rd);
+        wrD = rD;
         hit.t = 1e9f;  // main.glsl:354
         hit.u = hit.v = 0.0f;
         hit.tri = hit.inst = 0;
@@ -327,7 +328,7 @@ struct Traversal {
         if (cur == kSentinel) {
             o = wo;
             d = wd;
-            rD = rcp3(wd);
+            rD = wrD;
             in_blas = false;
             if (sp == 0) return;
             cur = pop(st);
