@@ -1,0 +1,11 @@
+#!/bin/bash
+# Bench lines for the other BASELINE configs (not the headline): C2, C4, HDR accumulation, reference-exact tree.
+cd "$GRAFT_REPO_ROOT"
+run() { label="$1"; shift; python bench.py --steps 5 --warmup 2 --no-cpu-baseline "$@" 2>&1 | grep '^{' | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$label |', d['value'], 'Mrays/s |', d['ms_per_step'], 'ms/step | rays/step', d['config']['rays_per_step'], '| build_s', d['config']['scene_build_s'])"; }
+run "C3 (headline)" 
+run "C3 hdr accumulation" --accum hdr
+run "C2 1280x720 4spp 3b" --width 1280 --height 720 --spp 4 --bounces 3
+run "C4 1024 inst x 1024 tris" --scene inst
+run "C5-size on 1 GPU 3840x2160 16spp 6b" --width 3840 --height 2160 --spp 16 --bounces 6
+run "C3 reference-exact tree" --builder exact
+run "C3 audit kernel" --kernel ref
