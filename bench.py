@@ -27,6 +27,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 # bytes one event touches in the flattened layout (DESIGN.md "Algorithmic bytes")
 WIDE_BYTES = dict(blas_expand=64, tri_tests=48, tlas_expand=64, inst_visits=64, rays=32 + 20)
+# native builder: four-child 128-byte records
+WIDE4_BYTES = dict(blas_expand=128, tri_tests=48, tlas_expand=128, inst_visits=64, rays=32 + 20)
 # the same events priced in the reference layout
 REF_BYTES = dict(blas_expand=96, tri_tests=48, tlas_expand=64, inst_visits=224, shaded_hits=320)
 
@@ -170,7 +172,8 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         mrays = rays * args.steps / elapsed / 1e6
         # roofline of the dominant kernel (this rank's share of the events ~ total / world)
-        alg = algorithmic_bytes(total, WIDE_BYTES) / world / n_trace_launches          # per launch
+        table = WIDE4_BYTES if (args.builder == "sah" and args.kernel == "wavefront") else WIDE_BYTES
+        alg = algorithmic_bytes(total, table) / world / n_trace_launches               # per launch
         alg_ref = (algorithmic_bytes(total, REF_BYTES) + n_pixels * spp * 48) / world / n_trace_launches
         achieved = alg / (kernel_ms * 1e-3) / 1e9
         # HBM traffic of the dominant kernel: PMC counters cannot be read from inside the process, so the

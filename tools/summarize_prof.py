@@ -24,7 +24,7 @@ def kname(s):
     m = re.search(r"(wf2?_\w+|ref_frame_kernel|assemble_kernel)", s)
     if not m:
         return s.split("(")[0][:40]
-    return m.group(1) + ("_counted" if "<true>" in s else "")
+    return m.group(1) + ("_counted" if "<true" in s else "")
 
 
 def main(src, dst, tag):
