@@ -20,6 +20,10 @@
 
 #include "jpt_trace_core.h"
 
+#ifndef JPT_PRIMARY_WAVES
+#define JPT_PRIMARY_WAVES JPT_WAVES_PER_SIMD
+#endif
+
 namespace jpt {
 
 namespace {
@@ -104,7 +108,7 @@ __device__ __forceinline__ uint32_t lanes_below(unsigned long long mask, int lan
 // ---- bounce 0: generate + trace ------------------------------------------------------------------------
 
 template <bool COUNT, bool W4>
-__global__ __launch_bounds__(kBlock, JPT_WAVES_PER_SIMD) void wf2_primary(WideSceneDev sc, Wf2Buffers wb, Wf2Dims dm, FrameParams fp, RefCamera cam,
+__global__ __launch_bounds__(kBlock, JPT_PRIMARY_WAVES) void wf2_primary(WideSceneDev sc, Wf2Buffers wb, Wf2Dims dm, FrameParams fp, RefCamera cam,
                                                       WfTune tune, DevCounters* __restrict__ counters)
 {
     __shared__ int32_t stack[kStackLds * kBlock];
@@ -125,7 +129,7 @@ __global__ __launch_bounds__(kBlock, JPT_WAVES_PER_SIMD) void wf2_primary(WideSc
     DevCounters cnt = {};
     Traversal<COUNT, W4> tr;
     bool active = false, exhausted = false;
-    uint32_t path = 0, sy_keep = 0;
+    uint32_t path = 0;
 
     for (;;) {
         const unsigned long long idle = __ballot(!active);
@@ -148,7 +152,6 @@ __global__ __launch_bounds__(kBlock, JPT_WAVES_PER_SIMD) void wf2_primary(WideSc
                         uint32_t sx, sy;
                         const Ray ray = primary_ray(cam, fp.width, fp.height, px, py, fp.frame_index + f, sx, sy);
                         path = f * dm.slots_per_frame + slot;
-                        sy_keep = sy;
                         tr.begin(sc, ray.o, ray.d);
                         active = true;
                         if (COUNT) cnt.rays++;
@@ -173,7 +176,7 @@ __global__ __launch_bounds__(kBlock, JPT_WAVES_PER_SIMD) void wf2_primary(WideSc
                     wb.hit_b[seg_base + j] = tr.hit.inst | (tr.hit.front ? 0x80000000u : 0u);
                 } else {                // sky: radiance += 1 * sampleSky(d), path over (main.glsl:380,395-397)
                     const f3 sky = mk3(0.0f, 0.0f, 0.0f) + mk3(1.0f, 1.0f, 1.0f) * sample_sky(tr.wd);
-                    wb.rad[path] = make_float4(sky.x, sky.y, sky.z, __uint_as_float(sy_keep));
+                    wb.rad[path] = make_float4(sky.x, sky.y, sky.z, 0.0f);  // path over: its seed is never used again
                     if (last_frame) wb.first_depth[path - f * dm.slots_per_frame] = cam.far_;
                 }
             }
