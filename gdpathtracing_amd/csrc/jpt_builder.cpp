@@ -845,6 +845,58 @@ int32_t collapse_root(const std::vector<WideNode>& src, std::vector<WideNode4>& 
 
 }  // namespace
 
+namespace {
+
+// worst-case pending entries below a record: near-first traversal keeps (children - 1) siblings pending while it
+// descends into one child
+uint32_t need2(const std::vector<WideNode>& nodes, int32_t ref, std::vector<int32_t>& memo)
+{
+    if (ref < 0 || (size_t)ref >= nodes.size()) return 0;
+    if (memo[(size_t)ref] >= 0) return (uint32_t)memo[(size_t)ref];
+    const WideNode& n = nodes[(size_t)ref];
+    uint32_t r = 0;
+    if (!(n.left == ref && n.right == ref)) {
+        memo[(size_t)ref] = 0;
+        r = 1u + std::max(need2(nodes, n.left, memo), need2(nodes, n.right, memo));
+    }
+    memo[(size_t)ref] = (int32_t)r;
+    return r;
+}
+uint32_t need4(const std::vector<WideNode4>& nodes, int32_t ref, std::vector<int32_t>& memo)
+{
+    if (ref < 0 || (size_t)ref >= nodes.size()) return 0;
+    if (memo[(size_t)ref] >= 0) return (uint32_t)memo[(size_t)ref];
+    const WideNode4& n = nodes[(size_t)ref];
+    memo[(size_t)ref] = 0;
+    uint32_t kids = 0, deepest = 0;
+    for (int i = 0; i < 4; i++)
+        if (n.child[i] != kEmptyChild) {
+            kids++;
+            deepest = std::max(deepest, need4(nodes, n.child[i], memo));
+        }
+    const uint32_t r = kids ? (kids - 1u) + deepest : 0u;
+    memo[(size_t)ref] = (int32_t)r;
+    return r;
+}
+
+}  // namespace
+
+void compute_stack_need(WideScene& out)
+{
+    {
+        std::vector<int32_t> mb(out.blas_nodes.size(), -1), mt(out.tlas_nodes.size(), -1);
+        uint32_t blas = 0;
+        for (const WideInstance& i : out.instances) blas = std::max(blas, need2(out.blas_nodes, i.root, mb));
+        out.stack_need2 = need2(out.tlas_nodes, out.tlas_root, mt) + 1u + blas;
+    }
+    {
+        std::vector<int32_t> mb(out.blas_nodes4.size(), -1), mt(out.tlas_nodes4.size(), -1);
+        uint32_t blas = 0;
+        for (const WideInstance& i : out.instances4) blas = std::max(blas, need4(out.blas_nodes4, i.root, mb));
+        out.stack_need4 = out.instances4.empty() ? 0u : need4(out.tlas_nodes4, out.tlas_root4, mt) + 1u + blas;
+    }
+}
+
 void flatten4(WideScene& out)
 {
     out.blas_nodes4.clear();

@@ -53,6 +53,9 @@ struct WideScene {
     std::vector<WideNode4> blas_nodes4, tlas_nodes4;
     std::vector<WideInstance> instances4;
     int32_t tlas_root4 = 0;
+    // worst-case number of live traversal-stack entries (TLAS pending + sentinel + BLAS pending) for the
+    // two-child and the four-child records; the kernels' stack capacity must cover it
+    uint32_t stack_need2 = 0, stack_need4 = 0;
 };
 
 enum class BuildMode { ReferenceExact = 0, Sah = 1 };
@@ -86,5 +89,8 @@ bool flatten(const RefScene& ref, WideScene& out, std::string& err);
 // replaced, largest box first, by their own children until four slots are used.  Boxes and leaves are kept as
 // they are, so the set of triangles a ray can reach is unchanged; only the visiting order differs.
 void flatten4(WideScene& out);
+
+// fills WideScene::stack_need2 / stack_need4 (call after flatten / flatten4)
+void compute_stack_need(WideScene& out);
 
 }  // namespace jpt

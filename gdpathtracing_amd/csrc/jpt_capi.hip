@@ -173,6 +173,15 @@ int upload_scene(jpt_ctx* c)
         c->wide.tlas_nodes4.clear();
         c->wide.instances4.clear();
     }
+    compute_stack_need(c->wide);
+    {
+        // the reference walks with two unchecked 64-entry stacks (main.glsl:272,307); here a deeper tree is an
+        // error at upload time instead of undefined behaviour at render time
+        const uint32_t need = use4 ? c->wide.stack_need4 : c->wide.stack_need2;
+        if (need > trace_stack_capacity())
+            return fail(c, JPT_E_LIMIT, "acceleration structure too deep: a traversal could need " + std::to_string(need) +
+                                            " stack entries, the kernels hold " + std::to_string(trace_stack_capacity()));
+    }
     if (c->device < 0) return JPT_OK;  // host-only context: arrays stay on the host, nothing can be rendered
     HIP_TRY(c, hipSetDevice(c->device));
     hipStream_t s = c->stream;

@@ -127,6 +127,7 @@ void launch_wide_render(hipStream_t stream, const DeviceScene& ds, const FramePa
 // wf2_segments() u32 of `workspace` are per-bounce, per-segment queue sizes afterwards; rows 1..max_bounces
 // sum to the secondary ray segments traced.  trace_events: pairs around wf2_primary and each wf2_trace.
 uint32_t wf2_segments();
+uint32_t trace_stack_capacity();  // entries a lane's traversal stack can hold (LDS + scratch)
 size_t wf2_workspace_bytes(int width, int local_rows, int n_frames, int max_bounces);
 void launch_wf2_render(hipStream_t stream, const DeviceScene& ds, const FrameParams& fp, const RefCamera& cam, void* workspace,
                        float4* accum, uint32_t* ldr, float* depth, DevCounters* counters, hipEvent_t* trace_events);

@@ -395,6 +395,7 @@ Wf2Dims make_dims(int width, int local_rows, int n_frames)
 }  // namespace
 
 uint32_t wf2_segments() { return kSegments; }
+uint32_t trace_stack_capacity() { return (uint32_t)(kStackLds + kStackSpill); }
 
 size_t wf2_workspace_bytes(int width, int local_rows, int n_frames, int max_bounces)
 {

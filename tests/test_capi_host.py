@@ -110,3 +110,31 @@ def test_host_mirror_classes(hiplib):
     assert g.get_bvh_node_count() == len(g.get_bvh_buffer())
     assert g.get_materials_buffer().dtype == wire.MATERIAL and len(g.get_materials_buffer()) == 7
     assert g.get_triangles_data_buffer().nbytes == 80 * sc.n_unique_tris
+
+
+def test_too_deep_tree_is_rejected_at_upload(hiplib, oracle):
+    """The reference walks with unchecked 64-entry stacks (main.glsl:272,307).  A tree whose worst-case stack
+    exceeds what the kernels hold is refused at upload (JPT_E_LIMIT) instead of rendering garbage."""
+    ref = oracle.build_scene(scenes.cornell_scene())
+    depth = 200
+    tri = np.repeat(ref.tri_geom[:1], depth + 1)
+    dat = np.repeat(ref.tri_data[:1], depth + 1)
+    nodes = np.zeros(2 * depth + 1, dtype=wire.BVH_NODE)
+    nodes["aabbMin"][:, :3] = -1
+    nodes["aabbMax"][:, :3] = 1
+    for i in range(depth):          # node 2i: internal, left = leaf 2i+1, right = 2i+2
+        nodes[2 * i]["left_child"], nodes[2 * i]["right_child"] = 2 * i + 1, 2 * i + 2
+        nodes[2 * i + 1]["first_tri_index"], nodes[2 * i + 1]["tri_count"] = i, 1
+    nodes[2 * depth]["first_tri_index"], nodes[2 * depth]["tri_count"] = depth, 1
+    inst = ref.instances[:1].copy()
+    inst["blas_index"] = 0
+    tlas = np.zeros(2, dtype=wire.TLAS_NODE)
+    tlas["aabbMin"], tlas["aabbMax"] = -1, 1
+    ctx = host.Context(-1)
+    with pytest.raises(capi.JptError, match="too deep"):
+        ctx.upload_reference_layout(tri, dat, ref.materials, nodes, inst, tlas)
+    shallow = nodes.copy()
+    shallow[2 * 40]["left_child"] = shallow[2 * 40]["right_child"] = 0   # cut the chain at depth 40
+    shallow[2 * 40]["first_tri_index"], shallow[2 * 40]["tri_count"] = 40, 1
+    ctx.upload_reference_layout(tri, dat, ref.materials, shallow, inst, tlas)
+    ctx.close()
