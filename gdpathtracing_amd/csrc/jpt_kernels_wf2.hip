@@ -250,94 +250,86 @@ template <bool COUNT>
 __global__ __launch_bounds__(kBlock) void wf2_shade(SceneShading sh, Wf2Buffers wb, Wf2Dims dm, FrameParams fp, RefCamera cam,
                                                     int bounce, DevCounters* __restrict__ counters)
 {
-    __shared__ uint32_t wave_count[kBlock / 64];
-    __shared__ uint32_t s_out_base;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t seg = blockIdx.x;
+    // grid = (chunks per segment, segments): every 256-entry chunk of every segment is its own block, so the
+    // launch is balanced however unevenly the segments are filled; blocks past a segment's end exit at once.
+    const int lane = threadIdx.x & 63;
+    const uint32_t seg = blockIdx.y;
     const uint32_t n = wb.qcount[(size_t)bounce * kSegments + seg];
+    const uint32_t base = blockIdx.x * kBlock;
+    if (base >= n) return;
     const size_t seg_base = (size_t)seg * dm.seg_cap;
     const int in = bounce & 1, out = (bounce + 1) & 1;
-    if (threadIdx.x == 0) s_out_base = 0;
-    __syncthreads();
     DevCounters cnt = {};
-    for (uint32_t base = 0; base < n; base += kBlock) {
-        const uint32_t i = base + threadIdx.x;
-        bool alive = false;
-        float4 no, nd;
-        if (i < n) {
-            const float4 ro = wb.ray_o[in][seg_base + i], rd = wb.ray_d[in][seg_base + i];
-            const uint32_t p = __float_as_uint(rd.w);
-            const float4 ha = wb.hit_a[seg_base + i];
-            const uint32_t hb = wb.hit_b[seg_base + i];
-            f3 throughput, radiance;
-            uint32_t sx, sy;
-            const uint32_t f = p / dm.slots_per_frame, slot = p - f * dm.slots_per_frame;
-            if (bounce == 0) {
-                // fresh path: the seed after the jitter draw (main.glsl:409-411), recomputed from (x, y, frame)
-                int px, ly;
-                slot_to_pixel(slot, dm, px, ly);
-                prng_seed((uint32_t)px, (uint32_t)local_to_global_row(ly, fp), fp.frame_index + f, sx, sy);
-                float r0, r1;
-                pcg2d(sx, sy, r0, r1);
-                throughput = mk3(1.0f, 1.0f, 1.0f);
-                radiance = mk3(0.0f, 0.0f, 0.0f);
-            } else {
-                const float4 t4 = wb.thr[p], r4 = wb.rad[p];
-                throughput = mk3(t4.x, t4.y, t4.z);
-                radiance = mk3(r4.x, r4.y, r4.z);
-                sx = __float_as_uint(t4.w);
-                sy = __float_as_uint(r4.w);
-            }
-            Ray ray;
-            ray.o = mk3(ro.x, ro.y, ro.z);
-            ray.d = mk3(rd.x, rd.y, rd.z);
-            if (COUNT && bounce > 0) cnt.rays++;
-            if (!(ha.x < 1e9f)) {  // main.glsl:349
-                radiance = radiance + throughput * sample_sky(ray.d);
-            } else {
-                if (COUNT) cnt.shaded_hits++;
-                Hit h;
-                h.t = ha.x;
-                h.u = ha.y;
-                h.v = ha.z;
-                h.tri = __float_as_uint(ha.w);
-                h.inst = hb & 0x7fffffffu;
-                // the hit instance's local ray: the expression ray_trace_tlas evaluates (main.glsl:319-320)
-                const RefInstance& b = sh.instances[h.inst];
-                h.lo = xform_point(b.inverse_transform, ray.o);
-                h.ld = xform_dir(b.inverse_transform, ray.d);
-                const Shading s = get_shading_data(sh, h, (hb >> 31) != 0u);
-                radiance = radiance + throughput * s.emission;
-                if (bounce == 0 && (int)f == fp.n_frames - 1) wb.first_depth[slot] = length3(s.position - ray.o);
-                if (bounce < fp.max_bounces) alive = bounce_step(s, sx, sy, ray, throughput);
-            }
-            wb.rad[p] = make_float4(radiance.x, radiance.y, radiance.z, __uint_as_float(sy));
-            if (alive) {
-                wb.thr[p] = make_float4(throughput.x, throughput.y, throughput.z, __uint_as_float(sx));
-                no = make_float4(ray.o.x, ray.o.y, ray.o.z, 0.0f);
-                nd = make_float4(ray.d.x, ray.d.y, ray.d.z, __uint_as_float(p));
-            }
+    const uint32_t i = base + threadIdx.x;
+    bool alive = false;
+    float4 no, nd;
+    if (i < n) {
+        const float4 ro = wb.ray_o[in][seg_base + i], rd = wb.ray_d[in][seg_base + i];
+        const uint32_t p = __float_as_uint(rd.w);
+        const float4 ha = wb.hit_a[seg_base + i];
+        const uint32_t hb = wb.hit_b[seg_base + i];
+        f3 throughput, radiance;
+        uint32_t sx, sy;
+        const uint32_t f = p / dm.slots_per_frame, slot = p - f * dm.slots_per_frame;
+        if (bounce == 0) {
+            // fresh path: the seed after the jitter draw (main.glsl:409-411), recomputed from (x, y, frame)
+            int px, ly;
+            slot_to_pixel(slot, dm, px, ly);
+            prng_seed((uint32_t)px, (uint32_t)local_to_global_row(ly, fp), fp.frame_index + f, sx, sy);
+            float r0, r1;
+            pcg2d(sx, sy, r0, r1);
+            throughput = mk3(1.0f, 1.0f, 1.0f);
+            radiance = mk3(0.0f, 0.0f, 0.0f);
+        } else {
+            const float4 t4 = wb.thr[p], r4 = wb.rad[p];
+            throughput = mk3(t4.x, t4.y, t4.z);
+            radiance = mk3(r4.x, r4.y, r4.z);
+            sx = __float_as_uint(t4.w);
+            sy = __float_as_uint(r4.w);
         }
-        // active-ray packing: wave ballot + prefix popcount; wave totals and the running base in LDS
-        const unsigned long long m = __ballot(alive);
-        if (lane == 0) wave_count[wave] = (uint32_t)__popcll(m);
-        __syncthreads();
-        uint32_t my_base = s_out_base;
-        for (int w = 0; w < wave; w++) my_base += wave_count[w];
+        Ray ray;
+        ray.o = mk3(ro.x, ro.y, ro.z);
+        ray.d = mk3(rd.x, rd.y, rd.z);
+        if (COUNT && bounce > 0) cnt.rays++;
+        if (!(ha.x < 1e9f)) {  // main.glsl:349
+            radiance = radiance + throughput * sample_sky(ray.d);
+        } else {
+            if (COUNT) cnt.shaded_hits++;
+            Hit h;
+            h.t = ha.x;
+            h.u = ha.y;
+            h.v = ha.z;
+            h.tri = __float_as_uint(ha.w);
+            h.inst = hb & 0x7fffffffu;
+            // the hit instance's local ray: the expression ray_trace_tlas evaluates (main.glsl:319-320)
+            const RefInstance& b = sh.instances[h.inst];
+            h.lo = xform_point(b.inverse_transform, ray.o);
+            h.ld = xform_dir(b.inverse_transform, ray.d);
+            const Shading s = get_shading_data(sh, h, (hb >> 31) != 0u);
+            radiance = radiance + throughput * s.emission;
+            if (bounce == 0 && (int)f == fp.n_frames - 1) wb.first_depth[slot] = length3(s.position - ray.o);
+            if (bounce < fp.max_bounces) alive = bounce_step(s, sx, sy, ray, throughput);
+        }
+        wb.rad[p] = make_float4(radiance.x, radiance.y, radiance.z, __uint_as_float(sy));
         if (alive) {
-            const size_t j = seg_base + my_base + lanes_below(m, lane);
+            wb.thr[p] = make_float4(throughput.x, throughput.y, throughput.z, __uint_as_float(sx));
+            no = make_float4(ray.o.x, ray.o.y, ray.o.z, 0.0f);
+            nd = make_float4(ray.d.x, ray.d.y, ray.d.z, __uint_as_float(p));
+        }
+    }
+    // active-ray packing: wave ballot + prefix popcount, one atomic per wave on the SEGMENT's counter (1792
+    // different words: no hot address); the order inside the next queue is irrelevant
+    const unsigned long long m = __ballot(alive);
+    if (m) {
+        uint32_t wbase = 0;
+        if (lane == 0) wbase = atomicAdd(&wb.qcount[(size_t)(bounce + 1) * kSegments + seg], (uint32_t)__popcll(m));
+        wbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)wbase);
+        if (alive) {
+            const size_t j = seg_base + wbase + lanes_below(m, lane);
             wb.ray_o[out][j] = no;
             wb.ray_d[out][j] = nd;
         }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            uint32_t tot = 0;
-            for (int w = 0; w < kBlock / 64; w++) tot += wave_count[w];
-            s_out_base += tot;
-        }
-        __syncthreads();
     }
-    if (threadIdx.x == 0) wb.qcount[(size_t)(bounce + 1) * kSegments + seg] = s_out_base;
     if (COUNT) flush_counters(cnt, counters);
 }
 
@@ -461,7 +453,9 @@ void launch_wf2_render(hipStream_t stream, const DeviceScene& ds, const FramePar
         return t;
     }();
 
-    // every queue size is written by its producer kernel; no memset needed
+    // queue sizes of bounces >= 1 are accumulated with atomics by wf2_shade: start from zero
+    (void)hipMemsetAsync(wb.qcount + kSegments, 0, (size_t)(nq - 1) * kSegments * sizeof(uint32_t), stream);
+    const dim3 sgrid((dm.seg_cap + kBlock - 1) / kBlock, kSegments);
     if (trace_events) (void)hipEventRecord(trace_events[0], stream);
     if (counters) {
         if (w4) hipLaunchKernelGGL((wf2_primary<true, true>), grid, block, 0, stream, sc, wb, dm, fp, cam, tune, counters);
@@ -472,8 +466,8 @@ void launch_wf2_render(hipStream_t stream, const DeviceScene& ds, const FramePar
     }
     if (trace_events) (void)hipEventRecord(trace_events[1], stream);
     for (int b = 0; b <= fp.max_bounces; b++) {
-        if (counters) hipLaunchKernelGGL(wf2_shade<true>, grid, block, 0, stream, sh, wb, dm, fp, cam, b, counters);
-        else hipLaunchKernelGGL(wf2_shade<false>, grid, block, 0, stream, sh, wb, dm, fp, cam, b, counters);
+        if (counters) hipLaunchKernelGGL(wf2_shade<true>, sgrid, block, 0, stream, sh, wb, dm, fp, cam, b, counters);
+        else hipLaunchKernelGGL(wf2_shade<false>, sgrid, block, 0, stream, sh, wb, dm, fp, cam, b, counters);
         if (b == fp.max_bounces) break;
         if (trace_events) (void)hipEventRecord(trace_events[2 * (b + 1)], stream);
         if (counters) {
