@@ -248,3 +248,57 @@ def test_c3_ldr8_bounds_and_hdr_mode(hiplib, c3):
     dark = hdr[..., :3].max(axis=-1) <= 0.99 * 1.0    # pixels that never clip agree to quantisation error
     assert np.abs(hdr[..., :3] - a[..., :3])[dark].max() <= SPP * 0.51 / 255 + 1e-5
     ctx.close()
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+@pytest.mark.parametrize("w,h", [(1, 1), (7, 5), (33, 17), (250, 131), (64, 9)])
+def test_ragged_resolutions(oracle, hiplib, w, h, kernel):
+    """Widths/heights that are not multiples of the 8x8 tile (padding lanes) or of the 8-row strip."""
+    sc = scenes.cornell_scene()
+    ref = oracle.build_scene(sc)
+    want, want_ldr, want_depth, cnt, _ = oracle.render(ref, scenes.camera_block(sc.camera, w, h), w, h, 3, 2, 1, wire.ACCUM_REF_LDR8)
+    ctx = make_ctx(sc, w, h, 3, wire.ACCUM_REF_LDR8, capi.BUILD_REFERENCE_EXACT, kernel)
+    ctx.render(2, 1)
+    assert np.array_equal(ctx.read_accum(), want)
+    assert np.array_equal(ctx.read_ldr(), want_ldr)
+    assert np.array_equal(ctx.read_depth(), want_depth)
+    if kernel != capi.KERNEL_REFERENCE_LAYOUT:
+        assert ctx.stats()["rays"] == cnt["rays"]
+    ctx.close()
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_ragged_partition_matches_single_context(hiplib, world):
+    """Strip partition with a height that leaves ranks unequal (and one partial strip)."""
+    sc = scenes.cornell_scene()
+    w, h = 96, 45
+    full = make_ctx(sc, w, h, 2, wire.ACCUM_REF_LDR8)
+    full.render(2, 1)
+    want = full.read_accum()
+    full.close()
+    got = np.zeros_like(want)
+    rows_seen = 0
+    for r in range(world):
+        ctx = make_ctx(sc, w, h, 2, wire.ACCUM_REF_LDR8, rank=r, world=world)
+        ctx.render(2, 1)
+        rows = partition.rows_of_rank(h, r, world)
+        assert ctx.local_rows() == len(rows)
+        part = ctx.read_accum()
+        got[rows] = part[rows]
+        rows_seen += len(rows)
+        ctx.close()
+    assert rows_seen == h and np.array_equal(got, want)
+
+
+def test_c5_like_config_reduced(oracle, hiplib):
+    """Config C5's depth (6 bounces, 16 spp) at 160x90 on one GPU."""
+    sc = scenes.demo_scene(51200)
+    w, h = 160, 90
+    ref = oracle.build_scene(sc)
+    want, _, _, cnt, _ = oracle.render(ref, scenes.camera_block(sc.camera, w, h), w, h, 6, 16, 1, wire.ACCUM_REF_LDR8)
+    ctx = make_ctx(sc, w, h, 6, wire.ACCUM_REF_LDR8)
+    ctx.render(16, 1)
+    got = ctx.read_accum()
+    assert rel_l2(got, want) <= 1e-4 and ctx.stats()["rays"] == cnt["rays"]
+    assert int((got != want).any(axis=-1).sum()) == 0
+    ctx.close()
