@@ -53,6 +53,9 @@ def main():
     ap.add_argument("--builder", default="sah", choices=["sah", "exact"])
     ap.add_argument("--accum", default="ldr8", choices=["ldr8", "hdr"])
     ap.add_argument("--kernel", default="wavefront", choices=["wavefront", "ref", "wavefront_v1"])
+    ap.add_argument("--camera", default="demo", choices=["demo", "closeup"],
+                    help="demo = demo.tscn's camera (the box covers ~1/6 of the frame); closeup = camera at the box opening "
+                         "(every pixel sees geometry; not the headline config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", default="auto")
     ap.add_argument("--pmc-json", default=os.path.join(ROOT, "profiles", "current_pmc.json"),
@@ -83,6 +86,8 @@ def main():
         sc = scenes.cornell_scene()
     else:
         sc = scenes.instanced_scene()
+    if args.camera == "closeup":
+        sc.camera = scenes.CameraDesc(scenes.transform12(None, (0.0, 0.0, 4.2)), fov_deg=75.0)
     W, H, spp, bounces = args.width, args.height, args.spp, args.bounces
     cam = scenes.camera_block(sc.camera, W, H)
     accum_mode = capi.ACCUM_REF_LDR8 if args.accum == "ldr8" else capi.ACCUM_HDR_F32
@@ -180,7 +185,7 @@ def main():
         # per-launch figure comes from the committed rocprofv3 passes of this same command (profiles/)
         traffic, traffic_src = None, None
         dom = "wf2_trace" if args.kernel == "wavefront" else "ref_frame_kernel"
-        default_run = (W, H, spp, bounces, args.tris, args.scene, args.builder, world) == (1920, 1080, 8, 4, 51200, "demo", "sah", 1)
+        default_run = (W, H, spp, bounces, args.tris, args.scene, args.builder, world, args.camera) == (1920, 1080, 8, 4, 51200, "demo", "sah", 1, "demo")
         if default_run and os.path.exists(args.pmc_json):
             try:
                 pj = json.load(open(args.pmc_json))
@@ -206,7 +211,7 @@ def main():
             "config": {
                 "workload": "C3: S-demo (open Cornell cube + light + 2 instances of a %d-tri procedural mesh), %dx%d, %d spp, "
                             "%d bounces, accum=%s, builder=%s, kernel=%s" % (args.tris, W, H, spp, bounces, args.accum, args.builder, args.kernel)
-                if args.scene == "demo" else "%s %dx%d %d spp %d bounces" % (sc.name, W, H, spp, bounces),
+                if (args.scene == "demo" and args.camera == "demo") else "%s (camera %s) %dx%d %d spp %d bounces" % (sc.name, args.camera, W, H, spp, bounces),
                 "unique_tris": sc.n_unique_tris, "instances": len(sc.instances),
                 "rays_per_step": rays, "nominal_rays_per_step": n_pixels * spp * (bounces + 1),
                 "parallelism": "screen strips x%d" % world,

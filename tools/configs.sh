@@ -7,5 +7,7 @@ run "C3 hdr accumulation" --accum hdr
 run "C2 1280x720 4spp 3b" --width 1280 --height 720 --spp 4 --bounces 3
 run "C4 1024 inst x 1024 tris" --scene inst
 run "C5-size on 1 GPU 3840x2160 16spp 6b" --width 3840 --height 2160 --spp 16 --bounces 6
+run "C3 scene, close-up camera (every pixel hits)" --camera closeup
+run "1 frame per render (interactive use)" --spp 1
 run "C3 reference-exact tree" --builder exact
 run "C3 audit kernel" --kernel ref
