@@ -400,6 +400,127 @@ bool build_tlas(const std::vector<RefInstance>& inst, std::vector<RefTlasNode>& 
     return true;
 }
 
+// Native TLAS: top-down binned SAH over the instances' world boxes, emitted in the reference's TLASNode format
+// (slot 0 = copy of the root, leaves 1..N, 16-bit child indices) so the rest of the pipeline is unchanged.
+// The reference's agglomerative clustering (build_tlas) is O(N^2) and yields deep, overlapping trees for grids
+// of instances; the closest hit does not depend on the TLAS shape.
+struct TlasSahBuilder {
+    const std::vector<RefInstance>& inst;
+    std::vector<RefTlasNode>& out;
+    std::vector<uint32_t> order;
+
+    static void box_of(const RefInstance& i, float* lo, float* hi)
+    {
+        lo[0] = i.aabbMin.x; lo[1] = i.aabbMin.y; lo[2] = i.aabbMin.z;
+        hi[0] = i.aabbMax.x; hi[1] = i.aabbMax.y; hi[2] = i.aabbMax.z;
+    }
+    uint32_t build(int lo, int hi)
+    {
+        if (hi - lo == 1) return 1u + order[(size_t)lo];
+        Box3 box, cbox;
+        for (int i = lo; i < hi; i++) {
+            float a[3], b[3];
+            box_of(inst[order[(size_t)i]], a, b);
+            box.grow(a);
+            box.grow(b);
+            const float c[3] = {0.5f * (a[0] + b[0]), 0.5f * (a[1] + b[1]), 0.5f * (a[2] + b[2])};
+            cbox.grow(c);
+        }
+        constexpr int kBins = 16;
+        int best_axis = -1, best_bin = -1;
+        float best_cost = FLT_MAX;
+        for (int axis = 0; axis < 3; axis++) {
+            const float c0 = cbox.lo[axis], c1 = cbox.hi[axis];
+            if (!(c1 > c0)) continue;
+            const float scale = float(kBins) / (c1 - c0);
+            Box3 bb[kBins];
+            int bn[kBins] = {0};
+            for (int i = lo; i < hi; i++) {
+                float a[3], b[3];
+                box_of(inst[order[(size_t)i]], a, b);
+                int k = (int)((0.5f * (a[axis] + b[axis]) - c0) * scale);
+                k = k < 0 ? 0 : (k >= kBins ? kBins - 1 : k);
+                bb[k].grow(a);
+                bb[k].grow(b);
+                bn[k]++;
+            }
+            float right_area[kBins];
+            int right_n[kBins];
+            Box3 acc;
+            int n = 0;
+            for (int k = kBins - 1; k > 0; k--) {
+                acc.grow(bb[k]);
+                n += bn[k];
+                right_area[k] = n ? acc.half_area() : 0.0f;
+                right_n[k] = n;
+            }
+            acc = Box3();
+            n = 0;
+            for (int k = 0; k < kBins - 1; k++) {
+                acc.grow(bb[k]);
+                n += bn[k];
+                if (n == 0 || right_n[k + 1] == 0) continue;
+                const float cost = acc.half_area() * float(n) + right_area[k + 1] * float(right_n[k + 1]);
+                if (cost < best_cost) {
+                    best_cost = cost;
+                    best_axis = axis;
+                    best_bin = k;
+                }
+            }
+        }
+        int mid = lo + (hi - lo) / 2;
+        if (best_axis >= 0) {
+            const float c0 = cbox.lo[best_axis], scale = float(kBins) / (cbox.hi[best_axis] - c0);
+            auto it = std::partition(order.begin() + lo, order.begin() + hi, [&](uint32_t id) {
+                float a[3], b[3];
+                box_of(inst[id], a, b);
+                int k = (int)((0.5f * (a[best_axis] + b[best_axis]) - c0) * scale);
+                k = k < 0 ? 0 : (k >= kBins ? kBins - 1 : k);
+                return k <= best_bin;
+            });
+            const int m = (int)(it - order.begin());
+            if (m > lo && m < hi) mid = m;
+        }
+        const uint32_t l = build(lo, mid), r = build(mid, hi);
+        RefTlasNode n;
+        std::memset(&n, 0, sizeof n);
+        n.leftRight = l + (r << 16);
+        for (int k = 0; k < 3; k++) {
+            n.aabbMin[k] = lo_(out[l].aabbMin[k], out[r].aabbMin[k]);
+            n.aabbMax[k] = hi_(out[l].aabbMax[k], out[r].aabbMax[k]);
+        }
+        out.push_back(n);
+        return (uint32_t)out.size() - 1u;
+    }
+};
+
+bool build_tlas_sah(const std::vector<RefInstance>& inst, std::vector<RefTlasNode>& out, std::string& err)
+{
+    const int count = (int)inst.size();
+    out.clear();
+    out.emplace_back();
+    std::memset(&out[0], 0, sizeof(RefTlasNode));
+    if (count == 0) return true;
+    if (count * 2 > 65535) {
+        err = "TLAS: more than 32767 instances do not fit the reference's 16-bit child indices";
+        return false;
+    }
+    for (int i = 0; i < count; i++) {
+        RefTlasNode n;
+        std::memset(&n, 0, sizeof n);
+        n.aabbMin[0] = inst[(size_t)i].aabbMin.x; n.aabbMin[1] = inst[(size_t)i].aabbMin.y; n.aabbMin[2] = inst[(size_t)i].aabbMin.z;
+        n.aabbMax[0] = inst[(size_t)i].aabbMax.x; n.aabbMax[1] = inst[(size_t)i].aabbMax.y; n.aabbMax[2] = inst[(size_t)i].aabbMax.z;
+        n.blas = (uint32_t)i;
+        out.push_back(n);
+    }
+    TlasSahBuilder b{inst, out, {}};
+    b.order.resize((size_t)count);
+    std::iota(b.order.begin(), b.order.end(), 0u);
+    const uint32_t root = b.build(0, count);
+    out[0] = out[root];
+    return true;
+}
+
 }  // namespace
 
 // godot Basis::invert (cofactors) + Transform3D::affine_inverse, float.  godot-cpp (branch 4.3) is an
@@ -534,7 +655,8 @@ bool SceneBuilder::commit(BuildMode mode, RefScene& out, std::string& err)
         }
         out.instances.push_back(inst);
     }
-    if (!build_tlas(out.instances, out.tlas_nodes, err)) return false;
+    if (mode == BuildMode::Sah ? !build_tlas_sah(out.instances, out.tlas_nodes, err) : !build_tlas(out.instances, out.tlas_nodes, err))
+        return false;
     // Triangle -> GpuTriangleGeometry / GpuTriangleData (geometry_group3d.cpp:356-365)
     out.tri_geom.resize(out.triangles.size());
     out.tri_data.resize(out.triangles.size());
