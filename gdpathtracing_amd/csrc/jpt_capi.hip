@@ -249,7 +249,57 @@ int validate_ref_scene(jpt_ctx* c)
     return JPT_OK;
 }
 
+int do_render_batch(jpt_ctx* c, int32_t n_frames, uint32_t first_frame_index, bool counted, bool blocking);
+
+// frames of one wavefront render that fit the workspace budget (all frames of a batch are in flight at once)
+int32_t frames_per_batch(const jpt_ctx* c, int32_t n_frames)
+{
+    static const size_t budget = [] {
+        const char* e = getenv("JPT_WORKSPACE_BUDGET_MB");
+        return (size_t)(e ? atoll(e) : 16384) << 20;
+    }();
+    if (c->kernel_variant == JPT_KERNEL_REFERENCE_LAYOUT || n_frames <= 1) return n_frames;
+    const size_t one = wf2_workspace_bytes(c->width, c->local_rows, 1, c->max_bounces);
+    const size_t fit = std::max<size_t>(1, budget / std::max<size_t>(one, 1));
+    return (int32_t)std::min<size_t>((size_t)n_frames, fit);
+}
+
 int do_render(jpt_ctx* c, int32_t n_frames, uint32_t first_frame_index, bool counted, bool blocking)
+{
+    if (!c) return JPT_E_INVALID;
+    if (c->device < 0 || !c->scene_ready || !c->params_set || !c->camera_set || n_frames <= 0)
+        return do_render_batch(c, n_frames, first_frame_index, counted, blocking);  // reports the error / no-op
+    const int32_t per = frames_per_batch(c, n_frames);
+    if (per >= n_frames) return do_render_batch(c, n_frames, first_frame_index, counted, blocking);
+    // more frames than the workspace budget holds at once: batches in frame order (the accumulation continues),
+    // statistics summed over the batches
+    jpt_stats sum;
+    std::memset(&sum, 0, sizeof sum);
+    for (int32_t done = 0; done < n_frames; done += per) {
+        const int32_t nb = std::min(per, n_frames - done);
+        const int rc = do_render_batch(c, nb, first_frame_index + (uint32_t)done, counted, true);
+        if (rc != JPT_OK) return rc;
+        sum.rays += c->stats.rays;
+        sum.blas_expand += c->stats.blas_expand;
+        sum.tri_tests += c->stats.tri_tests;
+        sum.tlas_expand += c->stats.tlas_expand;
+        sum.inst_visits += c->stats.inst_visits;
+        sum.shaded_hits += c->stats.shaded_hits;
+        sum.last_render_ms += c->stats.last_render_ms;
+        sum.last_trace_ms += c->stats.last_trace_ms;
+    }
+    c->stats.rays = sum.rays;
+    c->stats.blas_expand = sum.blas_expand;
+    c->stats.tri_tests = sum.tri_tests;
+    c->stats.tlas_expand = sum.tlas_expand;
+    c->stats.inst_visits = sum.inst_visits;
+    c->stats.shaded_hits = sum.shaded_hits;
+    c->stats.last_render_ms = sum.last_render_ms;
+    c->stats.last_trace_ms = sum.last_trace_ms;
+    return JPT_OK;
+}
+
+int do_render_batch(jpt_ctx* c, int32_t n_frames, uint32_t first_frame_index, bool counted, bool blocking)
 {
     if (!c) return JPT_E_INVALID;
     if (c->device < 0) return fail(c, JPT_E_DEVICE, "host-only context (JPT_DEVICE_HOST_ONLY) cannot render: there is no CPU fallback");

@@ -302,3 +302,25 @@ def test_c5_like_config_reduced(oracle, hiplib):
     assert rel_l2(got, want) <= 1e-4 and ctx.stats()["rays"] == cnt["rays"]
     assert int((got != want).any(axis=-1).sum()) == 0
     ctx.close()
+
+
+def test_frame_batching_under_a_workspace_budget(hiplib, monkeypatch):
+    """With a small workspace budget a many-frame render is split into batches in frame order: same image, same
+    ray count as the unbatched render."""
+    import subprocess, sys, json
+    code = r'''
+import sys, json, numpy as np
+sys.path.insert(0, %r)
+from gdpathtracing_amd import capi, host, scenes
+sc = scenes.cornell_scene(); w, h = 160, 96
+ctx = host.Context(0); ctx.build_scene(sc, capi.BUILD_SAH); ctx.set_params(w, h, 3, 0); ctx.set_camera(scenes.camera_block(sc.camera, w, h))
+ctx.render(7, 1)
+a = ctx.read_accum(); print(json.dumps(dict(sum=float(a.sum()), rays=ctx.stats()["rays"], crc=int(np.frombuffer(a.tobytes(), dtype=np.uint32).sum() %% (1 << 32)))))
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for budget in ("16384", "1"):   # 1 MiB: two frames per batch at this size
+        env = dict(os.environ, JPT_WORKSPACE_BUDGET_MB=budget)
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(json.loads(r.stdout.strip().splitlines()[-1]))
+    assert outs[0] == outs[1] and outs[0]["rays"] > 160 * 96 * 7
