@@ -481,7 +481,8 @@ static void tlas_build(jpto_builder *b)
     b->n_tlas++; /* slot 0 reserved for the root */
     if (blasCount == 0) return;
 
-    int *nodeIdx = (int *)malloc(sizeof(int) * (size_t)blasCount);
+    if (blasCount <= 0 || blasCount > 65535) return;
+    int *nodeIdx = (int *)malloc(sizeof(int) * (size_t)(unsigned)blasCount);
     int nodesUsed = 1;
     for (int i = 0; i < blasCount; i++) {
         jpto_tlas_node node;
