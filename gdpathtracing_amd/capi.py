@@ -25,7 +25,7 @@ SYMBOLS = [
     "jpt_scene_upload_reference_layout", "jpt_scene_begin", "jpt_scene_add_mesh", "jpt_scene_add_instance",
     "jpt_scene_set_materials", "jpt_scene_set_textures", "jpt_scene_commit", "jpt_scene_get_reference_buffer",
     "jpt_set_params", "jpt_set_kernel", "jpt_set_partition", "jpt_set_camera", "jpt_render", "jpt_render_counted", "jpt_render_async",
-    "jpt_sync", "jpt_accum_reset", "jpt_read_ldr_rgba8", "jpt_read_accum_f32", "jpt_read_depth_f32",
+    "jpt_sync", "jpt_accum_reset", "jpt_read_ldr_rgba8", "jpt_readback_ldr_begin", "jpt_readback_ldr_end", "jpt_read_accum_f32", "jpt_read_depth_f32",
     "jpt_device_accum", "jpt_assemble_from_ranks", "jpt_local_rows", "jpt_get_stats",
 ]
 
@@ -108,6 +108,8 @@ def lib():
     L.jpt_accum_reset.argtypes = [vp]
     L.jpt_read_ldr_rgba8.argtypes = [vp, vp]
     L.jpt_read_accum_f32.argtypes = [vp, vp]
+    L.jpt_readback_ldr_begin.argtypes = [vp]
+    L.jpt_readback_ldr_end.argtypes = [vp, vp]
     L.jpt_read_depth_f32.argtypes = [vp, vp]
     L.jpt_device_accum.argtypes = [vp, C.POINTER(C.c_size_t)]
     L.jpt_device_accum.restype = vp

@@ -100,6 +100,12 @@ struct jpt_ctx {
     DevBuf<uint32_t> d_full_ldr;
     bool assembled = false;
 
+    // pinned staging for the split read-back
+    uint32_t* h_ldr_pinned = nullptr;
+    size_t h_ldr_pinned_px = 0;
+    hipEvent_t ev_readback = nullptr;
+    bool readback_pending = false;
+
     jpt_stats stats;
 };
 
@@ -479,6 +485,8 @@ void jpt_destroy(jpt_ctx* c)
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     for (hipEvent_t e : c->trace_events) (void)hipEventDestroy(e);
+    if (c->ev_readback) (void)hipEventDestroy(c->ev_readback);
+    if (c->h_ldr_pinned) (void)hipHostFree(c->h_ldr_pinned);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -740,6 +748,47 @@ int jpt_read_ldr_rgba8(jpt_ctx* c, uint8_t* out)
     if (!local.empty()) HIP_TRY(c, hipMemcpy(local.data(), c->d_ldr.p, local.size() * 4, hipMemcpyDeviceToHost));
     if (c->world == 1) std::memcpy(out, local.data(), local.size() * 4);
     else {
+        std::memset(out, 0, full * 4);
+        scatter_rows(local, reinterpret_cast<uint32_t*>(out), c->width, c->height, c->rank, c->world, 1);
+    }
+    return JPT_OK;
+}
+
+int jpt_readback_ldr_begin(jpt_ctx* c)
+{
+    if (!c) return JPT_E_INVALID;
+    if (c->device < 0) return fail(c, JPT_E_DEVICE, "host-only context");
+    if (!c->params_set) return fail(c, JPT_E_STATE, "jpt_set_params not called");
+    if (c->readback_pending) return fail(c, JPT_E_STATE, "a read-back is already in flight (call jpt_readback_ldr_end)");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t px = c->assembled ? (size_t)c->width * c->height : (size_t)c->local_rows * c->width;
+    if (c->h_ldr_pinned_px < (size_t)c->width * c->height) {
+        if (c->h_ldr_pinned) (void)hipHostFree(c->h_ldr_pinned);
+        c->h_ldr_pinned = nullptr;
+        HIP_TRY(c, hipHostMalloc((void**)&c->h_ldr_pinned, (size_t)c->width * c->height * sizeof(uint32_t), hipHostMallocDefault));
+        c->h_ldr_pinned_px = (size_t)c->width * c->height;
+    }
+    if (!c->ev_readback) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_readback, hipEventDisableTiming));
+    if (px)
+        HIP_TRY(c, hipMemcpyAsync(c->h_ldr_pinned, c->assembled ? c->d_full_ldr.p : c->d_ldr.p, px * sizeof(uint32_t),
+                                  hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipEventRecord(c->ev_readback, c->stream));
+    c->readback_pending = true;
+    return JPT_OK;
+}
+
+int jpt_readback_ldr_end(jpt_ctx* c, uint8_t* out)
+{
+    if (!c || !out) return fail(c, JPT_E_INVALID, "null output");
+    if (!c->readback_pending) return fail(c, JPT_E_STATE, "no read-back in flight (call jpt_readback_ldr_begin)");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipEventSynchronize(c->ev_readback));
+    c->readback_pending = false;
+    const size_t full = (size_t)c->width * c->height;
+    if (c->assembled || c->world == 1) {
+        std::memcpy(out, c->h_ldr_pinned, full * 4);
+    } else {
+        std::vector<uint32_t> local(c->h_ldr_pinned, c->h_ldr_pinned + (size_t)c->local_rows * c->width);
         std::memset(out, 0, full * 4);
         scatter_rows(local, reinterpret_cast<uint32_t*>(out), c->width, c->height, c->rank, c->world, 1);
     }

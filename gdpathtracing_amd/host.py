@@ -125,6 +125,14 @@ class Context:
         self._ck(self._lib.jpt_read_ldr_rgba8(self.h, _ptr(out)), "jpt_read_ldr_rgba8")
         return out
 
+    def readback_ldr_begin(self):
+        self._ck(self._lib.jpt_readback_ldr_begin(self.h), "jpt_readback_ldr_begin")
+
+    def readback_ldr_end(self) -> np.ndarray:
+        out = np.zeros((self.height, self.width, 4), dtype=np.uint8)
+        self._ck(self._lib.jpt_readback_ldr_end(self.h, _ptr(out)), "jpt_readback_ldr_end")
+        return out
+
     def read_accum(self) -> np.ndarray:
         out = np.zeros((self.height, self.width, 4), dtype=np.float32)
         self._ck(self._lib.jpt_read_accum_f32(self.h, _ptr(out)), "jpt_read_accum_f32")

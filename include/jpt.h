@@ -180,6 +180,13 @@ int jpt_accum_reset(jpt_ctx *ctx);
 /* replaces: cs->get_image_uniform_buffer(output_texture_rid) (path_tracing_camera.cpp:228-229):
  * W*H*4 bytes, the screen image after ACES(sum / frame_count) (progressive_rendering.glsl:39-45). */
 int jpt_read_ldr_rgba8(jpt_ctx *ctx, uint8_t *out);
+/* Split form of jpt_read_ldr_rgba8 for double-buffered display (the reference stalls on
+ * the read-back every frame, path_tracing_camera.cpp:228-230): `begin` enqueues the device->host copy of the
+ * current screen image into a pinned staging buffer behind the work already queued on the context's stream
+ * and returns at once; the host may queue the next jpt_render_async; `end` waits for that copy only and hands
+ * the bytes out.  One read-back may be in flight per context. */
+int jpt_readback_ldr_begin(jpt_ctx *ctx);
+int jpt_readback_ldr_end(jpt_ctx *ctx, uint8_t *out);
 /* the rgba32f frameBuffer (progressive_rendering.glsl:10,37): W*H*4 floats */
 int jpt_read_accum_f32(jpt_ctx *ctx, float *out);
 /* the r32f depthBuffer (main.glsl:99,435), last frame: W*H floats */

@@ -324,3 +324,27 @@ a = ctx.read_accum(); print(json.dumps(dict(sum=float(a.sum()), rays=ctx.stats()
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append(json.loads(r.stdout.strip().splitlines()[-1]))
     assert outs[0] == outs[1] and outs[0]["rays"] > 160 * 96 * 7
+
+
+def test_split_readback_overlaps_the_next_render(hiplib):
+    """jpt_readback_ldr_begin/end: the copy of frame N's screen image is queued behind frame N, frame N+1 is
+    queued behind the copy; `end` returns frame N's image exactly."""
+    sc = scenes.cornell_scene()
+    w, h = 128, 72
+    ctx = make_ctx(sc, w, h, 2, wire.ACCUM_REF_LDR8)
+    ctx.render(1, 1)
+    want1 = ctx.read_ldr()
+    ctx.render(1, 2)
+    want2 = ctx.read_ldr()
+    ctx.accum_reset()
+    ctx.render(1, 1, asynchronous=True)
+    ctx.readback_ldr_begin()
+    with pytest.raises(capi.JptError, match="already in flight"):
+        ctx.readback_ldr_begin()
+    ctx.render(1, 2, asynchronous=True)          # queued behind the copy
+    got1 = ctx.readback_ldr_end()
+    with pytest.raises(capi.JptError, match="no read-back"):
+        ctx.readback_ldr_end()
+    assert np.array_equal(got1, want1)
+    assert np.array_equal(ctx.read_ldr(), want2)
+    ctx.close()
