@@ -1,0 +1,193 @@
+// jpt_gdcs_adapter.hpp -- a `ComputeShader`-shaped adapter over the C ABI, so that PathTracingCamera and
+// ProgressiveRendering of the reference compile UNCHANGED against it.
+//
+// The reference drives its GPU work through `gdcs::ComputeShader` (submodule src/gdcs, absent).  Its contract is
+// recoverable from the call sites:
+//
+//   ComputeShader(res_path, RenderingDevice*, std::vector<String> defines = {})   path_tracing_camera.cpp:139, progressive_rendering.cpp:25
+//   RID  create_storage_buffer_uniform(PackedByteArray, binding, set)            path_tracing_camera.cpp:142-143,170-175
+//   Ref<RDTextureFormat> create_texture_format(w, h, DataFormat)                 :148,163,182
+//   RID  create_image_uniform(Ref<Image>, format, Ref<RDTextureView>, binding, set)          :158,165
+//   RID  create_layered_image_uniform(std::vector<Ref<Image>>, format, view, binding, set)   :183
+//   void add_existing_buffer(RID, UniformType, binding, set)                     progressive_rendering.cpp:30
+//   void finish_create_uniforms()                                                :186
+//   bool check_ready()                                                           :195
+//   void update_storage_buffer_uniform(RID, PackedByteArray)                     :200
+//   void compute({gx, gy, gz})                                                   :204
+//   PackedByteArray get_image_uniform_buffer(RID)                                :229
+//
+// The adapter is a template over a small traits struct so it needs no Godot header: with godot-cpp the traits
+// map to godot::PackedByteArray / godot::RID / godot::String; the repository's test
+// (tests/cpp/gdcs_adapter_test.cpp) instantiates it with std:: types.  Descriptor roles are taken from the
+// shader's layout (main.glsl:98-155, progressive_rendering.glsl:5-16):
+//   main.glsl          set 0: b0 rgba8 out, b1 r32f depth, b2 Params, b3 Camera;  set 1: b0..b5 scene buffers;
+//                      set 2: b0 texture array
+//   progressive.glsl   set 0: b0 Params{w,h,frame_count}, b1 screen image (shared), b2 rgba32f frame buffer
+#pragma once
+
+#include <jpt.h>
+
+#include <array>
+#include <cstdint>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+namespace jpt_gdcs {
+
+// One jpt context shared by the main pass and the progressive pass that add_existing_buffer()s its image
+// (both ComputeShaders are created on the same RenderingDevice in the reference, path_tracing_camera.cpp:114,211).
+struct SharedDevice {
+    jpt_ctx* ctx = nullptr;
+    int width = 0, height = 0;
+    bool scene_ready = false, params_ready = false;
+    uint32_t camera_frame_index = 0;
+    bool restart = true;
+    bool frame_pending = false;  // main.glsl was dispatched, the frame has not been rendered yet
+    ~SharedDevice() { jpt_destroy(ctx); }
+};
+
+template <class Traits>
+class ComputeShader {
+  public:
+    using Bytes = typename Traits::Bytes;    // PackedByteArray-like: size(), ptr(), resize(), ptrw()
+    using RID = typename Traits::RID;        // integer-like handle
+    using String = typename Traits::String;
+
+    ComputeShader(const String& res_path, std::shared_ptr<SharedDevice> device, const std::vector<String>& /*defines*/ = {})
+        : dev_(std::move(device)), progressive_(Traits::contains(res_path, "progressive_rendering"))
+    {
+        if (!dev_->ctx && jpt_create(0, &dev_->ctx) != JPT_OK) error_ = jpt_last_error(nullptr);
+    }
+
+    RID create_storage_buffer_uniform(const Bytes& data, int binding, int set)
+    {
+        const RID id = next_rid_++;
+        Slot s{set, binding, std::vector<uint8_t>(Traits::ptr(data), Traits::ptr(data) + Traits::size(data))};
+        slots_.emplace_back(id, std::move(s));
+        return id;
+    }
+    // images: only their size matters here (the library owns the device images)
+    RID create_image_uniform(int width, int height, int binding, int set)
+    {
+        if (!progressive_ && set == 0 && binding == 0) {
+            dev_->width = width;
+            dev_->height = height;
+        }
+        return next_rid_++;
+    }
+    RID create_layered_image_uniform(const std::vector<Bytes>& layers, int resolution, int /*binding*/, int /*set*/)
+    {
+        tex_res_ = resolution;
+        tex_layers_ = (int)layers.size();
+        tex_.clear();
+        for (const Bytes& l : layers) tex_.insert(tex_.end(), Traits::ptr(l), Traits::ptr(l) + Traits::size(l));
+        return next_rid_++;
+    }
+    void add_existing_buffer(RID, int /*uniform_type*/, int /*binding*/, int /*set*/) {}
+
+    void finish_create_uniforms()
+    {
+        if (!dev_->ctx) return;
+        if (progressive_) {
+            ready_ = true;  // the progressive pass is fused into jpt_render
+            return;
+        }
+        const Slot* b[6] = {};
+        for (auto& kv : slots_)
+            if (kv.second.set == 1 && kv.second.binding >= 0 && kv.second.binding < 6) b[kv.second.binding] = &kv.second;
+        for (const Slot* p : b)
+            if (!p) {
+                error_ = "main.glsl needs the six scene buffers of set 1";
+                return;
+            }
+        // set 1: b0 GpuTriangleGeometry (48 B), b1 GpuTriangleData (80), b2 GpuMaterial (64), b3 BVHNode (48),
+        //        b4 BLASInstance (176), b5 TLASNode (32)   (main.glsl:121-155)
+        int rc = jpt_scene_upload_reference_layout(dev_->ctx, b[0]->bytes.data(), (uint32_t)(b[0]->bytes.size() / 48),
+                                                   b[1]->bytes.data(), b[2]->bytes.data(), (uint32_t)(b[2]->bytes.size() / 64),
+                                                   b[3]->bytes.data(), (uint32_t)(b[3]->bytes.size() / 48), b[4]->bytes.data(),
+                                                   (uint32_t)(b[4]->bytes.size() / 176), b[5]->bytes.data(),
+                                                   (uint32_t)(b[5]->bytes.size() / 32), tex_.empty() ? nullptr : tex_.data(),
+                                                   tex_res_, tex_layers_);
+        if (rc == JPT_OK)
+            rc = jpt_set_params(dev_->ctx, dev_->width, dev_->height, 4 /* the literal 5 of main.glsl:377 */, JPT_ACCUM_REF_LDR8,
+                                JPT_SAMPLER_NEAREST_CLAMP);
+        if (rc != JPT_OK) {
+            error_ = jpt_last_error(dev_->ctx);
+            return;
+        }
+        dev_->scene_ready = dev_->params_ready = true;
+        for (auto& kv : slots_)
+            if (kv.second.set == 0 && kv.second.binding == 3) upload_camera(kv.second.bytes);
+        ready_ = true;
+    }
+
+    bool check_ready() const { return ready_; }
+    const std::string& last_error() const { return error_; }
+
+    void update_storage_buffer_uniform(RID rid, const Bytes& data)
+    {
+        for (auto& kv : slots_)
+            if (kv.first == rid) {
+                kv.second.bytes.assign(Traits::ptr(data), Traits::ptr(data) + Traits::size(data));
+                if (!progressive_ && kv.second.set == 0 && kv.second.binding == 3) upload_camera(kv.second.bytes);
+                if (progressive_ && kv.second.set == 0 && kv.second.binding == 0 && kv.second.bytes.size() >= 12) {
+                    uint32_t frame_count;  // Params{width, height, frame_count} (progressive_rendering.h:14-27)
+                    std::memcpy(&frame_count, kv.second.bytes.data() + 8, 4);
+                    dev_->restart = frame_count == 1;  // camera moved (progressive_rendering.cpp:56-57)
+                }
+            }
+    }
+
+    // main shader: remembers that a frame is due.  progressive shader: runs the fused frame (trace + accumulate),
+    // because only now is frame_count known (the reference dispatches main first, then the progressive pass,
+    // path_tracing_camera.cpp:204,213).
+    void compute(const std::array<int32_t, 3>& /*groups*/)
+    {
+        if (!ready_ || !dev_->scene_ready) return;
+        if (!progressive_) {
+            dev_->frame_pending = true;
+            return;
+        }
+        if (!dev_->frame_pending) return;
+        if (dev_->restart) jpt_accum_reset(dev_->ctx);
+        if (jpt_render(dev_->ctx, 1, dev_->camera_frame_index) != JPT_OK) error_ = jpt_last_error(dev_->ctx);
+        dev_->frame_pending = false;
+    }
+    // denoising_mode == NONE: no progressive pass follows; the caller reads the image right after compute()
+    Bytes get_image_uniform_buffer(RID)
+    {
+        Bytes out;
+        Traits::resize(out, (size_t)dev_->width * dev_->height * 4);
+        if (dev_->frame_pending) {  // no progressive pass ran: every frame stands alone
+            jpt_accum_reset(dev_->ctx);
+            if (jpt_render(dev_->ctx, 1, dev_->camera_frame_index) != JPT_OK) error_ = jpt_last_error(dev_->ctx);
+            dev_->frame_pending = false;
+        }
+        if (jpt_read_ldr_rgba8(dev_->ctx, Traits::ptrw(out)) != JPT_OK) error_ = jpt_last_error(dev_->ctx);
+        return out;
+    }
+
+  private:
+    struct Slot {
+        int set, binding;
+        std::vector<uint8_t> bytes;
+    };
+    void upload_camera(const std::vector<uint8_t>& bytes)
+    {
+        if (bytes.size() < 160 || !dev_->params_ready) return;
+        jpt_set_camera(dev_->ctx, bytes.data());
+        std::memcpy(&dev_->camera_frame_index, bytes.data() + 144, 4);  // Camera::frame_index (render_parameters.h:19)
+    }
+    std::shared_ptr<SharedDevice> dev_;
+    bool progressive_;
+    bool ready_ = false;
+    std::vector<std::pair<RID, Slot>> slots_;
+    std::vector<uint8_t> tex_;
+    int tex_res_ = 0, tex_layers_ = 0;
+    RID next_rid_ = 1;
+    std::string error_;
+};
+
+}  // namespace jpt_gdcs

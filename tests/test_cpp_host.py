@@ -69,3 +69,39 @@ def test_cpp_path_tracing_camera_renders_like_the_oracle(oracle, host_demo, buil
     want, want_ldr, _, _, _ = oracle.render(ref, cam, w, h, 4, frames, 1, mode)
     assert np.array_equal(got, want)
     assert np.array_equal(got_ldr, want_ldr)
+
+
+@pytest.fixture(scope="module")
+def gdcs_test(hiplib, tmp_path_factory):
+    d = tmp_path_factory.mktemp("gdcs")
+    exe = str(d / "gdcs_adapter_test")
+    libdir = os.path.dirname(capi.LIB_PATH)
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "gdcs_adapter_test.cpp"), "-o", exe, "-L", libdir, "-ljpt_hip",
+                           "-Wl,-rpath," + libdir])
+    return exe, str(d)
+
+
+def test_gdcs_adapter_compiles(gdcs_test):
+    """The ComputeShader-shaped adapter (include/jpt_gdcs_adapter.hpp) and its driver build on the CPU box."""
+    assert os.path.exists(gdcs_test[0])
+
+
+@pytest.mark.gpu
+def test_gdcs_shaped_adapter_replays_the_reference_call_sequence(oracle, gdcs_test):
+    """The eleven ComputeShader methods the reference calls, in the reference's order, through the
+    adapter: three frames of render(); image identical to the oracle's for the same camera block."""
+    exe, d = gdcs_test
+    sc = scenes.cornell_scene()
+    path = os.path.join(d, "c.jpts")
+    scenes.write_scene_file(sc, path)
+    w, h, frames = 80, 48, 3
+    out = subprocess.run([exe, path, os.path.join(d, "g"), str(w), str(h), str(frames)], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    assert "frame_count %d" % frames in out.stdout
+    cam = np.frombuffer(open(os.path.join(d, "g_camera.bin"), "rb").read(), dtype=wire.CAMERA)[0]
+    got = np.frombuffer(open(os.path.join(d, "g_accum.bin"), "rb").read(), dtype=np.float32).reshape(h, w, 4)
+    got_ldr = np.frombuffer(open(os.path.join(d, "g_ldr.bin"), "rb").read(), dtype=np.uint8).reshape(h, w, 4)
+    ref = oracle.build_scene(sc)
+    want, want_ldr, _, _, _ = oracle.render(ref, cam, w, h, 4, frames, 1, wire.ACCUM_REF_LDR8)
+    assert np.array_equal(got, want) and np.array_equal(got_ldr, want_ldr)
