@@ -1,0 +1,68 @@
+"""Minimal Wavefront OBJ ingest for running the path without Godot.
+
+Produces a scenes.Mesh the way Godot's importer hands the reference an ArrayMesh: one surface per `usemtl`
+group, de-indexed (position, normal, uv) triples, polygons fan-triangulated, and the winding flipped to Godot's
+clockwise front faces (main.glsl:254-255 derives `front` from it).  Missing normals are replaced by the face
+normal, missing uvs by (0, 0).  Plumbing only: nothing here is on the timed path.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from .scenes import Mesh, Surface
+
+
+def load_obj(text: str) -> Mesh:
+    pos, nrm, uvs = [], [], []
+    groups = {}          # material name -> dict(key -> index), vertex lists, indices
+    order = []
+    cur = None
+
+    def group(name):
+        nonlocal cur
+        if name not in groups:
+            groups[name] = dict(lut={}, v=[], n=[], t=[], idx=[])
+            order.append(name)
+        cur = groups[name]
+
+    group("")
+    for line in text.splitlines():
+        p = line.split()
+        if not p or p[0].startswith("#"):
+            continue
+        if p[0] == "v":
+            pos.append([float(x) for x in p[1:4]])
+        elif p[0] == "vn":
+            nrm.append([float(x) for x in p[1:4]])
+        elif p[0] == "vt":
+            uvs.append([float(p[1]), float(p[2]) if len(p) > 2 else 0.0])
+        elif p[0] == "usemtl":
+            group(p[1] if len(p) > 1 else "")
+        elif p[0] == "f":
+            corners = []
+            for tok in p[1:]:
+                f = (tok.split("/") + ["", ""])[:3]
+                vi = int(f[0]); ti = int(f[1]) if f[1] else 0; ni = int(f[2]) if f[2] else 0
+                vi = vi - 1 if vi > 0 else len(pos) + vi
+                ti = (ti - 1 if ti > 0 else len(uvs) + ti) if f[1] else -1
+                ni = (ni - 1 if ni > 0 else len(nrm) + ni) if f[2] else -1
+                corners.append((vi, ti, ni))
+            fn = None
+            if any(c[2] < 0 for c in corners):
+                a, b, c = (np.asarray(pos[corners[k][0]]) for k in range(3))
+                fn = np.cross(b - a, c - a)
+                fn = fn / max(np.linalg.norm(fn), 1e-30)
+            ids = []
+            for k, (vi, ti, ni) in enumerate(corners):
+                key = (vi, ti, ni if ni >= 0 else ("f", len(cur["idx"]), k))
+                if key not in cur["lut"]:
+                    cur["lut"][key] = len(cur["v"])
+                    cur["v"].append(pos[vi])
+                    cur["n"].append(nrm[ni] if ni >= 0 else fn)
+                    cur["t"].append(uvs[ti] if ti >= 0 else [0.0, 0.0])
+                ids.append(cur["lut"][key])
+            for k in range(1, len(ids) - 1):          # fan; (0, k+1, k) = clockwise for Godot
+                cur["idx"] += [ids[0], ids[k + 1], ids[k]]
+    surfaces = [Surface(np.asarray(g["v"], np.float32), np.asarray(g["n"], np.float32), np.asarray(g["t"], np.float32),
+                        np.asarray(g["idx"], np.int32)) for g in (groups[n] for n in order) if g["idx"]]
+    return Mesh(surfaces)
