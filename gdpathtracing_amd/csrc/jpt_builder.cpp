@@ -5,6 +5,7 @@
 #include <cfloat>
 #include <cmath>
 #include <cstring>
+#include <future>
 #include <numeric>
 
 namespace jpt {
@@ -220,17 +221,20 @@ struct SahBlasBuilder {
         pad = m * 2e-6f + 1e-30f;
     }
 
-    uint32_t build(int lo, int hi)  // range in `order`
+    // Builds the subtree over order[lo, hi) into `out` (pre-order: left child = parent + 1); child indices are
+    // relative to out's first element, first_tri_index is absolute.  Large subtrees are built by parallel
+    // tasks on disjoint slices of `order` and spliced in a fixed order, so the result does not depend on timing.
+    void build_into(std::vector<RefBvhNode>& out, int lo, int hi, int depth)
     {
-        const uint32_t self = (uint32_t)nodes.size();
-        nodes.emplace_back();
+        const size_t self = out.size();
+        out.emplace_back();
         Box3 box, cbox;
         for (int i = lo; i < hi; i++) {
             box.grow(tri_box[order[i]]);
             cbox.grow(&centroid[(size_t)order[i] * 3]);
         }
         {
-            RefBvhNode& n = nodes[self];
+            RefBvhNode& n = out[self];
             n.aabbMin = Vec4{box.lo[0] - pad, box.lo[1] - pad, box.lo[2] - pad, 1.0f};
             n.aabbMax = Vec4{box.hi[0] + pad, box.hi[1] + pad, box.hi[2] + pad, 1.0f};
             n.left_child = n.right_child = 0;
@@ -238,74 +242,120 @@ struct SahBlasBuilder {
             n.tri_count = (uint32_t)(hi - lo);
         }
         const int count = hi - lo;
-        if (count <= 1) return self;
+        if (count <= 1) return;
 
+        // one pass over the triangles bins all three axes
+        Box3 bb[3][kBins];
+        int bn[3][kBins] = {};
+        float c0[3], scale[3];
+        bool usable[3];
+        for (int a = 0; a < 3; a++) {
+            c0[a] = cbox.lo[a];
+            usable[a] = cbox.hi[a] > cbox.lo[a];
+            scale[a] = usable[a] ? float(kBins) / (cbox.hi[a] - cbox.lo[a]) : 0.0f;
+        }
+        for (int i = lo; i < hi; i++) {
+            const uint32_t t = order[i];
+            const Box3& tb = tri_box[t];
+            for (int a = 0; a < 3; a++) {
+                if (!usable[a]) continue;
+                int k = (int)((centroid[(size_t)t * 3 + a] - c0[a]) * scale[a]);
+                k = k < 0 ? 0 : (k >= kBins ? kBins - 1 : k);
+                bb[a][k].grow(tb);
+                bn[a][k]++;
+            }
+        }
         int best_axis = -1, best_bin = -1;
         float best_cost = FLT_MAX;
         for (int axis = 0; axis < 3; axis++) {
-            const float c0 = cbox.lo[axis], c1 = cbox.hi[axis];
-            if (!(c1 > c0)) continue;
-            const float scale = float(kBins) / (c1 - c0);
-            Box3 bb[kBins];
-            int bn[kBins] = {0};
-            for (int i = lo; i < hi; i++) {
-                const uint32_t t = order[i];
-                int b = (int)((centroid[(size_t)t * 3 + axis] - c0) * scale);
-                b = b < 0 ? 0 : (b >= kBins ? kBins - 1 : b);
-                bb[b].grow(tri_box[t]);
-                bn[b]++;
-            }
+            if (!usable[axis]) continue;
             float right_area[kBins];
             int right_n[kBins];
             Box3 acc;
             int n = 0;
-            for (int b = kBins - 1; b > 0; b--) {
-                acc.grow(bb[b]);
-                n += bn[b];
-                right_area[b] = n ? acc.half_area() : 0.0f;
-                right_n[b] = n;
+            for (int k = kBins - 1; k > 0; k--) {
+                acc.grow(bb[axis][k]);
+                n += bn[axis][k];
+                right_area[k] = n ? acc.half_area() : 0.0f;
+                right_n[k] = n;
             }
             acc = Box3();
             n = 0;
-            for (int b = 0; b < kBins - 1; b++) {
-                acc.grow(bb[b]);
-                n += bn[b];
-                if (n == 0 || right_n[b + 1] == 0) continue;
-                const float cost = acc.half_area() * float(n) + right_area[b + 1] * float(right_n[b + 1]);
+            for (int k = 0; k < kBins - 1; k++) {
+                acc.grow(bb[axis][k]);
+                n += bn[axis][k];
+                if (n == 0 || right_n[k + 1] == 0) continue;
+                const float cost = acc.half_area() * float(n) + right_area[k + 1] * float(right_n[k + 1]);
                 if (cost < best_cost) {
                     best_cost = cost;
                     best_axis = axis;
-                    best_bin = b;
+                    best_bin = k;
                 }
             }
         }
         const float leaf_cost = float(count) * box.half_area();
         // traversal step ~ 1.2 triangle tests
         const bool split_pays = best_axis >= 0 && (best_cost + 1.2f * box.half_area()) < leaf_cost;
-        if (count <= kMaxLeaf && !split_pays) return self;
+        if (count <= kMaxLeaf && !split_pays) return;
 
-        int mid;
+        int mid = lo;
         if (best_axis >= 0) {
-            const float c0 = cbox.lo[best_axis], c1 = cbox.hi[best_axis];
-            const float scale = float(kBins) / (c1 - c0);
+            const float cc = c0[best_axis], sc = scale[best_axis];
             auto it = std::partition(order.begin() + lo, order.begin() + hi, [&](uint32_t t) {
-                int b = (int)((centroid[(size_t)t * 3 + best_axis] - c0) * scale);
-                b = b < 0 ? 0 : (b >= kBins ? kBins - 1 : b);
-                return b <= best_bin;
+                int k = (int)((centroid[(size_t)t * 3 + best_axis] - cc) * sc);
+                k = k < 0 ? 0 : (k >= kBins ? kBins - 1 : k);
+                return k <= best_bin;
             });
             mid = (int)(it - order.begin());
+        }
+        if (mid == lo || mid == hi) mid = lo + count / 2;  // all centroids coincide: split by index
+
+        if (count >= kParallelMin && depth < kParallelDepth) {
+            std::vector<RefBvhNode> left_nodes, right_nodes;
+            auto fut = std::async(std::launch::async, [&] { build_into(left_nodes, lo, mid, depth + 1); });
+            build_into(right_nodes, mid, hi, depth + 1);
+            fut.get();
+            const uint32_t l = (uint32_t)(self + 1), r = (uint32_t)(self + 1 + left_nodes.size());
+            splice(out, left_nodes, l);
+            splice(out, right_nodes, r);
+            out[self].left_child = l;
+            out[self].right_child = r;
         } else {
-            mid = lo;
+            const uint32_t l = (uint32_t)out.size();
+            build_into(out, lo, mid, depth + 1);
+            out[self].left_child = l;
+            const uint32_t r = (uint32_t)out.size();
+            build_into(out, mid, hi, depth + 1);
+            out[self].right_child = r;
         }
-        if (mid == lo || mid == hi) {  // all centroids coincide: split by index
-            mid = lo + count / 2;
+        out[self].tri_count = 0;
+    }
+
+    // append `sub` (indices relative to its own start) at position `at` of `out`
+    static void splice(std::vector<RefBvhNode>& out, const std::vector<RefBvhNode>& sub, uint32_t at)
+    {
+        for (const RefBvhNode& n : sub) {
+            RefBvhNode m = n;
+            if (m.tri_count == 0) {
+                m.left_child += at;
+                m.right_child += at;
+            }
+            out.push_back(m);
         }
-        const uint32_t l = build(lo, mid);
-        nodes[self].left_child = l;
-        const uint32_t r = build(mid, hi);
-        nodes[self].right_child = r;
-        nodes[self].tri_count = 0;
-        return self;
+    }
+
+    static constexpr int kParallelMin = 32768;
+    static constexpr int kParallelDepth = 4;  // up to 16 tasks
+
+    // appends the tree to the shared node array; returns the root's index there
+    uint32_t build(int lo, int hi)
+    {
+        std::vector<RefBvhNode> local;
+        local.reserve((size_t)(hi - lo));
+        build_into(local, lo, hi, 0);
+        const uint32_t root = (uint32_t)nodes.size();
+        splice(nodes, local, root);
+        return root;
     }
 
     void apply_order(int start, int end)
