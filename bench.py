@@ -159,10 +159,14 @@ def main():
             partition.gather_to_rank0(piece, dist, rank, world, gathered)
             if rank == 0:
                 ctx.assemble_from_ranks(gathered.data_ptr(), world)
-        ctx.sync()
-        st = ctx.stats()
-        render_ms.append(st["last_render_ms"])
-        trace_ms.append(st["last_trace_ms"])
+        if world == 1 or i == args.steps - 1:
+            # N = 1: every step ends with jpt_sync, which also reads the per-launch HIP-event times of the
+            # traversal kernels.  N > 1: steps are only queued (the closing barrier waits for all of them), so host
+            # launch latency overlaps device work; the kernel times are then those of the last step.
+            ctx.sync()
+            st = ctx.stats()
+            render_ms.append(st["last_render_ms"])
+            trace_ms.append(st["last_trace_ms"])
     barrier()
     elapsed = time.perf_counter() - t0
     t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")

@@ -851,8 +851,7 @@ int jpt_assemble_from_ranks(jpt_ctx* c, const void* device_gathered, int32_t wor
     launch_assemble(c->stream, (const float4*)device_gathered, world, c->width, c->height,
                     max_rows_of_any_rank(c->height, world), c->d_full_accum.p, c->d_full_ldr.p, c->frame_count);
     HIP_TRY(c, hipGetLastError());
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    c->assembled = true;
+    c->assembled = true;  // asynchronous on the context's stream; jpt_read_* / jpt_sync wait for it
     return JPT_OK;
 }
 
