@@ -104,6 +104,7 @@ def main():
     stream = torch.cuda.Stream()
     torch.cuda.set_stream(stream)
     ctx.set_stream(stream.cuda_stream)
+    ctx.set_kernel_timing(True)   # HIP events around every traversal launch (the roofline's kernel duration)
 
     # gather plumbing (N > 1): the local float4 piece viewed as a torch tensor, no copy
     piece = gathered = None

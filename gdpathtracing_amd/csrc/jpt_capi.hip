@@ -89,6 +89,7 @@ struct jpt_ctx {
     std::vector<uint32_t> h_qcount;  // per-bounce queue sizes of the last wavefront render
     std::vector<hipEvent_t> trace_events;  // pairs around each wf_trace launch of the last render
     int32_t trace_events_used = 0;
+    bool kernel_timing = false;
 
     // framebuffers (local rows of this partition)
     DevBuf<float4> d_accum;
@@ -346,7 +347,7 @@ int do_render_batch(jpt_ctx* c, int32_t n_frames, uint32_t first_frame_index, bo
             fp.frame_index = first_frame_index;
             fp.frame_count = c->frame_count + 1;
             fp.n_frames = n_frames;
-            const size_t need_ev = 2 * (size_t)(c->max_bounces + 1);
+            const size_t need_ev = c->kernel_timing ? 2 * (size_t)(c->max_bounces + 1) : 0;
             while (c->trace_events.size() < need_ev) {
                 hipEvent_t e;
                 HIP_TRY(c, hipEventCreate(&e));
@@ -355,10 +356,10 @@ int do_render_batch(jpt_ctx* c, int32_t n_frames, uint32_t first_frame_index, bo
             c->trace_events_used = (int32_t)need_ev;
             if (wf2)
                 launch_wf2_render(s, c->ds, fp, c->camera, c->d_workspace.p, c->d_accum.p, c->d_ldr.p, c->d_depth.p, cnt,
-                                  c->trace_events.data());
+                                  need_ev ? c->trace_events.data() : nullptr);
             else
                 launch_wide_render(s, c->ds, fp, c->camera, c->d_workspace.p, c->d_accum.p, c->d_ldr.p, c->d_depth.p, cnt,
-                                   c->trace_events.data());
+                                   need_ev ? c->trace_events.data() : nullptr);
         } else {
             for (int32_t f = 0; f < n_frames; f++) {
                 fp.frame_index = first_frame_index + (uint32_t)f;
@@ -714,6 +715,14 @@ int jpt_set_kernel(jpt_ctx* c, int32_t variant)
     if (!c) return JPT_E_INVALID;
     if (variant != JPT_KERNEL_WAVEFRONT && variant != JPT_KERNEL_REFERENCE_LAYOUT && variant != JPT_KERNEL_WAVEFRONT_V1) return fail(c, JPT_E_INVALID, "unknown kernel variant");
     c->kernel_variant = variant;
+    return JPT_OK;
+}
+
+int jpt_set_kernel_timing(jpt_ctx* c, int32_t enable)
+{
+    if (!c) return JPT_E_INVALID;
+    c->kernel_timing = enable != 0;
+    if (!c->kernel_timing) c->trace_events_used = 0;
     return JPT_OK;
 }
 

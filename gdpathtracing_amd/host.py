@@ -99,6 +99,9 @@ class Context:
     def set_kernel(self, variant):
         self._ck(self._lib.jpt_set_kernel(self.h, variant), "jpt_set_kernel")
 
+    def set_kernel_timing(self, enable: bool):
+        self._ck(self._lib.jpt_set_kernel_timing(self.h, 1 if enable else 0), "jpt_set_kernel_timing")
+
     def set_partition(self, rank, world):
         self._ck(self._lib.jpt_set_partition(self.h, rank, world), "jpt_set_partition")
 

@@ -152,6 +152,10 @@ enum { JPT_KERNEL_WAVEFRONT = 0, JPT_KERNEL_REFERENCE_LAYOUT = 1,
        JPT_KERNEL_WAVEFRONT_V1 = 2 /* earlier wavefront pipeline without lane refill, kept for A/B timing */ };
 int jpt_set_kernel(jpt_ctx *ctx, int32_t variant);
 
+/* Per-launch timing of the traversal kernels (HIP events recorded around each launch on the context's stream;
+ * jpt_stats.last_trace_ms).  Off by default: each event costs a few microseconds between kernels. */
+int jpt_set_kernel_timing(jpt_ctx *ctx, int32_t enable);
+
 /* Multi-GPU screen partition (no reference counterpart): this context renders the
  * 8-row strips s with s % world == rank.  Default rank 0 of 1 = whole image. */
 int jpt_set_partition(jpt_ctx *ctx, int32_t rank, int32_t world);
