@@ -104,7 +104,7 @@ def main():
     stream = torch.cuda.Stream()
     torch.cuda.set_stream(stream)
     ctx.set_stream(stream.cuda_stream)
-    ctx.set_kernel_timing(True)   # HIP events around every traversal launch (the roofline's kernel duration)
+    ctx.set_kernel_timing(world == 1)   # HIP events around every traversal launch (the roofline's kernel duration)
 
     # gather plumbing (N > 1): the local float4 piece viewed as a torch tensor, no copy
     piece = gathered = None
@@ -154,6 +154,8 @@ def main():
     render_ms, trace_ms = [], []
     t0 = time.perf_counter()
     for i in range(args.steps):
+        if world > 1 and i == args.steps - 1:
+            ctx.set_kernel_timing(True)   # N > 1: only the last step carries the timing events
         ctx.accum_reset()
         ctx.render(spp, 1, asynchronous=True)
         if world > 1:
