@@ -57,6 +57,8 @@ def main():
                     help="demo = demo.tscn's camera (the box covers ~1/6 of the frame); closeup = camera at the box opening "
                          "(every pixel sees geometry; not the headline config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--verify", action="store_true",
+                    help="after the timed region, rank 0 re-renders the whole image alone and checks the assembled one bit for bit")
     ap.add_argument("--cpu-sample", default="auto")
     ap.add_argument("--pmc-json", default=os.path.join(ROOT, "profiles", "current_pmc.json"),
                     help="per-launch HBM bytes of each kernel from the committed rocprofv3 --pmc passes (tools/pmc.sh)")
@@ -74,11 +76,19 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    # JPT_BENCH_BACKEND=gloo is a functional rehearsal of the N > 1 flow on a box with fewer GPUs than ranks
+    # (ranks share devices, the gather is staged through host memory); real runs use RCCL ("nccl").
+    backend = os.environ.get("JPT_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     if args.scene == "demo":
         sc = scenes.demo_scene(args.tris)
@@ -118,21 +128,31 @@ def main():
         if rank == 0:
             gathered = torch.empty((world, nbytes // 4), dtype=torch.float32, device=piece.device)
 
+    def exchange():
+        """the one exchange of a render: every rank's float4 piece to rank 0, then assembly on rank 0"""
+        if backend == "nccl":
+            # direct point-to-point gather: every peer sends its piece over its own xGMI link
+            partition.gather_to_rank0(piece, dist, rank, world, gathered)
+        else:
+            stream.synchronize()
+            g = partition.gather_to_rank0(piece.cpu(), dist, rank, world)
+            if rank == 0:
+                gathered.copy_(g)
+        if rank == 0:
+            ctx.assemble_from_ranks(gathered.data_ptr(), world)
+
     def step():
         ctx.accum_reset()
         ctx.render(spp, 1, asynchronous=True)
         if world > 1:
-            # direct point-to-point gather: every peer sends its piece over its own xGMI link
-            partition.gather_to_rank0(piece, dist, rank, world, gathered)
-            if rank == 0:
-                ctx.assemble_from_ranks(gathered.data_ptr(), world)
+            exchange()
 
     # exact event counts of one step (deterministic), outside the timed region
     ctx.accum_reset()
     ctx.render(spp, 1, counted=True)
     st = ctx.stats()
     counts = torch.tensor([st[k] for k in ("rays", "blas_expand", "tri_tests", "tlas_expand", "inst_visits", "shaded_hits")],
-                          dtype=torch.int64, device="cuda")
+                          dtype=torch.int64, device="cuda" if backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(counts)
     rays, blas_expand, tri_tests, tlas_expand, inst_visits, shaded_hits = [int(x) for x in counts.tolist()]
@@ -159,9 +179,7 @@ def main():
         ctx.accum_reset()
         ctx.render(spp, 1, asynchronous=True)
         if world > 1:
-            partition.gather_to_rank0(piece, dist, rank, world, gathered)
-            if rank == 0:
-                ctx.assemble_from_ranks(gathered.data_ptr(), world)
+            exchange()
         if world == 1 or i == args.steps - 1:
             # N = 1: every step ends with jpt_sync, which also reads the per-launch HIP-event times of the
             # traversal kernels.  N > 1: steps are only queued (the closing barrier waits for all of them), so host
@@ -172,12 +190,23 @@ def main():
             trace_ms.append(st["last_trace_ms"])
     barrier()
     elapsed = time.perf_counter() - t0
-    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
     n_trace_launches = (bounces + 1) if args.kernel != "ref" else spp
     kernel_ms = float(np.mean(trace_ms)) / n_trace_launches   # average duration of ONE launch of the dominant kernel
+
+    verified = None
+    if args.verify and rank == 0:
+        got = ctx.read_accum()
+        solo = host.Context(local_rank)
+        solo.build_scene(sc, capi.BUILD_SAH if args.builder == "sah" else capi.BUILD_REFERENCE_EXACT)
+        solo.set_params(W, H, bounces, accum_mode)
+        solo.set_camera(cam)
+        solo.render(spp, 1)
+        verified = bool(np.array_equal(got, solo.read_accum()))
+        solo.close()
 
     if rank == 0:
         n_pixels = W * H
@@ -238,6 +267,8 @@ def main():
             },
             "counters": total,
         }
+        if verified is not None:
+            out["verified_bit_identical_to_one_context"] = verified
         if world == 1 and not args.no_cpu_baseline:
             from oracle import binding as ob
             ref = ob.build_scene(sc)
