@@ -133,7 +133,7 @@ __global__ __launch_bounds__(kBlock, JPT_PRIMARY_WAVES) void wf2_primary(WideSce
     }
     __syncthreads();
     int32_t spill[kStackSpill];
-    const typename Traversal<COUNT, W4>::Stack my_stack{&stack[threadIdx.x], spill};
+    const typename Traversal<COUNT, W4>::Stack my_stack{&stack[threadIdx.x], spill, kTraceBlock, kStackLds};
     const size_t seg_base = (size_t)seg * dm.seg_cap;
     DevCounters cnt = {};
     Traversal<COUNT, W4> tr;
@@ -211,7 +211,7 @@ __global__ __launch_bounds__(kBlock, JPT_WAVES_PER_SIMD) void wf2_trace(WideScen
     if (threadIdx.x == 0) s_cursor = 0;
     __syncthreads();
     int32_t spill[kStackSpill];
-    const typename Traversal<COUNT, W4>::Stack my_stack{&stack[threadIdx.x], spill};
+    const typename Traversal<COUNT, W4>::Stack my_stack{&stack[threadIdx.x], spill, kTraceBlock, kStackLds};
     const size_t seg_base = (size_t)seg * dm.seg_cap;
     const float4* __restrict__ qo = wb.ray_o[bounce & 1] + seg_base;
     const float4* __restrict__ qd = wb.ray_d[bounce & 1] + seg_base;
@@ -249,6 +249,272 @@ __global__ __launch_bounds__(kBlock, JPT_WAVES_PER_SIMD) void wf2_trace(WideScen
                 wb.hit_b[seg_base + my_idx] = tr.hit.inst | (tr.hit.front ? 0x80000000u : 0u);
             }
         }
+    }
+    if (COUNT) flush_counters(cnt, counters);
+}
+
+// ---- experimental: bounces >= 1 with a per-wave ray pool in LDS (JPT_TRACE_POOL=1) ---------------------------
+//
+// wf2_trace keeps one ray per lane in registers, so a turn of the node / triangle / instance code only serves the
+// lanes that happen to be in that state (28 / 13 / 18 of 64 on the demo scene).  Here a wave owns a pool of 128
+// rays whose state lives in LDS; every round it sorts the pool by state (ballot + prefix popcount into index
+// lists) and runs each state as dense 64-wide passes over its list.  One record per ray per round; every ray still
+// sees its own records in its own order, so results are unchanged.
+
+constexpr int kPoolRays = 128;
+constexpr int kPoolStack = 16;
+enum : uint32_t { PS_EMPTY = 0, PS_NODE = 1, PS_LEAF = 2, PS_INST = 3, PS_EXIT = 4, PS_DONE = 5 };
+
+struct WavePool {
+    float ox[kPoolRays], oy[kPoolRays], oz[kPoolRays], dx[kPoolRays], dy[kPoolRays], dz[kPoolRays];
+    float rx[kPoolRays], ry[kPoolRays], rz[kPoolRays];
+    float t[kPoolRays], u[kPoolRays], v[kPoolRays];
+    uint32_t tri[kPoolRays], meta[kPoolRays];  // meta: best hit's instance id | front << 30
+    uint32_t level[kPoolRays];                 // instance being walked | in_blas << 31
+    uint32_t qidx[kPoolRays], state[kPoolRays];
+    int32_t cur[kPoolRays], sp[kPoolRays];
+    int32_t stack[kPoolStack][kPoolRays];
+    uint16_t list[4][kPoolRays];
+};
+
+__device__ __forceinline__ void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// after a record: take the next one off the ray's stack and classify it
+template <bool COUNT, bool W4>
+__device__ __forceinline__ void pool_advance(WavePool& P, int slot, Traversal<COUNT, W4>& tr,
+                                             const typename Traversal<COUNT, W4>::Stack& st)
+{
+    uint32_t state;
+    if (!tr.have) {
+        if (tr.sp == 0) {
+            state = PS_DONE;
+        } else {
+            const int32_t e = tr.pop(st);
+            if (e == kSentinel) {
+                state = PS_EXIT;
+            } else {
+                tr.cur = e;
+                tr.have = true;
+                state = tr.cur >= 0 ? PS_NODE : (tr.in_blas ? PS_LEAF : PS_INST);
+            }
+        }
+    } else {
+        state = tr.cur >= 0 ? PS_NODE : (tr.in_blas ? PS_LEAF : PS_INST);
+    }
+    P.cur[slot] = tr.cur;
+    P.sp[slot] = tr.sp;
+    P.state[slot] = state;
+}
+
+template <bool COUNT, bool W4>
+__global__ __launch_bounds__(kBlock, 2) void wf3_trace(WideSceneDev sc, Wf2Buffers wb, Wf2Dims dm, int bounce, WfTune tune,
+                                                       int32_t* __restrict__ spill_all, DevCounters* __restrict__ counters)
+{
+    __shared__ WavePool pools[kBlock / 64];
+    __shared__ uint32_t s_cursor;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t seg = blockIdx.x;
+    const uint32_t n = wb.qcount[(size_t)bounce * kSegments + seg];
+    if (n == 0) return;
+    if (threadIdx.x == 0) s_cursor = 0;
+    __syncthreads();
+    WavePool& P = pools[wave];
+    const size_t seg_base = (size_t)seg * dm.seg_cap;
+    const float4* __restrict__ qo = wb.ray_o[bounce & 1] + seg_base;
+    const float4* __restrict__ qd = wb.ray_d[bounce & 1] + seg_base;
+    int32_t* const spill_wave = spill_all + ((size_t)blockIdx.x * (kBlock / 64) + wave) * kPoolRays * kStackSpill;
+    using Tr = Traversal<COUNT, W4>;
+    auto stack_of = [&](int slot) { return typename Tr::Stack{&P.stack[0][slot], spill_wave + (size_t)slot * kStackSpill, kPoolRays, kPoolStack}; };
+    DevCounters cnt = {};
+    P.state[lane] = PS_EMPTY;
+    P.state[lane + 64] = PS_EMPTY;
+    wave_lds_sync();
+    bool exhausted = false;
+
+    for (;;) {
+        // ---- retire finished rays, count free slots
+        bool free_h[2];
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int slot = lane + 64 * h;
+            uint32_t st = P.state[slot];
+            if (st == PS_DONE) {
+                const uint32_t q = P.qidx[slot], meta = P.meta[slot];
+                wb.hit_a[seg_base + q] = make_float4(P.t[slot], P.u[slot], P.v[slot], __uint_as_float(P.tri[slot]));
+                wb.hit_b[seg_base + q] = (meta & 0x00ffffffu) | ((meta & 0x40000000u) ? 0x80000000u : 0u);
+                st = PS_EMPTY;
+                P.state[slot] = PS_EMPTY;
+            }
+            free_h[h] = st == PS_EMPTY;
+        }
+        const unsigned long long f0 = __ballot(free_h[0]), f1 = __ballot(free_h[1]);
+        const int n_free = __popcll(f0) + __popcll(f1);
+        // ---- refill
+        if (!exhausted && n_free >= tune.refill_idle) {
+            uint32_t start = 0;
+            if (lane == 0) start = atomicAdd(&s_cursor, (uint32_t)n_free);
+            start = (uint32_t)__builtin_amdgcn_readfirstlane((int)start);
+            if (start + (uint32_t)n_free >= n) exhausted = true;
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const int slot = lane + 64 * h;
+                const uint32_t idx = start + (h ? (uint32_t)__popcll(f0) + lanes_below(f1, lane) : lanes_below(f0, lane));
+                if (free_h[h] && idx < n) {
+                    const float4 ro = qo[idx], rd = qd[idx];
+                    const f3 d = mk3(rd.x, rd.y, rd.z), r = rcp3(d);
+                    P.ox[slot] = ro.x; P.oy[slot] = ro.y; P.oz[slot] = ro.z;
+                    P.dx[slot] = d.x; P.dy[slot] = d.y; P.dz[slot] = d.z;
+                    P.rx[slot] = r.x; P.ry[slot] = r.y; P.rz[slot] = r.z;
+                    P.t[slot] = 1e9f;  // main.glsl:354
+                    P.u[slot] = 0.0f; P.v[slot] = 0.0f;
+                    P.tri[slot] = 0;
+                    P.meta[slot] = 0;
+                    P.level[slot] = 0;
+                    P.qidx[slot] = idx;
+                    P.cur[slot] = sc.tlas_root;
+                    P.sp[slot] = 0;
+                    P.state[slot] = sc.n_instances == 0 ? PS_DONE : (sc.tlas_root >= 0 ? PS_NODE : PS_INST);
+                    free_h[h] = false;
+                }
+            }
+        }
+        wave_lds_sync();
+        // ---- sort the pool by state
+        int count[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int slot = lane + 64 * h;
+            const uint32_t st = P.state[slot];
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const bool mine = st == (uint32_t)(PS_NODE + c);
+                const unsigned long long m = __ballot(mine);
+                if (mine) P.list[c][count[c] + (int)lanes_below(m, lane)] = (uint16_t)slot;
+                count[c] += __popcll(m);
+            }
+        }
+        const int busy = count[0] + count[1] + count[2] + count[3];
+        if (busy == 0) {
+            const int done_now = __popcll(__ballot(P.state[lane] == PS_DONE)) + __popcll(__ballot(P.state[lane + 64] == PS_DONE));
+            if (done_now == 0 && exhausted) break;
+            continue;
+        }
+        wave_lds_sync();
+        if (COUNT && lane == 0) cnt.phase[0]++;
+        // the states with few waiting rays are held back while the node list is long enough to fill a pass
+        const bool starving = count[0] < 32;
+
+        // ---- internal records
+        if (count[0] > 0) {
+            for (int base = 0; base < count[0]; base += 64) {
+                const int i = base + lane;
+                if (COUNT && lane == 0) {
+                    cnt.phase[1]++;
+                    cnt.phase[2] += (unsigned long long)(count[0] - base < 64 ? count[0] - base : 64);
+                }
+                if (i < count[0]) {
+                    const int slot = P.list[0][i];
+                    Tr tr;
+                    tr.o = mk3(P.ox[slot], P.oy[slot], P.oz[slot]);
+                    tr.rD = mk3(P.rx[slot], P.ry[slot], P.rz[slot]);
+                    tr.hit.t = P.t[slot];
+                    tr.cur = P.cur[slot];
+                    tr.sp = P.sp[slot];
+                    tr.in_blas = (P.level[slot] >> 31) != 0u;
+                    tr.have = true;
+                    const typename Tr::Stack st = stack_of(slot);
+                    tr.node_step(sc, st, cnt);
+                    pool_advance<COUNT, W4>(P, slot, tr, st);
+                }
+            }
+        }
+        // ---- triangles: one per ray per round
+        if (count[1] > 0 && (count[1] >= tune.node_min_lanes || starving)) {
+            for (int base = 0; base < count[1]; base += 64) {
+                const int i = base + lane;
+                if (COUNT && lane == 0) {
+                    cnt.phase[3]++;
+                    cnt.phase[4] += (unsigned long long)(count[1] - base < 64 ? count[1] - base : 64);
+                }
+                if (i < count[1]) {
+                    const int slot = P.list[1][i];
+                    Tr tr;
+                    tr.o = mk3(P.ox[slot], P.oy[slot], P.oz[slot]);
+                    tr.d = mk3(P.dx[slot], P.dy[slot], P.dz[slot]);
+                    tr.hit.t = P.t[slot];
+                    tr.hit.tri = 0xffffffffu;
+                    tr.cur = P.cur[slot];
+                    tr.sp = P.sp[slot];
+                    tr.cur_inst = P.level[slot] & 0x00ffffffu;
+                    tr.in_blas = true;
+                    tr.have = true;
+                    tr.leaf_one(sc, cnt);
+                    if (tr.hit.tri != 0xffffffffu) {  // accepted (also on an exact tie, like main.glsl:247)
+                        P.t[slot] = tr.hit.t;
+                        P.u[slot] = tr.hit.u;
+                        P.v[slot] = tr.hit.v;
+                        P.tri[slot] = tr.hit.tri;
+                        P.meta[slot] = tr.cur_inst | (tr.hit.front ? 0x40000000u : 0u);
+                    }
+                    pool_advance<COUNT, W4>(P, slot, tr, stack_of(slot));
+                }
+            }
+        }
+        // ---- instance entries
+        if (count[2] > 0 && (count[2] >= tune.node_min_lanes || starving)) {
+            for (int base = 0; base < count[2]; base += 64) {
+                const int i = base + lane;
+                if (COUNT && lane == 0) {
+                    cnt.phase[5]++;
+                    cnt.phase[6] += (unsigned long long)(count[2] - base < 64 ? count[2] - base : 64);
+                }
+                if (i < count[2]) {
+                    const int slot = P.list[2][i];
+                    Tr tr;
+                    tr.wo = mk3(P.ox[slot], P.oy[slot], P.oz[slot]);  // at the TLAS level the pool holds the world ray
+                    tr.wd = mk3(P.dx[slot], P.dy[slot], P.dz[slot]);
+                    tr.cur = P.cur[slot];
+                    tr.sp = P.sp[slot];
+                    tr.in_blas = false;
+                    tr.have = true;
+                    const typename Tr::Stack st = stack_of(slot);
+                    tr.instance_step(sc, st, cnt);
+                    P.ox[slot] = tr.o.x; P.oy[slot] = tr.o.y; P.oz[slot] = tr.o.z;
+                    P.dx[slot] = tr.d.x; P.dy[slot] = tr.d.y; P.dz[slot] = tr.d.z;
+                    P.rx[slot] = tr.rD.x; P.ry[slot] = tr.rD.y; P.rz[slot] = tr.rD.z;
+                    P.level[slot] = 0x80000000u | tr.cur_inst;
+                    pool_advance<COUNT, W4>(P, slot, tr, st);
+                }
+            }
+        }
+        // ---- leaving an instance: the world ray comes back from the queue
+        if (count[3] > 0) {
+            for (int base = 0; base < count[3]; base += 64) {
+                const int i = base + lane;
+                if (i < count[3]) {
+                    const int slot = P.list[3][i];
+                    const uint32_t q = P.qidx[slot];
+                    const float4 ro = qo[q], rd = qd[q];
+                    const f3 d = mk3(rd.x, rd.y, rd.z), r = rcp3(d);
+                    P.ox[slot] = ro.x; P.oy[slot] = ro.y; P.oz[slot] = ro.z;
+                    P.dx[slot] = d.x; P.dy[slot] = d.y; P.dz[slot] = d.z;
+                    P.rx[slot] = r.x; P.ry[slot] = r.y; P.rz[slot] = r.z;
+                    P.level[slot] = 0u;
+                    Tr tr;
+                    tr.cur = 0;
+                    tr.sp = P.sp[slot];
+                    tr.in_blas = false;
+                    tr.have = false;
+                    pool_advance<COUNT, W4>(P, slot, tr, stack_of(slot));
+                }
+            }
+        }
+        wave_lds_sync();
     }
     if (COUNT) flush_counters(cnt, counters);
 }
@@ -395,6 +661,16 @@ Wf2Dims make_dims(int width, int local_rows, int n_frames)
 
 }  // namespace
 
+static bool pool_enabled()
+{
+    static const bool on = [] {
+        const char* e = getenv("JPT_TRACE_POOL");
+        return e && atoi(e) != 0;
+    }();
+    return on;
+}
+static size_t pool_spill_bytes() { return pool_enabled() ? (size_t)kSegments * (kBlock / 64) * kPoolRays * kStackSpill * sizeof(int32_t) : 0; }
+
 uint32_t wf2_segments() { return kSegments; }
 uint32_t trace_stack_capacity() { return (uint32_t)(kStackLds + kStackSpill); }
 
@@ -410,7 +686,8 @@ size_t wf2_workspace_bytes(int width, int local_rows, int n_frames, int max_boun
     b += paths * sizeof(float4) * 2;  // thr, rad
     b += (size_t)dm.slots_per_frame * sizeof(float);
     b += (size_t)(max_bounces + 2) * kSegments * sizeof(uint32_t);
-    return b + 16 * 256;
+    b += pool_spill_bytes();  // only touched by the experimental pool kernel
+    return b + 17 * 256;
 }
 
 void launch_wf2_render(hipStream_t stream, const DeviceScene& ds, const FrameParams& fp, const RefCamera& cam, void* workspace,
@@ -438,6 +715,8 @@ void launch_wf2_render(hipStream_t stream, const DeviceScene& ds, const FramePar
     wb.thr = (float4*)carve(paths * sizeof(float4));
     wb.rad = (float4*)carve(paths * sizeof(float4));
     wb.first_depth = (float*)carve((size_t)dm.slots_per_frame * sizeof(float));
+    const bool use_pool = pool_enabled();
+    int32_t* pool_spill = use_pool ? (int32_t*)carve(pool_spill_bytes()) : nullptr;
 
     static const bool allow4 = [] {
         const char* e = getenv("JPT_BVH_WIDTH");
@@ -481,7 +760,15 @@ void launch_wf2_render(hipStream_t stream, const DeviceScene& ds, const FramePar
         else hipLaunchKernelGGL(wf2_shade<false>, sgrid, block, 0, stream, sh, wb, dm, fp, cam, b, counters);
         if (b == fp.max_bounces) break;
         if (trace_events) (void)hipEventRecord(trace_events[2 * (b + 1)], stream);
-        if (counters) {
+        if (use_pool) {
+            if (counters) {
+                if (w4) hipLaunchKernelGGL((wf3_trace<true, true>), grid, block, 0, stream, sc, wb, dm, b + 1, tune, pool_spill, counters);
+                else hipLaunchKernelGGL((wf3_trace<true, false>), grid, block, 0, stream, sc, wb, dm, b + 1, tune, pool_spill, counters);
+            } else {
+                if (w4) hipLaunchKernelGGL((wf3_trace<false, true>), grid, block, 0, stream, sc, wb, dm, b + 1, tune, pool_spill, counters);
+                else hipLaunchKernelGGL((wf3_trace<false, false>), grid, block, 0, stream, sc, wb, dm, b + 1, tune, pool_spill, counters);
+            }
+        } else if (counters) {
             if (w4) hipLaunchKernelGGL((wf2_trace<true, true>), grid, block, 0, stream, sc, wb, dm, b + 1, tune, counters);
             else hipLaunchKernelGGL((wf2_trace<true, false>), grid, block, 0, stream, sc, wb, dm, b + 1, tune, counters);
         } else {

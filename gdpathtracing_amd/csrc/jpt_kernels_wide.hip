@@ -31,7 +31,7 @@ __device__ __forceinline__ void trace_ray(const WideSceneDev& sc, const f3 wo, c
 {
     (void)wrD;
     int32_t spill[kStackSpill];
-    const typename Traversal<COUNT>::Stack st{lds_stack, spill};
+    const typename Traversal<COUNT>::Stack st{lds_stack, spill, kTraceBlock, kStackLds};
     Traversal<COUNT> tr;
     tr.begin(sc, wo, wd);
     while (tr.step(sc, st, cnt)) {

@@ -66,8 +66,10 @@ struct Traversal {
     // The stack: entries 0..kStackLds-1 in LDS (`lds` = this lane's column), deeper ones in `spill`, a
     // per-lane scratch array owned by the kernel (kept OUT of this struct so the struct stays in registers).
     struct Stack {
-        int32_t* __restrict__ lds;
-        int32_t* __restrict__ spill;
+        int32_t* __restrict__ lds;    // entry k of this ray at lds[k * stride]
+        int32_t* __restrict__ spill;  // entries past kStackLds (scratch or global)
+        int stride = kTraceBlock;
+        int lds_entries = kStackLds;
     };
 
     __device__ __forceinline__ void push(const Stack& st, int32_t v)
@@ -75,8 +77,8 @@ struct Traversal {
 #ifdef JPT_NO_SPILL  // experiment only: valid when the scene's stack depth never exceeds kStackLds
         st.lds[sp * kTraceBlock] = v;
 #else
-        if (sp < kStackLds) st.lds[sp * kTraceBlock] = v;
-        else if (sp < kStackLds + kStackSpill) st.spill[sp - kStackLds] = v;
+        if (sp < st.lds_entries) st.lds[sp * st.stride] = v;
+        else if (sp < st.lds_entries + kStackSpill) st.spill[sp - st.lds_entries] = v;
 #endif
         sp++;
     }
@@ -86,8 +88,8 @@ struct Traversal {
 #ifdef JPT_NO_SPILL
         return st.lds[sp * kTraceBlock];
 #else
-        if (sp < kStackLds) return st.lds[sp * kTraceBlock];
-        if (sp < kStackLds + kStackSpill) return st.spill[sp - kStackLds];
+        if (sp < st.lds_entries) return st.lds[sp * st.stride];
+        if (sp < st.lds_entries + kStackSpill) return st.spill[sp - st.lds_entries];
         return kSentinel;
 #endif
     }
