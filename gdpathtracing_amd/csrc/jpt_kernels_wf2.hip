@@ -263,6 +263,7 @@ __global__ __launch_bounds__(kBlock, JPT_WAVES_PER_SIMD) void wf2_trace(WideScen
 
 constexpr int kPoolRays = 128;
 constexpr int kPoolStack = 16;
+constexpr int kPoolMaxSegs = 8;            // segments one pool block may chain (grid >= kSegments / 8)
 enum : uint32_t { PS_EMPTY = 0, PS_NODE = 1, PS_LEAF = 2, PS_INST = 3, PS_EXIT = 4, PS_DONE = 5 };
 
 struct WavePool {
@@ -317,16 +318,33 @@ __global__ __launch_bounds__(kBlock, 2) void wf3_trace(WideSceneDev sc, Wf2Buffe
 {
     __shared__ WavePool pools[kBlock / 64];
     __shared__ uint32_t s_cursor;
+    __shared__ uint32_t s_prefix[kPoolMaxSegs + 1];  // this block's segments, flattened into one index space
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t seg = blockIdx.x;
-    const uint32_t n = wb.qcount[(size_t)bounce * kSegments + seg];
-    if (n == 0) return;
-    if (threadIdx.x == 0) s_cursor = 0;
+    // block b walks segments b, b + gridDim.x, ... as ONE stream of rays, so its pools stay full until the end
+    if (threadIdx.x == 0) {
+        s_cursor = 0;
+        uint32_t tot = 0;
+        int k = 0;
+        for (uint32_t sg = blockIdx.x; sg < kSegments && k < kPoolMaxSegs; sg += gridDim.x, k++) {
+            s_prefix[k] = tot;
+            tot += wb.qcount[(size_t)bounce * kSegments + sg];
+        }
+        for (; k <= kPoolMaxSegs; k++) s_prefix[k] = tot;
+    }
     __syncthreads();
+    const uint32_t n = s_prefix[kPoolMaxSegs];
+    if (n == 0) return;
     WavePool& P = pools[wave];
-    const size_t seg_base = (size_t)seg * dm.seg_cap;
-    const float4* __restrict__ qo = wb.ray_o[bounce & 1] + seg_base;
-    const float4* __restrict__ qd = wb.ray_d[bounce & 1] + seg_base;
+    const float4* __restrict__ qo = wb.ray_o[bounce & 1];
+    const float4* __restrict__ qd = wb.ray_d[bounce & 1];
+    // flattened index -> position in the queue arrays
+    auto locate = [&](uint32_t g) -> uint32_t {
+        int k = 0;
+#pragma unroll
+        for (int j = 1; j < kPoolMaxSegs; j++) k += (g >= s_prefix[j]) ? 1 : 0;
+        const uint32_t sg = blockIdx.x + (uint32_t)k * gridDim.x;
+        return sg * dm.seg_cap + (g - s_prefix[k]);
+    };
     int32_t* const spill_wave = spill_all + ((size_t)blockIdx.x * (kBlock / 64) + wave) * kPoolRays * kStackSpill;
     using Tr = Traversal<COUNT, W4>;
     auto stack_of = [&](int slot) { return typename Tr::Stack{&P.stack[0][slot], spill_wave + (size_t)slot * kStackSpill, kPoolRays, kPoolStack}; };
@@ -345,8 +363,8 @@ __global__ __launch_bounds__(kBlock, 2) void wf3_trace(WideSceneDev sc, Wf2Buffe
             uint32_t st = P.state[slot];
             if (st == PS_DONE) {
                 const uint32_t q = P.qidx[slot], meta = P.meta[slot];
-                wb.hit_a[seg_base + q] = make_float4(P.t[slot], P.u[slot], P.v[slot], __uint_as_float(P.tri[slot]));
-                wb.hit_b[seg_base + q] = (meta & 0x00ffffffu) | ((meta & 0x40000000u) ? 0x80000000u : 0u);
+                wb.hit_a[q] = make_float4(P.t[slot], P.u[slot], P.v[slot], __uint_as_float(P.tri[slot]));
+                wb.hit_b[q] = (meta & 0x00ffffffu) | ((meta & 0x40000000u) ? 0x80000000u : 0u);
                 st = PS_EMPTY;
                 P.state[slot] = PS_EMPTY;
             }
@@ -365,7 +383,8 @@ __global__ __launch_bounds__(kBlock, 2) void wf3_trace(WideSceneDev sc, Wf2Buffe
                 const int slot = lane + 64 * h;
                 const uint32_t idx = start + (h ? (uint32_t)__popcll(f0) + lanes_below(f1, lane) : lanes_below(f0, lane));
                 if (free_h[h] && idx < n) {
-                    const float4 ro = qo[idx], rd = qd[idx];
+                    const uint32_t qpos = locate(idx);
+                    const float4 ro = qo[qpos], rd = qd[qpos];
                     const f3 d = mk3(rd.x, rd.y, rd.z), r = rcp3(d);
                     P.ox[slot] = ro.x; P.oy[slot] = ro.y; P.oz[slot] = ro.z;
                     P.dx[slot] = d.x; P.dy[slot] = d.y; P.dz[slot] = d.z;
@@ -375,7 +394,7 @@ __global__ __launch_bounds__(kBlock, 2) void wf3_trace(WideSceneDev sc, Wf2Buffe
                     P.tri[slot] = 0;
                     P.meta[slot] = 0;
                     P.level[slot] = 0;
-                    P.qidx[slot] = idx;
+                    P.qidx[slot] = qpos;
                     P.cur[slot] = sc.tlas_root;
                     P.sp[slot] = 0;
                     P.state[slot] = sc.n_instances == 0 ? PS_DONE : (sc.tlas_root >= 0 ? PS_NODE : PS_INST);
@@ -669,7 +688,7 @@ static bool pool_enabled()
     }();
     return on;
 }
-static size_t pool_spill_bytes() { return pool_enabled() ? (size_t)kSegments * (kBlock / 64) * kPoolRays * kStackSpill * sizeof(int32_t) : 0; }
+static size_t pool_spill_bytes() { return pool_enabled() ? (size_t)512 * (kBlock / 64) * kPoolRays * kStackSpill * sizeof(int32_t) : 0; }
 
 uint32_t wf2_segments() { return kSegments; }
 uint32_t trace_stack_capacity() { return (uint32_t)(kStackLds + kStackSpill); }
@@ -716,6 +735,7 @@ void launch_wf2_render(hipStream_t stream, const DeviceScene& ds, const FramePar
     wb.rad = (float4*)carve(paths * sizeof(float4));
     wb.first_depth = (float*)carve((size_t)dm.slots_per_frame * sizeof(float));
     const bool use_pool = pool_enabled();
+    const dim3 pgrid(512);  // 2 resident blocks per CU (75 KiB of LDS each); each chains kSegments / 512 segments
     int32_t* pool_spill = use_pool ? (int32_t*)carve(pool_spill_bytes()) : nullptr;
 
     static const bool allow4 = [] {
@@ -762,11 +782,11 @@ void launch_wf2_render(hipStream_t stream, const DeviceScene& ds, const FramePar
         if (trace_events) (void)hipEventRecord(trace_events[2 * (b + 1)], stream);
         if (use_pool) {
             if (counters) {
-                if (w4) hipLaunchKernelGGL((wf3_trace<true, true>), grid, block, 0, stream, sc, wb, dm, b + 1, tune, pool_spill, counters);
-                else hipLaunchKernelGGL((wf3_trace<true, false>), grid, block, 0, stream, sc, wb, dm, b + 1, tune, pool_spill, counters);
+                if (w4) hipLaunchKernelGGL((wf3_trace<true, true>), pgrid, block, 0, stream, sc, wb, dm, b + 1, tune, pool_spill, counters);
+                else hipLaunchKernelGGL((wf3_trace<true, false>), pgrid, block, 0, stream, sc, wb, dm, b + 1, tune, pool_spill, counters);
             } else {
-                if (w4) hipLaunchKernelGGL((wf3_trace<false, true>), grid, block, 0, stream, sc, wb, dm, b + 1, tune, pool_spill, counters);
-                else hipLaunchKernelGGL((wf3_trace<false, false>), grid, block, 0, stream, sc, wb, dm, b + 1, tune, pool_spill, counters);
+                if (w4) hipLaunchKernelGGL((wf3_trace<false, true>), pgrid, block, 0, stream, sc, wb, dm, b + 1, tune, pool_spill, counters);
+                else hipLaunchKernelGGL((wf3_trace<false, false>), pgrid, block, 0, stream, sc, wb, dm, b + 1, tune, pool_spill, counters);
             }
         } else if (counters) {
             if (w4) hipLaunchKernelGGL((wf2_trace<true, true>), grid, block, 0, stream, sc, wb, dm, b + 1, tune, counters);
