@@ -428,27 +428,54 @@ __global__ __launch_bounds__(kBlock, 2) void wf3_trace(WideSceneDev sc, Wf2Buffe
         // the states with few waiting rays are held back while the node list is long enough to fill a pass
         const bool starving = count[0] < 32;
 
-        // ---- internal records
+        // ---- internal records: two list entries per lane per pass (their fetches overlap); a remainder of fewer
+        // than half a wave stays in the list for the next round unless the wave has little else to do
         if (count[0] > 0) {
-            for (int base = 0; base < count[0]; base += 64) {
-                const int i = base + lane;
+            int todo = count[0];
+            if (todo > 64 && (todo & 63) < 32 && !starving) todo &= ~63;
+            for (int base = 0; base < todo; base += 128) {
+                const int i0 = base + lane, i1 = base + 64 + lane;
+                const bool a0 = i0 < todo, a1 = i1 < todo;
                 if (COUNT && lane == 0) {
+                    const int n0 = todo - base < 64 ? todo - base : 64;
                     cnt.phase[1]++;
-                    cnt.phase[2] += (unsigned long long)(count[0] - base < 64 ? count[0] - base : 64);
+                    cnt.phase[2] += (unsigned long long)n0;
+                    if (todo - base > 64) {
+                        cnt.phase[1]++;
+                        cnt.phase[2] += (unsigned long long)(todo - base - 64 < 64 ? todo - base - 64 : 64);
+                    }
                 }
-                if (i < count[0]) {
-                    const int slot = P.list[0][i];
-                    Tr tr;
-                    tr.o = mk3(P.ox[slot], P.oy[slot], P.oz[slot]);
-                    tr.rD = mk3(P.rx[slot], P.ry[slot], P.rz[slot]);
-                    tr.hit.t = P.t[slot];
-                    tr.cur = P.cur[slot];
-                    tr.sp = P.sp[slot];
-                    tr.in_blas = (P.level[slot] >> 31) != 0u;
-                    tr.have = true;
-                    const typename Tr::Stack st = stack_of(slot);
-                    tr.node_step(sc, st, cnt);
-                    pool_advance<COUNT, W4>(P, slot, tr, st);
+                const int s0 = a0 ? P.list[0][i0] : 0, s1 = a1 ? P.list[0][i1] : 0;
+                Tr t0, t1;
+                t0.have = t1.have = true;
+                if (a0) {
+                    t0.o = mk3(P.ox[s0], P.oy[s0], P.oz[s0]);
+                    t0.rD = mk3(P.rx[s0], P.ry[s0], P.rz[s0]);
+                    t0.hit.t = P.t[s0];
+                    t0.cur = P.cur[s0];
+                    t0.sp = P.sp[s0];
+                    t0.in_blas = (P.level[s0] >> 31) != 0u;
+                }
+                if (a1) {
+                    t1.o = mk3(P.ox[s1], P.oy[s1], P.oz[s1]);
+                    t1.rD = mk3(P.rx[s1], P.ry[s1], P.rz[s1]);
+                    t1.hit.t = P.t[s1];
+                    t1.cur = P.cur[s1];
+                    t1.sp = P.sp[s1];
+                    t1.in_blas = (P.level[s1] >> 31) != 0u;
+                }
+                typename Tr::NodeData n0, n1;
+                if (a0) n0 = t0.node_fetch(sc);
+                if (a1) n1 = t1.node_fetch(sc);
+                if (a0) {
+                    const typename Tr::Stack st = stack_of(s0);
+                    t0.node_apply(n0, st, cnt);
+                    pool_advance<COUNT, W4>(P, s0, t0, st);
+                }
+                if (a1) {
+                    const typename Tr::Stack st = stack_of(s1);
+                    t1.node_apply(n1, st, cnt);
+                    pool_advance<COUNT, W4>(P, s1, t1, st);
                 }
             }
         }

@@ -122,12 +122,37 @@ struct Traversal {
 
     // four-child record (128 B = one L1 line): four slab tests, children visited nearest first.  The order
     // among children is a performance choice only (the closest hit does not depend on it).
+    struct NodeData {  // one record as fetched (7 float4 for the four-child form, 4 for the two-child form)
+        float4 q[7];
+    };
+    __device__ __forceinline__ NodeData node_fetch(const WideSceneDev& sc) const
+    {
+        NodeData nd;
+        if (W4) {
+            const WideNode4* n = (in_blas ? sc.blas_nodes4 : sc.tlas_nodes4) + cur;
+            nd.q[0] = ld4(&n->lo_x[0]); nd.q[1] = ld4(&n->lo_y[0]); nd.q[2] = ld4(&n->lo_z[0]);
+            nd.q[3] = ld4(&n->hi_x[0]); nd.q[4] = ld4(&n->hi_y[0]); nd.q[5] = ld4(&n->hi_z[0]);
+            nd.q[6] = ld4(&n->child[0]);
+        } else {
+            const WideNode* n = (in_blas ? sc.blas_nodes : sc.tlas_nodes) + cur;
+            nd.q[0] = ld4(&n->lmin[0]); nd.q[1] = ld4(&n->lmax[1]); nd.q[2] = ld4(&n->rmin[2]); nd.q[3] = ld4(&n->left);
+        }
+        return nd;
+    }
+    __device__ __forceinline__ void node_apply(const NodeData& nd, const Stack& st, DevCounters& cnt)
+    {
+        if (W4) node_apply4(nd, st, cnt);
+        else node_apply2(nd, st, cnt);
+    }
     __device__ __forceinline__ void node_step4(const WideSceneDev& sc, const Stack& st, DevCounters& cnt)
     {
-        const WideNode4* n = (in_blas ? sc.blas_nodes4 : sc.tlas_nodes4) + cur;
-        const float4 lx = ld4(&n->lo_x[0]), ly = ld4(&n->lo_y[0]), lz = ld4(&n->lo_z[0]);
-        const float4 hx = ld4(&n->hi_x[0]), hy = ld4(&n->hi_y[0]), hz = ld4(&n->hi_z[0]);
-        const float4 cf = ld4(&n->child[0]);
+        node_apply4(node_fetch(sc), st, cnt);
+    }
+    __device__ __forceinline__ void node_apply4(const NodeData& nd, const Stack& st, DevCounters& cnt)
+    {
+        const float4 lx = nd.q[0], ly = nd.q[1], lz = nd.q[2];
+        const float4 hx = nd.q[3], hy = nd.q[4], hz = nd.q[5];
+        const float4 cf = nd.q[6];
         if (COUNT) {
             if (in_blas) cnt.blas_expand++;
             else cnt.tlas_expand++;
@@ -177,12 +202,15 @@ struct Traversal {
             node_step4(sc, st, cnt);
             return;
         }
-        const WideNode* n = (in_blas ? sc.blas_nodes : sc.tlas_nodes) + cur;
-        const float4 a = ld4(&n->lmin[0]);  // lmin.xyz lmax.x
-        const float4 b = ld4(&n->lmax[1]);  // lmax.yz rmin.xy
-        const float4 c = ld4(&n->rmin[2]);  // rmin.z rmax.xyz
-        const float4 e = ld4(&n->left);     // left right pad pad
-#ifdef JPT_ABL_EXTRA_LOADS  // ablation: the same 4 fetches again (L1 hits) -- is the memory pipe the limiter?
+        node_apply2(node_fetch(sc), st, cnt);
+    }
+    __device__ __forceinline__ void node_apply2(const NodeData& nd, const Stack& st, DevCounters& cnt)
+    {
+        const float4 a = nd.q[0];  // lmin.xyz lmax.x
+        const float4 b = nd.q[1];  // lmax.yz rmin.xy
+        const float4 c = nd.q[2];  // rmin.z rmax.xyz
+        const float4 e = nd.q[3];  // left right pad pad
+#if 0  // (ablation used for DESIGN.md section 4: the same 4 fetches again)
         {
             float4 x0, x1, x2, x3;
             asm volatile("global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %4, off offset:16\n\t"
