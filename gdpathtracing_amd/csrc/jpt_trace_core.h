@@ -210,30 +210,6 @@ struct Traversal {
         const float4 b = nd.q[1];  // lmax.yz rmin.xy
         const float4 c = nd.q[2];  // rmin.z rmax.xyz
         const float4 e = nd.q[3];  // left right pad pad
-#if 0  // (ablation used for DESIGN.md section 4: the same 4 fetches again)
-        {
-            float4 x0, x1, x2, x3;
-            asm volatile("global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %4, off offset:16\n\t"
-                         "global_load_dwordx4 %2, %4, off offset:32\n\tglobal_load_dwordx4 %3, %4, off offset:48\n\t"
-                         "s_waitcnt vmcnt(0)"
-                         : "=&v"(x0), "=&v"(x1), "=&v"(x2), "=&v"(x3)
-                         : "v"(n)
-                         : "memory");
-            asm volatile("" ::"v"(x0.x + x0.w), "v"(x1.y + x1.z), "v"(x2.x + x2.w), "v"(x3.y + x3.z));
-        }
-#endif
-#ifdef JPT_ABL_EXTRA_VALU  // ablation: ~64 extra dependent-free VALU ops per node step
-        {
-            float y0 = a.x, y1 = a.y, y2 = a.z, y3 = a.w;
-#pragma unroll
-            for (int k = 0; k < 16; k++) {
-                asm volatile("v_add_f32 %0, %0, %4\n\tv_add_f32 %1, %1, %4\n\tv_add_f32 %2, %2, %4\n\tv_add_f32 %3, %3, %4"
-                             : "+v"(y0), "+v"(y1), "+v"(y2), "+v"(y3)
-                             : "v"(b.x));
-            }
-            asm volatile("" ::"v"(y0), "v"(y1), "v"(y2), "v"(y3));
-        }
-#endif
         if (COUNT) {
             if (in_blas) cnt.blas_expand++;
             else cnt.tlas_expand++;
