@@ -567,8 +567,11 @@ __global__ __launch_bounds__(kBlock, 2) void wf3_trace(WideSceneDev sc, Wf2Buffe
 
 // ---- shading: one path vertex per queue entry (main.glsl:378-397) -------------------------------------------
 
+#ifndef JPT_SHADE_WAVES
+#define JPT_SHADE_WAVES 1
+#endif
 template <bool COUNT>
-__global__ __launch_bounds__(kBlock) void wf2_shade(SceneShading sh, Wf2Buffers wb, Wf2Dims dm, FrameParams fp, RefCamera cam,
+__global__ __launch_bounds__(kBlock, JPT_SHADE_WAVES) void wf2_shade(SceneShading sh, Wf2Buffers wb, Wf2Dims dm, FrameParams fp, RefCamera cam,
                                                     int bounce, DevCounters* __restrict__ counters)
 {
     // grid = (chunks per segment, segments): every 256-entry chunk of every segment is its own block, so the
