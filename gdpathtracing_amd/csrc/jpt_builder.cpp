@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <future>
 #include <numeric>
@@ -196,7 +197,16 @@ struct SahBlasBuilder {
     float pad = 0.0f;
 
     static constexpr int kBins = 16;
-    static constexpr int kMaxLeaf = 4;
+    // largest leaf the builder keeps without a split that pays (JPT_MAX_LEAF overrides, for tuning runs)
+    static int max_leaf()
+    {
+        static const int v = [] {
+            const char* e = getenv("JPT_MAX_LEAF");
+            const int k = e ? atoi(e) : 4;
+            return k < 1 ? 1 : (k > 16 ? 16 : k);
+        }();
+        return v;
+    }
 
     void prepare(int start, int end)
     {
@@ -296,7 +306,7 @@ struct SahBlasBuilder {
         const float leaf_cost = float(count) * box.half_area();
         // traversal step ~ 1.2 triangle tests
         const bool split_pays = best_axis >= 0 && (best_cost + 1.2f * box.half_area()) < leaf_cost;
-        if (count <= kMaxLeaf && !split_pays) return;
+        if (count <= max_leaf() && !split_pays) return;
 
         int mid = lo;
         if (best_axis >= 0) {
