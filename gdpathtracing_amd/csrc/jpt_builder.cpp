@@ -202,7 +202,7 @@ struct SahBlasBuilder {
     {
         static const int v = [] {
             const char* e = getenv("JPT_MAX_LEAF");
-            const int k = e ? atoi(e) : 4;
+            const int k = e ? atoi(e) : 2;
             return k < 1 ? 1 : (k > 16 ? 16 : k);
         }();
         return v;
