@@ -650,35 +650,22 @@ bool SceneBuilder::add_instance(uint32_t mesh_id, const float* t12, const int32_
     return true;
 }
 
-bool SceneBuilder::commit(BuildMode mode, RefScene& out, std::string& err)
+bool SceneBuilder::set_instance_transform(uint32_t instance, const float* transform12)
 {
-    out.clear();
-    // per unique mesh: append triangles, build its BLAS into the shared node array (geometry_group3d.cpp:308-313)
-    for (const PendingMesh& pm : meshes_) {
-        const int start = (int)out.triangles.size();
-        out.triangles.insert(out.triangles.end(), pm.tris.begin(), pm.tris.end());
-        const int end = (int)out.triangles.size();
-        uint32_t root = 0;
-        if (end > start) {
-            if (mode == BuildMode::ReferenceExact) {
-                ExactBlasBuilder b{out.bvh_nodes, out.triangles};
-                root = b.build(start, end);
-            } else {
-                SahBlasBuilder b{out.bvh_nodes, out.triangles};
-                b.prepare(start, end);
-                root = b.build(0, end - start);
-                b.apply_order(start, end);
-            }
-        } else {
-            // BuildBVH on an empty mesh returns 0 (bvh.cpp:111-112); keep a valid empty leaf instead
-            root = (uint32_t)out.bvh_nodes.size();
-            RefBvhNode n;
-            std::memset(&n, 0, sizeof n);
-            out.bvh_nodes.push_back(n);
-        }
-        out.mesh_roots.push_back(root);
+    if (instance >= instances_.size() || !transform12) return false;
+    std::memcpy(instances_[instance].t12, transform12, sizeof(float) * 12);
+    return true;
+}
+
+// instances (geometry_group3d.cpp:322-341) and TLAS::build (bvh.cpp:264-317) over the BLASes already in `out`
+bool SceneBuilder::rebuild_instances(BuildMode mode, RefScene& out, std::string& err)
+{
+    if (out.mesh_roots.size() != meshes_.size()) {
+        err = "instances can only be rebuilt over the scene of the last commit";
+        return false;
     }
-    // instances (geometry_group3d.cpp:322-341)
+    out.instances.clear();
+    out.tlas_nodes.clear();
     for (const PendingInstance& pi : instances_) {
         RefInstance inst;
         std::memset(&inst, 0, sizeof inst);
@@ -717,6 +704,38 @@ bool SceneBuilder::commit(BuildMode mode, RefScene& out, std::string& err)
     }
     if (mode == BuildMode::Sah ? !build_tlas_sah(out.instances, out.tlas_nodes, err) : !build_tlas(out.instances, out.tlas_nodes, err))
         return false;
+    return true;
+}
+
+bool SceneBuilder::commit(BuildMode mode, RefScene& out, std::string& err)
+{
+    out.clear();
+    // per unique mesh: append triangles, build its BLAS into the shared node array (geometry_group3d.cpp:308-313)
+    for (const PendingMesh& pm : meshes_) {
+        const int start = (int)out.triangles.size();
+        out.triangles.insert(out.triangles.end(), pm.tris.begin(), pm.tris.end());
+        const int end = (int)out.triangles.size();
+        uint32_t root = 0;
+        if (end > start) {
+            if (mode == BuildMode::ReferenceExact) {
+                ExactBlasBuilder b{out.bvh_nodes, out.triangles};
+                root = b.build(start, end);
+            } else {
+                SahBlasBuilder b{out.bvh_nodes, out.triangles};
+                b.prepare(start, end);
+                root = b.build(0, end - start);
+                b.apply_order(start, end);
+            }
+        } else {
+            // BuildBVH on an empty mesh returns 0 (bvh.cpp:111-112); keep a valid empty leaf instead
+            root = (uint32_t)out.bvh_nodes.size();
+            RefBvhNode n;
+            std::memset(&n, 0, sizeof n);
+            out.bvh_nodes.push_back(n);
+        }
+        out.mesh_roots.push_back(root);
+    }
+    if (!rebuild_instances(mode, out, err)) return false;
     // Triangle -> GpuTriangleGeometry / GpuTriangleData (geometry_group3d.cpp:356-365)
     out.tri_geom.resize(out.triangles.size());
     out.tri_data.resize(out.triangles.size());
@@ -1077,6 +1096,38 @@ void compute_stack_need(WideScene& out)
         for (const WideInstance& i : out.instances4) blas = std::max(blas, need4(out.blas_nodes4, i.root, mb));
         out.stack_need4 = out.instances4.empty() ? 0u : need4(out.tlas_nodes4, out.tlas_root4, mt) + 1u + blas;
     }
+}
+
+bool reflatten_tlas(const RefScene& ref, WideScene& out, bool with4, std::string& err)
+{
+    if (out.instances.size() != ref.instances.size()) {
+        err = "instance count changed: upload the whole scene again";
+        return false;
+    }
+    for (size_t i = 0; i < ref.instances.size(); i++) {
+        const float* m = ref.instances[i].inverse_transform;
+        for (int c = 0; c < 4; c++)
+            for (int r = 0; r < 3; r++) out.instances[i].inv[c * 3 + r] = m[c * 4 + r];
+        if (with4) std::memcpy(out.instances4[i].inv, out.instances[i].inv, sizeof out.instances[i].inv);
+    }
+    out.tlas_nodes.clear();
+    out.tlas_nodes4.clear();
+    out.max_tlas_depth = 0;
+    out.tlas_root = out.tlas_root4 = 0;
+    if (!ref.tlas_nodes.empty() && !ref.instances.empty()) {
+        Flattener f{ref, out, {}, {}};
+        out.tlas_root = f.tlas_child(0, 1);
+        if (!f.err.empty()) {
+            err = f.err;
+            return false;
+        }
+    }
+    if (with4) {
+        std::vector<int32_t> memo_t(out.tlas_nodes.size(), -1);
+        out.tlas_root4 = collapse_root(out.tlas_nodes, out.tlas_nodes4, out.tlas_root, memo_t);
+    }
+    compute_stack_need(out);
+    return true;
 }
 
 void flatten4(WideScene& out)

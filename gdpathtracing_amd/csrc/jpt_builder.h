@@ -70,6 +70,11 @@ class SceneBuilder {
     // runs the per-mesh builds, instance AABBs, TLAS::build (bvh.cpp:264-317) and the GpuTriangle split
     // (geometry_group3d.cpp:356-365); fills `out`
     bool commit(BuildMode mode, RefScene& out, std::string& err);
+    // moving instances: new transform for instance `instance` of the committed scene, then rebuild_instances()
+    // recomputes every BLASInstance record and the TLAS over the unchanged BLASes of `out`
+    bool set_instance_transform(uint32_t instance, const float* transform12);
+    bool rebuild_instances(BuildMode mode, RefScene& out, std::string& err);
+    size_t instance_count() const { return instances_.size(); }
 
   private:
     struct PendingMesh { std::vector<RefTriangle> tris; };
@@ -84,6 +89,10 @@ void affine_inverse12(const float* t12, float* out12);
 // Reference layout -> flattened layout.  Keeps topology, boxes and child order, so traversal visits the
 // same nodes in the same order as main.glsl:270-350 does on the reference arrays.
 bool flatten(const RefScene& ref, WideScene& out, std::string& err);
+
+// Instances and TLAS of `ref` changed, BLASes did not: rewrites the instance records (keeping each one's BLAS
+// root) and the TLAS records of `out`, including the four-child collapse when `with4`, and the stack need.
+bool reflatten_tlas(const RefScene& ref, WideScene& out, bool with4, std::string& err);
 
 // Collapses the two-child records of `out` (after flatten) into four-child records: a node's children are
 // replaced, largest box first, by their own children until four slots are used.  Boxes and leaves are kept as

@@ -59,7 +59,8 @@ struct jpt_ctx {
     SceneBuilder builder;
     RefScene ref;
     WideScene wide;
-    bool building = false, scene_ready = false, ref_is_exact = false, native_tree = false;
+    bool building = false, scene_ready = false, ref_is_exact = false, native_tree = false, tlas_dirty = false;
+    bool host_scene_ready = false;  // c->ref / c->wide hold a complete scene (also true on host-only contexts)
     std::vector<RefMaterial> pending_materials;
     std::vector<uint8_t> pending_tex;
     int32_t pending_tex_res = 0, pending_layers = 0;
@@ -189,6 +190,8 @@ int upload_scene(jpt_ctx* c)
             return fail(c, JPT_E_LIMIT, "acceleration structure too deep: a traversal could need " + std::to_string(need) +
                                             " stack entries, the kernels hold " + std::to_string(trace_stack_capacity()));
     }
+    c->host_scene_ready = true;
+    c->tlas_dirty = false;
     if (c->device < 0) return JPT_OK;  // host-only context: arrays stay on the host, nothing can be rendered
     HIP_TRY(c, hipSetDevice(c->device));
     hipStream_t s = c->stream;
@@ -512,7 +515,7 @@ int jpt_scene_upload_reference_layout(jpt_ctx* c, const void* tri_geometry, uint
         return fail(c, JPT_E_INVALID, "null buffer with non-zero count");
     if (n_tlas_nodes > 65536) return fail(c, JPT_E_LIMIT, "TLAS has more nodes than 16-bit child indices address (bvh.h:59)");
     const auto t0 = std::chrono::steady_clock::now();
-    c->scene_ready = false;
+    c->scene_ready = c->host_scene_ready = false;
     RefScene& r = c->ref;
     r.clear();
     auto put = [](auto& vec, const void* src, uint32_t n) {
@@ -607,7 +610,7 @@ int jpt_scene_commit(jpt_ctx* c, int32_t builder)
     if (!c || !c->building) return fail(c, JPT_E_STATE, "jpt_scene_begin not called");
     if (builder != JPT_BUILD_REFERENCE_EXACT && builder != JPT_BUILD_SAH) return fail(c, JPT_E_INVALID, "unknown builder");
     const auto t0 = std::chrono::steady_clock::now();
-    c->scene_ready = false;
+    c->scene_ready = c->host_scene_ready = false;
     std::string err;
     if (!c->builder.commit(builder == JPT_BUILD_SAH ? BuildMode::Sah : BuildMode::ReferenceExact, c->ref, err))
         return fail(c, JPT_E_LIMIT, err);
@@ -621,6 +624,114 @@ int jpt_scene_commit(jpt_ctx* c, int32_t builder)
     if (rc != JPT_OK) return rc;
     rc = upload_scene(c);
     c->building = false;
+    c->stats.last_build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return rc;
+}
+
+namespace {
+
+// instances / TLAS of c->ref changed (BLASes did not): re-flatten that part and upload it
+int upload_tlas_update(jpt_ctx* c)
+{
+    std::string err;
+    const bool use4 = !c->ref_is_exact && c->native_tree;
+    if (!reflatten_tlas(c->ref, c->wide, use4, err)) return fail(c, JPT_E_INVALID, "tlas update: " + err);
+    const uint32_t need = use4 ? c->wide.stack_need4 : c->wide.stack_need2;
+    if (need > trace_stack_capacity()) {
+        c->scene_ready = c->host_scene_ready = false;
+        return fail(c, JPT_E_LIMIT, "acceleration structure too deep after the TLAS update: a traversal could need " +
+                                        std::to_string(need) + " stack entries, the kernels hold " + std::to_string(trace_stack_capacity()));
+    }
+    if (c->device < 0) return JPT_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    // renders already queued on the stream still read the old records: let them finish before the buffers move
+    HIP_TRY(c, hipStreamSynchronize(s));
+    HIP_TRY(c, c->d_instances.upload(c->ref.instances, s));
+    HIP_TRY(c, c->d_tlas.upload(c->ref.tlas_nodes, s));
+    HIP_TRY(c, c->d_wtlas.upload(c->wide.tlas_nodes, s));
+    HIP_TRY(c, c->d_winst.upload(c->wide.instances, s));
+    HIP_TRY(c, c->d_winst4.upload(c->wide.instances4, s));
+    HIP_TRY(c, c->d_wtlas4.upload(c->wide.tlas_nodes4, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    DeviceScene& d = c->ds;
+    d.ref_instances = c->d_instances.p;
+    d.ref_tlas = c->d_tlas.p;
+    d.n_ref_tlas = (uint32_t)c->ref.tlas_nodes.size();
+    d.tlas_nodes = c->d_wtlas.p;
+    d.wide_instances = c->d_winst.p;
+    d.tlas_root = c->wide.tlas_root;
+    d.n_tlas_nodes = (uint32_t)c->wide.tlas_nodes.size();
+    d.tlas_nodes4 = c->d_wtlas4.p;
+    d.wide_instances4 = c->d_winst4.p;
+    d.tlas_root4 = c->wide.tlas_root4;
+    return JPT_OK;
+}
+
+}  // namespace
+
+int jpt_scene_set_instance_transform(jpt_ctx* c, uint32_t instance, const float* transform12)
+{
+    if (!c) return JPT_E_INVALID;
+    if (!c->host_scene_ready || c->building || !(c->ref_is_exact || c->native_tree))
+        return fail(c, JPT_E_STATE, "jpt_scene_set_instance_transform needs a scene made by jpt_scene_commit");
+    if (!transform12) return fail(c, JPT_E_INVALID, "null transform");
+    if (!c->builder.set_instance_transform(instance, transform12)) return fail(c, JPT_E_INVALID, "no such instance");
+    c->tlas_dirty = true;
+    return JPT_OK;
+}
+
+int jpt_scene_update_tlas(jpt_ctx* c)
+{
+    if (!c) return JPT_E_INVALID;
+    if (!c->host_scene_ready || c->building || !(c->ref_is_exact || c->native_tree))
+        return fail(c, JPT_E_STATE, "jpt_scene_update_tlas needs a scene made by jpt_scene_commit");
+    if (!c->tlas_dirty) return JPT_OK;
+    const auto t0 = std::chrono::steady_clock::now();
+    std::string err;
+    if (!c->builder.rebuild_instances(c->native_tree ? BuildMode::Sah : BuildMode::ReferenceExact, c->ref, err)) {
+        c->scene_ready = c->host_scene_ready = false;
+        return fail(c, JPT_E_LIMIT, err);
+    }
+    const int rc = upload_tlas_update(c);
+    if (rc == JPT_OK) c->tlas_dirty = false;
+    c->stats.last_build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return rc;
+}
+
+int jpt_scene_update_reference_tlas(jpt_ctx* c, const void* blas_instances, uint32_t n_instances, const void* tlas_nodes,
+                                    uint32_t n_tlas_nodes)
+{
+    if (!c) return JPT_E_INVALID;
+    if (!c->host_scene_ready || c->building) return fail(c, JPT_E_STATE, "no scene to update");
+    if ((n_instances && !blas_instances) || (n_tlas_nodes && !tlas_nodes)) return fail(c, JPT_E_INVALID, "null buffer with non-zero count");
+    if (n_tlas_nodes > 65536) return fail(c, JPT_E_LIMIT, "TLAS has more nodes than 16-bit child indices address (bvh.h:59)");
+    if (n_instances != c->ref.instances.size())
+        return fail(c, JPT_E_INVALID, "instance count changed: upload the whole scene again");
+    const RefInstance* in = static_cast<const RefInstance*>(blas_instances);
+    for (uint32_t i = 0; i < n_instances; i++) {
+        RefInstance one;
+        std::memcpy(&one, reinterpret_cast<const char*>(in) + (size_t)i * sizeof(RefInstance), sizeof one);
+        if (one.blas_index != c->ref.instances[i].blas_index)
+            return fail(c, JPT_E_INVALID, "an instance now names another BLAS: upload the whole scene again");
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    // keep the old arrays until the new ones are known to flatten
+    std::vector<RefInstance> old_inst = c->ref.instances;
+    std::vector<RefTlasNode> old_tlas = c->ref.tlas_nodes;
+    if (n_instances) std::memcpy(c->ref.instances.data(), blas_instances, (size_t)n_instances * sizeof(RefInstance));
+    c->ref.tlas_nodes.resize(n_tlas_nodes);
+    if (n_tlas_nodes) std::memcpy(c->ref.tlas_nodes.data(), tlas_nodes, (size_t)n_tlas_nodes * sizeof(RefTlasNode));
+    int rc = upload_tlas_update(c);
+    if (rc != JPT_OK && rc != JPT_E_DEVICE) {
+        const std::string msg = c->error;
+        c->ref.instances = old_inst;
+        c->ref.tlas_nodes = old_tlas;
+        const int back = upload_tlas_update(c);
+        c->host_scene_ready = (back == JPT_OK);
+        c->scene_ready = c->host_scene_ready && c->device >= 0;
+        c->error = msg;
+    }
     c->stats.last_build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return rc;
 }

@@ -83,6 +83,18 @@ class Context:
             self._ck(L.jpt_scene_set_textures(self.h, _ptr(tex), tex.shape[1], tex.shape[0]), "jpt_scene_set_textures")
         self._ck(L.jpt_scene_commit(self.h, builder), "jpt_scene_commit")
 
+    # ---- moving instances (no full rebuild: BLASes stay on the device)
+    def set_instance_transform(self, instance: int, transform12):
+        t = np.ascontiguousarray(transform12, dtype=np.float32).reshape(12)
+        self._ck(self._lib.jpt_scene_set_instance_transform(self.h, instance, _ptr(t)), "jpt_scene_set_instance_transform")
+
+    def update_tlas(self):
+        self._ck(self._lib.jpt_scene_update_tlas(self.h), "jpt_scene_update_tlas")
+
+    def update_reference_tlas(self, instances, tlas_nodes):
+        a, b = np.ascontiguousarray(instances), np.ascontiguousarray(tlas_nodes)
+        self._ck(self._lib.jpt_scene_update_reference_tlas(self.h, _ptr(a), len(a), _ptr(b), len(b)), "jpt_scene_update_reference_tlas")
+
     def reference_buffer(self, which: int, dtype) -> np.ndarray:
         n = C.c_size_t()
         self._ck(self._lib.jpt_scene_get_reference_buffer(self.h, which, None, 0, C.byref(n)), "jpt_scene_get_reference_buffer")

@@ -136,6 +136,21 @@ int jpt_scene_commit(jpt_ctx *ctx, int32_t builder);
  * out may be NULL to query the size. */
 int jpt_scene_get_reference_buffer(jpt_ctx *ctx, int32_t which, void *out, size_t capacity, size_t *size_out);
 
+/* ---- moving instances ---------------------------------------------------------
+ * The reference has no incremental path: a moved MeshInstance3D means GeometryGroup3D::build() again
+ * (geometry_group3d.cpp:78-366) and new ComputeShader buffers; its README lists a runtime TLAS update as wanted
+ * (README.md:39-40).  Here the BLASes stay on the device; only the BLASInstance records
+ * (BLASInstance::set_transform + update_aabb, bvh.h:81-115) and the TLAS (TLAS::build, bvh.cpp:264-317) are
+ * redone and uploaded.  The result equals a fresh commit / upload of the moved scene. */
+/*   route (ii): new Transform3D for instance `instance` (index in jpt_scene_add_instance order) ... */
+int jpt_scene_set_instance_transform(jpt_ctx *ctx, uint32_t instance, const float *transform12);
+/*   ... then one call that rebuilds instance records + TLAS with the builder of the last commit */
+int jpt_scene_update_tlas(jpt_ctx *ctx);
+/*   route (i): the caller re-ran BLASInstance::set_transform / TLAS::build itself; same instance count and
+ *   the same blas_index per instance as the uploaded scene (otherwise: JPT_E_INVALID, upload the whole scene) */
+int jpt_scene_update_reference_tlas(jpt_ctx *ctx, const void *blas_instances, uint32_t n_instances,
+                                    const void *tlas_nodes, uint32_t n_tlas_nodes);
+
 /* ---- per-render state ------------------------------------------------------------------------- */
 
 /* replaces: Params upload (RenderParameters, path_tracing_camera.cpp:129-133,142; only width/height are

@@ -1,0 +1,122 @@
+"""Moving instances without a full rebuild: jpt_scene_set_instance_transform +
+jpt_scene_update_tlas (route ii) and jpt_scene_update_reference_tlas (route i).  The bar: the arrays after an
+update equal the arrays of a fresh build of the moved scene, byte for byte, and (reference-exact builder) equal
+what the oracle's restatement of BLASInstance::set_transform / TLAS::build (bvh.h:81-115, bvh.cpp:264-317) emits.
+Host-only contexts: no GPU needed; the rendered result is compared in test_gpu_parity.py."""
+import copy
+
+import numpy as np
+import pytest
+
+from gdpathtracing_amd import capi, host, scenes, wire
+
+
+def moved(scene, moves):
+    out = copy.deepcopy(scene)
+    for i, t in moves.items():
+        out.instances[i].transform = np.asarray(t, dtype=np.float32)
+    return out
+
+
+def some_moves(scene, seed=3, n=5):
+    rng = np.random.RandomState(seed)
+    moves = {}
+    for i in rng.choice(len(scene.instances), size=min(n, len(scene.instances)), replace=False):
+        b = scenes.rot_y(rng.uniform(0, 360)) * rng.uniform(0.5, 1.5)
+        moves[int(i)] = scenes.transform12(b, rng.uniform(-3, 3, size=3))
+    return moves
+
+
+def arrays(ctx):
+    return (ctx.reference_buffer(capi.BUF_INSTANCES, wire.BLAS_INSTANCE), ctx.reference_buffer(capi.BUF_TLAS_NODES, wire.TLAS_NODE),
+            ctx.reference_buffer(capi.BUF_BVH_NODES, wire.BVH_NODE))
+
+
+@pytest.mark.parametrize("builder", [capi.BUILD_REFERENCE_EXACT, capi.BUILD_SAH])
+@pytest.mark.parametrize("scene_name", ["demo", "inst"])
+def test_update_equals_fresh_commit(hiplib, builder, scene_name):
+    sc = scenes.demo_scene(200) if scene_name == "demo" else scenes.instanced_scene(n_side=5, n_unique=3, tris_per_mesh=64)
+    moves = some_moves(sc)
+    a = host.Context(-1)
+    a.build_scene(sc, builder)
+    inst0, tlas0, bvh0 = arrays(a)
+    for i, t in moves.items():
+        a.set_instance_transform(i, t)
+    a.update_tlas()
+    inst1, tlas1, bvh1 = arrays(a)
+    b = host.Context(-1)
+    b.build_scene(moved(sc, moves), builder)
+    inst2, tlas2, bvh2 = arrays(b)
+    assert bvh1.tobytes() == bvh0.tobytes() == bvh2.tobytes()          # BLASes untouched
+    assert inst1.tobytes() == inst2.tobytes() and tlas1.tobytes() == tlas2.tobytes()
+    assert inst1.tobytes() != inst0.tobytes()
+    # a second update with nothing moved changes nothing; moving back restores the first arrays
+    a.update_tlas()
+    assert arrays(a)[0].tobytes() == inst1.tobytes()
+    for i in moves:
+        a.set_instance_transform(i, sc.instances[i].transform)
+    a.update_tlas()
+    inst3, tlas3, _ = arrays(a)
+    assert inst3.tobytes() == inst0.tobytes() and tlas3.tobytes() == tlas0.tobytes()
+    a.close(); b.close()
+
+
+def test_update_equals_the_oracle_builder(hiplib, oracle):
+    sc = scenes.instanced_scene(n_side=4, n_unique=2, tris_per_mesh=48)
+    moves = some_moves(sc, seed=11, n=7)
+    a = host.Context(-1)
+    a.build_scene(sc, capi.BUILD_REFERENCE_EXACT)
+    for i, t in moves.items():
+        a.set_instance_transform(i, t)
+    a.update_tlas()
+    inst, tlas, _ = arrays(a)
+    ref = oracle.build_scene(moved(sc, moves))
+    # masks: BLASInstance.material[k >= surfaces] and TLASNode.blas of internal nodes are uninitialised in the reference (SURVEY A-6)
+    for f in ("transform", "inverse_transform", "aabbMin", "aabbMax", "blas_index"):
+        assert np.array_equal(inst[f], ref.instances[f]), f
+    assert np.array_equal(tlas["aabbMin"], ref.tlas_nodes["aabbMin"]) and np.array_equal(tlas["aabbMax"], ref.tlas_nodes["aabbMax"])
+    assert np.array_equal(tlas["leftRight"], ref.tlas_nodes["leftRight"])
+    leaf = tlas["leftRight"] == 0
+    assert np.array_equal(tlas["blas"][leaf], ref.tlas_nodes["blas"][leaf])
+    a.close()
+
+
+def test_reference_layout_route(hiplib, oracle):
+    sc = scenes.instanced_scene(n_side=4, n_unique=2, tris_per_mesh=48)
+    moves = some_moves(sc, seed=5, n=4)
+    r0 = oracle.build_scene(sc)
+    r1 = oracle.build_scene(moved(sc, moves))
+    ctx = host.Context(-1)
+    ctx.upload_reference_layout(r0.tri_geom, r0.tri_data, r0.materials, r0.bvh_nodes, r0.instances, r0.tlas_nodes)
+    ctx.update_reference_tlas(r1.instances, r1.tlas_nodes)
+    inst, tlas, _ = arrays(ctx)
+    assert inst.tobytes() == r1.instances.tobytes() and tlas.tobytes() == r1.tlas_nodes.tobytes()
+    # errors leave the scene as it was
+    with pytest.raises(capi.JptError, match="instance count changed"):
+        ctx.update_reference_tlas(r1.instances[:-1], r1.tlas_nodes)
+    other = r1.instances.copy()
+    other["blas_index"][2] = other["blas_index"][0]
+    with pytest.raises(capi.JptError, match="another BLAS"):
+        ctx.update_reference_tlas(other, r1.tlas_nodes)
+    bad = r1.tlas_nodes.copy()
+    bad["leftRight"][0] = 0xFFFF_FFFF            # slot 0 is the root (bvh.cpp:314-316)
+    with pytest.raises(capi.JptError, match="TLAS child index out of range"):
+        ctx.update_reference_tlas(r1.instances, bad)
+    inst2, tlas2, _ = arrays(ctx)
+    assert inst2.tobytes() == r1.instances.tobytes() and tlas2.tobytes() == r1.tlas_nodes.tobytes()
+    # the builder-route calls are refused on an uploaded scene
+    with pytest.raises(capi.JptError, match="jpt_scene_commit"):
+        ctx.set_instance_transform(0, sc.instances[0].transform)
+    ctx.close()
+
+
+def test_call_order_errors(hiplib):
+    ctx = host.Context(-1)
+    with pytest.raises(capi.JptError, match="jpt_scene_commit"):
+        ctx.update_tlas()
+    sc = scenes.cornell_scene()
+    ctx.build_scene(sc, capi.BUILD_SAH)
+    with pytest.raises(capi.JptError, match="no such instance"):
+        ctx.set_instance_transform(len(sc.instances), sc.instances[0].transform)
+    assert hiplib.jpt_scene_set_instance_transform(ctx.h, 0, None) == -1
+    ctx.close()
