@@ -187,6 +187,21 @@ class GeometryGroup3D:
     def build(self, ctx: Context):                      # geometry_group3d.cpp:228
         self.ctx = ctx
         ctx.build_scene(self.scene, self.builder)
+        self._built = [np.array(i.transform, dtype=np.float32) for i in self.scene.instances]
+
+    def update_transforms(self) -> int:
+        """Moving nodes without build() again (the reference has no such call; README.md:39-40 wants one): hands
+        the changed instance transforms to the library, which redoes BLASInstance records + TLAS only."""
+        moved = 0
+        for i, inst in enumerate(self.scene.instances):
+            now = np.asarray(inst.transform, dtype=np.float32)
+            if now.tobytes() != self._built[i].tobytes():
+                self.ctx.set_instance_transform(i, now)
+                self._built[i] = now.copy()
+                moved += 1
+        if moved:
+            self.ctx.update_tlas()
+        return moved
 
     def get_triangles_geometry_buffer(self):            # geometry_group3d.cpp:40
         return self.ctx.reference_buffer(capi.BUF_TRI_GEOMETRY, wire.TRI_GEOMETRY)

@@ -16,6 +16,7 @@
 #include <jpt.h>
 
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -267,9 +268,12 @@ class GeometryGroup3D {
             check(ctx, jpt_scene_add_mesh(ctx, sv.data(), (int32_t)sv.size(), &id), "jpt_scene_add_mesh");
             ids.push_back(id);
         }
+        built_transforms_.clear();
         for (const NodeRef& r : nodes) {  // :322-341
             float t12[12];
             r.t.to_float12(t12);
+            built_transforms_.emplace_back();
+            std::memcpy(built_transforms_.back().data(), t12, sizeof t12);
             check(ctx, jpt_scene_add_instance(ctx, ids[r.mesh_id], t12, r.material_ids.data(), (int32_t)r.material_ids.size()),
                   "jpt_scene_add_instance");
         }
@@ -280,6 +284,33 @@ class GeometryGroup3D {
             check(ctx, jpt_scene_set_textures(ctx, all.data(), texture_array_resolution, (int32_t)textures.size()), "jpt_scene_set_textures");
         }
         check(ctx, jpt_scene_commit(ctx, builder), "jpt_scene_commit");
+    }
+
+    // Moving nodes.  The reference has no such call -- a moved MeshInstance3D needs build() again -- but lists a
+    // runtime TLAS update as wanted (README.md:39-40): re-reads every child's global transform, hands the changed
+    // ones to the library and lets it redo the BLASInstance records + TLAS (BLASes stay on the device).
+    // Returns the number of instances that moved.
+    MeshInstance3D& get_child(size_t i) { return children.at(i); }
+    size_t get_child_count() const { return children.size(); }
+    int update_transforms()
+    {
+        if (!ctx_) throw std::runtime_error("GeometryGroup3D::update_transforms before build");
+        int moved = 0;
+        uint32_t instance = 0;
+        for (const MeshInstance3D& n : children) {
+            if (!n.mesh) continue;  // build() skipped it too
+            float now[12];
+            n.global_transform.to_float12(now);
+            if (instance >= built_transforms_.size()) throw std::runtime_error("children changed since build(): build() again");
+            if (std::memcmp(now, built_transforms_[instance].data(), sizeof now) != 0) {
+                check(ctx_, jpt_scene_set_instance_transform(ctx_, instance, now), "jpt_scene_set_instance_transform");
+                std::memcpy(built_transforms_[instance].data(), now, sizeof now);
+                moved++;
+            }
+            instance++;
+        }
+        if (moved) check(ctx_, jpt_scene_update_tlas(ctx_), "jpt_scene_update_tlas");
+        return moved;
     }
 
     // geometry_group3d.cpp:40-68 (bytes as the reference emits them after a REFERENCE_EXACT build)
@@ -306,6 +337,7 @@ class GeometryGroup3D {
     }
     std::vector<MeshInstance3D> children;
     std::vector<GpuMaterial> materials_;
+    std::vector<std::array<float, 12>> built_transforms_;  // per instance, as handed to the library
     jpt_ctx* ctx_ = nullptr;
 };
 

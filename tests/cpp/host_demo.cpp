@@ -103,6 +103,27 @@ int main(int argc, char** argv)
             jpt_destroy(ctx);
             return 0;
         }
+        if (mode == "moved") {
+            // animation step on a host-only context: shift child i by (0.25 i, 0, -0.125 i), update_transforms(),
+            // dump the BLASInstance / TLASNode arrays the addon's other consumers would read
+            jpt_ctx* ctx = nullptr;
+            check(nullptr, jpt_create(JPT_DEVICE_HOST_ONLY, &ctx), "jpt_create");
+            group.builder = JPT_BUILD_REFERENCE_EXACT;
+            group.build(ctx);
+            const PackedByteArray bvh_before = group.get_bvh_buffer();
+            for (size_t i = 1; i < group.get_child_count(); i++) {
+                group.get_child(i).global_transform.origin.x += 0.25f * (float)i;
+                group.get_child(i).global_transform.origin.z -= 0.125f * (float)i;
+            }
+            const int moved = group.update_transforms();
+            const int again = group.update_transforms();
+            std::printf("moved %d then %d, bvh unchanged %d\n", moved, again, (int)(bvh_before == group.get_bvh_buffer()));
+            const PackedByteArray a = group.get_blas_buffer(), b = group.get_tlas_buffer();
+            dump(prefix + "_buf4.bin", a.data(), a.size());
+            dump(prefix + "_buf5.bin", b.data(), b.size());
+            jpt_destroy(ctx);
+            return 0;
+        }
         if (mode == "render" && argc >= 9) {
             const int w = std::atoi(argv[4]), h = std::atoi(argv[5]), frames = std::atoi(argv[6]);
             PathTracingCamera cam(0);

@@ -47,6 +47,31 @@ def test_cpp_geometry_group_emits_the_reference_buffers(oracle, host_demo):
     assert tuple(cam["position"]) == tuple(want["position"]) and (cam["near"], cam["far"]) == (want["near"], want["far"])
 
 
+def test_cpp_update_transforms_equals_a_rebuild(oracle, host_demo):
+    """GeometryGroup3D::update_transforms (moving nodes, no rebuild): instance records and TLAS equal the oracle
+    builder's arrays for the moved scene."""
+    import copy
+    exe, d = host_demo
+    sc = scenes.instanced_scene(n_side=4, n_unique=2, tris_per_mesh=64)
+    path = os.path.join(d, "m.jpts")
+    scenes.write_scene_file(sc, path)
+    out = subprocess.run([exe, "moved", path, os.path.join(d, "m")], capture_output=True, text=True, check=True).stdout
+    assert "moved %d then 0, bvh unchanged 1" % (len(sc.instances) - 1) in out
+    moved = copy.deepcopy(sc)
+    for i in range(1, len(moved.instances)):
+        t = moved.instances[i].transform.astype(np.float32).copy()
+        t[9] = np.float32(t[9]) + np.float32(0.25) * np.float32(i)
+        t[11] = np.float32(t[11]) - np.float32(0.125) * np.float32(i)
+        moved.instances[i].transform = t
+    ref = oracle.build_scene(moved)
+    inst = np.frombuffer(open(os.path.join(d, "m_buf4.bin"), "rb").read(), dtype=wire.BLAS_INSTANCE)
+    tlas = np.frombuffer(open(os.path.join(d, "m_buf5.bin"), "rb").read(), dtype=wire.TLAS_NODE)
+    for f in ("transform", "inverse_transform", "aabbMin", "aabbMax", "blas_index"):
+        assert np.array_equal(inst[f], ref.instances[f]), f
+    for f in ("aabbMin", "aabbMax", "leftRight"):
+        assert np.array_equal(tlas[f], ref.tlas_nodes[f]), f
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("builder,mode", [(capi.BUILD_REFERENCE_EXACT, wire.ACCUM_REF_LDR8), (capi.BUILD_SAH, wire.ACCUM_HDR_F32)])
 def test_cpp_path_tracing_camera_renders_like_the_oracle(oracle, host_demo, builder, mode):
