@@ -17,6 +17,7 @@ OK = 0
 ACCUM_REF_LDR8, ACCUM_HDR_F32 = 0, 1
 BUILD_REFERENCE_EXACT, BUILD_SAH = 0, 1
 KERNEL_WAVEFRONT, KERNEL_REFERENCE_LAYOUT, KERNEL_WAVEFRONT_V1 = 0, 1, 2
+DENOISE_PROGRESSIVE, DENOISE_TEMPORAL, DENOISE_NONE = 0, 1, 2
 BUF_TRI_GEOMETRY, BUF_TRI_DATA, BUF_MATERIALS, BUF_BVH_NODES, BUF_INSTANCES, BUF_TLAS_NODES, BUF_TRIANGLES = range(7)
 
 # every symbol include/jpt.h declares
@@ -26,7 +27,7 @@ SYMBOLS = [
     "jpt_scene_set_materials", "jpt_scene_set_textures", "jpt_scene_commit", "jpt_scene_get_reference_buffer",
     "jpt_scene_set_instance_transform", "jpt_scene_update_tlas", "jpt_scene_update_reference_tlas",
     "jpt_set_params", "jpt_set_kernel", "jpt_set_kernel_timing", "jpt_set_partition", "jpt_set_camera", "jpt_render", "jpt_render_counted", "jpt_render_async",
-    "jpt_sync", "jpt_accum_reset", "jpt_read_ldr_rgba8", "jpt_readback_ldr_begin", "jpt_readback_ldr_end", "jpt_read_accum_f32", "jpt_read_depth_f32",
+    "jpt_sync", "jpt_accum_reset", "jpt_set_denoising_mode", "jpt_set_temporal_params", "jpt_read_ldr_rgba8", "jpt_readback_ldr_begin", "jpt_readback_ldr_end", "jpt_read_accum_f32", "jpt_read_depth_f32",
     "jpt_device_accum", "jpt_assemble_from_ranks", "jpt_local_rows", "jpt_get_stats",
 ]
 
@@ -111,6 +112,8 @@ def lib():
         getattr(L, n).argtypes = [vp, i32, u32]
     L.jpt_sync.argtypes = [vp]
     L.jpt_accum_reset.argtypes = [vp]
+    L.jpt_set_denoising_mode.argtypes = [vp, i32]
+    L.jpt_set_temporal_params.argtypes = [vp, vp]
     L.jpt_read_ldr_rgba8.argtypes = [vp, vp]
     L.jpt_read_accum_f32.argtypes = [vp, vp]
     L.jpt_readback_ldr_begin.argtypes = [vp]

@@ -102,6 +102,13 @@ struct jpt_ctx {
     DevBuf<uint32_t> d_full_ldr;
     bool assembled = false;
 
+    // post-processing mode (PathTracingCamera::Denoising) and the temporal pass's state
+    int32_t denoise = JPT_DENOISE_PROGRESSIVE;
+    RefTemporalParams temporal;
+    bool temporal_set = false, hist_valid = false;
+    DevBuf<float4> d_hist1, d_hist2;   // frameBuffer1 / frameBuffer2 of temporal_reprojection.glsl:16-17
+    float4* hist_written = nullptr;    // the one the last temporal pass wrote
+
     // pinned staging for the split read-back
     uint32_t* h_ldr_pinned = nullptr;
     size_t h_ldr_pinned_px = 0;
@@ -320,6 +327,27 @@ int do_render_batch(jpt_ctx* c, int32_t n_frames, uint32_t first_frame_index, bo
     HIP_TRY(c, hipSetDevice(c->device));
     hipStream_t s = c->stream;
     c->assembled = false;
+    if (c->denoise == JPT_DENOISE_TEMPORAL) {
+        // the pass runs once per displayed frame and reads other pixels' depth and history (temporal_reprojection.glsl:57-61)
+        if (n_frames > 1) return fail(c, JPT_E_INVALID, "temporal reprojection renders one frame per call");
+        if (c->world != 1) return fail(c, JPT_E_STATE, "temporal reprojection needs the whole image in one context (world == 1)");
+        if (!c->temporal_set) return fail(c, JPT_E_STATE, "jpt_set_temporal_params not called");
+        if (c->temporal.width != c->width || c->temporal.height != c->height)
+            return fail(c, JPT_E_INVALID, "temporal RenderParameters width/height differ from jpt_set_params");
+        const size_t npx = (size_t)c->width * c->height;
+        if (!c->hist_valid || c->d_hist1.n != npx) {
+            // Image::create(...) zero-filled history images (temporal_reprojection.cpp:42-43)
+            HIP_TRY(c, hipStreamSynchronize(s));
+            HIP_TRY(c, c->d_hist1.resize(npx));
+            HIP_TRY(c, c->d_hist2.resize(npx));
+            if (npx) {
+                HIP_TRY(c, hipMemsetAsync(c->d_hist1.p, 0, npx * sizeof(float4), s));
+                HIP_TRY(c, hipMemsetAsync(c->d_hist2.p, 0, npx * sizeof(float4), s));
+            }
+            c->hist_valid = true;
+            c->hist_written = nullptr;
+        }
+    }
     DevCounters* cnt = nullptr;
     if (counted) {
         cnt = c->d_counters.p;
@@ -346,6 +374,7 @@ int do_render_batch(jpt_ctx* c, int32_t n_frames, uint32_t first_frame_index, bo
         fp.world = c->world;
         fp.max_bounces = c->max_bounces;
         fp.accum_mode = c->accum_mode;
+        fp.display_mode = c->denoise == JPT_DENOISE_PROGRESSIVE ? 0 : 1;
         if (wavefront) {
             fp.frame_index = first_frame_index;
             fp.frame_count = c->frame_count + 1;
@@ -370,6 +399,12 @@ int do_render_batch(jpt_ctx* c, int32_t n_frames, uint32_t first_frame_index, bo
                 fp.n_frames = 1;
                 launch_ref_frame(s, c->ds, fp, c->camera, c->d_accum.p, c->d_ldr.p, c->d_depth.p, cnt);
             }
+        }
+        if (c->denoise == JPT_DENOISE_TEMPORAL) {
+            // TemporalReprojection::render's dispatch (temporal_reprojection.cpp:71): screen + depth of this frame in,
+            // blended history and the displayed screen out
+            launch_temporal(s, c->temporal, c->d_ldr.p, c->d_depth.p, c->d_hist1.p, c->d_hist2.p);
+            c->hist_written = (c->temporal.frame_count % 2u) == 0u ? c->d_hist2.p : c->d_hist1.p;
         }
         HIP_TRY(c, hipGetLastError());
     }
@@ -843,6 +878,32 @@ int jpt_accum_reset(jpt_ctx* c)
     c->frame_count = 0;  // frame_count == 1 on the next frame overwrites the sum (progressive_rendering.glsl:34)
     c->stats.frames = 0;
     c->assembled = false;
+    c->hist_valid = false;  // temporal mode: history images start from zero again (a new TemporalReprojection object)
+    return JPT_OK;
+}
+
+int jpt_set_denoising_mode(jpt_ctx* c, int32_t mode)
+{
+    if (!c) return JPT_E_INVALID;
+    if (mode != JPT_DENOISE_PROGRESSIVE && mode != JPT_DENOISE_TEMPORAL && mode != JPT_DENOISE_NONE)
+        return fail(c, JPT_E_INVALID, "unknown denoising mode");
+    if (mode != c->denoise) {
+        // the modes do not share state: the progressive sum and the temporal history both start over
+        c->frame_count = 0;
+        c->stats.frames = 0;
+        c->hist_valid = false;
+        c->assembled = false;
+    }
+    c->denoise = mode;
+    return JPT_OK;
+}
+
+int jpt_set_temporal_params(jpt_ctx* c, const void* render_parameters)
+{
+    if (!c) return JPT_E_INVALID;
+    if (!render_parameters) return fail(c, JPT_E_INVALID, "null RenderParameters");
+    std::memcpy(&c->temporal, render_parameters, sizeof(RefTemporalParams));
+    c->temporal_set = true;
     return JPT_OK;
 }
 
@@ -920,6 +981,12 @@ int jpt_read_accum_f32(jpt_ctx* c, float* out)
     int rc = read_common(c, out);
     if (rc) return rc;
     const size_t full = (size_t)c->width * c->height;
+    if (c->denoise == JPT_DENOISE_TEMPORAL) {
+        // the rgba32f image of this mode is the history image the last pass wrote
+        if (!c->hist_written) return fail(c, JPT_E_STATE, "no temporal pass has run since the last reset");
+        HIP_TRY(c, hipMemcpy(out, c->hist_written, full * sizeof(float4), hipMemcpyDeviceToHost));
+        return JPT_OK;
+    }
     if (c->assembled) {
         HIP_TRY(c, hipMemcpy(out, c->d_full_accum.p, full * sizeof(float4), hipMemcpyDeviceToHost));
         return JPT_OK;
@@ -964,6 +1031,8 @@ int jpt_assemble_from_ranks(jpt_ctx* c, const void* device_gathered, int32_t wor
     if (c->device < 0) return fail(c, JPT_E_DEVICE, "host-only context");
     if (!c->params_set) return fail(c, JPT_E_STATE, "jpt_set_params not called");
     if (world != c->world) return fail(c, JPT_E_INVALID, "world differs from jpt_set_partition");
+    if (c->denoise != JPT_DENOISE_PROGRESSIVE)
+        return fail(c, JPT_E_STATE, "assembling re-derives the progressive display image; the other denoising modes run on one context");
     HIP_TRY(c, hipSetDevice(c->device));
     const size_t full = (size_t)c->width * c->height;
     HIP_TRY(c, c->d_full_accum.resize(full));

@@ -85,5 +85,13 @@ __device__ __forceinline__ uint32_t unorm8(float x)
     return (uint32_t)__builtin_floorf(clamp_(x, 0.0f, 1.0f) * 255.0f + 0.5f);
 }
 __device__ __forceinline__ float from_unorm8(uint32_t q) { return (float)q / 255.0f; }
+// ivec2(vec2): truncation; out of range saturates, NaN gives 0 (pinned; GLSL leaves both undefined)
+__device__ __forceinline__ int32_t f2i_sat(float f)
+{
+    if (f != f) return 0;
+    if (f >= 2147483648.0f) return 2147483647;
+    if (f <= -2147483648.0f) return (int32_t)0x80000000;
+    return (int32_t)f;
+}
 
 }  // namespace jpt

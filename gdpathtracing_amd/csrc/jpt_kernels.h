@@ -28,6 +28,8 @@ struct FrameParams {
     uint32_t frame_index;       // camera.frame_index of this frame (main.glsl:409)
     uint32_t frame_count;       // ProgressiveRendering frame_count of this frame (progressive_rendering.cpp:53-60)
     int32_t n_frames;           // frames rendered by one launch (wide kernels)
+    int32_t display_mode;       // 0: screen = ACES of the running mean (progressive_rendering.glsl:39-45)
+                                // 1: screen = the last frame's own rgba8 store (main.glsl:434), no pass after it
 };
 
 // All device-resident scene data of a context.
@@ -93,6 +95,10 @@ __device__ __forceinline__ void accumulate_pixel(const FrameParams& fp, size_t i
         sum = mk3(cur.x + prev.x, cur.y + prev.y, cur.z + prev.z);
     }
     accum[idx] = make_float4(sum.x, sum.y, sum.z, 1.0f);
+    if (fp.display_mode == 1) {
+        ldr[idx] = unorm8(radiance.x) | (unorm8(radiance.y) << 8) | (unorm8(radiance.z) << 16) | 0xFF000000u;
+        return;
+    }
     const float fc = (float)fp.frame_count;
     const f3 col = aces_film(mk3(sum.x / fc, sum.y / fc, sum.z / fc) * 1.0f);
     ldr[idx] = unorm8(col.x) | (unorm8(col.y) << 8) | (unorm8(col.z) << 16) | 0xFF000000u;
@@ -131,6 +137,11 @@ uint32_t trace_stack_capacity();  // entries a lane's traversal stack can hold (
 size_t wf2_workspace_bytes(int width, int local_rows, int n_frames, int max_bounces);
 void launch_wf2_render(hipStream_t stream, const DeviceScene& ds, const FrameParams& fp, const RefCamera& cam, void* workspace,
                        float4* accum, uint32_t* ldr, float* depth, DevCounters* counters, hipEvent_t* trace_events);
+
+// one dispatch of temporal_reprojection.glsl over a whole image (jpt_kernels_post.hip): screen rgba8 in/out, depth
+// read-only, hist1 / hist2 the two rgba32f history images
+void launch_temporal(hipStream_t stream, const RefTemporalParams& tp, uint32_t* screen, const float* depth, float4* hist1,
+                     float4* hist2);
 
 // rank-major gathered strips -> full framebuffer (multi-GPU assemble)
 void launch_assemble(hipStream_t stream, const float4* gathered, int world, int width, int height, int max_local_rows,

@@ -1,4 +1,5 @@
-// jpt_kernels_post.hip -- multi-GPU epilogue: the rank-major pieces an RCCL gather delivers are
+// jpt_kernels_post.hip -- post-processing that is not fused into the render: temporal reprojection
+// (temporal_reprojection.glsl) and the multi-GPU epilogue: the rank-major pieces an RCCL gather delivers are
 // scattered back to image rows, and the display image (ACES of the mean, progressive_rendering.glsl:39-45)
 // is re-derived from the assembled sums.  No reference counterpart (the reference is single-device).
 #include "jpt_kernels.h"
@@ -21,6 +22,61 @@ __global__ __launch_bounds__(256) void assemble_kernel(const float4* __restrict_
     const float fc = (float)(frame_count ? frame_count : 1u);
     const f3 col = aces_film(mk3(v.x / fc, v.y / fc, v.z / fc) * 1.0f);
     ldr_full[idx] = unorm8(col.x) | (unorm8(col.y) << 8) | (unorm8(col.z) << 16) | 0xFF000000u;
+}
+
+// temporal_reprojection.glsl:30-72, one thread per pixel.  Reads its own screen pixel, the depth image at its own
+// and at the reprojected position, and the previous history image at the reprojected position; writes its own
+// pixel of the other history image and of the screen -- no pixel is written by one thread and read by another.
+__global__ __launch_bounds__(256) void temporal_kernel(RefTemporalParams tp, uint32_t* __restrict__ screen,
+                                                       const float* __restrict__ depth, const float4* __restrict__ prev,
+                                                       float4* __restrict__ next)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    const int W = tp.width, H = tp.height;
+    if (x >= W || y >= H) return;
+    const size_t i = (size_t)y * W + x;
+    const uint32_t q = screen[i];
+    const f3 cur = mk3(from_unorm8(q & 255u), from_unorm8((q >> 8) & 255u), from_unorm8((q >> 16) & 255u));  // :35
+    f3 rep = cur;                                                                                              // :48
+    const float d = depth[i];                                                                                  // :36
+    const float fw = (float)(uint32_t)W, fh = (float)(uint32_t)H;
+    const float nx = ((float)x + 0.5f) / fw * 2.0f - 1.0f;   // :38-43
+    const float ny = ((float)y + 0.5f) / fh * -2.0f + 1.0f;
+    if (tp.frame_count > 0u) {                                // :49
+        const float* m = tp.deltaMatrix;                      // column-major mat4 * vec4(ndc, 1), summed left to right
+        float cx = m[0] * nx + m[4] * ny + m[8] * d + m[12] * 1.0f;
+        float cy = m[1] * nx + m[5] * ny + m[9] * d + m[13] * 1.0f;
+        float cz = m[2] * nx + m[6] * ny + m[10] * d + m[14] * 1.0f;
+        const float cw = m[3] * nx + m[7] * ny + m[11] * d + m[15] * 1.0f;
+        cx = cx / cw; cy = cy / cw; cz = cz / cw;             // :51
+        const float u = (cx + 1.0f) * 0.5f;                   // :53-56
+        const float v = (1.0f - cy) * 0.5f;
+        const int32_t px = f2i_sat(u * fw), py = f2i_sat(v * fh);  // :57
+        if (px >= 0 && px < W && py >= 0 && py < H) {         // :59
+            const size_t j = (size_t)py * W + px;
+            if (fabsf(depth[j] - cz) < 0.1f) {
+                const float4 h = prev[j];                     // :60
+                rep = mk3(h.x, h.y, h.z);
+            }
+        }
+    }
+    // mix(cur, rep, 0.75) = cur * (1 - 0.75) + rep * 0.75 (:64, the literal -- blendFactor is not read)
+    const f3 blended = mk3(cur.x * (1.0f - 0.75f) + rep.x * 0.75f, cur.y * (1.0f - 0.75f) + rep.y * 0.75f,
+                           cur.z * (1.0f - 0.75f) + rep.z * 0.75f);
+    next[i] = make_float4(blended.x, blended.y, blended.z, 1.0f);  // :66
+    const f3 col = aces_film(blended);                             // :68-70
+    screen[i] = unorm8(col.x) | (unorm8(col.y) << 8) | (unorm8(col.z) << 16) | 0xFF000000u;
+}
+
+void launch_temporal(hipStream_t stream, const RefTemporalParams& tp, uint32_t* screen, const float* depth, float4* hist1,
+                     float4* hist2)
+{
+    if (tp.width <= 0 || tp.height <= 0) return;
+    const bool use_first = (tp.frame_count % 2u) == 0u;  // :46
+    dim3 grid((tp.width + 255) / 256, tp.height), block(256);
+    hipLaunchKernelGGL(temporal_kernel, grid, block, 0, stream, tp, screen, depth, use_first ? hist1 : hist2,
+                       use_first ? hist2 : hist1);
 }
 
 void launch_assemble(hipStream_t stream, const float4* gathered, int world, int width, int height, int max_local_rows,

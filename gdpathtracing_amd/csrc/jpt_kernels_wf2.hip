@@ -676,9 +676,11 @@ __global__ __launch_bounds__(kBlock) void wf2_accumulate(Wf2Buffers wb, Wf2Dims 
         const float4 prev = accum[idx];
         sum = mk3(prev.x, prev.y, prev.z);
     }
+    f3 last = mk3(0.0f, 0.0f, 0.0f);
     for (int f = 0; f < fp.n_frames; f++) {
         const float4 r = wb.rad[(size_t)f * dm.slots_per_frame + slot];
         f3 cur = mk3(r.x, r.y, r.z);
+        last = cur;
         if (fp.accum_mode == 0)  // rgba8 store of main.glsl:434, load of progressive_rendering.glsl:33
             cur = mk3(from_unorm8(unorm8(cur.x)), from_unorm8(unorm8(cur.y)), from_unorm8(unorm8(cur.z)));
         sum = have_prev ? cur + sum : cur;  // progressive_rendering.glsl:34-36
@@ -687,7 +689,7 @@ __global__ __launch_bounds__(kBlock) void wf2_accumulate(Wf2Buffers wb, Wf2Dims 
     if (fp.n_frames > 0) {
         accum[idx] = make_float4(sum.x, sum.y, sum.z, 1.0f);
         const float fc = (float)(fp.frame_count + (uint32_t)fp.n_frames - 1u);
-        const f3 col = aces_film(mk3(sum.x / fc, sum.y / fc, sum.z / fc) * 1.0f);
+        const f3 col = fp.display_mode == 1 ? last : aces_film(mk3(sum.x / fc, sum.y / fc, sum.z / fc) * 1.0f);
         ldr[idx] = unorm8(col.x) | (unorm8(col.y) << 8) | (unorm8(col.z) << 16) | 0xFF000000u;
         if (depth_out) {
             const float dist = wb.first_depth[slot];

@@ -78,6 +78,15 @@ struct RefCamera {  // Camera, render_parameters.h:14-21 == main.glsl:110-117
     uint32_t _pad;
 };
 
+struct RefTemporalParams {  // TemporalReprojection::RenderParameters, temporal_reprojection.h:16-23 == temporal_reprojection.glsl:4-11
+    float deltaMatrix[16];
+    int32_t width, height;
+    uint32_t frame_count;
+    float blendFactor;  // not read by the shader (literal 0.75, temporal_reprojection.glsl:64)
+    float nearPlane, farPlane;
+};
+
+static_assert(sizeof(RefTemporalParams) == 88, "TemporalReprojection::RenderParameters");
 static_assert(sizeof(RefTriangle) == 144, "Triangle");
 static_assert(sizeof(RefBvhNode) == 48, "BVHNode");
 static_assert(sizeof(RefTlasNode) == 32, "TLASNode");

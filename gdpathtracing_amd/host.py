@@ -134,6 +134,13 @@ class Context:
     def accum_reset(self):
         self._ck(self._lib.jpt_accum_reset(self.h), "jpt_accum_reset")
 
+    def set_denoising_mode(self, mode: int):
+        self._ck(self._lib.jpt_set_denoising_mode(self.h, mode), "jpt_set_denoising_mode")
+
+    def set_temporal_params(self, params: np.ndarray):
+        p = np.ascontiguousarray(params, dtype=wire.TEMPORAL_PARAMS).reshape(1)
+        self._ck(self._lib.jpt_set_temporal_params(self.h, _ptr(p)), "jpt_set_temporal_params")
+
     # ---- outputs
     def read_ldr(self) -> np.ndarray:
         out = np.zeros((self.height, self.width, 4), dtype=np.uint8)
@@ -234,6 +241,24 @@ class GeometryGroup3D:
         return len(self.get_tlas_buffer())
 
 
+class TemporalReprojection:
+    """temporal_reprojection.h:11-60 / temporal_reprojection.cpp:16-73, host half: keeps previous_vp and
+    frame_count and produces the 88-byte RenderParameters each frame; the dispatch itself is part of jpt_render."""
+
+    def __init__(self, width: int, height: int):
+        self.params = np.zeros((), dtype=wire.TEMPORAL_PARAMS)
+        self.params["width"], self.params["height"] = width, height
+        self.params["frame_count"] = 1                                   # temporal_reprojection.cpp:25
+        self.params["blendFactor"], self.params["nearPlane"], self.params["farPlane"] = 0.75, 0.01, 1000.0
+        self.previous_vp = np.eye(4)                                     # Projection() is the identity
+
+    def render(self, vp: np.ndarray) -> np.ndarray:                      # temporal_reprojection.cpp:56-72
+        self.params["deltaMatrix"] = scenes.temporal_delta(self.previous_vp, vp)
+        self.previous_vp = vp.copy()
+        self.params["frame_count"] += 1
+        return self.params.copy()
+
+
 class PathTracingCamera:
     """path_tracing_camera.h:25-112: init() creates the device state, render() advances one frame
     (frame_index pre-incremented, path_tracing_camera.cpp:199) and accumulates progressively; the
@@ -251,6 +276,7 @@ class PathTracingCamera:
         self.frame_index = 0          # the reference never initialises it (render_parameters.h:19); 0 here
         self.ctx = Context(device)
         self._prev_transform = None
+        self.temporal_reprojection: Optional[TemporalReprojection] = None
         self.width = self.height = 0
 
     def init(self, width: int, height: int):                        # path_tracing_camera.cpp:111-187
@@ -259,15 +285,22 @@ class PathTracingCamera:
         self.ctx.set_params(width, height, self.max_bounces, self.accum_mode)
 
     def render(self, n_frames: int = 1):                            # path_tracing_camera.cpp:193-232
-        if self.denoising_mode == self.TEMPORAL_REPROJECTION:
-            raise NotImplementedError("temporal reprojection is out of scope (SURVEY.md 8(f)-4)")
-        t = np.asarray(self.camera_desc.transform, dtype=np.float32)
-        moved = self._prev_transform is None or not np.allclose(self._prev_transform, t, rtol=0, atol=1e-5)
-        self._prev_transform = t.copy()
-        if moved or self.denoising_mode == self.NONE:
-            self.ctx.accum_reset()                                  # frame_count = 1 (progressive_rendering.cpp:56-57)
+        self.ctx.set_denoising_mode(self.denoising_mode)            # the switch at :207-225
         self.ctx.set_camera(scenes.camera_block(self.camera_desc, self.width, self.height))
         first = self.frame_index + 1                                # camera.frame_index++ before the dispatch
+        if self.denoising_mode == self.PROGRESSIVE_RENDERING:
+            t = np.asarray(self.camera_desc.transform, dtype=np.float32)
+            moved = self._prev_transform is None or not np.allclose(self._prev_transform, t, rtol=0, atol=1e-5)
+            self._prev_transform = t.copy()
+            if moved:
+                self.ctx.accum_reset()                              # frame_count = 1 (progressive_rendering.cpp:56-57)
+        elif self.denoising_mode == self.TEMPORAL_REPROJECTION:
+            if self.temporal_reprojection is None:                  # :216-219
+                self.temporal_reprojection = TemporalReprojection(self.width, self.height)
+            if n_frames != 1:
+                raise ValueError("temporal reprojection advances one frame per render()")
+            vp = scenes.view_projection(self.camera_desc, self.width, self.height)
+            self.ctx.set_temporal_params(self.temporal_reprojection.render(vp))   # :220
         self.ctx.render(n_frames, first)
         self.frame_index += n_frames
         return self.ctx.read_ldr()                                  # get_image_uniform_buffer (:228-229)

@@ -320,6 +320,21 @@ def camera_block(cam: CameraDesc, width: int, height: int, frame_index: int = 0)
     return c
 
 
+def view_projection(cam: CameraDesc, width: int, height: int) -> np.ndarray:
+    """projection_matrix * Projection(get_global_transform().affine_inverse()) -- the `vp` of
+    TemporalReprojection::render (temporal_reprojection.cpp:62; arguments from path_tracing_camera.cpp:220)."""
+    return perspective(cam.fov_deg, float(width) / float(height), cam.near, cam.far) @ np.linalg.inv(_t12_to_mat4(cam.transform))
+
+
+def temporal_delta(previous_vp: np.ndarray, vp: np.ndarray) -> np.ndarray:
+    """temporal_reprojection.cpp:63,66: `Transform3D deltaMatrix = previous_vp * vp.inverse()` keeps the upper
+    3x4 of the 4x4 product (Projection -> Transform3D drops the bottom row), and projection_to_float() of that
+    Transform3D writes it back with bottom row 0 0 0 1.  Returns the 16 floats, column-major."""
+    d = previous_vp @ np.linalg.inv(vp)
+    d[3, :] = (0.0, 0.0, 0.0, 1.0)
+    return d.T.reshape(-1).astype(np.float32)
+
+
 def write_scene_file(scene: Scene, path: str) -> None:
     """Binary scene description read by tests/cpp/host_demo.cpp (the C++ host layer's test driver)."""
     import struct

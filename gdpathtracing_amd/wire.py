@@ -32,6 +32,9 @@ TRI_DATA = np.dtype([
 MATERIAL = np.dtype([
     ("albedo", "<f4", (4,)), ("emission", "<f4", (4,)), ("metallic", "<f4"), ("roughness", "<f4"),
     ("albedo_texture_index", "<i4"), ("padding", "<f4", (5,))])
+TEMPORAL_PARAMS = np.dtype([   # TemporalReprojection::RenderParameters, temporal_reprojection.h:16-23
+    ("deltaMatrix", "<f4", (16,)), ("width", "<i4"), ("height", "<i4"), ("frame_count", "<u4"),
+    ("blendFactor", "<f4"), ("nearPlane", "<f4"), ("farPlane", "<f4")])
 CAMERA = np.dtype([
     ("vp", "<f4", (16,)), ("ivp", "<f4", (16,)), ("position", "<f4", (4,)), ("frame_index", "<u4"),
     ("near", "<f4"), ("far", "<f4"), ("_pad", "<u4")])

@@ -44,6 +44,14 @@ enum {
 /* texture sampler (state lives in absent gdcs; parity unpinned) */
 enum { JPT_SAMPLER_NEAREST_CLAMP = 0 };
 
+/* post-processing after the path-tracing pass: PathTracingCamera::Denoising (path_tracing_camera.h:30-34,
+ * the switch at path_tracing_camera.cpp:207-225) */
+enum {
+    JPT_DENOISE_PROGRESSIVE = 0, /* ProgressiveRendering: running sum, screen = ACES(mean) (progressive_rendering.glsl) */
+    JPT_DENOISE_TEMPORAL = 1,    /* TemporalReprojection: blend with the reprojected history (temporal_reprojection.glsl) */
+    JPT_DENOISE_NONE = 2         /* nothing: the screen is main.glsl's own rgba8 store (main.glsl:434) */
+};
+
 /* BVH builders */
 enum {
     JPT_BUILD_REFERENCE_EXACT = 0, /* reproduces src/bvh/bvh.cpp node-for-node (incl. its default-box quirk);
@@ -191,8 +199,26 @@ int jpt_render_counted(jpt_ctx *ctx, int32_t n_frames, uint32_t first_frame_inde
 int jpt_render_async(jpt_ctx *ctx, int32_t n_frames, uint32_t first_frame_index);
 int jpt_sync(jpt_ctx *ctx);
 
-/* replaces: camera_moved -> frame_count = 1 (progressive_rendering.cpp:53-57) */
+/* replaces: camera_moved -> frame_count = 1 (progressive_rendering.cpp:53-57).  In temporal mode: the history
+ * images start from zero again, as for a newly created TemporalReprojection (temporal_reprojection.cpp:42-43). */
 int jpt_accum_reset(jpt_ctx *ctx);
+
+/* replaces: the denoising_mode switch of PathTracingCamera::render (path_tracing_camera.cpp:207-225).
+ *   JPT_DENOISE_PROGRESSIVE (default)  as described above.
+ *   JPT_DENOISE_NONE       the screen (jpt_read_ldr_rgba8) is the rgba8 image main.glsl stored for the LAST frame
+ *                          of the call, no tone mapping (path_tracing_camera.cpp:222-224).
+ *   JPT_DENOISE_TEMPORAL   jpt_render takes n_frames = 1: trace the frame, then one dispatch of
+ *                          temporal_reprojection.glsl with the parameters of jpt_set_temporal_params: the screen is
+ *                          ACES(mix(frame, reprojected history, 0.75)); jpt_read_accum_f32 returns the rgba32f
+ *                          history image that dispatch wrote.  Whole image on one context (no partition).
+ * Changing the mode restarts the accumulation / history. */
+int jpt_set_denoising_mode(jpt_ctx *ctx, int32_t mode);
+/* replaces: cs->update_storage_buffer_uniform(render_parameters_rid, ...) of TemporalReprojection::render
+ * (temporal_reprojection.cpp:67): the 88-byte TemporalReprojection::RenderParameters (temporal_reprojection.h:16-23:
+ * deltaMatrix[16] column-major, width, height, frame_count, blendFactor, nearPlane, farPlane).  frame_count picks
+ * the history image to read (even: frameBuffer1) and to write; blendFactor is not read by the shader
+ * (temporal_reprojection.glsl:64 uses the literal 0.75) and is not read here. */
+int jpt_set_temporal_params(jpt_ctx *ctx, const void *render_parameters88);
 
 /* ---- outputs ---------------------------------------------------------------------------------- */
 

@@ -99,6 +99,8 @@ def lib():
         L.jpto_sample_brdf.argtypes = [C.POINTER(Shading), C.c_void_p, C.c_void_p]
         L.jpto_brdf_density.argtypes = [C.POINTER(Shading), C.c_void_p]
         L.jpto_brdf_density.restype = C.c_float
+        L.jpto_screen_rgba8.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
+        L.jpto_temporal_reproject.argtypes = [C.c_void_p] * 5
         L.jpto_unorm8.argtypes = [C.c_float]
         L.jpto_unorm8.restype = C.c_uint8
         L.jpto_aces.argtypes = [C.c_void_p, C.c_void_p]
@@ -208,3 +210,20 @@ def trace_frame(ref: RefLayoutScene, camera: np.ndarray, width: int, height: int
     L.jpto_trace_frame(C.byref(v), _ptr(cam), width, height, max_bounces, flags, 0, height, _ptr(rad), _ptr(depth),
                        C.byref(cnt))
     return rad, depth, cnt.as_dict()
+
+
+def screen_rgba8(radiance: np.ndarray) -> np.ndarray:
+    """imageStore(outputImage rgba8) of main.glsl:434 for a whole frame of float radiance."""
+    rad = np.ascontiguousarray(radiance, dtype=np.float32)
+    out = np.zeros(rad.shape[:-1] + (4,), dtype=np.uint8)
+    lib().jpto_screen_rgba8(_ptr(rad), rad.size // 4, _ptr(out))
+    return out
+
+
+def temporal_reproject(params: np.ndarray, screen: np.ndarray, depth: np.ndarray, fb1: np.ndarray, fb2: np.ndarray):
+    """One dispatch of temporal_reprojection.glsl; screen (u8 [H,W,4]) and fb1/fb2 (f32 [H,W,4]) are updated in place."""
+    p = np.ascontiguousarray(params, dtype=wire.TEMPORAL_PARAMS).reshape(1)
+    for a in (screen, fb1, fb2):
+        assert a.flags["C_CONTIGUOUS"]
+    d = np.ascontiguousarray(depth, dtype=np.float32)
+    lib().jpto_temporal_reproject(_ptr(p), _ptr(screen), _ptr(d), _ptr(fb1), _ptr(fb2))

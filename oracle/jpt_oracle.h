@@ -190,6 +190,22 @@ int32_t jpto_render(const jpto_scene_view *scene, const jpto_camera *camera,
                     float *accum_rgba, uint8_t *ldr_rgba8, float *depth,
                     jpto_counters *counters);
 
+/* ---- temporal reprojection (oracle_post.c) ---- */
+
+/* TemporalReprojection::RenderParameters, temporal_reprojection.h:16-23 == temporal_reprojection.glsl:4-11 (88 B) */
+typedef struct {
+    float    deltaMatrix[16];
+    int32_t  width, height;
+    uint32_t frame_count;
+    float    blendFactor;   /* ignored by the shader (literal 0.75, temporal_reprojection.glsl:64) */
+    float    nearPlane, farPlane;
+} jpto_temporal_params;
+
+/* imageStore(outputImage rgba8) of main.glsl:434 for n_pixels radiance values */
+void jpto_screen_rgba8(const float *radiance_rgba, size_t n_pixels, uint8_t *screen_rgba8);
+/* one dispatch of temporal_reprojection.glsl:30-72; screen in/out, fb1/fb2 = the two history images */
+void jpto_temporal_reproject(const jpto_temporal_params *p, uint8_t *screen_rgba8, const float *depth, float *fb1, float *fb2);
+
 /* ---- small pieces exposed for known-answer tests ---- */
 void  jpto_prng_seed(uint32_t px, uint32_t py, uint32_t frame, uint32_t seed_out[2]);   /* main.glsl:176-181 */
 void  jpto_pcg2d(uint32_t seed[2], float out[2]);                                       /* main.glsl:163-174 */

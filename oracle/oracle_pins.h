@@ -101,6 +101,15 @@ static inline uint8_t p_unorm8(float x)
     float c = p_min(p_max(x, 0.0f), 1.0f);
     return (uint8_t)floorf(c * 255.0f + 0.5f);
 }
+/* ivec2(vec2): truncation toward zero; out of range saturates and NaN gives 0 (GLSL leaves both undefined;
+ * this is what v_cvt_i32_f32 does) */
+static inline int32_t p_f2i(float f)
+{
+    if (f != f) return 0;
+    if (f >= 2147483648.0f) return INT32_MAX;
+    if (f <= -2147483648.0f) return INT32_MIN;
+    return (int32_t)f;
+}
 /* imageLoad from rgba8 */
 static inline float p_from_unorm8(uint8_t q) { return (float)q / 255.0f; }
 

@@ -176,3 +176,43 @@ def sky(d):  # M:189-192
     lo = np.array([0.95, 0.95, 0.95])
     hi = np.array([0.9, 0.94, 1.0])
     return lo * (1 - t[..., None]) + hi * t[..., None]
+
+
+def temporal_reproject(delta_colmajor, frame_count, screen_u8, depth, fb1, fb2):
+    """temporal_reprojection.glsl:30-72 (T) vectorised in float32, one operation per numpy call so the rounding
+    sequence is the shader's.  Returns (new_screen u8, written history f32, which) with which = 1 or 2 for the
+    history image written."""
+    f = np.float32
+    H, W = depth.shape
+    m = np.asarray(delta_colmajor, dtype=f)
+    prev, which = (fb1, 2) if frame_count % 2 == 0 else (fb2, 1)          # T:46,61,67
+    cur = screen_u8[..., :3].astype(f) / f(255.0)                          # T:35
+    rep = cur.copy()
+    ys, xs = np.mgrid[0:H, 0:W]
+    with np.errstate(all="ignore"):
+        nx = (xs.astype(f) + f(0.5)) / f(W) * f(2.0) - f(1.0)             # T:38-43
+        ny = (ys.astype(f) + f(0.5)) / f(H) * f(-2.0) + f(1.0)
+        if frame_count > 0:
+            row = lambda r: ((m[r] * nx + m[4 + r] * ny) + m[8 + r] * depth) + m[12 + r] * f(1.0)   # T:50
+            cw = row(3)
+            cx, cy, cz = row(0) / cw, row(1) / cw, row(2) / cw             # T:51
+            u = (cx + f(1.0)) * f(0.5)                                     # T:53-56
+            v = (f(1.0) - cy) * f(0.5)
+
+            def to_int(a):                                                 # T:57, pinned: NaN -> 0, saturating
+                a = np.where(np.isnan(a), f(0.0), a)
+                return np.clip(np.trunc(a.astype(np.float64)), -2.0 ** 31, 2.0 ** 31 - 1).astype(np.int64)
+            px, py = to_int(u * f(W)), to_int(v * f(H))
+            ok = (px >= 0) & (px < W) & (py >= 0) & (py < H)               # T:59
+            pxc, pyc = np.clip(px, 0, W - 1), np.clip(py, 0, H - 1)
+            ok &= np.abs(depth[pyc, pxc] - cz) < f(0.1)
+            rep[ok] = prev[pyc, pxc][..., :3][ok]                          # T:60
+    blended = cur * (f(1.0) - f(0.75)) + rep * f(0.75)                     # T:64 mix()
+    hist = np.concatenate([blended, np.ones((H, W, 1), f)], axis=-1)       # T:66
+    x = blended
+    a, b, c, d, e = f(2.51), f(0.03), f(2.43), f(0.59), f(0.14)
+    col = np.clip((x * (a * x + b)) / (x * (c * x + d) + e), f(0.0), f(1.0))  # T:19-27
+    out = np.zeros((H, W, 4), np.uint8)
+    out[..., :3] = np.floor(col * f(255.0) + f(0.5)).astype(np.uint8)
+    out[..., 3] = 255
+    return out, hist, which
