@@ -213,7 +213,8 @@ _CHAR1_T = transform12([[0.982635, -0.208021, 0.656626], [0.0853118, 1.17191, 0.
                         [-0.68348, -0.152791, 0.974428]], (-1.16402, -1.55573, -0.923088))               # demo.tscn:86
 _CHAR2_T = transform12([[0.934979, 0.0872355, -0.747128], [0.0853118, 1.17191, 0.243597],
                         [0.74735, -0.242915, 0.906899]], (1.27032, -0.951083, -0.923088))                # demo.tscn:91
-_CAMERA = CameraDesc(transform12(None, (0, 0, 9.7694)))                                                  # demo.tscn:50-53
+def _demo_camera() -> CameraDesc:   # demo.tscn:50-53; a new object per scene so a test may move it
+    return CameraDesc(transform12(None, (0, 0, 9.7694)))
 
 
 def cornell_scene() -> Scene:
@@ -225,7 +226,7 @@ def cornell_scene() -> Scene:
         Instance(2, transform12(rot_y(-17.0), (1.0, -3.0 + 0.85, 0.9)), [2]),
         Instance(3, transform12(rot_y(20.0), (-1.0, -3.0 + 1.7, -0.9)), [2]),
     ]
-    return Scene("cornell", meshes, inst, _demo_materials(), _CAMERA)
+    return Scene("cornell", meshes, inst, _demo_materials(), _demo_camera())
 
 
 def demo_scene(n_tris=51200, seed=1) -> Scene:
@@ -239,7 +240,7 @@ def demo_scene(n_tris=51200, seed=1) -> Scene:
         Instance(2, _CHAR1_T, [5]),
         Instance(2, _CHAR2_T, [6]),
     ]
-    return Scene("demo%d" % n_tris, meshes, inst, _demo_materials(), _CAMERA)
+    return Scene("demo%d" % n_tris, meshes, inst, _demo_materials(), _demo_camera())
 
 
 def instanced_scene(n_side=32, n_unique=8, tris_per_mesh=1024, seed=7) -> Scene:
