@@ -23,6 +23,8 @@
 //   main.glsl          set 0: b0 rgba8 out, b1 r32f depth, b2 Params, b3 Camera;  set 1: b0..b5 scene buffers;
 //                      set 2: b0 texture array
 //   progressive.glsl   set 0: b0 Params{w,h,frame_count}, b1 screen image (shared), b2 rgba32f frame buffer
+//   temporal_reprojection.glsl  set 0: b0 RenderParameters (88 B), b1 screen image (shared), b2 depth image (shared),
+//                      b3 / b4 the two rgba32f history images (temporal_reprojection.cpp:32-49)
 #pragma once
 
 #include <jpt.h>
@@ -56,7 +58,9 @@ class ComputeShader {
     using String = typename Traits::String;
 
     ComputeShader(const String& res_path, std::shared_ptr<SharedDevice> device, const std::vector<String>& /*defines*/ = {})
-        : dev_(std::move(device)), progressive_(Traits::contains(res_path, "progressive_rendering"))
+        : dev_(std::move(device)),
+          progressive_(Traits::contains(res_path, "progressive_rendering")),
+          temporal_(Traits::contains(res_path, "temporal_reprojection"))
     {
         if (!dev_->ctx && jpt_create(0, &dev_->ctx) != JPT_OK) error_ = jpt_last_error(nullptr);
     }
@@ -90,8 +94,8 @@ class ComputeShader {
     void finish_create_uniforms()
     {
         if (!dev_->ctx) return;
-        if (progressive_) {
-            ready_ = true;  // the progressive pass is fused into jpt_render
+        if (progressive_ || temporal_) {
+            ready_ = true;  // both post-processing passes run inside jpt_render
             return;
         }
         const Slot* b[6] = {};
@@ -131,7 +135,7 @@ class ComputeShader {
         for (auto& kv : slots_)
             if (kv.first == rid) {
                 kv.second.bytes.assign(Traits::ptr(data), Traits::ptr(data) + Traits::size(data));
-                if (!progressive_ && kv.second.set == 0 && kv.second.binding == 3) upload_camera(kv.second.bytes);
+                if (!progressive_ && !temporal_ && kv.second.set == 0 && kv.second.binding == 3) upload_camera(kv.second.bytes);
                 if (progressive_ && kv.second.set == 0 && kv.second.binding == 0 && kv.second.bytes.size() >= 12) {
                     uint32_t frame_count;  // Params{width, height, frame_count} (progressive_rendering.h:14-27)
                     std::memcpy(&frame_count, kv.second.bytes.data() + 8, 4);
@@ -143,16 +147,30 @@ class ComputeShader {
     // main shader: remembers that a frame is due.  progressive shader: runs the fused frame (trace + accumulate),
     // because only now is frame_count known (the reference dispatches main first, then the progressive pass,
     // path_tracing_camera.cpp:204,213).
+    // temporal shader: the same, with the 88-byte RenderParameters of set 0 binding 0
+    // (temporal_reprojection.cpp:32,67) handed over first.
     void compute(const std::array<int32_t, 3>& /*groups*/)
     {
         if (!ready_ || !dev_->scene_ready) return;
-        if (!progressive_) {
+        if (!progressive_ && !temporal_) {
             dev_->frame_pending = true;
             return;
         }
         if (!dev_->frame_pending) return;
-        if (dev_->restart) jpt_accum_reset(dev_->ctx);
-        if (jpt_render(dev_->ctx, 1, dev_->camera_frame_index) != JPT_OK) error_ = jpt_last_error(dev_->ctx);
+        int rc = jpt_set_denoising_mode(dev_->ctx, temporal_ ? JPT_DENOISE_TEMPORAL : JPT_DENOISE_PROGRESSIVE);
+        if (rc == JPT_OK && temporal_) {
+            const Slot* p = nullptr;
+            for (auto& kv : slots_)
+                if (kv.second.set == 0 && kv.second.binding == 0 && kv.second.bytes.size() >= 88) p = &kv.second;
+            if (!p) {
+                error_ = "temporal_reprojection.glsl needs its RenderParameters at set 0 binding 0";
+                return;
+            }
+            rc = jpt_set_temporal_params(dev_->ctx, p->bytes.data());
+        }
+        if (rc == JPT_OK && progressive_ && dev_->restart) rc = jpt_accum_reset(dev_->ctx);
+        if (rc == JPT_OK) rc = jpt_render(dev_->ctx, 1, dev_->camera_frame_index);
+        if (rc != JPT_OK) error_ = jpt_last_error(dev_->ctx);
         dev_->frame_pending = false;
     }
     // denoising_mode == NONE: no progressive pass follows; the caller reads the image right after compute()
@@ -160,9 +178,10 @@ class ComputeShader {
     {
         Bytes out;
         Traits::resize(out, (size_t)dev_->width * dev_->height * 4);
-        if (dev_->frame_pending) {  // no progressive pass ran: every frame stands alone
-            jpt_accum_reset(dev_->ctx);
-            if (jpt_render(dev_->ctx, 1, dev_->camera_frame_index) != JPT_OK) error_ = jpt_last_error(dev_->ctx);
+        if (dev_->frame_pending) {  // no post-processing pass ran (denoising_mode == NONE): main.glsl's own rgba8 image
+            int rc = jpt_set_denoising_mode(dev_->ctx, JPT_DENOISE_NONE);
+            if (rc == JPT_OK) rc = jpt_render(dev_->ctx, 1, dev_->camera_frame_index);
+            if (rc != JPT_OK) error_ = jpt_last_error(dev_->ctx);
             dev_->frame_pending = false;
         }
         if (jpt_read_ldr_rgba8(dev_->ctx, Traits::ptrw(out)) != JPT_OK) error_ = jpt_last_error(dev_->ctx);
@@ -181,7 +200,7 @@ class ComputeShader {
         std::memcpy(&dev_->camera_frame_index, bytes.data() + 144, 4);  // Camera::frame_index (render_parameters.h:19)
     }
     std::shared_ptr<SharedDevice> dev_;
-    bool progressive_;
+    bool progressive_, temporal_;
     bool ready_ = false;
     std::vector<std::pair<RID, Slot>> slots_;
     std::vector<uint8_t> tex_;

@@ -97,23 +97,37 @@ struct Projection {  // godot: columns[4][4]
         p.columns[3][3] = 0;
         return p;
     }
-    // Projection * Transform3D (the transform promoted to a 4x4 with last row 0 0 0 1)
-    Projection operator*(const Transform3D& t) const
+    Projection() = default;
+    // Projection(const Transform3D&): the transform promoted to a 4x4 with last row 0 0 0 1
+    explicit Projection(const Transform3D& t)
     {
-        float m[4][4];  // columns of t
         for (int c = 0; c < 3; c++) {
-            m[c][0] = t.basis[0][c]; m[c][1] = t.basis[1][c]; m[c][2] = t.basis[2][c]; m[c][3] = 0;
+            columns[c][0] = t.basis[0][c]; columns[c][1] = t.basis[1][c]; columns[c][2] = t.basis[2][c]; columns[c][3] = 0;
         }
-        m[3][0] = t.origin.x; m[3][1] = t.origin.y; m[3][2] = t.origin.z; m[3][3] = 1;
+        columns[3][0] = t.origin.x; columns[3][1] = t.origin.y; columns[3][2] = t.origin.z; columns[3][3] = 1;
+    }
+    // Projection -> Transform3D keeps the upper 3x4 and drops the bottom row (godot: operator Transform3D())
+    Transform3D to_transform3d() const
+    {
+        Transform3D t;
+        for (int c = 0; c < 3; c++) {
+            t.basis[0][c] = columns[c][0]; t.basis[1][c] = columns[c][1]; t.basis[2][c] = columns[c][2];
+        }
+        t.origin.x = columns[3][0]; t.origin.y = columns[3][1]; t.origin.z = columns[3][2];
+        return t;
+    }
+    Projection operator*(const Projection& m) const
+    {
         Projection r;
         for (int j = 0; j < 4; j++)
             for (int i = 0; i < 4; i++) {
                 float ab = 0;
-                for (int k = 0; k < 4; k++) ab += columns[k][i] * m[j][k];
+                for (int k = 0; k < 4; k++) ab += columns[k][i] * m.columns[j][k];
                 r.columns[j][i] = ab;
             }
         return r;
     }
+    Projection operator*(const Transform3D& t) const { return *this * Projection(t); }
     Projection inverse() const  // Gauss-Jordan with partial pivoting, double accumulators
     {
         double a[4][8];
@@ -360,6 +374,45 @@ class ProgressiveRendering {
     Transform3D previous_transform;  // identity initially (progressive_rendering.h:44)
 };
 
+// temporal_reprojection.h:11-60 / temporal_reprojection.cpp:16-73, host half: previous_vp, frame_count and the
+// 88-byte RenderParameters; the dispatch itself is part of jpt_render in JPT_DENOISE_TEMPORAL mode.
+class TemporalReprojection {
+  public:
+    struct RenderParameters {  // temporal_reprojection.h:16-23
+        float deltaMatrix[16];
+        int width = 0, height = 0;
+        unsigned int frame_count = 1;
+        float blendFactor = 0.75f;
+        float nearPlane = 0.01f;
+        float farPlane = 1000.0f;
+    };
+    RenderParameters render_parameters;
+
+    void init(int w, int h)  // temporal_reprojection.cpp:16-28
+    {
+        render_parameters.width = w;
+        render_parameters.height = h;
+        render_parameters.frame_count = 1;
+    }
+    // temporal_reprojection.cpp:56-72; view_matrix = get_global_transform().affine_inverse() (path_tracing_camera.cpp:220)
+    void render(jpt_ctx* ctx, const Transform3D& view_matrix, const Projection& projection_matrix)
+    {
+        const Projection vp = projection_matrix * Projection(view_matrix);
+        // `Transform3D deltaMatrix = previous_vp * vp.inverse()`: the conversion drops the projective row, and
+        // projection_to_float() of that Transform3D writes 0 0 0 1 back (:63,66)
+        const Projection delta((previous_vp * vp.inverse()).to_transform3d());
+        previous_vp = vp;
+        render_parameters.frame_count++;
+        for (int i = 0; i < 4; i++)
+            for (int j = 0; j < 4; j++) render_parameters.deltaMatrix[i * 4 + j] = delta.columns[i][j];
+        check(ctx, jpt_set_temporal_params(ctx, &render_parameters), "jpt_set_temporal_params");  // :67
+    }
+
+  private:
+    Projection previous_vp;  // identity initially (temporal_reprojection.h:49)
+};
+static_assert(sizeof(TemporalReprojection::RenderParameters) == 88, "TemporalReprojection::RenderParameters");
+
 class PathTracingCamera {
   public:
     enum Denoising { PROGRESSIVE_RENDERING, TEMPORAL_REPROJECTION, NONE };  // path_tracing_camera.h:30-34
@@ -396,13 +449,27 @@ class PathTracingCamera {
     PackedByteArray render()
     {
         if (!ready) return {};                                                      // :195
-        if (denoising_mode == TEMPORAL_REPROJECTION) throw std::runtime_error("temporal reprojection is out of scope");
         camera.set_camera_transform(global_transform, projection_matrix);           // :198
         camera.frame_index++;                                                       // :199
         check(ctx, jpt_set_camera(ctx, &camera), "jpt_set_camera");                 // :200
-        const bool restart = progressive_renderer.render(global_transform) || denoising_mode == NONE;   // :208-214
-        if (restart) check(ctx, jpt_accum_reset(ctx), "jpt_accum_reset");
-        check(ctx, jpt_render(ctx, 1, camera.frame_index), "jpt_render");           // :204 + progressive pass
+        switch (denoising_mode) {                                                   // :207-225
+            case PROGRESSIVE_RENDERING:
+                check(ctx, jpt_set_denoising_mode(ctx, JPT_DENOISE_PROGRESSIVE), "jpt_set_denoising_mode");
+                if (progressive_renderer.render(global_transform)) check(ctx, jpt_accum_reset(ctx), "jpt_accum_reset");
+                break;
+            case TEMPORAL_REPROJECTION:
+                check(ctx, jpt_set_denoising_mode(ctx, JPT_DENOISE_TEMPORAL), "jpt_set_denoising_mode");
+                if (!temporal_ready) {                                              // :216-219
+                    temporal_reprojection.init(width, height);
+                    temporal_ready = true;
+                }
+                temporal_reprojection.render(ctx, global_transform.affine_inverse(), projection_matrix);  // :220
+                break;
+            case NONE:
+                check(ctx, jpt_set_denoising_mode(ctx, JPT_DENOISE_NONE), "jpt_set_denoising_mode");
+                break;
+        }
+        check(ctx, jpt_render(ctx, 1, camera.frame_index), "jpt_render");           // :204 + the post-processing pass
         PackedByteArray out((size_t)width * height * 4);
         check(ctx, jpt_read_ldr_rgba8(ctx, out.data()), "jpt_read_ldr_rgba8");      // :228-229
         return out;
@@ -410,6 +477,7 @@ class PathTracingCamera {
 
     Camera camera;
     ProgressiveRendering progressive_renderer;
+    TemporalReprojection temporal_reprojection;
 
   private:
     int create(int device) { return jpt_create(device, &ctx); }
@@ -420,7 +488,7 @@ class PathTracingCamera {
     Denoising denoising_mode = PROGRESSIVE_RENDERING;
     float fov = 90.0f;  // path_tracing_camera.h:80
     int width = 0, height = 0;
-    bool ready = false;
+    bool ready = false, temporal_ready = false;
 };
 
 }  // namespace jpt_host

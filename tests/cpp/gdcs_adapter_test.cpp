@@ -3,7 +3,7 @@
 // progressive_rendering.cpp:25-65), against include/jpt_gdcs_adapter.hpp instantiated with std:: types.
 // The six scene buffers come from the C++ host layer's GeometryGroup3D on a host-only context
 // (REFERENCE_EXACT = what the addon's own builder emits).
-//   gdcs_adapter_test <scene.bin> <prefix> <w> <h> <frames>
+//   gdcs_adapter_test <scene.bin> <prefix> <w> <h> <frames> [denoising_mode: 0 progressive, 1 temporal, 2 none]
 #include <jpt_gdcs_adapter.hpp>
 #include <jpt_host.hpp>
 
@@ -54,6 +54,7 @@ int main(int argc, char** argv)
     Reader r(argv[1]);
     const std::string prefix = argv[2];
     const int w = std::atoi(argv[3]), h = std::atoi(argv[4]), frames = std::atoi(argv[5]);
+    const int denoise = argc >= 7 ? std::atoi(argv[6]) : 0;
     if (r.get<uint32_t>() != 0x5354504au) return 3;
     std::vector<std::unique_ptr<ArrayMesh>> meshes;
     for (uint32_t m = r.get<uint32_t>(); m > 0; m--) {
@@ -104,7 +105,7 @@ int main(int argc, char** argv)
     cs->create_storage_buffer_uniform(bytes_of(rp), 2, 0);
     const uint64_t camera_rid = cs->create_storage_buffer_uniform(bytes_of(camera), 3, 0);
     const uint64_t output_texture_rid = cs->create_image_uniform(w, h, 0, 0);
-    cs->create_image_uniform(w, h, 1, 0);  // depth
+    const uint64_t depth_texture_rid = cs->create_image_uniform(w, h, 1, 0);
     cs->create_storage_buffer_uniform(group.get_triangles_geometry_buffer(), 0, 1);
     cs->create_storage_buffer_uniform(group.get_triangles_data_buffer(), 1, 1);
     cs->create_storage_buffer_uniform(group.get_materials_buffer(), 2, 1);
@@ -124,25 +125,59 @@ int main(int argc, char** argv)
     pcs->finish_create_uniforms();
     ProgressiveRendering prog;  // host-side frame_count logic of jpt_host.hpp == progressive_rendering.cpp:53-60
 
+    // ---- TemporalReprojection::init (temporal_reprojection.cpp:16-54), created on first use like :216-219
+    CS* tcs = nullptr;
+    uint64_t tp_rid = 0;
+    TemporalReprojection temporal;  // host half of jpt_host.hpp: previous_vp, frame_count, deltaMatrix
+
     std::vector<uint8_t> screen;
+    Transform3D t = cam_t;
     for (int f = 0; f < frames; f++) {  // PathTracingCamera::render (path_tracing_camera.cpp:193-232)
         if (!cs->check_ready()) return 6;
-        camera.set_camera_transform(cam_t, projection);
+        if (denoise != 0 && f > 0) {    // same camera path as host_demo.cpp
+            t.origin.x += 0.05f;
+            t.origin.y += 0.01f * (float)f;
+        }
+        camera.set_camera_transform(t, projection);
         camera.frame_index++;
         cs->update_storage_buffer_uniform(camera_rid, bytes_of(camera));
         cs->compute({(w + 31) / 32, (h + 31) / 32, 1});
-        prog.render(cam_t);  // progressive_renderer->render(get_global_transform())
-        pp.frame_count = prog.frame_count;
-        pcs->update_storage_buffer_uniform(pp_rid, bytes_of(pp));
-        pcs->compute({(w + 31) / 32, (h + 31) / 32, 1});
+        if (denoise == 0) {
+            prog.render(t);  // progressive_renderer->render(get_global_transform())
+            pp.frame_count = prog.frame_count;
+            pcs->update_storage_buffer_uniform(pp_rid, bytes_of(pp));
+            pcs->compute({(w + 31) / 32, (h + 31) / 32, 1});
+        } else if (denoise == 1) {
+            if (!tcs) {
+                temporal.init(w, h);
+                tcs = new CS("res://addons/jar_path_tracing/src/shaders/temporal_reprojection.glsl", dev);
+                tp_rid = tcs->create_storage_buffer_uniform(bytes_of(temporal.render_parameters), 0, 0);
+                tcs->add_existing_buffer(output_texture_rid, 0, 1, 0);
+                tcs->add_existing_buffer(depth_texture_rid, 0, 2, 0);
+                tcs->create_image_uniform(w, h, 3, 0);
+                tcs->create_image_uniform(w, h, 4, 0);
+                tcs->finish_create_uniforms();
+            }
+            if (!tcs->check_ready()) return 8;
+            temporal.render(host_ctx, t.affine_inverse(), projection);   // fills render_parameters (:62-66)
+            tcs->update_storage_buffer_uniform(tp_rid, bytes_of(temporal.render_parameters));
+            tcs->compute({(w + 31) / 32, (h + 31) / 32, 1});
+            if (!tcs->last_error().empty()) { std::fprintf(stderr, "temporal: %s\n", tcs->last_error().c_str()); return 9; }
+        }
         screen = cs->get_image_uniform_buffer(output_texture_rid);
+        if (denoise != 0) {
+            std::ofstream(prefix + "_camera_f" + std::to_string(f) + ".bin", std::ios::binary).write(reinterpret_cast<const char*>(&camera), sizeof camera);
+            std::ofstream(prefix + "_tp_f" + std::to_string(f) + ".bin", std::ios::binary)
+                .write(reinterpret_cast<const char*>(&temporal.render_parameters), sizeof temporal.render_parameters);
+        }
     }
     std::vector<float> accum((size_t)w * h * 4);
-    if (jpt_read_accum_f32(dev->ctx, accum.data()) != JPT_OK) return 7;
+    if (denoise != 2 && jpt_read_accum_f32(dev->ctx, accum.data()) != JPT_OK) return 7;
     std::ofstream(prefix + "_accum.bin", std::ios::binary).write(reinterpret_cast<const char*>(accum.data()), (std::streamsize)(accum.size() * 4));
     std::ofstream(prefix + "_ldr.bin", std::ios::binary).write(reinterpret_cast<const char*>(screen.data()), (std::streamsize)screen.size());
     std::ofstream(prefix + "_camera.bin", std::ios::binary).write(reinterpret_cast<const char*>(&camera), sizeof camera);
     std::printf("adapter rendered %d frames, frame_count %u\n", frames, prog.frame_count);
+    delete tcs;
     delete pcs;
     delete cs;
     jpt_destroy(host_ctx);

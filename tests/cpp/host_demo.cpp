@@ -4,7 +4,8 @@
 // (gdpathtracing_amd/scenes.py -> write_scene_file), results go to <prefix>_*.bin.
 //
 //   host_demo buffers <scene.bin> <prefix>                      host-only context, REFERENCE_EXACT, dumps get_*_buffer()
-//   host_demo render  <scene.bin> <prefix> <w> <h> <frames> <builder> <accum_mode>   GPU 0
+//   host_demo render  <scene.bin> <prefix> <w> <h> <frames> <builder> <accum_mode> [denoising_mode]   GPU 0
+//   host_demo moved   <scene.bin> <prefix>                      host-only context, update_transforms()
 #include <jpt_host.hpp>
 
 #include <cstdio>
@@ -133,11 +134,26 @@ int main(int argc, char** argv)
             cam.set_geometry_group(&group);
             cam.set_global_transform(cam_t);
             cam.camera.frame_index = 0;
+            const int denoise = argc >= 10 ? std::atoi(argv[9]) : 0;
+            cam.set_denoising_mode(static_cast<PathTracingCamera::Denoising>(denoise));
             cam.init(w, h);
             PackedByteArray screen;
-            for (int f = 0; f < frames; f++) screen = cam.render();   // one frame per call, like the addon
+            Transform3D t = cam_t;
+            for (int f = 0; f < frames; f++) {   // one frame per call, like the addon
+                if (denoise != 0 && f > 0) {     // a camera that moves every frame (the modes that do not accumulate)
+                    t.origin.x += 0.05f;
+                    t.origin.y += 0.01f * (float)f;
+                    cam.set_global_transform(t);
+                }
+                screen = cam.render();
+                if (denoise != 0) {
+                    dump(prefix + "_camera_f" + std::to_string(f) + ".bin", &cam.camera, sizeof(Camera));
+                    dump(prefix + "_tp_f" + std::to_string(f) + ".bin", &cam.temporal_reprojection.render_parameters,
+                         sizeof(TemporalReprojection::RenderParameters));
+                }
+            }
             std::vector<float> accum((size_t)w * h * 4);
-            check(cam.context(), jpt_read_accum_f32(cam.context(), accum.data()), "jpt_read_accum_f32");
+            if (denoise != 2) check(cam.context(), jpt_read_accum_f32(cam.context(), accum.data()), "jpt_read_accum_f32");
             dump(prefix + "_accum.bin", accum.data(), accum.size() * 4);
             dump(prefix + "_ldr.bin", screen.data(), screen.size());
             dump(prefix + "_camera.bin", &cam.camera, sizeof(Camera));

@@ -96,6 +96,54 @@ def test_cpp_path_tracing_camera_renders_like_the_oracle(oracle, host_demo, buil
     assert np.array_equal(got_ldr, want_ldr)
 
 
+def _check_other_modes(oracle, pre, sc, w, h, frames, denoise):
+    """Replays the dumped per-frame Camera blocks (and temporal RenderParameters) through the oracle."""
+    ref = oracle.build_scene(sc)
+    fb = [np.zeros((h, w, 4), np.float32), np.zeros((h, w, 4), np.float32)]
+    screen = written = None
+    for f in range(frames):
+        cam = np.frombuffer(open("%s_camera_f%d.bin" % (pre, f), "rb").read(), dtype=wire.CAMERA)[0]
+        assert int(cam["frame_index"]) == f + 1
+        rad, depth, _ = oracle.trace_frame(ref, cam, w, h, 4)
+        screen = oracle.screen_rgba8(rad)
+        if denoise == 1:
+            tp = np.frombuffer(open("%s_tp_f%d.bin" % (pre, f), "rb").read(), dtype=wire.TEMPORAL_PARAMS)[0]
+            assert int(tp["frame_count"]) == f + 2 and (int(tp["width"]), int(tp["height"])) == (w, h)
+            assert tuple(tp["deltaMatrix"][[3, 7, 11, 15]]) == (0.0, 0.0, 0.0, 1.0)   # the Projection -> Transform3D truncation
+            oracle.temporal_reproject(tp, screen, depth, fb[0], fb[1])
+            written = fb[1] if int(tp["frame_count"]) % 2 == 0 else fb[0]
+    got_ldr = np.frombuffer(open(pre + "_ldr.bin", "rb").read(), dtype=np.uint8).reshape(h, w, 4)
+    assert np.array_equal(got_ldr, screen)
+    if denoise == 1:
+        got = np.frombuffer(open(pre + "_accum.bin", "rb").read(), dtype=np.float32).reshape(h, w, 4)
+        assert np.array_equal(got, written)
+        # the delta matrix of the last step agrees with the float64 helper (it is an input, not a parity claim)
+        import copy
+        c0, c1 = copy.deepcopy(sc.camera), copy.deepcopy(sc.camera)
+        c0.transform = sc.camera.transform.copy(); c1.transform = sc.camera.transform.copy()
+        c0.transform[9] += np.float32(0.05) * 2; c0.transform[10] += np.float32(0.01) * 3
+        c1.transform[9] += np.float32(0.05) * 3; c1.transform[10] += np.float32(0.01) * 6
+        want = scenes.temporal_delta(scenes.view_projection(c0, w, h), scenes.view_projection(c1, w, h))
+        assert np.allclose(tp["deltaMatrix"], want, rtol=5e-3, atol=5e-3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("denoise", [1, 2])
+def test_cpp_camera_other_denoising_modes(oracle, host_demo, denoise):
+    """PathTracingCamera::render() with denoising_mode TEMPORAL_REPROJECTION (1) / NONE (2) and a camera that moves
+    every frame: the C++ layer's Camera blocks and temporal RenderParameters, fed to the oracle, give the same images."""
+    exe, d = host_demo
+    sc = scenes.cornell_scene()
+    path = os.path.join(d, "c.jpts")
+    scenes.write_scene_file(sc, path)
+    w, h, frames = 80, 48, 4
+    pre = os.path.join(d, "dn%d" % denoise)
+    out = subprocess.run([exe, "render", path, pre, str(w), str(h), str(frames), str(capi.BUILD_REFERENCE_EXACT),
+                          str(wire.ACCUM_REF_LDR8), str(denoise)], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    _check_other_modes(oracle, pre, sc, w, h, frames, denoise)
+
+
 @pytest.fixture(scope="module")
 def gdcs_test(hiplib, tmp_path_factory):
     d = tmp_path_factory.mktemp("gdcs")
@@ -130,3 +178,19 @@ def test_gdcs_shaped_adapter_replays_the_reference_call_sequence(oracle, gdcs_te
     ref = oracle.build_scene(sc)
     want, want_ldr, _, _, _ = oracle.render(ref, cam, w, h, 4, frames, 1, wire.ACCUM_REF_LDR8)
     assert np.array_equal(got, want) and np.array_equal(got_ldr, want_ldr)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("denoise", [1, 2])
+def test_gdcs_adapter_other_denoising_modes(oracle, gdcs_test, denoise):
+    """The adapter with a third ComputeShader on temporal_reprojection.glsl (TemporalReprojection::init/render call
+    for call), and with no post-processing shader at all (denoising_mode NONE: the raw rgba8 frame)."""
+    exe, d = gdcs_test
+    sc = scenes.cornell_scene()
+    path = os.path.join(d, "c.jpts")
+    scenes.write_scene_file(sc, path)
+    w, h, frames = 80, 48, 4
+    pre = os.path.join(d, "gd%d" % denoise)
+    out = subprocess.run([exe, path, pre, str(w), str(h), str(frames), str(denoise)], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    _check_other_modes(oracle, pre, sc, w, h, frames, denoise)
