@@ -120,7 +120,7 @@ template <bool COUNT, bool W4>
 __global__ __launch_bounds__(kBlock, JPT_PRIMARY_WAVES) void wf2_primary(WideSceneDev sc, Wf2Buffers wb, Wf2Dims dm, FrameParams fp, RefCamera cam,
                                                       WfTune tune, DevCounters* __restrict__ counters)
 {
-    __shared__ int32_t stack[(kStackLds + 1) * kBlock];  // + the spare row of Traversal::Stack
+    __shared__ int32_t stack[kStackLds * kBlock];
     __shared__ uint32_t s_cursor, s_out;
     const int lane = threadIdx.x & 63;
     const uint32_t seg = blockIdx.x;
@@ -202,7 +202,7 @@ template <bool COUNT, bool W4>
 __global__ __launch_bounds__(kBlock, JPT_WAVES_PER_SIMD) void wf2_trace(WideSceneDev sc, Wf2Buffers wb, Wf2Dims dm, int bounce, WfTune tune,
                                                     DevCounters* __restrict__ counters)
 {
-    __shared__ int32_t stack[(kStackLds + 1) * kBlock];  // + the spare row of Traversal::Stack
+    __shared__ int32_t stack[kStackLds * kBlock];
     __shared__ uint32_t s_cursor;
     const int lane = threadIdx.x & 63;
     const uint32_t seg = blockIdx.x;
@@ -347,7 +347,7 @@ __global__ __launch_bounds__(kBlock, 2) void wf3_trace(WideSceneDev sc, Wf2Buffe
     };
     int32_t* const spill_wave = spill_all + ((size_t)blockIdx.x * (kBlock / 64) + wave) * kPoolRays * kStackSpill;
     using Tr = Traversal<COUNT, W4>;
-    auto stack_of = [&](int slot) { return typename Tr::Stack{&P.stack[0][slot], spill_wave + (size_t)slot * kStackSpill, kPoolRays, kPoolStack - 1}; };
+    auto stack_of = [&](int slot) { return typename Tr::Stack{&P.stack[0][slot], spill_wave + (size_t)slot * kStackSpill, kPoolRays, kPoolStack}; };
     DevCounters cnt = {};
     P.state[lane] = PS_EMPTY;
     P.state[lane + 64] = PS_EMPTY;

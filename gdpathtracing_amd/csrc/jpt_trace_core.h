@@ -15,16 +15,6 @@ constexpr int kTraceBlock = 256;
 #ifndef JPT_STACK_LDS
 #define JPT_STACK_LDS 20
 #endif
-// node_apply4 variants (measured in DESIGN.md section 4)
-#ifndef JPT_NODE4_PACKED
-#define JPT_NODE4_PACKED 0
-#endif
-#ifndef JPT_NODE4_PAIRSORT
-#define JPT_NODE4_PAIRSORT 0
-#endif
-#ifndef JPT_NODE4_FLATPUSH
-#define JPT_NODE4_FLATPUSH 0
-#endif
 #ifndef JPT_WAVES_PER_SIMD
 #define JPT_WAVES_PER_SIMD 7
 #endif
@@ -57,6 +47,20 @@ __device__ __forceinline__ float slab(const f3& o, const f3& rD, float mnx, floa
     return (tmax >= tmin && tmax > 0.0f) ? tmin : 1e30f;
 }
 
+// the same test with the entry distance and the verdict kept apart (no 1e30 select on the way to a sort key)
+__device__ __forceinline__ float slab_entry(const f3& o, const f3& rD, float mnx, float mny, float mnz, float mxx, float mxy,
+                                            float mxz, bool& hit)
+{
+    const float tx1 = (mnx - o.x) * rD.x, tx2 = (mxx - o.x) * rD.x;
+    float tmin = fmin_(tx1, tx2), tmax = fmax_(tx1, tx2);
+    const float ty1 = (mny - o.y) * rD.y, ty2 = (mxy - o.y) * rD.y;
+    tmin = fmax_(tmin, fmin_(ty1, ty2)), tmax = fmin_(tmax, fmax_(ty1, ty2));
+    const float tz1 = (mnz - o.z) * rD.z, tz2 = (mxz - o.z) * rD.z;
+    tmin = fmax_(tmin, fmin_(tz1, tz2)), tmax = fmin_(tmax, fmax_(tz1, tz2));
+    hit = (tmax >= tmin) & (tmax > 0.0f);
+    return tmin;
+}
+
 struct TraceHit {
     float t, u, v;
     uint32_t tri, inst;
@@ -76,8 +80,7 @@ struct Traversal {
     // The stack: entries 0..kStackLds-1 in LDS (`lds` = this lane's column), deeper ones in `spill`, a
     // per-lane scratch array owned by the kernel (kept OUT of this struct so the struct stays in registers).
     struct Stack {
-        int32_t* __restrict__ lds;    // entry k of this ray at lds[k * stride]; rows 0..lds_entries, the last one is a
-                                      // write-only spare for the branch-free pushes of node_apply4
+        int32_t* __restrict__ lds;    // entry k of this ray at lds[k * stride]
         int32_t* __restrict__ spill;  // entries past kStackLds (scratch or global)
         int stride = kTraceBlock;
         int lds_entries = kStackLds;
@@ -169,57 +172,24 @@ struct Traversal {
             else cnt.tlas_expand++;
         }
         int32_t r0 = __float_as_int(cf.x), r1 = __float_as_int(cf.y), r2 = __float_as_int(cf.z), r3 = __float_as_int(cf.w);
+        bool h0, h1, h2, h3;
+        const float d0 = slab_entry(o, rD, lx.x, ly.x, lz.x, hx.x, hy.x, hz.x, h0);
+        const float d1 = slab_entry(o, rD, lx.y, ly.y, lz.y, hx.y, hy.y, hz.y, h1);
+        const float d2 = slab_entry(o, rD, lx.z, ly.z, lz.z, hx.z, hy.z, hz.z, h2);
+        const float d3 = slab_entry(o, rD, lx.w, ly.w, lz.w, hx.w, hy.w, hz.w, h3);
         // sort keys: distance clamped to >= 0 (so the bit pattern orders like the value), child slot in the two
-        // low mantissa bits; unusable children (empty slot, or not closer than the current hit) sort last
+        // low mantissa bits (keys are distinct); unusable children (empty slot, box missed, or not closer than
+        // the current hit) sort last
         constexpr uint32_t kInvalid = 0x7f800000u;
-        uint32_t k0, k1, k2, k3;
-#if JPT_NODE4_PACKED
-        {
-            // The slab test of main.glsl:259-268 on two children at a time: the subtractions and multiplications
-            // are written on 2-vectors so they issue as v_pk_add_f32 / v_pk_mul_f32 (same IEEE operations)
-            typedef float v2f __attribute__((ext_vector_type(2)));
-            const v2f ox = {o.x, o.x}, oy = {o.y, o.y}, oz = {o.z, o.z};
-            const v2f rx = {rD.x, rD.x}, ry = {rD.y, rD.y}, rz = {rD.z, rD.z};
-            const float tcur = hit.t;
-            auto one = [&](float x1, float x2, float y1, float y2, float z1, float z2, int32_t c, uint32_t slot) -> uint32_t {
-                float tmin = fmin_(x1, x2), tmax = fmax_(x1, x2);
-                tmin = fmax_(tmin, fmin_(y1, y2)), tmax = fmin_(tmax, fmax_(y1, y2));
-                tmin = fmax_(tmin, fmin_(z1, z2)), tmax = fmin_(tmax, fmax_(z1, z2));
-                const bool ok = (tmax >= tmin) & (tmax > 0.0f) & (tmin < tcur) & (c != kEmptyChild);
-                const uint32_t bits = (__float_as_uint(fmax_(tmin, 0.0f)) & ~3u) | slot;
-                return ok ? bits : (kInvalid | slot);
-            };
-            {
-                const v2f x1 = (v2f{lx.x, lx.y} - ox) * rx, x2 = (v2f{hx.x, hx.y} - ox) * rx;
-                const v2f y1 = (v2f{ly.x, ly.y} - oy) * ry, y2 = (v2f{hy.x, hy.y} - oy) * ry;
-                const v2f z1 = (v2f{lz.x, lz.y} - oz) * rz, z2 = (v2f{hz.x, hz.y} - oz) * rz;
-                k0 = one(x1.x, x2.x, y1.x, y2.x, z1.x, z2.x, r0, 0u);
-                k1 = one(x1.y, x2.y, y1.y, y2.y, z1.y, z2.y, r1, 1u);
-            }
-            {
-                const v2f x1 = (v2f{lx.z, lx.w} - ox) * rx, x2 = (v2f{hx.z, hx.w} - ox) * rx;
-                const v2f y1 = (v2f{ly.z, ly.w} - oy) * ry, y2 = (v2f{hy.z, hy.w} - oy) * ry;
-                const v2f z1 = (v2f{lz.z, lz.w} - oz) * rz, z2 = (v2f{hz.z, hz.w} - oz) * rz;
-                k2 = one(x1.x, x2.x, y1.x, y2.x, z1.x, z2.x, r2, 2u);
-                k3 = one(x1.y, x2.y, y1.y, y2.y, z1.y, z2.y, r3, 3u);
-            }
-        }
-#else
-        {
-            const float d0 = slab(o, rD, lx.x, ly.x, lz.x, hx.x, hy.x, hz.x);
-            const float d1 = slab(o, rD, lx.y, ly.y, lz.y, hx.y, hy.y, hz.y);
-            const float d2 = slab(o, rD, lx.z, ly.z, lz.z, hx.z, hy.z, hz.z);
-            const float d3 = slab(o, rD, lx.w, ly.w, lz.w, hx.w, hy.w, hz.w);
-            auto key = [&](float d, int32_t c, uint32_t slot) -> uint32_t {
-                const bool ok = (c != kEmptyChild) && (d < hit.t);
-                const uint32_t bits = (__float_as_uint(fmax_(d, 0.0f)) & ~3u) | slot;
-                return ok ? bits : (kInvalid | slot);
-            };
-            k0 = key(d0, r0, 0u), k1 = key(d1, r1, 1u), k2 = key(d2, r2, 2u), k3 = key(d3, r3, 3u);
-        }
-#endif
-#if JPT_NODE4_PAIRSORT
-        // 5-comparator network on (key, child reference) pairs; keys are distinct (slot bits)
+        const float tcur = hit.t;
+        auto key = [&](float d, bool h, int32_t c, uint32_t slot) -> uint32_t {
+            const bool ok = h & (c != kEmptyChild) & (d < tcur);
+            const uint32_t bits = (__float_as_uint(fmax_(d, 0.0f)) & ~3u) | slot;
+            return ok ? bits : (kInvalid | slot);
+        };
+        uint32_t k0 = key(d0, h0, r0, 0u), k1 = key(d1, h1, r1, 1u), k2 = key(d2, h2, r2, 2u), k3 = key(d3, h3, r3, 3u);
+        // 5-comparator network on (key, child reference) pairs: one compare, min, max and two selects per
+        // exchange.  (Looking the references up by slot after a key-only sort compiled to nested branches.)
         auto cswap = [](uint32_t& ka, uint32_t& kb, int32_t& ra, int32_t& rb) {
             const bool lt = ka < kb;
             const uint32_t klo = lt ? ka : kb, khi = lt ? kb : ka;
@@ -231,54 +201,16 @@ struct Traversal {
         cswap(k0, k2, r0, r2);
         cswap(k1, k3, r1, r3);
         cswap(k1, k2, r1, r2);
-#else
-        {
-            const int32_t c0 = r0, c1 = r1, c2 = r2, c3 = r3;
-            auto cswap = [](uint32_t& a, uint32_t& b) {
-                const uint32_t lo = a < b ? a : b, hi = a < b ? b : a;
-                a = lo;
-                b = hi;
-            };
-            cswap(k0, k1);
-            cswap(k2, k3);
-            cswap(k0, k2);
-            cswap(k1, k3);
-            cswap(k1, k2);
-            auto ref_of = [&](uint32_t k) -> int32_t {
-                const uint32_t slot = k & 3u;
-                return slot == 0u ? c0 : slot == 1u ? c1 : slot == 2u ? c2 : c3;
-            };
-            r0 = ref_of(k0), r1 = ref_of(k1), r2 = ref_of(k2), r3 = ref_of(k3);
-        }
-#endif
         // usable children are now a prefix: descend into the nearest, push the others farthest first
-#if JPT_NODE4_FLATPUSH
-        const int n = (int)(k0 < kInvalid) + (int)(k1 < kInvalid) + (int)(k2 < kInvalid) + (int)(k3 < kInvalid);
-        have = n > 0;
+        have = k0 < kInvalid;
         cur = have ? r0 : cur;
-        if (__builtin_expect(sp + 3 > st.lds_entries, 0)) {  // near the end of the LDS part: the general path
-            if (n > 3) push(st, r3);
-            if (n > 2) push(st, r2);
-            if (n > 1) push(st, r1);
-            return;
+        if (k1 < kInvalid) {
+            if (k2 < kInvalid) {
+                if (k3 < kInvalid) push(st, r3);
+                push(st, r2);
+            }
+            push(st, r1);
         }
-        // branch-free: child j (1..3) lands on row sp + (n - 1 - j); rows below sp mean "not pushed" and are
-        // redirected to the spare row st.lds_entries, which nothing reads
-        const int e1 = sp + n - 2, e2 = sp + n - 3, e3 = sp + n - 4;
-        st.lds[(e1 >= sp ? e1 : st.lds_entries) * st.stride] = r1;
-        st.lds[(e2 >= sp ? e2 : st.lds_entries) * st.stride] = r2;
-        st.lds[(e3 >= sp ? e3 : st.lds_entries) * st.stride] = r3;
-        sp += n > 1 ? n - 1 : 0;
-#else
-        have = false;
-        if (k0 < kInvalid) {
-            if (k3 < kInvalid) push(st, r3);
-            if (k2 < kInvalid) push(st, r2);
-            if (k1 < kInvalid) push(st, r1);
-            cur = r0;
-            have = true;
-        }
-#endif
     }
 
     // internal record: both children's boxes in one 64-byte fetch; descends into the nearer valid child
