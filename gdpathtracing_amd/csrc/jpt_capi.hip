@@ -76,7 +76,7 @@ struct jpt_ctx {
     DevBuf<WideNode> d_wblas, d_wtlas;
     DevBuf<WideTri> d_wtris;
     DevBuf<WideInstance> d_winst, d_winst4;
-    DevBuf<WideNode4> d_wblas4, d_wtlas4;
+    DevBuf<WideNode4> d_nodes4;   // four-child records: BLAS part, then room for the TLAS part (one index space)
     DeviceScene ds;
 
     // per-render state
@@ -174,6 +174,35 @@ int alloc_framebuffers(jpt_ctx* c)
     return JPT_OK;
 }
 
+// Four-child records on the device: [ BLAS records | TLAS records ], internal child references of the TLAS part and
+// the TLAS root shifted by the BLAS count.  The TLAS part has room for the largest TLAS of this instance count
+// (<= one record per instance), so a TLAS update rewrites the tail only.
+int upload_nodes4(jpt_ctx* c, bool tlas_only)
+{
+    const WideScene& w = c->wide;
+    const size_t nb = w.blas_nodes4.size(), nt = w.tlas_nodes4.size();
+    const size_t cap = nb + std::max<size_t>(w.instances4.size(), std::max<size_t>(nt, 1));
+    hipStream_t s = c->stream;
+    if (w.instances4.empty() && nb == 0) {
+        c->ds.nodes4 = nullptr;
+        c->ds.tlas_root4 = 0;
+        return JPT_OK;
+    }
+    if (!tlas_only || c->d_nodes4.n < cap) {
+        HIP_TRY(c, c->d_nodes4.resize(cap));
+        if (nb) HIP_TRY(c, hipMemcpyAsync(c->d_nodes4.p, w.blas_nodes4.data(), nb * sizeof(WideNode4), hipMemcpyHostToDevice, s));
+    }
+    std::vector<WideNode4> tail(w.tlas_nodes4);
+    for (WideNode4& n : tail)
+        for (int k = 0; k < 4; k++)
+            if (n.child[k] >= 0) n.child[k] += (int32_t)nb;
+    if (nt) HIP_TRY(c, hipMemcpyAsync(c->d_nodes4.p + nb, tail.data(), nt * sizeof(WideNode4), hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipStreamSynchronize(s));  // `tail` is pageable host memory
+    c->ds.nodes4 = c->d_nodes4.p;
+    c->ds.tlas_root4 = w.tlas_root4 >= 0 ? w.tlas_root4 + (int32_t)nb : w.tlas_root4;
+    return JPT_OK;
+}
+
 // host RefScene (+ flatten) -> device
 int upload_scene(jpt_ctx* c)
 {
@@ -214,9 +243,11 @@ int upload_scene(jpt_ctx* c)
     HIP_TRY(c, c->d_wtris.upload(c->wide.tris, s));
     HIP_TRY(c, c->d_winst.upload(c->wide.instances, s));
     HIP_TRY(c, c->d_winst4.upload(c->wide.instances4, s));
-    HIP_TRY(c, c->d_wblas4.upload(c->wide.blas_nodes4, s));
-    HIP_TRY(c, c->d_wtlas4.upload(c->wide.tlas_nodes4, s));
     HIP_TRY(c, hipStreamSynchronize(s));
+    {
+        const int rc4 = upload_nodes4(c, false);
+        if (rc4 != JPT_OK) return rc4;
+    }
     DeviceScene& d = c->ds;
     d.ref_tri_geom = c->d_tri_geom.p;
     d.ref_tri_data = c->d_tri_data.p;
@@ -240,10 +271,7 @@ int upload_scene(jpt_ctx* c)
     d.n_blas_nodes = (uint32_t)c->wide.blas_nodes.size();
     d.n_tlas_nodes = (uint32_t)c->wide.tlas_nodes.size();
     d.use4 = use4;
-    d.blas_nodes4 = c->d_wblas4.p;
-    d.tlas_nodes4 = c->d_wtlas4.p;
     d.wide_instances4 = c->d_winst4.p;
-    d.tlas_root4 = c->wide.tlas_root4;
     c->scene_ready = true;
     return JPT_OK;
 }
@@ -687,8 +715,11 @@ int upload_tlas_update(jpt_ctx* c)
     HIP_TRY(c, c->d_wtlas.upload(c->wide.tlas_nodes, s));
     HIP_TRY(c, c->d_winst.upload(c->wide.instances, s));
     HIP_TRY(c, c->d_winst4.upload(c->wide.instances4, s));
-    HIP_TRY(c, c->d_wtlas4.upload(c->wide.tlas_nodes4, s));
     HIP_TRY(c, hipStreamSynchronize(s));
+    {
+        const int rc4 = upload_nodes4(c, true);
+        if (rc4 != JPT_OK) return rc4;
+    }
     DeviceScene& d = c->ds;
     d.ref_instances = c->d_instances.p;
     d.ref_tlas = c->d_tlas.p;
@@ -697,9 +728,7 @@ int upload_tlas_update(jpt_ctx* c)
     d.wide_instances = c->d_winst.p;
     d.tlas_root = c->wide.tlas_root;
     d.n_tlas_nodes = (uint32_t)c->wide.tlas_nodes.size();
-    d.tlas_nodes4 = c->d_wtlas4.p;
     d.wide_instances4 = c->d_winst4.p;
-    d.tlas_root4 = c->wide.tlas_root4;
     return JPT_OK;
 }
 

@@ -53,8 +53,7 @@ struct DeviceScene {
     uint32_t n_blas_nodes = 0, n_tlas_nodes = 0;
     // four-child collapse of the same trees (native builder only; null otherwise)
     bool use4 = false;
-    const WideNode4* blas_nodes4 = nullptr;
-    const WideNode4* tlas_nodes4 = nullptr;
+    const WideNode4* nodes4 = nullptr;       // BLAS records followed by the TLAS records, one index space
     const WideInstance* wide_instances4 = nullptr;
     int32_t tlas_root4 = 0;
 

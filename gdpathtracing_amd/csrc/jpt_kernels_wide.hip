@@ -303,8 +303,7 @@ void launch_wide_render(hipStream_t stream, const DeviceScene& ds, const FramePa
 
     WideSceneDev sc;
     sc.blas_nodes = ds.blas_nodes;
-    sc.blas_nodes4 = nullptr;
-    sc.tlas_nodes4 = nullptr;
+    sc.nodes4 = nullptr;
     sc.tris = ds.wide_tris;
     sc.tlas_nodes = ds.tlas_nodes;
     sc.instances = ds.wide_instances;

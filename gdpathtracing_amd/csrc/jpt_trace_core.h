@@ -25,8 +25,9 @@ constexpr int32_t kSentinel = 0x7fffffff;  // "leave the instance" marker on the
 struct WideSceneDev {
     const WideNode* __restrict__ blas_nodes;   // two-child records (W4 = false)
     const WideNode* __restrict__ tlas_nodes;
-    const WideNode4* __restrict__ blas_nodes4; // four-child records (W4 = true)
-    const WideNode4* __restrict__ tlas_nodes4;
+    const WideNode4* __restrict__ nodes4;      // four-child records (W4 = true): BLAS records, then the TLAS records, in
+                                               // ONE array (internal child references of both levels index it), so a
+                                               // step needs no per-lane choice of base pointer
     const WideTri* __restrict__ tris;
     const WideInstance* __restrict__ instances;  // roots refer to the record kind in use
     int32_t tlas_root;
@@ -102,9 +103,11 @@ struct Traversal {
 #ifdef JPT_NO_SPILL
         return st.lds[sp * kTraceBlock];
 #else
-        if (sp < st.lds_entries) return st.lds[sp * st.stride];
-        if (sp < st.lds_entries + kStackSpill) return st.spill[sp - st.lds_entries];
-        return kSentinel;
+        // the LDS read is issued unconditionally (row clamped); only a walk deeper than the LDS part branches
+        const int row = sp < st.lds_entries ? sp : st.lds_entries - 1;
+        int32_t v = st.lds[row * st.stride];
+        if (__builtin_expect(sp >= st.lds_entries, 0)) v = sp < st.lds_entries + kStackSpill ? st.spill[sp - st.lds_entries] : kSentinel;
+        return v;
 #endif
     }
 
@@ -143,7 +146,7 @@ struct Traversal {
     {
         NodeData nd;
         if (W4) {
-            const WideNode4* n = (in_blas ? sc.blas_nodes4 : sc.tlas_nodes4) + cur;
+            const WideNode4* n = sc.nodes4 + cur;
             nd.q[0] = ld4(&n->lo_x[0]); nd.q[1] = ld4(&n->lo_y[0]); nd.q[2] = ld4(&n->lo_z[0]);
             nd.q[3] = ld4(&n->hi_x[0]); nd.q[4] = ld4(&n->hi_y[0]); nd.q[5] = ld4(&n->hi_z[0]);
             nd.q[6] = ld4(&n->child[0]);
