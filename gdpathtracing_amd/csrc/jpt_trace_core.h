@@ -254,7 +254,10 @@ struct Traversal {
         }
     }
 
-    // triangle leaf (main.glsl:280-283, intersectTriangle :224-257)
+    // triangle leaf (main.glsl:280-283, intersectTriangle :224-257).  The early returns of the shader are folded
+    // into one predicate (each comparison as written there, so NaNs take the same side): lanes of a wave
+    // rarely agree on where to leave, so the straight-line form costs the wave the same arithmetic and no
+    // branches.
     __device__ __forceinline__ void leaf_step(const WideSceneDev& sc, DevCounters& cnt)
     {
         const uint32_t bits = (uint32_t)~cur;
@@ -271,22 +274,21 @@ struct Traversal {
             const f3 v0 = mk3(q0.x, q0.y, q0.z), edge1 = mk3(q1.x, q1.y, q1.z), edge2 = mk3(q2.x, q2.y, q2.z);
             const f3 pvec = cross3(d, edge2);
             const float det = dot3(edge1, pvec);
-            if (__builtin_fabsf(det) < 1e-5f) continue;
             const float invDet = 1.0f / det;
             const f3 tvec = o - v0;
             const float u = dot3(tvec, pvec) * invDet;
-            if (u < 0.0f || u > 1.0f) continue;
             const f3 qvec = cross3(tvec, edge1);
             const float v = dot3(d, qvec) * invDet;
-            if (v < 0.0f || u + v > 1.0f) continue;
             const float t = dot3(edge2, qvec) * invDet;
-            if (t < 0.0f || t > hit.t) continue;
-            hit.t = t;
-            hit.u = u;
-            hit.v = v;
-            hit.tri = ti;
-            hit.inst = cur_inst;
-            hit.front = dot3(cross3(edge1, edge2), d) > 0.0f;
+            const bool out = (__builtin_fabsf(det) < 1e-5f) | (u < 0.0f) | (u > 1.0f) | (v < 0.0f) | (u + v > 1.0f) | (t < 0.0f) |
+                             (t > hit.t);
+            const bool front = dot3(cross3(edge1, edge2), d) > 0.0f;
+            hit.t = out ? hit.t : t;
+            hit.u = out ? hit.u : u;
+            hit.v = out ? hit.v : v;
+            hit.tri = out ? hit.tri : ti;
+            hit.inst = out ? hit.inst : cur_inst;
+            hit.front = out ? hit.front : front;
         }
     }
 
