@@ -786,7 +786,7 @@ void launch_wf2_render(hipStream_t stream, const DeviceScene& ds, const FramePar
     const SceneShading sh = ds.shading();
     const dim3 grid(kSegments), block(kBlock);
     static const WfTune tune = [] {
-        WfTune t{16, 12, 1, 1};
+        WfTune t{32, 16, 1, 1};
         if (const char* e = getenv("JPT_REFILL_IDLE")) t.refill_idle = atoi(e);
         if (const char* e = getenv("JPT_NODE_MIN_LANES")) t.node_min_lanes = atoi(e);
         if (const char* e = getenv("JPT_LEAF_MIN")) t.leaf_min = atoi(e);
