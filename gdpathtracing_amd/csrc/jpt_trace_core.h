@@ -254,10 +254,12 @@ struct Traversal {
         }
     }
 
-    // triangle leaf (main.glsl:280-283, intersectTriangle :224-257).  The early returns of the shader are folded
-    // into one predicate (each comparison as written there, so NaNs take the same side): lanes of a wave
-    // rarely agree on where to leave, so the straight-line form costs the wave the same arithmetic and no
-    // branches.
+    // triangle leaf (main.glsl:280-283, intersectTriangle :224-257).  Two forms of the same test.  On the native
+    // tree (leaves of one or two triangles, W4) the early returns of the shader are folded into one predicate,
+    // each comparison as written there so NaNs take the same side: lanes of a wave rarely agree on where to leave,
+    // so the straight-line form costs the wave the same arithmetic and no branches (-3.5 % on the traversal
+    // launches).  On reference-layout trees (leaves of up to 64 triangles, few lanes per leaf turn) the early
+    // returns do skip work, and the branching form is 30 % faster.
     __device__ __forceinline__ void leaf_step(const WideSceneDev& sc, DevCounters& cnt)
     {
         const uint32_t bits = (uint32_t)~cur;
@@ -272,23 +274,44 @@ struct Traversal {
             const float4 q2 = ld4(&tp->e2[0]);
             if (COUNT) cnt.tri_tests++;
             const f3 v0 = mk3(q0.x, q0.y, q0.z), edge1 = mk3(q1.x, q1.y, q1.z), edge2 = mk3(q2.x, q2.y, q2.z);
-            const f3 pvec = cross3(d, edge2);
-            const float det = dot3(edge1, pvec);
-            const float invDet = 1.0f / det;
-            const f3 tvec = o - v0;
-            const float u = dot3(tvec, pvec) * invDet;
-            const f3 qvec = cross3(tvec, edge1);
-            const float v = dot3(d, qvec) * invDet;
-            const float t = dot3(edge2, qvec) * invDet;
-            const bool out = (__builtin_fabsf(det) < 1e-5f) | (u < 0.0f) | (u > 1.0f) | (v < 0.0f) | (u + v > 1.0f) | (t < 0.0f) |
-                             (t > hit.t);
-            const bool front = dot3(cross3(edge1, edge2), d) > 0.0f;
-            hit.t = out ? hit.t : t;
-            hit.u = out ? hit.u : u;
-            hit.v = out ? hit.v : v;
-            hit.tri = out ? hit.tri : ti;
-            hit.inst = out ? hit.inst : cur_inst;
-            hit.front = out ? hit.front : front;
+            if (W4) {
+                const f3 pvec = cross3(d, edge2);
+                const float det = dot3(edge1, pvec);
+                const float invDet = 1.0f / det;
+                const f3 tvec = o - v0;
+                const float u = dot3(tvec, pvec) * invDet;
+                const f3 qvec = cross3(tvec, edge1);
+                const float v = dot3(d, qvec) * invDet;
+                const float t = dot3(edge2, qvec) * invDet;
+                const bool out = (__builtin_fabsf(det) < 1e-5f) | (u < 0.0f) | (u > 1.0f) | (v < 0.0f) | (u + v > 1.0f) |
+                                 (t < 0.0f) | (t > hit.t);
+                const bool front = dot3(cross3(edge1, edge2), d) > 0.0f;
+                hit.t = out ? hit.t : t;
+                hit.u = out ? hit.u : u;
+                hit.v = out ? hit.v : v;
+                hit.tri = out ? hit.tri : ti;
+                hit.inst = out ? hit.inst : cur_inst;
+                hit.front = out ? hit.front : front;
+            } else {
+                const f3 pvec = cross3(d, edge2);
+                const float det = dot3(edge1, pvec);
+                if (__builtin_fabsf(det) < 1e-5f) continue;
+                const float invDet = 1.0f / det;
+                const f3 tvec = o - v0;
+                const float u = dot3(tvec, pvec) * invDet;
+                if (u < 0.0f || u > 1.0f) continue;
+                const f3 qvec = cross3(tvec, edge1);
+                const float v = dot3(d, qvec) * invDet;
+                if (v < 0.0f || u + v > 1.0f) continue;
+                const float t = dot3(edge2, qvec) * invDet;
+                if (t < 0.0f || t > hit.t) continue;
+                hit.t = t;
+                hit.u = u;
+                hit.v = v;
+                hit.tri = ti;
+                hit.inst = cur_inst;
+                hit.front = dot3(cross3(edge1, edge2), d) > 0.0f;
+            }
         }
     }
 
