@@ -59,6 +59,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--verify", action="store_true",
                     help="after the timed region, rank 0 re-renders the whole image alone and checks the assembled one bit for bit")
+    ap.add_argument("--gather", choices=["ldr", "accum"], default="ldr",
+                    help="N > 1: what crosses the links each render -- the rgba8 display rows (4 B/pixel, what the reference reads "
+                         "back) or the float4 accumulation rows (16 B/pixel)")
     ap.add_argument("--cpu-sample", default="auto")
     ap.add_argument("--pmc-json", default=os.path.join(ROOT, "profiles", "current_pmc.json"),
                     help="per-launch HBM bytes of each kernel from the committed rocprofv3 --pmc passes (tools/pmc.sh)")
@@ -116,17 +119,18 @@ def main():
     ctx.set_stream(stream.cuda_stream)
     ctx.set_kernel_timing(world == 1)   # HIP events around every traversal launch (the roofline's kernel duration)
 
-    # gather plumbing (N > 1): the local float4 piece viewed as a torch tensor, no copy
+    # gather plumbing (N > 1): the local piece (rgba8 display rows, or float4 sums) viewed as a torch tensor, no copy
     piece = gathered = None
     if world > 1:
-        ptr, nbytes = ctx.device_accum()
+        ptr, nbytes = ctx.device_ldr() if args.gather == "ldr" else ctx.device_accum()
+        typestr, tdtype = ("<i4", torch.int32) if args.gather == "ldr" else ("<f4", torch.float32)
 
         class _View:
-            __cuda_array_interface__ = {"shape": (nbytes // 4,), "typestr": "<f4", "data": (ptr, False), "version": 2}
+            __cuda_array_interface__ = {"shape": (nbytes // 4,), "typestr": typestr, "data": (ptr, False), "version": 2}
 
         piece = torch.as_tensor(_View(), device=torch.device("cuda", local_rank))
         if rank == 0:
-            gathered = torch.empty((world, nbytes // 4), dtype=torch.float32, device=piece.device)
+            gathered = torch.empty((world, nbytes // 4), dtype=tdtype, device=piece.device)
 
     def exchange():
         """the one exchange of a render: every rank's float4 piece to rank 0, then assembly on rank 0"""
@@ -139,7 +143,10 @@ def main():
             if rank == 0:
                 gathered.copy_(g)
         if rank == 0:
-            ctx.assemble_from_ranks(gathered.data_ptr(), world)
+            if args.gather == "ldr":
+                ctx.assemble_ldr_from_ranks(gathered.data_ptr(), world)
+            else:
+                ctx.assemble_from_ranks(gathered.data_ptr(), world)
 
     def step():
         ctx.accum_reset()
@@ -199,13 +206,13 @@ def main():
 
     verified = None
     if args.verify and rank == 0:
-        got = ctx.read_accum()
+        got = ctx.read_ldr() if (world > 1 and args.gather == "ldr") else ctx.read_accum()
         solo = host.Context(local_rank)
         solo.build_scene(sc, capi.BUILD_SAH if args.builder == "sah" else capi.BUILD_REFERENCE_EXACT)
         solo.set_params(W, H, bounces, accum_mode)
         solo.set_camera(cam)
         solo.render(spp, 1)
-        verified = bool(np.array_equal(got, solo.read_accum()))
+        verified = bool(np.array_equal(got, solo.read_ldr() if (world > 1 and args.gather == "ldr") else solo.read_accum()))
         solo.close()
 
     if rank == 0:
@@ -250,7 +257,7 @@ def main():
                 if (args.scene == "demo" and args.camera == "demo") else "%s (camera %s) %dx%d %d spp %d bounces" % (sc.name, args.camera, W, H, spp, bounces),
                 "unique_tris": sc.n_unique_tris, "instances": len(sc.instances),
                 "rays_per_step": rays, "nominal_rays_per_step": n_pixels * spp * (bounces + 1),
-                "parallelism": "screen strips x%d" % world,
+                "parallelism": "screen strips x%d" % world + ("" if world == 1 else ", gather of %s rows to rank 0" % ("rgba8 display" if args.gather == "ldr" else "float4 accumulation")),
                 "scene_build_s": round(build_s, 4),
             },
             "roofline": {

@@ -28,7 +28,7 @@ SYMBOLS = [
     "jpt_scene_set_instance_transform", "jpt_scene_update_tlas", "jpt_scene_update_reference_tlas",
     "jpt_set_params", "jpt_set_kernel", "jpt_set_kernel_timing", "jpt_set_partition", "jpt_set_camera", "jpt_render", "jpt_render_counted", "jpt_render_async",
     "jpt_sync", "jpt_accum_reset", "jpt_set_denoising_mode", "jpt_set_temporal_params", "jpt_read_ldr_rgba8", "jpt_readback_ldr_begin", "jpt_readback_ldr_end", "jpt_read_accum_f32", "jpt_read_depth_f32",
-    "jpt_device_accum", "jpt_assemble_from_ranks", "jpt_local_rows", "jpt_get_stats",
+    "jpt_device_accum", "jpt_assemble_from_ranks", "jpt_device_ldr", "jpt_assemble_ldr_from_ranks", "jpt_local_rows", "jpt_get_stats",
 ]
 
 
@@ -122,6 +122,9 @@ def lib():
     L.jpt_device_accum.argtypes = [vp, C.POINTER(C.c_size_t)]
     L.jpt_device_accum.restype = vp
     L.jpt_assemble_from_ranks.argtypes = [vp, vp, i32]
+    L.jpt_device_ldr.argtypes = [vp, C.POINTER(C.c_size_t)]
+    L.jpt_device_ldr.restype = vp
+    L.jpt_assemble_ldr_from_ranks.argtypes = [vp, vp, i32]
     L.jpt_local_rows.argtypes = [vp]
     L.jpt_local_rows.restype = i32
     L.jpt_get_stats.argtypes = [vp, C.POINTER(Stats)]

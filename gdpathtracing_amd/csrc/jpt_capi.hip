@@ -100,7 +100,8 @@ struct jpt_ctx {
     // assembled full image on the gathering rank
     DevBuf<float4> d_full_accum;
     DevBuf<uint32_t> d_full_ldr;
-    bool assembled = false;
+    bool assembled = false;      // d_full_accum + d_full_ldr hold the whole image (jpt_assemble_from_ranks)
+    bool assembled_ldr = false;  // d_full_ldr only (jpt_assemble_ldr_from_ranks)
 
     // post-processing mode (PathTracingCamera::Denoising) and the temporal pass's state
     int32_t denoise = JPT_DENOISE_PROGRESSIVE;
@@ -114,6 +115,7 @@ struct jpt_ctx {
     size_t h_ldr_pinned_px = 0;
     hipEvent_t ev_readback = nullptr;
     bool readback_pending = false;
+    bool readback_full = false;  // the read-back in flight copies the assembled image (else: this context's rows)
 
     jpt_stats stats;
 };
@@ -170,7 +172,7 @@ int alloc_framebuffers(jpt_ctx* c)
         HIP_TRY(c, hipMemsetAsync(c->d_depth.p, 0, npx * sizeof(float), c->stream));
     }
     c->frame_count = 0;
-    c->assembled = false;
+    c->assembled = c->assembled_ldr = false;
     return JPT_OK;
 }
 
@@ -354,7 +356,7 @@ int do_render_batch(jpt_ctx* c, int32_t n_frames, uint32_t first_frame_index, bo
     if (n_frames < 0) return fail(c, JPT_E_INVALID, "n_frames < 0");
     HIP_TRY(c, hipSetDevice(c->device));
     hipStream_t s = c->stream;
-    c->assembled = false;
+    c->assembled = c->assembled_ldr = false;
     if (c->denoise == JPT_DENOISE_TEMPORAL) {
         // the pass runs once per displayed frame and reads other pixels' depth and history (temporal_reprojection.glsl:57-61)
         if (n_frames > 1) return fail(c, JPT_E_INVALID, "temporal reprojection renders one frame per call");
@@ -906,7 +908,7 @@ int jpt_accum_reset(jpt_ctx* c)
     if (!c) return JPT_E_INVALID;
     c->frame_count = 0;  // frame_count == 1 on the next frame overwrites the sum (progressive_rendering.glsl:34)
     c->stats.frames = 0;
-    c->assembled = false;
+    c->assembled = c->assembled_ldr = false;
     c->hist_valid = false;  // temporal mode: history images start from zero again (a new TemporalReprojection object)
     return JPT_OK;
 }
@@ -921,7 +923,7 @@ int jpt_set_denoising_mode(jpt_ctx* c, int32_t mode)
         c->frame_count = 0;
         c->stats.frames = 0;
         c->hist_valid = false;
-        c->assembled = false;
+        c->assembled = c->assembled_ldr = false;
     }
     c->denoise = mode;
     return JPT_OK;
@@ -950,7 +952,7 @@ int jpt_read_ldr_rgba8(jpt_ctx* c, uint8_t* out)
     int rc = read_common(c, out);
     if (rc) return rc;
     const size_t full = (size_t)c->width * c->height;
-    if (c->assembled) {
+    if (c->assembled || c->assembled_ldr) {
         HIP_TRY(c, hipMemcpy(out, c->d_full_ldr.p, full * 4, hipMemcpyDeviceToHost));
         return JPT_OK;
     }
@@ -971,7 +973,8 @@ int jpt_readback_ldr_begin(jpt_ctx* c)
     if (!c->params_set) return fail(c, JPT_E_STATE, "jpt_set_params not called");
     if (c->readback_pending) return fail(c, JPT_E_STATE, "a read-back is already in flight (call jpt_readback_ldr_end)");
     HIP_TRY(c, hipSetDevice(c->device));
-    const size_t px = c->assembled ? (size_t)c->width * c->height : (size_t)c->local_rows * c->width;
+    c->readback_full = c->assembled || c->assembled_ldr;
+    const size_t px = c->readback_full ? (size_t)c->width * c->height : (size_t)c->local_rows * c->width;
     if (c->h_ldr_pinned_px < (size_t)c->width * c->height) {
         if (c->h_ldr_pinned) (void)hipHostFree(c->h_ldr_pinned);
         c->h_ldr_pinned = nullptr;
@@ -980,7 +983,7 @@ int jpt_readback_ldr_begin(jpt_ctx* c)
     }
     if (!c->ev_readback) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_readback, hipEventDisableTiming));
     if (px)
-        HIP_TRY(c, hipMemcpyAsync(c->h_ldr_pinned, c->assembled ? c->d_full_ldr.p : c->d_ldr.p, px * sizeof(uint32_t),
+        HIP_TRY(c, hipMemcpyAsync(c->h_ldr_pinned, c->readback_full ? c->d_full_ldr.p : c->d_ldr.p, px * sizeof(uint32_t),
                                   hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipEventRecord(c->ev_readback, c->stream));
     c->readback_pending = true;
@@ -995,7 +998,7 @@ int jpt_readback_ldr_end(jpt_ctx* c, uint8_t* out)
     HIP_TRY(c, hipEventSynchronize(c->ev_readback));
     c->readback_pending = false;
     const size_t full = (size_t)c->width * c->height;
-    if (c->assembled || c->world == 1) {
+    if (c->readback_full || c->world == 1) {
         std::memcpy(out, c->h_ldr_pinned, full * 4);
     } else {
         std::vector<uint32_t> local(c->h_ldr_pinned, c->h_ldr_pinned + (size_t)c->local_rows * c->width);
@@ -1052,6 +1055,13 @@ void* jpt_device_accum(jpt_ctx* c, size_t* bytes_out)
     return c->d_accum.p;
 }
 
+void* jpt_device_ldr(jpt_ctx* c, size_t* bytes_out)
+{
+    if (!c) return nullptr;
+    if (bytes_out) *bytes_out = c->d_ldr.n * sizeof(uint32_t);
+    return c->d_ldr.p;
+}
+
 int32_t jpt_local_rows(jpt_ctx* c) { return c ? c->local_rows : 0; }
 
 int jpt_assemble_from_ranks(jpt_ctx* c, const void* device_gathered, int32_t world)
@@ -1070,6 +1080,21 @@ int jpt_assemble_from_ranks(jpt_ctx* c, const void* device_gathered, int32_t wor
                     max_rows_of_any_rank(c->height, world), c->d_full_accum.p, c->d_full_ldr.p, c->frame_count);
     HIP_TRY(c, hipGetLastError());
     c->assembled = true;  // asynchronous on the context's stream; jpt_read_* / jpt_sync wait for it
+    return JPT_OK;
+}
+
+int jpt_assemble_ldr_from_ranks(jpt_ctx* c, const void* device_gathered, int32_t world)
+{
+    if (!c || !device_gathered) return fail(c, JPT_E_INVALID, "null gathered buffer");
+    if (c->device < 0) return fail(c, JPT_E_DEVICE, "host-only context");
+    if (!c->params_set) return fail(c, JPT_E_STATE, "jpt_set_params not called");
+    if (world != c->world) return fail(c, JPT_E_INVALID, "world differs from jpt_set_partition");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, c->d_full_ldr.resize((size_t)c->width * c->height));
+    launch_assemble_ldr(c->stream, (const uint32_t*)device_gathered, world, c->width, c->height,
+                        max_rows_of_any_rank(c->height, world), c->d_full_ldr.p);
+    HIP_TRY(c, hipGetLastError());
+    c->assembled_ldr = true;  // asynchronous on the context's stream; jpt_read_ldr_rgba8 / jpt_sync wait for it
     return JPT_OK;
 }
 

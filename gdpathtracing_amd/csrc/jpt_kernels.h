@@ -146,4 +146,8 @@ void launch_temporal(hipStream_t stream, const RefTemporalParams& tp, uint32_t* 
 void launch_assemble(hipStream_t stream, const float4* gathered, int world, int width, int height, int max_local_rows,
                      float4* accum_full, uint32_t* ldr_full, uint32_t frame_count);
 
+// the display image alone (each rank has already tone-mapped its own rows)
+void launch_assemble_ldr(hipStream_t stream, const uint32_t* gathered, int world, int width, int height, int max_local_rows,
+                         uint32_t* ldr_full);
+
 }  // namespace jpt

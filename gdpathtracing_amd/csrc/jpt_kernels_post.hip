@@ -24,6 +24,19 @@ __global__ __launch_bounds__(256) void assemble_kernel(const float4* __restrict_
     ldr_full[idx] = unorm8(col.x) | (unorm8(col.y) << 8) | (unorm8(col.z) << 16) | 0xFF000000u;
 }
 
+// the same scatter for the display image alone: 4 bytes per pixel cross the links instead of 16
+__global__ __launch_bounds__(256) void assemble_ldr_kernel(const uint32_t* __restrict__ gathered, int world, int width, int height,
+                                                           int max_local_rows, uint32_t* __restrict__ ldr_full)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= width || y >= height) return;
+    const int strip = y / kStripRows;
+    const int rank = strip % world;
+    const int ly = (strip / world) * kStripRows + (y - strip * kStripRows);
+    ldr_full[(size_t)y * width + x] = gathered[((size_t)rank * max_local_rows + ly) * width + x];
+}
+
 // temporal_reprojection.glsl:30-72, one thread per pixel.  Reads its own screen pixel, the depth image at its own
 // and at the reprojected position, and the previous history image at the reprojected position; writes its own
 // pixel of the other history image and of the screen -- no pixel is written by one thread and read by another.
@@ -77,6 +90,13 @@ void launch_temporal(hipStream_t stream, const RefTemporalParams& tp, uint32_t* 
     dim3 grid((tp.width + 255) / 256, tp.height), block(256);
     hipLaunchKernelGGL(temporal_kernel, grid, block, 0, stream, tp, screen, depth, use_first ? hist1 : hist2,
                        use_first ? hist2 : hist1);
+}
+
+void launch_assemble_ldr(hipStream_t stream, const uint32_t* gathered, int world, int width, int height, int max_local_rows,
+                         uint32_t* ldr_full)
+{
+    dim3 grid((width + 255) / 256, height), block(256);
+    hipLaunchKernelGGL(assemble_ldr_kernel, grid, block, 0, stream, gathered, world, width, height, max_local_rows, ldr_full);
 }
 
 void launch_assemble(hipStream_t stream, const float4* gathered, int world, int width, int height, int max_local_rows,

@@ -170,6 +170,14 @@ class Context:
         p = self._lib.jpt_device_accum(self.h, C.byref(n))
         return p, n.value
 
+    def device_ldr(self):
+        n = C.c_size_t()
+        p = self._lib.jpt_device_ldr(self.h, C.byref(n))
+        return p, n.value
+
+    def assemble_ldr_from_ranks(self, device_ptr: int, world: int):
+        self._ck(self._lib.jpt_assemble_ldr_from_ranks(self.h, device_ptr, world), "jpt_assemble_ldr_from_ranks")
+
     def local_rows(self) -> int:
         return self._lib.jpt_local_rows(self.h)
 

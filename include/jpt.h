@@ -243,6 +243,12 @@ void *jpt_device_accum(jpt_ctx *ctx, size_t *bytes_out);
 /* Rank 0 after the gather: scatter `world` rank-major local buffers (device pointer) into this context's
  * full W*H framebuffers so jpt_read_* return the assembled image. */
 int jpt_assemble_from_ranks(jpt_ctx *ctx, const void *device_gathered, int32_t world);
+/* The display image alone.  Every rank holds the complete sums of its own rows, so its rgba8 rows are final:
+ * gathering them (4 bytes per pixel instead of 16) is all a displayed frame needs -- what the reference reads back
+ * is this image (path_tracing_camera.cpp:228-229).  Afterwards jpt_read_ldr_rgba8 / jpt_readback_ldr_* on the
+ * gathering rank return the whole image; the accumulation buffers stay distributed. */
+void *jpt_device_ldr(jpt_ctx *ctx, size_t *bytes_out);
+int jpt_assemble_ldr_from_ranks(jpt_ctx *ctx, const void *device_gathered_rgba8, int32_t world);
 int32_t jpt_local_rows(jpt_ctx *ctx);
 
 int jpt_get_stats(jpt_ctx *ctx, jpt_stats *out);

@@ -208,7 +208,7 @@ def test_c3_screen_partition_is_bit_identical(hiplib, c3):
     """Two contexts render the strips of rank 0 and rank 1 of 2; the gathered pieces assembled on the
     device reproduce the single-context image exactly."""
     import torch
-    pieces = []
+    pieces, ldr_pieces = [], []
     ctxs = []
     for r in range(2):
         ctx = make_ctx(c3["sc"], W, H, B, wire.ACCUM_REF_LDR8, rank=r, world=2)
@@ -219,11 +219,25 @@ def test_c3_screen_partition_is_bit_identical(hiplib, c3):
         class V:
             __cuda_array_interface__ = {"shape": (nbytes // 4,), "typestr": "<f4", "data": (ptr, False), "version": 2}
         pieces.append(torch.as_tensor(V(), device="cuda:0").clone())
+        lptr, lbytes = ctx.device_ldr()
+
+        class L:
+            __cuda_array_interface__ = {"shape": (lbytes // 4,), "typestr": "<i4", "data": (lptr, False), "version": 2}
+        ldr_pieces.append(torch.as_tensor(L(), device="cuda:0").clone())
         # the host-side read of a partial context returns its rows in place
         part = ctx.read_accum()
         rows = partition.rows_of_rank(H, r, 2)
         assert np.array_equal(part[rows], c3["accum"][rows])
         ctxs.append(ctx)
+    # the display rows alone (4 bytes per pixel): every rank's rgba8 rows are final
+    gathered_ldr = torch.stack(ldr_pieces).contiguous()
+    torch.cuda.synchronize()
+    ctxs[0].assemble_ldr_from_ranks(gathered_ldr.data_ptr(), 2)
+    assert np.array_equal(ctxs[0].read_ldr(), c3["ldr"])
+    ctxs[0]._ck(ctxs[0]._lib.jpt_readback_ldr_begin(ctxs[0].h), "jpt_readback_ldr_begin")
+    split = np.zeros((H, W, 4), np.uint8)
+    ctxs[0]._ck(ctxs[0]._lib.jpt_readback_ldr_end(ctxs[0].h, split.ctypes.data), "jpt_readback_ldr_end")
+    assert np.array_equal(split, c3["ldr"])
     gathered = torch.stack(pieces).contiguous()
     torch.cuda.synchronize()
     ctxs[0].assemble_from_ranks(gathered.data_ptr(), 2)
