@@ -267,6 +267,53 @@ def instanced_scene(n_side=32, n_unique=8, tris_per_mesh=1024, seed=7) -> Scene:
     return Scene("inst%d" % (n_side * n_side), meshes, inst, _demo_materials(), cam)
 
 
+def random_scene(seed: int, n_meshes: int = 4, n_instances: int = 9, tris_per_surface: int = 40, textured: bool = True,
+                 coincident: bool = True) -> Scene:
+    """Fuzz input: triangle soups (slivers, a few degenerate triangles, non-unit and inconsistent vertex normals,
+    uvs outside [0,1]), meshes of 1..3 surfaces, instances with non-uniform scale, shear and mirroring, random
+    materials (fractional metallic, roughness 0, emitters, textured and untextured)."""
+    rng = np.random.RandomState(seed)
+    meshes = []
+    for _ in range(n_meshes):
+        surfaces = []
+        for _s in range(rng.randint(1, 4)):
+            n = tris_per_surface
+            centres = rng.uniform(-1.0, 1.0, size=(n, 1, 3))
+            v = (centres + rng.normal(0.0, 0.35, size=(n, 3, 3))).astype(np.float32)
+            v[0, 2] = v[0, 1]                                   # a degenerate triangle (two equal vertices)
+            v[1, 2] = v[1, 0] + (v[1, 1] - v[1, 0]) * 0.5       # a zero-area triangle (collinear)
+            if coincident:
+                v[2] = v[3]                                     # two coincident triangles (equal t on every ray: the
+                                                                # winner depends on the visiting order, i.e. on the tree)
+            nrm = rng.normal(size=(n, 3, 3)).astype(np.float32) * rng.uniform(0.2, 3.0, size=(n, 1, 1)).astype(np.float32)
+            uv = rng.uniform(-0.5, 1.5, size=(n, 3, 2)).astype(np.float32)
+            surfaces.append(Surface(v.reshape(-1, 3), nrm.reshape(-1, 3), uv.reshape(-1, 2), np.arange(3 * n, dtype=np.int32)))
+        meshes.append(Mesh(surfaces))
+    n_mat = 8
+    mats = [material()]
+    for k in range(1, n_mat):
+        emit = rng.rand() < 0.35
+        mats.append(material(albedo=tuple(rng.uniform(0.05, 1.0, size=3)),
+                             emission=tuple(rng.uniform(0, 1, size=3)) if emit else (0.0, 0.0, 0.0),
+                             energy=float(rng.uniform(0.5, 6.0)) if emit else 1.0,
+                             metallic=float(rng.choice([0.0, 1.0, rng.rand()])),
+                             roughness=float(rng.choice([0.0, 0.003, 0.3, 1.0, rng.rand()])),
+                             texture=int(rng.randint(0, 2)) if (textured and rng.rand() < 0.5) else -1))
+    inst = []
+    for _ in range(n_instances):
+        m = int(rng.randint(n_meshes))
+        basis = rot_y(rng.uniform(0, 360)) @ np.diag(rng.uniform(0.4, 1.6, size=3)) + rng.normal(0, 0.08, size=(3, 3))
+        if rng.rand() < 0.3:
+            basis[:, 0] = -basis[:, 0]                          # mirrored instance (negative determinant)
+        ids = [int(rng.randint(0, n_mat)) for _ in meshes[m].surfaces]
+        inst.append(Instance(m, transform12(basis, rng.uniform(-2.0, 2.0, size=3)), ids))
+    tex = None
+    if textured:
+        tex = np.concatenate([checker_texture(32, 4), rng.randint(0, 256, size=(1, 32, 32, 4)).astype(np.uint8)])
+    cam = CameraDesc(transform12(None, (0.0, 0.3, 6.5)), fov_deg=70.0)
+    return Scene("fuzz%d" % seed, meshes, inst, np.stack(mats), cam, tex)
+
+
 def checker_texture(res=64, cells=8) -> np.ndarray:
     y, x = np.mgrid[0:res, 0:res]
     c = (((x * cells // res) + (y * cells // res)) & 1).astype(np.uint8)
