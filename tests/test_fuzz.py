@@ -90,6 +90,12 @@ def test_native_tree_matches_the_tree_independent_answer(oracle, hiplib, seed):
         got = ctx.read_accum()
     finally:
         ctx.close()
-    ndiff = int((got != want).any(axis=-1).sum())
-    print("fuzz", seed, "differing pixels", ndiff, "rel_l2", rel_l2(got, want))
-    assert rel_l2(got, want) <= 1e-4
+    # soups with degenerate triangles and arbitrary normals produce a few NaN pixels (0/0 in the shading frame); they
+    # must be the same pixels on both sides, and the finite ones are compared by relative L2
+    nan_got, nan_want = np.isnan(got).any(axis=-1), np.isnan(want).any(axis=-1)
+    ok = ~(nan_got | nan_want)
+    ndiff = int((got[ok] != want[ok]).any(axis=-1).sum())
+    err = rel_l2(got[ok], want[ok])
+    print("fuzz", seed, "differing pixels", ndiff, "rel_l2", err, "nan pixels", int(nan_got.sum()), int(nan_want.sum()))
+    assert np.array_equal(nan_got, nan_want)
+    assert err <= 1e-4
