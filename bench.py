@@ -117,7 +117,7 @@ def main():
     stream = torch.cuda.Stream()
     torch.cuda.set_stream(stream)
     ctx.set_stream(stream.cuda_stream)
-    ctx.set_kernel_timing(world == 1)   # HIP events around every traversal launch (the roofline's kernel duration)
+    ctx.set_kernel_timing(False)   # per-launch HIP events serialise the frame groups: they are collected after the timed region
 
     # gather plumbing (N > 1): the local piece (rgba8 display rows, or float4 sums) viewed as a torch tensor, no copy
     piece = gathered = None
@@ -176,31 +176,40 @@ def main():
         step()
     barrier()
     # Timed region.  Every step ends with jpt_sync (the reference reads the image back after every render,
-    # path_tracing_camera.cpp:228-229); the library brackets each wf_trace launch with HIP events on the
-    # stream it launches on, so the dominant kernel's duration is measured live, per step.
-    render_ms, trace_ms = [], []
+    # path_tracing_camera.cpp:228-229).
+    render_ms = []
     t0 = time.perf_counter()
     for i in range(args.steps):
-        if world > 1 and i == args.steps - 1:
-            ctx.set_kernel_timing(True)   # N > 1: only the last step carries the timing events
         ctx.accum_reset()
         ctx.render(spp, 1, asynchronous=True)
         if world > 1:
             exchange()
-        if world == 1 or i == args.steps - 1:
-            # N = 1: every step ends with jpt_sync, which also reads the per-launch HIP-event times of the
-            # traversal kernels.  N > 1: steps are only queued (the closing barrier waits for all of them), so host
-            # launch latency overlaps device work; the kernel times are then those of the last step.
+        if world == 1:
+            # N = 1: every step ends with jpt_sync (the reference reads the image back after every render).
+            # N > 1: steps are only queued (the closing barrier waits for all of them), so host launch latency
+            # overlaps device work.
             ctx.sync()
-            st = ctx.stats()
-            render_ms.append(st["last_render_ms"])
-            trace_ms.append(st["last_trace_ms"])
+            render_ms.append(ctx.stats()["last_render_ms"])
     barrier()
     elapsed = time.perf_counter() - t0
     t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
+    # Duration of the dominant kernel, measured live with HIP events on the stream it is launched on: the library
+    # brackets every traversal launch when kernel timing is on, which also makes it run the launches one after
+    # another (in the timed region above, the frame groups' launches overlap, so a per-launch duration is not
+    # defined there).  Three untimed renders, after the timed region.
+    ctx.set_kernel_timing(True)
+    trace_ms = []
+    for _ in range(3):
+        ctx.accum_reset()
+        ctx.render(spp, 1)
+        st = ctx.stats()
+        trace_ms.append(st["last_trace_ms"])
+        if world > 1:
+            render_ms.append(st["last_render_ms"])
+    ctx.set_kernel_timing(False)
     n_trace_launches = (bounces + 1) if args.kernel != "ref" else spp
     kernel_ms = float(np.mean(trace_ms)) / n_trace_launches   # average duration of ONE launch of the dominant kernel
 

@@ -53,6 +53,7 @@ struct jpt_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    Wf2Async async;  // helper streams / events of the frame groups (launch_wf2_render)
     std::string error;
 
     // host scene
@@ -118,6 +119,7 @@ struct jpt_ctx {
     bool readback_full = false;  // the read-back in flight copies the assembled image (else: this context's rows)
 
     jpt_stats stats;
+    int32_t stats_frames = 0;  // n_frames of the render stats.rays belongs to
 };
 
 namespace {
@@ -409,6 +411,7 @@ int do_render_batch(jpt_ctx* c, int32_t n_frames, uint32_t first_frame_index, bo
             fp.frame_index = first_frame_index;
             fp.frame_count = c->frame_count + 1;
             fp.n_frames = n_frames;
+            fp.depth_frame = n_frames - 1;
             const size_t need_ev = c->kernel_timing ? 2 * (size_t)(c->max_bounces + 1) : 0;
             while (c->trace_events.size() < need_ev) {
                 hipEvent_t e;
@@ -416,9 +419,10 @@ int do_render_batch(jpt_ctx* c, int32_t n_frames, uint32_t first_frame_index, bo
                 c->trace_events.push_back(e);
             }
             c->trace_events_used = (int32_t)need_ev;
+            if (wf2) c->async.last_rays = (c->stats_frames == n_frames) ? (size_t)c->stats.rays : 0;
             if (wf2)
                 launch_wf2_render(s, c->ds, fp, c->camera, c->d_workspace.p, c->d_accum.p, c->d_ldr.p, c->d_depth.p, cnt,
-                                  need_ev ? c->trace_events.data() : nullptr);
+                                  need_ev ? c->trace_events.data() : nullptr, c->async);
             else
                 launch_wide_render(s, c->ds, fp, c->camera, c->d_workspace.p, c->d_accum.p, c->d_ldr.p, c->d_depth.p, cnt,
                                    need_ev ? c->trace_events.data() : nullptr);
@@ -427,6 +431,7 @@ int do_render_batch(jpt_ctx* c, int32_t n_frames, uint32_t first_frame_index, bo
                 fp.frame_index = first_frame_index + (uint32_t)f;
                 fp.frame_count = c->frame_count + (uint32_t)f + 1;
                 fp.n_frames = 1;
+                fp.depth_frame = 0;
                 launch_ref_frame(s, c->ds, fp, c->camera, c->d_accum.p, c->d_ldr.p, c->d_depth.p, cnt);
             }
         }
@@ -465,6 +470,7 @@ int do_render_batch(jpt_ctx* c, int32_t n_frames, uint32_t first_frame_index, bo
             for (int b = 1; b <= c->max_bounces; b++)
                 for (size_t k = 0; k < per_row; k++) rays += c->h_qcount[(size_t)b * per_row + k];
             c->stats.rays = rays;
+            c->stats_frames = n_frames;
         }
         if (counted) {
             DevCounters h;
@@ -538,6 +544,20 @@ int jpt_create(int device_id, jpt_ctx** out)
         return JPT_E_DEVICE;
     }
     c->stream = c->own_stream;
+    // helper streams of the frame groups; without them (creation failed) renders simply run serially
+    bool ok = hipEventCreateWithFlags(&c->async.fork, hipEventDisableTiming) == hipSuccess;
+    for (int k = 0; k < 3 && ok; k++)
+        ok = hipStreamCreateWithFlags(&c->async.aux_stream[k], hipStreamNonBlocking) == hipSuccess &&
+             hipEventCreateWithFlags(&c->async.join[k], hipEventDisableTiming) == hipSuccess;
+    if (!ok) {
+        (void)hipGetLastError();
+        for (int k = 0; k < 3; k++) {
+            if (c->async.aux_stream[k]) (void)hipStreamDestroy(c->async.aux_stream[k]);
+            if (c->async.join[k]) (void)hipEventDestroy(c->async.join[k]);
+            c->async.aux_stream[k] = nullptr;
+            c->async.join[k] = nullptr;
+        }
+    }
     *out = c;
     return JPT_OK;
 }
@@ -556,6 +576,14 @@ void jpt_destroy(jpt_ctx* c)
     for (hipEvent_t e : c->trace_events) (void)hipEventDestroy(e);
     if (c->ev_readback) (void)hipEventDestroy(c->ev_readback);
     if (c->h_ldr_pinned) (void)hipHostFree(c->h_ldr_pinned);
+    for (int k = 0; k < 3; k++) {
+        if (c->async.aux_stream[k]) {
+            (void)hipStreamSynchronize(c->async.aux_stream[k]);
+            (void)hipStreamDestroy(c->async.aux_stream[k]);
+        }
+        if (c->async.join[k]) (void)hipEventDestroy(c->async.join[k]);
+    }
+    if (c->async.fork) (void)hipEventDestroy(c->async.fork);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }

@@ -28,6 +28,7 @@ struct FrameParams {
     uint32_t frame_index;       // camera.frame_index of this frame (main.glsl:409)
     uint32_t frame_count;       // ProgressiveRendering frame_count of this frame (progressive_rendering.cpp:53-60)
     int32_t n_frames;           // frames rendered by one launch (wide kernels)
+    int32_t depth_frame;        // launch-local index of the frame whose first-hit distance is the depth image (-1: none)
     int32_t display_mode;       // 0: screen = ACES of the running mean (progressive_rendering.glsl:39-45)
                                 // 1: screen = the last frame's own rgba8 store (main.glsl:434), no pass after it
 };
@@ -134,8 +135,15 @@ void launch_wide_render(hipStream_t stream, const DeviceScene& ds, const FramePa
 uint32_t wf2_segments();
 uint32_t trace_stack_capacity();  // entries a lane's traversal stack can hold (LDS + scratch)
 size_t wf2_workspace_bytes(int width, int local_rows, int n_frames, int max_bounces);
+// helper streams / events for running frame groups concurrently (all null: serial); owned by the context
+struct Wf2Async {
+    hipStream_t aux_stream[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t fork = nullptr, join[3] = {nullptr, nullptr, nullptr};
+    size_t last_rays = 0;  // ray segments of this context's previous render of the same size (0: unknown)
+};
 void launch_wf2_render(hipStream_t stream, const DeviceScene& ds, const FrameParams& fp, const RefCamera& cam, void* workspace,
-                       float4* accum, uint32_t* ldr, float* depth, DevCounters* counters, hipEvent_t* trace_events);
+                       float4* accum, uint32_t* ldr, float* depth, DevCounters* counters, hipEvent_t* trace_events,
+                       const Wf2Async& async);
 
 // one dispatch of temporal_reprojection.glsl over a whole image (jpt_kernels_post.hip): screen rgba8 in/out, depth
 // read-only, hist1 / hist2 the two rgba32f history images

@@ -176,7 +176,7 @@ __global__ __launch_bounds__(kBlock, JPT_PRIMARY_WAVES) void wf2_primary(WideSce
             if (walk_round<COUNT, W4>(tr, active, sc, my_stack, cnt, tune.node_min_lanes, tune.leaf_min, tune.inst_min)) {
                 active = false;
                 const uint32_t f = path / dm.slots_per_frame;
-                const bool last_frame = (int)f == fp.n_frames - 1;
+                const bool last_frame = (int)f == fp.depth_frame;
                 if (tr.hit.t < 1e9f) {  // main.glsl:349: packed into the segment's bounce-0 queue
                     const uint32_t j = atomicAdd(&s_out, 1u);
                     wb.ray_o[0][seg_base + j] = make_float4(tr.wo.x, tr.wo.y, tr.wo.z, 0.0f);
@@ -631,7 +631,7 @@ __global__ __launch_bounds__(kBlock, JPT_SHADE_WAVES) void wf2_shade(SceneShadin
             h.ld = xform_dir(b.inverse_transform, ray.d);
             const Shading s = get_shading_data(sh, h, (hb >> 31) != 0u);
             radiance = radiance + throughput * s.emission;
-            if (bounce == 0 && (int)f == fp.n_frames - 1) wb.first_depth[slot] = length3(s.position - ray.o);
+            if (bounce == 0 && (int)f == fp.depth_frame) wb.first_depth[slot] = length3(s.position - ray.o);
             if (bounce < fp.max_bounces) alive = bounce_step(s, sx, sy, ray, throughput);
         }
         wb.rad[p] = make_float4(radiance.x, radiance.y, radiance.z, __uint_as_float(sy));
@@ -725,47 +725,116 @@ static size_t pool_spill_bytes() { return pool_enabled() ? (size_t)512 * (kBlock
 uint32_t wf2_segments() { return kSegments; }
 uint32_t trace_stack_capacity() { return (uint32_t)(kStackLds + kStackSpill); }
 
-size_t wf2_workspace_bytes(int width, int local_rows, int n_frames, int max_bounces)
+// Frame groups.  Every launch of the pipeline ends with a tail: a few long rays in a few waves while the rest of the
+// chip has nothing left to do (a ray's latency under full load is ~20 us on average, ~100 us for the longest; C3's ten
+// launch boundaries cost 0.5 ms of 1.85 -- render time is 0.48 + 0.17 * spp ms).  Balancing the queues does not
+// help (tried: equal ray counts per block, same time) and neither does fusing the bounce loop into one persistent
+// kernel (the barriers move into the blocks).  What helps is having other work ready when a launch drains: the
+// frames of a render are split into groups, each group runs the pipeline on its own stream with its own queues,
+// and the hardware fills the slots one group's kernel frees with the blocks of the other group's next kernel.
+// Paths never cross groups and the per-pixel accumulation still reads the frames in order: results are unchanged.
+// Measured on one MI355X (ms per render, 1 / 2 / 3 / 4 groups): 3840x2160x16 spp 13.2 / 11.9 / 12.2 / 13.1;
+// 1920x1080x32 spp 5.92 / 5.38 / 5.75 / 6.18; x16 spp 3.13 / 2.98; x8 spp (C3, 22 M segments) 1.81 / 1.80 / 2.09 / 2.54; x8 spp close-up
+// (50 M segments) 6.88 / 6.41; x4 spp 1.17 / 1.31.  Every extra launch costs ~25 us, so two groups pay once a group still holds >= ~12 M paths.
+constexpr int kMaxGroups = 4;
+static int frame_groups(int n_frames, bool serial, size_t paths, size_t last_rays = 0)
 {
-    const Wf2Dims dm = make_dims(width, local_rows, n_frames);
-    const size_t q = (size_t)dm.seg_cap * kSegments;                  // queue entries
-    const size_t paths = (size_t)dm.slots_per_frame * (size_t)n_frames;
-    size_t b = 0;
-    b += q * sizeof(float4) * 4;    // two ray queues (o, d)
-    b += q * sizeof(float4);        // hit_a
-    b += q * sizeof(uint32_t);      // hit_b
-    b += paths * sizeof(float4) * 2;  // thr, rad
-    b += (size_t)dm.slots_per_frame * sizeof(float);
-    b += (size_t)(max_bounces + 2) * kSegments * sizeof(uint32_t);
-    b += pool_spill_bytes();  // only touched by the experimental pool kernel
-    return b + 17 * 256;
+    const int forced = [] {  // JPT_GROUPS=n overrides the rule (tuning runs, tests); read on every render
+        const char* e = getenv("JPT_GROUPS");
+        const int g = e ? atoi(e) : 0;
+        return g < 0 ? 0 : (g > kMaxGroups ? kMaxGroups : g);
+    }();
+    if (serial || pool_enabled() || n_frames < 2) return 1;
+    // (a render of fewer paths that traced many segments last time -- every pixel on geometry -- qualifies too)
+    const int wanted = forced ? forced : ((paths >= ((size_t)24 << 20) || last_rays >= ((size_t)24 << 20)) ? 2 : 1);
+    return n_frames < wanted ? n_frames : wanted;
+}
+static void group_frames(int n_frames, int groups, int g, int& first, int& count)
+{
+    const int base = n_frames / groups, extra = n_frames % groups;
+    first = g * base + (g < extra ? g : extra);
+    count = base + (g < extra ? 1 : 0);
 }
 
-void launch_wf2_render(hipStream_t stream, const DeviceScene& ds, const FrameParams& fp, const RefCamera& cam, void* workspace,
-                       float4* accum, uint32_t* ldr, float* depth, DevCounters* counters, hipEvent_t* trace_events)
+size_t wf2_workspace_bytes(int width, int local_rows, int n_frames, int max_bounces)
 {
-    const Wf2Dims dm = make_dims(fp.width, fp.local_rows, fp.n_frames);
-    if (dm.n_chunks == 0) return;
-    const size_t q = (size_t)dm.seg_cap * kSegments;
-    const size_t paths = (size_t)dm.slots_per_frame * (size_t)fp.n_frames;
+    // sized for every layout a render of this size may use (the group count depends on kernel timing, on the
+    // previous render's ray count and on JPT_GROUPS): the largest of 1..kMaxGroups groups
+    size_t worst = 0;
+    for (int groups = 1; groups <= kMaxGroups && groups <= (n_frames < 1 ? 1 : n_frames); groups++) {
+        size_t b = 0;
+        for (int g = 0; g < groups; g++) {
+            int f0, nf;
+            group_frames(n_frames, groups, g, f0, nf);
+            const Wf2Dims dm = make_dims(width, local_rows, nf);
+            const size_t q = (size_t)dm.seg_cap * kSegments;                  // queue entries
+            const size_t paths = (size_t)dm.slots_per_frame * (size_t)nf;
+            b += q * sizeof(float4) * 4 + 4 * 256;    // two ray queues (o, d)
+            b += q * sizeof(float4) + 256;            // hit_a
+            b += q * sizeof(uint32_t) + 256;          // hit_b
+            b += paths * sizeof(float4) + 256;        // thr
+            b += (size_t)(max_bounces + 2) * kSegments * sizeof(uint32_t) + 256;
+        }
+        const Wf2Dims all = make_dims(width, local_rows, n_frames);
+        b += (size_t)all.slots_per_frame * (size_t)n_frames * sizeof(float4) + 256;  // rad: [frame][slot], shared by the groups
+        b += (size_t)all.slots_per_frame * sizeof(float) + 256;
+        b += pool_spill_bytes();  // only touched by the experimental pool kernel
+        worst = b > worst ? b : worst;
+    }
+    return worst + 17 * 256;
+}
+
+namespace {
+__global__ void add_queue_counts(uint32_t* __restrict__ dst, const uint32_t* __restrict__ src, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] += src[i];
+}
+}  // namespace
+
+void launch_wf2_render(hipStream_t stream, const DeviceScene& ds, const FrameParams& fp, const RefCamera& cam, void* workspace,
+                       float4* accum, uint32_t* ldr, float* depth, DevCounters* counters, hipEvent_t* trace_events,
+                       const Wf2Async& async)
+{
+    const Wf2Dims dm_all = make_dims(fp.width, fp.local_rows, fp.n_frames);
+    if (dm_all.n_chunks == 0) return;
     char* w = reinterpret_cast<char*>(workspace);
     auto carve = [&](size_t bytes) {
         void* p = w;
         w += (bytes + 255) & ~(size_t)255;
         return p;
     };
-    Wf2Buffers wb;
     const int nq = fp.max_bounces + 2;
-    wb.qcount = (uint32_t*)carve((size_t)nq * kSegments * sizeof(uint32_t));
-    wb.ray_o[0] = (float4*)carve(q * sizeof(float4));
-    wb.ray_o[1] = (float4*)carve(q * sizeof(float4));
-    wb.ray_d[0] = (float4*)carve(q * sizeof(float4));
-    wb.ray_d[1] = (float4*)carve(q * sizeof(float4));
-    wb.hit_a = (float4*)carve(q * sizeof(float4));
-    wb.hit_b = (uint32_t*)carve(q * sizeof(uint32_t));
-    wb.thr = (float4*)carve(paths * sizeof(float4));
-    wb.rad = (float4*)carve(paths * sizeof(float4));
-    wb.first_depth = (float*)carve((size_t)dm.slots_per_frame * sizeof(float));
+    // per-launch events and event counters want the launches one after another
+    const int groups = frame_groups(fp.n_frames, trace_events != nullptr || counters != nullptr || !async.aux_stream[0],
+                                    (size_t)fp.width * (size_t)fp.local_rows * (size_t)fp.n_frames, async.last_rays);
+    Wf2Buffers gb[kMaxGroups];
+    Wf2Dims gdm[kMaxGroups];
+    FrameParams gfp[kMaxGroups];
+    for (int g = 0; g < groups; g++) gb[g].qcount = (uint32_t*)carve((size_t)nq * kSegments * sizeof(uint32_t));  // group 0 first: the host reads it
+    float4* rad_all = (float4*)carve((size_t)dm_all.slots_per_frame * (size_t)fp.n_frames * sizeof(float4));
+    float* first_depth = (float*)carve((size_t)dm_all.slots_per_frame * sizeof(float));
+    for (int g = 0; g < groups; g++) {
+        int f0, nf;
+        group_frames(fp.n_frames, groups, g, f0, nf);
+        gdm[g] = make_dims(fp.width, fp.local_rows, nf);
+        const size_t q = (size_t)gdm[g].seg_cap * kSegments;
+        const size_t paths = (size_t)gdm[g].slots_per_frame * (size_t)nf;
+        Wf2Buffers& wb = gb[g];
+        wb.ray_o[0] = (float4*)carve(q * sizeof(float4));
+        wb.ray_o[1] = (float4*)carve(q * sizeof(float4));
+        wb.ray_d[0] = (float4*)carve(q * sizeof(float4));
+        wb.ray_d[1] = (float4*)carve(q * sizeof(float4));
+        wb.hit_a = (float4*)carve(q * sizeof(float4));
+        wb.hit_b = (uint32_t*)carve(q * sizeof(uint32_t));
+        wb.thr = (float4*)carve(paths * sizeof(float4));
+        wb.rad = rad_all + (size_t)f0 * dm_all.slots_per_frame;  // this group's frames of the [frame][slot] array
+        wb.first_depth = first_depth;
+        gfp[g] = fp;
+        gfp[g].frame_index = fp.frame_index + (uint32_t)f0;
+        gfp[g].n_frames = nf;
+        gfp[g].depth_frame = (f0 + nf == fp.n_frames) ? nf - 1 : -1;  // the render's last frame writes the depth image
+    }
     const bool use_pool = pool_enabled();
     const dim3 pgrid(512);  // 2 resident blocks per CU (75 KiB of LDS each); each chains kSegments / 512 segments
     int32_t* pool_spill = use_pool ? (int32_t*)carve(pool_spill_bytes()) : nullptr;
@@ -794,42 +863,67 @@ void launch_wf2_render(hipStream_t stream, const DeviceScene& ds, const FramePar
         return t;
     }();
 
-    // queue sizes of bounces >= 1 are accumulated with atomics by wf2_shade: start from zero
-    (void)hipMemsetAsync(wb.qcount + kSegments, 0, (size_t)(nq - 1) * kSegments * sizeof(uint32_t), stream);
-    const dim3 sgrid((dm.seg_cap + kBlock - 1) / kBlock, kSegments);
-    if (trace_events) (void)hipEventRecord(trace_events[0], stream);
-    if (counters) {
-        if (w4) hipLaunchKernelGGL((wf2_primary<true, true>), grid, block, 0, stream, sc, wb, dm, fp, cam, tune, counters);
-        else hipLaunchKernelGGL((wf2_primary<true, false>), grid, block, 0, stream, sc, wb, dm, fp, cam, tune, counters);
-    } else {
-        if (w4) hipLaunchKernelGGL((wf2_primary<false, true>), grid, block, 0, stream, sc, wb, dm, fp, cam, tune, counters);
-        else hipLaunchKernelGGL((wf2_primary<false, false>), grid, block, 0, stream, sc, wb, dm, fp, cam, tune, counters);
-    }
-    if (trace_events) (void)hipEventRecord(trace_events[1], stream);
-    for (int b = 0; b <= fp.max_bounces; b++) {
-        if (counters) hipLaunchKernelGGL(wf2_shade<true>, sgrid, block, 0, stream, sh, wb, dm, fp, cam, b, counters);
-        else hipLaunchKernelGGL(wf2_shade<false>, sgrid, block, 0, stream, sh, wb, dm, fp, cam, b, counters);
-        if (b == fp.max_bounces) break;
-        if (trace_events) (void)hipEventRecord(trace_events[2 * (b + 1)], stream);
-        if (use_pool) {
-            if (counters) {
-                if (w4) hipLaunchKernelGGL((wf3_trace<true, true>), pgrid, block, 0, stream, sc, wb, dm, b + 1, tune, pool_spill, counters);
-                else hipLaunchKernelGGL((wf3_trace<true, false>), pgrid, block, 0, stream, sc, wb, dm, b + 1, tune, pool_spill, counters);
-            } else {
-                if (w4) hipLaunchKernelGGL((wf3_trace<false, true>), pgrid, block, 0, stream, sc, wb, dm, b + 1, tune, pool_spill, counters);
-                else hipLaunchKernelGGL((wf3_trace<false, false>), pgrid, block, 0, stream, sc, wb, dm, b + 1, tune, pool_spill, counters);
-            }
-        } else if (counters) {
-            if (w4) hipLaunchKernelGGL((wf2_trace<true, true>), grid, block, 0, stream, sc, wb, dm, b + 1, tune, counters);
-            else hipLaunchKernelGGL((wf2_trace<true, false>), grid, block, 0, stream, sc, wb, dm, b + 1, tune, counters);
+    // the pipeline of one group on one stream
+    auto run_group = [&](hipStream_t st, const Wf2Buffers& wb, const Wf2Dims& dm, const FrameParams& gp, hipEvent_t* ev) {
+        // queue sizes of bounces >= 1 are accumulated with atomics by wf2_shade: start from zero
+        (void)hipMemsetAsync(wb.qcount + kSegments, 0, (size_t)(nq - 1) * kSegments * sizeof(uint32_t), st);
+        const dim3 sgrid((dm.seg_cap + kBlock - 1) / kBlock, kSegments);
+        if (ev) (void)hipEventRecord(ev[0], st);
+        if (counters) {
+            if (w4) hipLaunchKernelGGL((wf2_primary<true, true>), grid, block, 0, st, sc, wb, dm, gp, cam, tune, counters);
+            else hipLaunchKernelGGL((wf2_primary<true, false>), grid, block, 0, st, sc, wb, dm, gp, cam, tune, counters);
         } else {
-            if (w4) hipLaunchKernelGGL((wf2_trace<false, true>), grid, block, 0, stream, sc, wb, dm, b + 1, tune, counters);
-            else hipLaunchKernelGGL((wf2_trace<false, false>), grid, block, 0, stream, sc, wb, dm, b + 1, tune, counters);
+            if (w4) hipLaunchKernelGGL((wf2_primary<false, true>), grid, block, 0, st, sc, wb, dm, gp, cam, tune, counters);
+            else hipLaunchKernelGGL((wf2_primary<false, false>), grid, block, 0, st, sc, wb, dm, gp, cam, tune, counters);
         }
-        if (trace_events) (void)hipEventRecord(trace_events[2 * (b + 1) + 1], stream);
+        if (ev) (void)hipEventRecord(ev[1], st);
+        for (int b = 0; b <= gp.max_bounces; b++) {
+            if (counters) hipLaunchKernelGGL(wf2_shade<true>, sgrid, block, 0, st, sh, wb, dm, gp, cam, b, counters);
+            else hipLaunchKernelGGL(wf2_shade<false>, sgrid, block, 0, st, sh, wb, dm, gp, cam, b, counters);
+            if (b == gp.max_bounces) break;
+            if (ev) (void)hipEventRecord(ev[2 * (b + 1)], st);
+            if (use_pool) {
+                if (counters) {
+                    if (w4) hipLaunchKernelGGL((wf3_trace<true, true>), pgrid, block, 0, st, sc, wb, dm, b + 1, tune, pool_spill, counters);
+                    else hipLaunchKernelGGL((wf3_trace<true, false>), pgrid, block, 0, st, sc, wb, dm, b + 1, tune, pool_spill, counters);
+                } else {
+                    if (w4) hipLaunchKernelGGL((wf3_trace<false, true>), pgrid, block, 0, st, sc, wb, dm, b + 1, tune, pool_spill, counters);
+                    else hipLaunchKernelGGL((wf3_trace<false, false>), pgrid, block, 0, st, sc, wb, dm, b + 1, tune, pool_spill, counters);
+                }
+            } else if (counters) {
+                if (w4) hipLaunchKernelGGL((wf2_trace<true, true>), grid, block, 0, st, sc, wb, dm, b + 1, tune, counters);
+                else hipLaunchKernelGGL((wf2_trace<true, false>), grid, block, 0, st, sc, wb, dm, b + 1, tune, counters);
+            } else {
+                if (w4) hipLaunchKernelGGL((wf2_trace<false, true>), grid, block, 0, st, sc, wb, dm, b + 1, tune, counters);
+                else hipLaunchKernelGGL((wf2_trace<false, false>), grid, block, 0, st, sc, wb, dm, b + 1, tune, counters);
+            }
+            if (ev) (void)hipEventRecord(ev[2 * (b + 1) + 1], st);
+        }
+    };
+
+    if (groups == 1) {
+        run_group(stream, gb[0], gdm[0], gfp[0], trace_events);
+    } else {
+        // fork: the helper streams start after everything already queued on the context's stream
+        (void)hipEventRecord(async.fork, stream);
+        for (int g = 1; g < groups; g++) (void)hipStreamWaitEvent(async.aux_stream[g - 1], async.fork, 0);
+        // issue the groups' launches interleaved, so none of the streams runs ahead of the others on the host side
+        // (run_group enqueues a whole pipeline; the hardware queues of the streams drain concurrently)
+        for (int g = 0; g < groups; g++) run_group(g == 0 ? stream : async.aux_stream[g - 1], gb[g], gdm[g], gfp[g], nullptr);
+        // join, then fold the other groups' queue sizes into group 0's (the host reads those for the ray count)
+        for (int g = 1; g < groups; g++) {
+            (void)hipEventRecord(async.join[g - 1], async.aux_stream[g - 1]);
+            (void)hipStreamWaitEvent(stream, async.join[g - 1], 0);
+        }
+        const uint32_t nqc = (uint32_t)nq * kSegments;
+        for (int g = 1; g < groups; g++)
+            hipLaunchKernelGGL(add_queue_counts, dim3((nqc + 255) / 256), dim3(256), 0, stream, gb[0].qcount, gb[g].qcount, nqc);
     }
-    const uint32_t ablocks = (dm.slots_per_frame + kBlock - 1) / kBlock;
-    hipLaunchKernelGGL(wf2_accumulate, dim3(ablocks), block, 0, stream, wb, dm, fp, cam, accum, ldr, depth);
+    Wf2Buffers wb_all = gb[0];
+    wb_all.rad = rad_all;
+    wb_all.first_depth = first_depth;
+    const uint32_t ablocks = (dm_all.slots_per_frame + kBlock - 1) / kBlock;
+    hipLaunchKernelGGL(wf2_accumulate, dim3(ablocks), block, 0, stream, wb_all, dm_all, fp, cam, accum, ldr, depth);
 }
 
 }  // namespace jpt

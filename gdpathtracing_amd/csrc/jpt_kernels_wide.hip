@@ -182,7 +182,7 @@ __global__ __launch_bounds__(kShadeBlock) void wf_shade(SceneShading sh, WfBuffe
         }
         if (bounce == 0) {
             const uint32_t f = p / dm.slots_per_frame;
-            if ((int)f == fp.n_frames - 1) wb.first_depth[p - f * dm.slots_per_frame] = first_dist;
+            if ((int)f == fp.depth_frame) wb.first_depth[p - f * dm.slots_per_frame] = first_dist;
         }
         wb.rad[p] = make_float4(radiance.x, radiance.y, radiance.z, __uint_as_float(sy));
         if (alive) {

@@ -362,3 +362,30 @@ def test_split_readback_overlaps_the_next_render(hiplib):
     assert np.array_equal(got1, want1)
     assert np.array_equal(ctx.read_ldr(), want2)
     ctx.close()
+
+
+@pytest.mark.parametrize("groups", [2, 3, 4])
+def test_frame_groups_on_concurrent_streams(oracle, hiplib, monkeypatch, groups):
+    """Large renders split their frames into groups that run the pipeline concurrently on helper streams
+    (launch_wf2_render); paths never cross groups and the accumulation reads the frames in order, so the result is the
+    serial one bit for bit -- accumulation buffer, display image, depth (written by the last frame's group) and the
+    ray count (summed over the groups)."""
+    sc = scenes.demo_scene(3000)
+    w, h, bounces, frames = 200, 120, 3, 7          # 7 frames: uneven groups
+    ref = oracle.build_scene(sc)
+    cam = scenes.camera_block(sc.camera, w, h)
+    want, want_ldr, want_depth, cnt, _ = oracle.render(ref, cam, w, h, bounces, frames, 3, wire.ACCUM_REF_LDR8)
+    monkeypatch.setenv("JPT_GROUPS", str(groups))
+    ctx = make_ctx(sc, w, h, bounces, wire.ACCUM_REF_LDR8, capi.BUILD_REFERENCE_EXACT)
+    ctx.render(frames, 3)
+    assert np.array_equal(ctx.read_accum(), want) and np.array_equal(ctx.read_ldr(), want_ldr)
+    assert np.array_equal(ctx.read_depth(), want_depth)
+    assert ctx.stats()["rays"] == cnt["rays"]
+    # a second render continues the accumulation (frame_count carries over) exactly like the serial path
+    ctx.render(2, 10)
+    monkeypatch.setenv("JPT_GROUPS", "1")
+    solo = make_ctx(sc, w, h, bounces, wire.ACCUM_REF_LDR8, capi.BUILD_REFERENCE_EXACT)
+    solo.render(frames, 3)
+    solo.render(2, 10)
+    assert np.array_equal(ctx.read_accum(), solo.read_accum()) and np.array_equal(ctx.read_ldr(), solo.read_ldr())
+    ctx.close(); solo.close()
