@@ -88,6 +88,13 @@ struct jpt_ctx {
     uint32_t frame_count = 0;  // frames accumulated since reset
     int32_t kernel_variant = JPT_KERNEL_WAVEFRONT;
     DevBuf<char> d_workspace;
+    // render pipelining (jpt_render_async): consecutive asynchronous renders run their path kernels on two helper
+    // streams with two workspaces, so one render's launch tails overlap the next render's kernels; the accumulation
+    // kernels stay on the context's stream, in order
+    DevBuf<char> d_workspace_b;
+    uint64_t async_seq = 0;
+    hipEvent_t ev_paths_done[2] = {nullptr, nullptr}, ev_acc_done[2] = {nullptr, nullptr};
+    bool acc_done_valid[2] = {false, false};
     std::vector<uint32_t> h_qcount;  // per-bounce queue sizes of the last wavefront render
     std::vector<hipEvent_t> trace_events;  // pairs around each wf_trace launch of the last render
     int32_t trace_events_used = 0;
@@ -397,6 +404,7 @@ int do_render_batch(jpt_ctx* c, int32_t n_frames, uint32_t first_frame_index, bo
         }
     }
     HIP_TRY(c, hipEventRecord(c->ev0, s));
+    bool pipelined = false;
     if (c->local_rows > 0 && c->width > 0 && n_frames > 0) {
         FrameParams fp;
         fp.width = c->width;
@@ -420,7 +428,34 @@ int do_render_batch(jpt_ctx* c, int32_t n_frames, uint32_t first_frame_index, bo
             }
             c->trace_events_used = (int32_t)need_ev;
             if (wf2) c->async.last_rays = (c->stats_frames == n_frames) ? (size_t)c->stats.rays : 0;
-            if (wf2)
+            static const bool pipelining = [] {
+                const char* e = getenv("JPT_PIPELINE");
+                return !(e && atoi(e) == 0);
+            }();
+            if (wf2 && pipelining && !blocking && !counted && !need_ev && c->ev_paths_done[1] && c->async.aux_stream[2]) {
+                // asynchronous render: path kernels on a helper stream + the other workspace; the accumulation on `s`
+                const int slot = (int)(c->async_seq & 1u);
+                hipStream_t ps = c->async.aux_stream[1 + slot];
+                DevBuf<char>& ws = slot ? c->d_workspace_b : c->d_workspace;
+                const size_t need = wf2_workspace_bytes(c->width, c->local_rows, n_frames, c->max_bounces);
+                if (ws.n < need) {
+                    HIP_TRY(c, hipStreamSynchronize(s));  // every earlier render ends with a kernel on `s`
+                    HIP_TRY(c, ws.resize(need));
+                    c->acc_done_valid[slot] = false;
+                }
+                // this workspace was last read by the accumulation of the render two renders ago
+                if (c->acc_done_valid[slot]) HIP_TRY(c, hipStreamWaitEvent(ps, c->ev_acc_done[slot], 0));
+                // (one frame group: overlapping with the neighbouring render does what groups do, without extra launches:
+                // 3840x2160x16 spp 11.56 ms against 11.96 with two groups, instanced scene 3.80 against 4.05)
+                Wf2Async one_group = c->async;
+                one_group.aux_stream[0] = nullptr;
+                launch_wf2_render(ps, c->ds, fp, c->camera, ws.p, c->d_accum.p, c->d_ldr.p, c->d_depth.p, nullptr, nullptr, one_group, s,
+                                  c->ev_paths_done[slot]);
+                HIP_TRY(c, hipEventRecord(c->ev_acc_done[slot], s));
+                c->acc_done_valid[slot] = true;
+                c->async_seq++;
+                pipelined = true;
+            } else if (wf2)
                 launch_wf2_render(s, c->ds, fp, c->camera, c->d_workspace.p, c->d_accum.p, c->d_ldr.p, c->d_depth.p, cnt,
                                   need_ev ? c->trace_events.data() : nullptr, c->async);
             else
@@ -444,6 +479,11 @@ int do_render_batch(jpt_ctx* c, int32_t n_frames, uint32_t first_frame_index, bo
         HIP_TRY(c, hipGetLastError());
     }
     HIP_TRY(c, hipEventRecord(c->ev1, s));
+    if (wavefront && !pipelined && c->ev_acc_done[0]) {
+        // a render that went through d_workspace on `s` itself: the next pipelined render into that workspace waits for it
+        HIP_TRY(c, hipEventRecord(c->ev_acc_done[0], s));
+        c->acc_done_valid[0] = true;
+    }
     c->frame_count += (uint32_t)n_frames;
     c->stats.frames = c->frame_count;
     if (blocking || counted) {
@@ -549,6 +589,9 @@ int jpt_create(int device_id, jpt_ctx** out)
     for (int k = 0; k < 3 && ok; k++)
         ok = hipStreamCreateWithFlags(&c->async.aux_stream[k], hipStreamNonBlocking) == hipSuccess &&
              hipEventCreateWithFlags(&c->async.join[k], hipEventDisableTiming) == hipSuccess;
+    for (int k = 0; k < 2 && ok; k++)
+        ok = hipEventCreateWithFlags(&c->ev_paths_done[k], hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&c->ev_acc_done[k], hipEventDisableTiming) == hipSuccess;
     if (!ok) {
         (void)hipGetLastError();
         for (int k = 0; k < 3; k++) {
@@ -584,6 +627,10 @@ void jpt_destroy(jpt_ctx* c)
         if (c->async.join[k]) (void)hipEventDestroy(c->async.join[k]);
     }
     if (c->async.fork) (void)hipEventDestroy(c->async.fork);
+    for (int k = 0; k < 2; k++) {
+        if (c->ev_paths_done[k]) (void)hipEventDestroy(c->ev_paths_done[k]);
+        if (c->ev_acc_done[k]) (void)hipEventDestroy(c->ev_acc_done[k]);
+    }
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }

@@ -143,7 +143,7 @@ struct Wf2Async {
 };
 void launch_wf2_render(hipStream_t stream, const DeviceScene& ds, const FrameParams& fp, const RefCamera& cam, void* workspace,
                        float4* accum, uint32_t* ldr, float* depth, DevCounters* counters, hipEvent_t* trace_events,
-                       const Wf2Async& async);
+                       const Wf2Async& async, hipStream_t acc_stream = nullptr, hipEvent_t paths_done = nullptr);
 
 // one dispatch of temporal_reprojection.glsl over a whole image (jpt_kernels_post.hip): screen rgba8 in/out, depth
 // read-only, hist1 / hist2 the two rgba32f history images

@@ -794,7 +794,7 @@ __global__ void add_queue_counts(uint32_t* __restrict__ dst, const uint32_t* __r
 
 void launch_wf2_render(hipStream_t stream, const DeviceScene& ds, const FrameParams& fp, const RefCamera& cam, void* workspace,
                        float4* accum, uint32_t* ldr, float* depth, DevCounters* counters, hipEvent_t* trace_events,
-                       const Wf2Async& async)
+                       const Wf2Async& async, hipStream_t acc_stream, hipEvent_t paths_done)
 {
     const Wf2Dims dm_all = make_dims(fp.width, fp.local_rows, fp.n_frames);
     if (dm_all.n_chunks == 0) return;
@@ -922,8 +922,16 @@ void launch_wf2_render(hipStream_t stream, const DeviceScene& ds, const FramePar
     Wf2Buffers wb_all = gb[0];
     wb_all.rad = rad_all;
     wb_all.first_depth = first_depth;
+    // the accumulation touches the framebuffers, so it runs where the context's renders are ordered: on acc_stream,
+    // which may differ from the stream the path kernels of this render ran on (render pipelining, jpt_capi.hip)
+    if (acc_stream && acc_stream != stream) {
+        (void)hipEventRecord(paths_done, stream);
+        (void)hipStreamWaitEvent(acc_stream, paths_done, 0);
+    } else {
+        acc_stream = stream;
+    }
     const uint32_t ablocks = (dm_all.slots_per_frame + kBlock - 1) / kBlock;
-    hipLaunchKernelGGL(wf2_accumulate, dim3(ablocks), block, 0, stream, wb_all, dm_all, fp, cam, accum, ldr, depth);
+    hipLaunchKernelGGL(wf2_accumulate, dim3(ablocks), block, 0, acc_stream, wb_all, dm_all, fp, cam, accum, ldr, depth);
 }
 
 }  // namespace jpt

@@ -389,3 +389,33 @@ def test_frame_groups_on_concurrent_streams(oracle, hiplib, monkeypatch, groups)
     solo.render(2, 10)
     assert np.array_equal(ctx.read_accum(), solo.read_accum()) and np.array_equal(ctx.read_ldr(), solo.read_ldr())
     ctx.close(); solo.close()
+
+
+def test_asynchronous_renders_pipeline_in_order(oracle, hiplib):
+    """jpt_render_async: consecutive asynchronous renders run their path kernels on alternating helper streams and
+    workspaces while the accumulation stays in order on the context's stream.  Five queued renders (continuing one
+    accumulation, then a reset, then a blocking render in between) give exactly what the same calls give one by one."""
+    sc = scenes.demo_scene(2500)
+    w, h, bounces = 176, 100, 3
+    cam = scenes.camera_block(sc.camera, w, h)
+    calls = [(2, 1), (1, 3), (3, 4), (2, 7), (1, 9)]
+
+    def run(asynchronous):
+        ctx = make_ctx(sc, w, h, bounces, wire.ACCUM_REF_LDR8, capi.BUILD_REFERENCE_EXACT)
+        outs = []
+        for k, (n, first) in enumerate(calls):
+            if k == 3:
+                ctx.accum_reset()
+            ctx.render(n, first, asynchronous=asynchronous and k != 2)   # call 2 is blocking in both runs
+            if k in (1, 4):
+                outs.append((ctx.read_accum(), ctx.read_ldr(), ctx.read_depth()))
+        ctx.close()
+        return outs
+
+    a, b = run(True), run(False)
+    for (x, y) in zip(a, b):
+        for u, v in zip(x, y):
+            assert np.array_equal(u, v)
+    ref = oracle.build_scene(sc)
+    want, want_ldr, _, _, _ = oracle.render(ref, cam, w, h, bounces, 3, 7, wire.ACCUM_REF_LDR8)   # frames 7, 8, 9 after the reset
+    assert np.array_equal(a[1][0], want) and np.array_equal(a[1][1], want_ldr)
