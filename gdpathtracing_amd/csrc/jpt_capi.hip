@@ -91,10 +91,12 @@ struct jpt_ctx {
     // render pipelining (jpt_render_async): consecutive asynchronous renders run their path kernels on two helper
     // streams with two workspaces, so one render's launch tails overlap the next render's kernels; the accumulation
     // kernels stay on the context's stream, in order
-    DevBuf<char> d_workspace_b;
+    static constexpr int kPipeSlots = 3;
+    DevBuf<char> d_workspace_more[kPipeSlots - 1];  // slot 0 is d_workspace
+    hipStream_t pipe_stream[kPipeSlots] = {};
     uint64_t async_seq = 0;
-    hipEvent_t ev_paths_done[2] = {nullptr, nullptr}, ev_acc_done[2] = {nullptr, nullptr};
-    bool acc_done_valid[2] = {false, false};
+    hipEvent_t ev_paths_done[kPipeSlots] = {}, ev_acc_done[kPipeSlots] = {};
+    bool acc_done_valid[kPipeSlots] = {};
     std::vector<uint32_t> h_qcount;  // per-bounce queue sizes of the last wavefront render
     std::vector<hipEvent_t> trace_events;  // pairs around each wf_trace launch of the last render
     int32_t trace_events_used = 0;
@@ -432,18 +434,23 @@ int do_render_batch(jpt_ctx* c, int32_t n_frames, uint32_t first_frame_index, bo
                 const char* e = getenv("JPT_PIPELINE");
                 return !(e && atoi(e) == 0);
             }();
-            if (wf2 && pipelining && !blocking && !counted && !need_ev && c->ev_paths_done[1] && c->async.aux_stream[2]) {
+            static const int pipe_slots = [] {
+                const char* e = getenv("JPT_PIPE_SLOTS");
+                const int k = e ? atoi(e) : 2;
+                return k < 2 ? 2 : (k > jpt_ctx::kPipeSlots ? jpt_ctx::kPipeSlots : k);
+            }();
+            if (wf2 && pipelining && !blocking && !counted && !need_ev && c->pipe_stream[jpt_ctx::kPipeSlots - 1]) {
                 // asynchronous render: path kernels on a helper stream + the other workspace; the accumulation on `s`
-                const int slot = (int)(c->async_seq & 1u);
-                hipStream_t ps = c->async.aux_stream[1 + slot];
-                DevBuf<char>& ws = slot ? c->d_workspace_b : c->d_workspace;
+                const int slot = (int)(c->async_seq % (uint64_t)pipe_slots);
+                hipStream_t ps = c->pipe_stream[slot];
+                DevBuf<char>& ws = slot ? c->d_workspace_more[slot - 1] : c->d_workspace;
                 const size_t need = wf2_workspace_bytes(c->width, c->local_rows, n_frames, c->max_bounces);
                 if (ws.n < need) {
                     HIP_TRY(c, hipStreamSynchronize(s));  // every earlier render ends with a kernel on `s`
                     HIP_TRY(c, ws.resize(need));
                     c->acc_done_valid[slot] = false;
                 }
-                // this workspace was last read by the accumulation of the render two renders ago
+                // this workspace was last read by the accumulation of the render `pipe_slots` renders ago
                 if (c->acc_done_valid[slot]) HIP_TRY(c, hipStreamWaitEvent(ps, c->ev_acc_done[slot], 0));
                 // (one frame group: overlapping with the neighbouring render does what groups do, without extra launches:
                 // 3840x2160x16 spp 11.56 ms against 11.96 with two groups, instanced scene 3.80 against 4.05)
@@ -589,8 +596,9 @@ int jpt_create(int device_id, jpt_ctx** out)
     for (int k = 0; k < 3 && ok; k++)
         ok = hipStreamCreateWithFlags(&c->async.aux_stream[k], hipStreamNonBlocking) == hipSuccess &&
              hipEventCreateWithFlags(&c->async.join[k], hipEventDisableTiming) == hipSuccess;
-    for (int k = 0; k < 2 && ok; k++)
-        ok = hipEventCreateWithFlags(&c->ev_paths_done[k], hipEventDisableTiming) == hipSuccess &&
+    for (int k = 0; k < jpt_ctx::kPipeSlots && ok; k++)
+        ok = hipStreamCreateWithFlags(&c->pipe_stream[k], hipStreamNonBlocking) == hipSuccess &&
+             hipEventCreateWithFlags(&c->ev_paths_done[k], hipEventDisableTiming) == hipSuccess &&
              hipEventCreateWithFlags(&c->ev_acc_done[k], hipEventDisableTiming) == hipSuccess;
     if (!ok) {
         (void)hipGetLastError();
@@ -599,6 +607,10 @@ int jpt_create(int device_id, jpt_ctx** out)
             if (c->async.join[k]) (void)hipEventDestroy(c->async.join[k]);
             c->async.aux_stream[k] = nullptr;
             c->async.join[k] = nullptr;
+        }
+        for (int k = 0; k < jpt_ctx::kPipeSlots; k++) {
+            if (c->pipe_stream[k]) (void)hipStreamDestroy(c->pipe_stream[k]);
+            c->pipe_stream[k] = nullptr;
         }
     }
     *out = c;
@@ -627,7 +639,11 @@ void jpt_destroy(jpt_ctx* c)
         if (c->async.join[k]) (void)hipEventDestroy(c->async.join[k]);
     }
     if (c->async.fork) (void)hipEventDestroy(c->async.fork);
-    for (int k = 0; k < 2; k++) {
+    for (int k = 0; k < jpt_ctx::kPipeSlots; k++) {
+        if (c->pipe_stream[k]) {
+            (void)hipStreamSynchronize(c->pipe_stream[k]);
+            (void)hipStreamDestroy(c->pipe_stream[k]);
+        }
         if (c->ev_paths_done[k]) (void)hipEventDestroy(c->ev_paths_done[k]);
         if (c->ev_acc_done[k]) (void)hipEventDestroy(c->ev_acc_done[k]);
     }
