@@ -190,6 +190,17 @@ def main():
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
+    verified = None
+    if args.verify and rank == 0:
+        got = ctx.read_ldr() if (world > 1 and args.gather == "ldr") else ctx.read_accum()
+        solo = host.Context(local_rank)
+        solo.build_scene(sc, capi.BUILD_SAH if args.builder == "sah" else capi.BUILD_REFERENCE_EXACT)
+        solo.set_params(W, H, bounces, accum_mode)
+        solo.set_camera(cam)
+        solo.render(spp, 1)
+        verified = bool(np.array_equal(got, solo.read_ldr() if (world > 1 and args.gather == "ldr") else solo.read_accum()))
+        solo.close()
+
     # Duration of the dominant kernel, measured live with HIP events on the stream it is launched on: the library
     # brackets every traversal launch when kernel timing is on, which also makes it run the launches one after
     # another (in the timed region above, the frame groups' launches overlap, so a per-launch duration is not
@@ -205,17 +216,6 @@ def main():
     ctx.set_kernel_timing(False)
     n_trace_launches = (bounces + 1) if args.kernel != "ref" else spp
     kernel_ms = float(np.mean(trace_ms)) / n_trace_launches   # average duration of ONE launch of the dominant kernel
-
-    verified = None
-    if args.verify and rank == 0:
-        got = ctx.read_ldr() if (world > 1 and args.gather == "ldr") else ctx.read_accum()
-        solo = host.Context(local_rank)
-        solo.build_scene(sc, capi.BUILD_SAH if args.builder == "sah" else capi.BUILD_REFERENCE_EXACT)
-        solo.set_params(W, H, bounces, accum_mode)
-        solo.set_camera(cam)
-        solo.render(spp, 1)
-        verified = bool(np.array_equal(got, solo.read_ldr() if (world > 1 and args.gather == "ldr") else solo.read_accum()))
-        solo.close()
 
     if rank == 0:
         n_pixels = W * H
