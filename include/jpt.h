@@ -195,7 +195,10 @@ int jpt_set_camera(jpt_ctx *ctx, const void *camera160);
 int jpt_render(jpt_ctx *ctx, int32_t n_frames, uint32_t first_frame_index);
 /* Same result, kernels compiled with event counters; fills the jpt_stats counter fields. */
 int jpt_render_counted(jpt_ctx *ctx, int32_t n_frames, uint32_t first_frame_index);
-/* Asynchronous form: enqueue on the ctx stream and return; jpt_sync() or a jpt_read_* waits. */
+/* Asynchronous form: enqueue and return; jpt_sync() or a jpt_read_* waits.  Consecutive asynchronous renders are
+ * pipelined: their path kernels run on alternating internal streams with separate workspaces (one render's launch
+ * tails overlap the next render's kernels), the accumulation kernels run in call order on the ctx stream, so the
+ * framebuffers hold exactly what serial execution would leave (C3: 1.82 -> 1.5 ms per render when queued). */
 int jpt_render_async(jpt_ctx *ctx, int32_t n_frames, uint32_t first_frame_index);
 int jpt_sync(jpt_ctx *ctx);
 

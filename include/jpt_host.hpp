@@ -449,6 +449,45 @@ class PathTracingCamera {
     PackedByteArray render()
     {
         if (!ready) return {};                                                      // :195
+        advance_frame();
+        check(ctx, jpt_render(ctx, 1, camera.frame_index), "jpt_render");           // :204 + the post-processing pass
+        PackedByteArray out((size_t)width * height * 4);
+        check(ctx, jpt_read_ldr_rgba8(ctx, out.data()), "jpt_read_ldr_rgba8");      // :228-229
+        return out;
+    }
+
+    // The same frame loop with one frame of latency and no stall: queues this frame (jpt_render_async) and its
+    // read-back into pinned memory, and returns the image of the PREVIOUS call (empty on the first call).  The
+    // reference stalls on get_image_uniform_buffer every frame (:228-229); here the GPU renders frame k while the host
+    // displays frame k-1, and the library overlaps the launches of consecutive queued renders.  flush() returns the
+    // last queued frame.
+    PackedByteArray render_overlapped()
+    {
+        if (!ready) return {};
+        PackedByteArray previous = flush();
+        advance_frame();
+        check(ctx, jpt_render_async(ctx, 1, camera.frame_index), "jpt_render_async");
+        check(ctx, jpt_readback_ldr_begin(ctx), "jpt_readback_ldr_begin");
+        readback_queued = true;
+        return previous;
+    }
+    PackedByteArray flush()
+    {
+        if (!readback_queued) return {};
+        PackedByteArray out((size_t)width * height * 4);
+        check(ctx, jpt_readback_ldr_end(ctx, out.data()), "jpt_readback_ldr_end");
+        readback_queued = false;
+        return out;
+    }
+
+    Camera camera;
+    ProgressiveRendering progressive_renderer;
+    TemporalReprojection temporal_reprojection;
+
+  private:
+    // camera block, frame index and the post-processing mode's host half (path_tracing_camera.cpp:198-225)
+    void advance_frame()
+    {
         camera.set_camera_transform(global_transform, projection_matrix);           // :198
         camera.frame_index++;                                                       // :199
         check(ctx, jpt_set_camera(ctx, &camera), "jpt_set_camera");                 // :200
@@ -469,17 +508,7 @@ class PathTracingCamera {
                 check(ctx, jpt_set_denoising_mode(ctx, JPT_DENOISE_NONE), "jpt_set_denoising_mode");
                 break;
         }
-        check(ctx, jpt_render(ctx, 1, camera.frame_index), "jpt_render");           // :204 + the post-processing pass
-        PackedByteArray out((size_t)width * height * 4);
-        check(ctx, jpt_read_ldr_rgba8(ctx, out.data()), "jpt_read_ldr_rgba8");      // :228-229
-        return out;
     }
-
-    Camera camera;
-    ProgressiveRendering progressive_renderer;
-    TemporalReprojection temporal_reprojection;
-
-  private:
     int create(int device) { return jpt_create(device, &ctx); }
     jpt_ctx* ctx = nullptr;
     GeometryGroup3D* geometry_group = nullptr;
@@ -488,7 +517,7 @@ class PathTracingCamera {
     Denoising denoising_mode = PROGRESSIVE_RENDERING;
     float fov = 90.0f;  // path_tracing_camera.h:80
     int width = 0, height = 0;
-    bool ready = false, temporal_ready = false;
+    bool ready = false, temporal_ready = false, readback_queued = false;
 };
 
 }  // namespace jpt_host

@@ -4,7 +4,7 @@
 // (gdpathtracing_amd/scenes.py -> write_scene_file), results go to <prefix>_*.bin.
 //
 //   host_demo buffers <scene.bin> <prefix>                      host-only context, REFERENCE_EXACT, dumps get_*_buffer()
-//   host_demo render  <scene.bin> <prefix> <w> <h> <frames> <builder> <accum_mode> [denoising_mode]   GPU 0
+//   host_demo render  <scene.bin> <prefix> <w> <h> <frames> <builder> <accum_mode> [denoising_mode] [overlapped]   GPU 0
 //   host_demo moved   <scene.bin> <prefix>                      host-only context, update_transforms()
 #include <jpt_host.hpp>
 
@@ -135,6 +135,7 @@ int main(int argc, char** argv)
             cam.set_global_transform(cam_t);
             cam.camera.frame_index = 0;
             const int denoise = argc >= 10 ? std::atoi(argv[9]) : 0;
+            const bool overlapped = argc >= 11 && std::atoi(argv[10]) != 0;   // render_overlapped(): frame k-1 comes back from call k
             cam.set_denoising_mode(static_cast<PathTracingCamera::Denoising>(denoise));
             cam.init(w, h);
             PackedByteArray screen;
@@ -145,13 +146,14 @@ int main(int argc, char** argv)
                     t.origin.y += 0.01f * (float)f;
                     cam.set_global_transform(t);
                 }
-                screen = cam.render();
+                screen = overlapped ? cam.render_overlapped() : cam.render();
                 if (denoise != 0) {
                     dump(prefix + "_camera_f" + std::to_string(f) + ".bin", &cam.camera, sizeof(Camera));
                     dump(prefix + "_tp_f" + std::to_string(f) + ".bin", &cam.temporal_reprojection.render_parameters,
                          sizeof(TemporalReprojection::RenderParameters));
                 }
             }
+            if (overlapped) screen = cam.flush();   // the last queued frame
             std::vector<float> accum((size_t)w * h * 4);
             if (denoise != 2) check(cam.context(), jpt_read_accum_f32(cam.context(), accum.data()), "jpt_read_accum_f32");
             dump(prefix + "_accum.bin", accum.data(), accum.size() * 4);

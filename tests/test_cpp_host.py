@@ -96,6 +96,26 @@ def test_cpp_path_tracing_camera_renders_like_the_oracle(oracle, host_demo, buil
     assert np.array_equal(got_ldr, want_ldr)
 
 
+@pytest.mark.gpu
+def test_cpp_camera_overlapped_frames(oracle, host_demo):
+    """PathTracingCamera::render_overlapped(): frames queued with jpt_render_async + split read-back, image k-1
+    returned by call k; after flush() the accumulation and the last image equal the stalling loop's."""
+    exe, d = host_demo
+    sc = scenes.cornell_scene()
+    path = os.path.join(d, "c.jpts")
+    scenes.write_scene_file(sc, path)
+    w, h, frames = 96, 64, 5
+    out = subprocess.run([exe, "render", path, os.path.join(d, "ov"), str(w), str(h), str(frames), str(capi.BUILD_REFERENCE_EXACT),
+                          str(wire.ACCUM_REF_LDR8), "0", "1"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    cam = np.frombuffer(open(os.path.join(d, "ov_camera.bin"), "rb").read(), dtype=wire.CAMERA)[0]
+    got = np.frombuffer(open(os.path.join(d, "ov_accum.bin"), "rb").read(), dtype=np.float32).reshape(h, w, 4)
+    got_ldr = np.frombuffer(open(os.path.join(d, "ov_ldr.bin"), "rb").read(), dtype=np.uint8).reshape(h, w, 4)
+    ref = oracle.build_scene(sc)
+    want, want_ldr, _, _, _ = oracle.render(ref, cam, w, h, 4, frames, 1, wire.ACCUM_REF_LDR8)
+    assert np.array_equal(got, want) and np.array_equal(got_ldr, want_ldr)
+
+
 def _check_other_modes(oracle, pre, sc, w, h, frames, denoise):
     """Replays the dumped per-frame Camera blocks (and temporal RenderParameters) through the oracle."""
     ref = oracle.build_scene(sc)
