@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <chrono>
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <new>
@@ -307,6 +308,109 @@ int validate_ref_scene(jpt_ctx* c)
     return JPT_OK;
 }
 
+// Screen rectangles of the boxes the TLAS root offers (SkyCull, jpt_kernels.h).  A primary ray is the half-line from
+// camera.position through ivp * (ndc, 1, 1) (main.glsl:411-420).  The projection used here is the double-precision
+// inverse of that same ivp, and every projected corner is checked to lie on the ray of its own projection; if the
+// camera block does not behave like a pinhole seen from `position` (inconsistent vp / ivp / position, a corner at or
+// behind the camera), culling is off for this render.  Rectangles are widened by two pixels: the jitter stays inside
+// the pixel (main.glsl:183-187) and float rounding of the ray set-up is orders of magnitude below a pixel.
+void compute_sky_cull(const jpt_ctx* c, SkyCull& out)
+{
+    out.n = -1;
+    static const bool enabled = [] {
+        const char* e = getenv("JPT_SKY_CULL");
+        return !(e && atoi(e) == 0);
+    }();
+    if (!enabled || c->width <= 0 || c->height <= 0) return;
+    // the boxes: children of the TLAS root record in the layout the kernels walk
+    double lo[4][3], hi[4][3];
+    int n = 0;
+    const WideScene& w = c->wide;
+    const bool use4 = !c->ref_is_exact && c->native_tree;
+    if (w.instances.empty()) return;
+    if (use4) {
+        if (w.tlas_root4 < 0 || (size_t)w.tlas_root4 >= w.tlas_nodes4.size()) return;  // the root is a single instance
+        const WideNode4& r = w.tlas_nodes4[(size_t)w.tlas_root4];
+        for (int k = 0; k < 4; k++)
+            if (r.child[k] != kEmptyChild) {
+                lo[n][0] = r.lo_x[k]; lo[n][1] = r.lo_y[k]; lo[n][2] = r.lo_z[k];
+                hi[n][0] = r.hi_x[k]; hi[n][1] = r.hi_y[k]; hi[n][2] = r.hi_z[k];
+                n++;
+            }
+    } else {
+        if (w.tlas_root < 0 || (size_t)w.tlas_root >= w.tlas_nodes.size()) return;
+        const WideNode& r = w.tlas_nodes[(size_t)w.tlas_root];
+        if (r.left == w.tlas_root && r.right == w.tlas_root) return;
+        for (int k = 0; k < 3; k++) {
+            lo[0][k] = r.lmin[k]; hi[0][k] = r.lmax[k];
+            lo[1][k] = r.rmin[k]; hi[1][k] = r.rmax[k];
+        }
+        n = 2;
+    }
+    // vp' = inverse of ivp (column-major), in double
+    double a[4][8];
+    for (int r = 0; r < 4; r++)
+        for (int col = 0; col < 4; col++) {
+            a[r][col] = (double)c->camera.ivp[col * 4 + r];
+            a[r][4 + col] = r == col ? 1.0 : 0.0;
+        }
+    for (int col = 0; col < 4; col++) {
+        int piv = col;
+        for (int r = col + 1; r < 4; r++)
+            if (std::fabs(a[r][col]) > std::fabs(a[piv][col])) piv = r;
+        if (!(std::fabs(a[piv][col]) > 0.0) || !std::isfinite(a[piv][col])) return;
+        if (piv != col)
+            for (int k = 0; k < 8; k++) std::swap(a[piv][k], a[col][k]);
+        const double d = a[col][col];
+        for (int k = 0; k < 8; k++) a[col][k] /= d;
+        for (int r = 0; r < 4; r++)
+            if (r != col) {
+                const double f = a[r][col];
+                for (int k = 0; k < 8; k++) a[r][k] -= f * a[col][k];
+            }
+    }
+    auto vp = [&](int r, int col) { return a[r][4 + col]; };
+    const double O[3] = {(double)c->camera.position.x, (double)c->camera.position.y, (double)c->camera.position.z};
+    const double W = (double)c->width, H = (double)c->height;
+    for (int b = 0; b < n; b++) {
+        double x0 = 1e300, y0 = 1e300, x1 = -1e300, y1 = -1e300;
+        for (int corner = 0; corner < 8; corner++) {
+            const double C[3] = {(corner & 1) ? hi[b][0] : lo[b][0], (corner & 2) ? hi[b][1] : lo[b][1], (corner & 4) ? hi[b][2] : lo[b][2]};
+            if (!std::isfinite(C[0]) || !std::isfinite(C[1]) || !std::isfinite(C[2])) return;
+            double clip[4];
+            for (int r = 0; r < 4; r++) clip[r] = vp(r, 0) * C[0] + vp(r, 1) * C[1] + vp(r, 2) * C[2] + vp(r, 3);
+            if (!(std::fabs(clip[3]) > 1e-12)) return;
+            const double nx = clip[0] / clip[3], ny = clip[1] / clip[3];
+            if (!std::isfinite(nx) || !std::isfinite(ny) || std::fabs(nx) > 1e6 || std::fabs(ny) > 1e6) return;
+            // the ray of that projection, as the kernel builds it: from O through F = ivp * (nx, ny, 1, 1) / w
+            double F[4];
+            for (int r = 0; r < 4; r++)
+                F[r] = (double)c->camera.ivp[0 * 4 + r] * nx + (double)c->camera.ivp[1 * 4 + r] * ny + (double)c->camera.ivp[2 * 4 + r] +
+                       (double)c->camera.ivp[3 * 4 + r];
+            if (!(std::fabs(F[3]) > 1e-300)) return;
+            const double D[3] = {F[0] / F[3] - O[0], F[1] / F[3] - O[1], F[2] / F[3] - O[2]};
+            const double V[3] = {C[0] - O[0], C[1] - O[1], C[2] - O[2]};
+            const double dd = D[0] * D[0] + D[1] * D[1] + D[2] * D[2], vv = V[0] * V[0] + V[1] * V[1] + V[2] * V[2];
+            const double dv = D[0] * V[0] + D[1] * V[1] + D[2] * V[2];
+            if (!(dd > 0.0) || !(vv > 0.0) || !(dv > 0.0)) return;  // corner at / behind the camera, or a degenerate ray
+            // distance of the corner from that ray, relative to its distance from the camera
+            const double cross2 = vv - dv * dv / dd;
+            if (!(cross2 <= 1e-8 * vv)) return;  // the block is not a pinhole seen from `position`
+            const double px = (nx + 1.0) * 0.5 * W, py = (1.0 - ny) * 0.5 * H;  // main.glsl:411-412 inverted
+            x0 = std::min(x0, px); x1 = std::max(x1, px);
+            y0 = std::min(y0, py); y1 = std::max(y1, py);
+        }
+        const double margin = 2.0;
+        auto clampi = [](double v) { return (int32_t)std::max(-1.0e9, std::min(1.0e9, v)); };
+        out.x0[b] = clampi(std::floor(x0 - margin));
+        out.y0[b] = clampi(std::floor(y0 - margin));
+        out.x1[b] = clampi(std::ceil(x1 + margin));
+        out.y1[b] = clampi(std::ceil(y1 + margin));
+    }
+    for (int b = n; b < 4; b++) out.x0[b] = out.y0[b] = 1, out.x1[b] = out.y1[b] = 0;
+    out.n = n;
+}
+
 int do_render_batch(jpt_ctx* c, int32_t n_frames, uint32_t first_frame_index, bool counted, bool blocking);
 
 // frames of one wavefront render that fit the workspace budget (all frames of a batch are in flight at once)
@@ -430,6 +534,7 @@ int do_render_batch(jpt_ctx* c, int32_t n_frames, uint32_t first_frame_index, bo
             }
             c->trace_events_used = (int32_t)need_ev;
             if (wf2) c->async.last_rays = (c->stats_frames == n_frames) ? (size_t)c->stats.rays : 0;
+            if (wf2) compute_sky_cull(c, c->async.cull);
             static const bool pipelining = [] {
                 const char* e = getenv("JPT_PIPELINE");
                 return !(e && atoi(e) == 0);

@@ -135,11 +135,20 @@ void launch_wide_render(hipStream_t stream, const DeviceScene& ds, const FramePa
 uint32_t wf2_segments();
 uint32_t trace_stack_capacity();  // entries a lane's traversal stack can hold (LDS + scratch)
 size_t wf2_workspace_bytes(int width, int local_rows, int n_frames, int max_bounces);
+// Screen rectangles (pixels, inclusive) of the boxes the TLAS root offers a ray; a primary ray through a pixel
+// outside all of them is known to fail all of the root's box tests, i.e. to reach the sky after exactly one TLAS
+// expansion, without being traced.  n < 0: unknown, trace everything.  Filled on the host (jpt_capi.hip).
+struct SkyCull {
+    int32_t n = -1;
+    int32_t x0[4], y0[4], x1[4], y1[4];
+};
+
 // helper streams / events for running frame groups concurrently (all null: serial); owned by the context
 struct Wf2Async {
     hipStream_t aux_stream[3] = {nullptr, nullptr, nullptr};
     hipEvent_t fork = nullptr, join[3] = {nullptr, nullptr, nullptr};
     size_t last_rays = 0;  // ray segments of this context's previous render of the same size (0: unknown)
+    SkyCull cull;          // for the primary launch of this render
 };
 void launch_wf2_render(hipStream_t stream, const DeviceScene& ds, const FrameParams& fp, const RefCamera& cam, void* workspace,
                        float4* accum, uint32_t* ldr, float* depth, DevCounters* counters, hipEvent_t* trace_events,

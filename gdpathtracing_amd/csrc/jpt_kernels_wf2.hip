@@ -118,7 +118,7 @@ __device__ __forceinline__ uint32_t lanes_below(unsigned long long mask, int lan
 
 template <bool COUNT, bool W4>
 __global__ __launch_bounds__(kBlock, JPT_PRIMARY_WAVES) void wf2_primary(WideSceneDev sc, Wf2Buffers wb, Wf2Dims dm, FrameParams fp, RefCamera cam,
-                                                      WfTune tune, DevCounters* __restrict__ counters)
+                                                      WfTune tune, SkyCull cull, DevCounters* __restrict__ counters)
 {
     __shared__ int32_t stack[kStackLds * kBlock];
     __shared__ uint32_t s_cursor, s_out;
@@ -161,9 +161,21 @@ __global__ __launch_bounds__(kBlock, JPT_PRIMARY_WAVES) void wf2_primary(WideSce
                         uint32_t sx, sy;
                         const Ray ray = primary_ray(cam, fp.width, fp.height, px, py, fp.frame_index + f, sx, sy);
                         path = f * dm.slots_per_frame + slot;
-                        tr.begin(sc, ray.o, ray.d);
-                        active = true;
                         if (COUNT) cnt.rays++;
+                        // a pixel outside the screen rectangles of all the boxes the TLAS root offers: the walk would
+                        // expand the root, fail every box test and end -- the result is written here instead
+                        bool outside = cull.n >= 0;
+                        for (int k = 0; k < 4; k++)
+                            if (k < cull.n && px >= cull.x0[k] && px <= cull.x1[k] && py >= cull.y0[k] && py <= cull.y1[k]) outside = false;
+                        if (outside) {
+                            if (COUNT) cnt.tlas_expand++;
+                            const f3 sky = mk3(0.0f, 0.0f, 0.0f) + mk3(1.0f, 1.0f, 1.0f) * sample_sky(ray.d);
+                            wb.rad[path] = make_float4(sky.x, sky.y, sky.z, 0.0f);
+                            if ((int)f == fp.depth_frame) wb.first_depth[slot] = cam.far_;
+                        } else {
+                            tr.begin(sc, ray.o, ray.d);
+                            active = true;
+                        }
                     }
                 }
             }
@@ -870,11 +882,11 @@ void launch_wf2_render(hipStream_t stream, const DeviceScene& ds, const FramePar
         const dim3 sgrid((dm.seg_cap + kBlock - 1) / kBlock, kSegments);
         if (ev) (void)hipEventRecord(ev[0], st);
         if (counters) {
-            if (w4) hipLaunchKernelGGL((wf2_primary<true, true>), grid, block, 0, st, sc, wb, dm, gp, cam, tune, counters);
-            else hipLaunchKernelGGL((wf2_primary<true, false>), grid, block, 0, st, sc, wb, dm, gp, cam, tune, counters);
+            if (w4) hipLaunchKernelGGL((wf2_primary<true, true>), grid, block, 0, st, sc, wb, dm, gp, cam, tune, async.cull, counters);
+            else hipLaunchKernelGGL((wf2_primary<true, false>), grid, block, 0, st, sc, wb, dm, gp, cam, tune, async.cull, counters);
         } else {
-            if (w4) hipLaunchKernelGGL((wf2_primary<false, true>), grid, block, 0, st, sc, wb, dm, gp, cam, tune, counters);
-            else hipLaunchKernelGGL((wf2_primary<false, false>), grid, block, 0, st, sc, wb, dm, gp, cam, tune, counters);
+            if (w4) hipLaunchKernelGGL((wf2_primary<false, true>), grid, block, 0, st, sc, wb, dm, gp, cam, tune, async.cull, counters);
+            else hipLaunchKernelGGL((wf2_primary<false, false>), grid, block, 0, st, sc, wb, dm, gp, cam, tune, async.cull, counters);
         }
         if (ev) (void)hipEventRecord(ev[1], st);
         for (int b = 0; b <= gp.max_bounces; b++) {

@@ -139,3 +139,53 @@ def test_reference_tlas_update_route(oracle, hiplib):
         ctx.close()
     want, want_ldr, _, _, _ = oracle.render(r1, cam, w, h, 3, 2, 5, wire.ACCUM_REF_LDR8)
     assert np.array_equal(got, want) and np.array_equal(got_ldr, want_ldr)
+
+
+# ---- primary rays that cannot reach any root box are not traced (SkyCull) ------------------------------------------
+
+def _look_at(eye, target, up=(0.0, 1.0, 0.0)):
+    eye, target, up = (np.asarray(v, dtype=np.float64) for v in (eye, target, up))
+    z = eye - target
+    z /= np.linalg.norm(z)                      # godot cameras look down -Z
+    x = np.cross(up, z); x /= np.linalg.norm(x)
+    y = np.cross(z, x)
+    return scenes.transform12(np.stack([x, y, z], axis=1), eye)   # basis columns = camera axes
+
+
+@pytest.mark.parametrize("builder", [capi.BUILD_REFERENCE_EXACT, capi.BUILD_SAH])
+@pytest.mark.parametrize("view", ["demo", "tilted", "grazing", "inside", "behind", "far", "narrow"])
+def test_sky_cull_is_exact(oracle, hiplib, view, builder):
+    """The host projects the TLAS root's boxes to screen rectangles and the primary kernel skips the walk for pixels
+    outside all of them.  Whatever the camera does -- rolled, grazing a box, inside the scene (culling must switch
+    itself off), looking away, far away, narrow lens -- image, depth and all event counters equal the oracle's."""
+    sc = scenes.demo_scene(1500)
+    cams = {
+        "demo": sc.camera,
+        "tilted": scenes.CameraDesc(_look_at((6.0, 4.0, 7.0), (0.5, -0.5, 0.0), up=(0.3, 1.0, 0.1)), fov_deg=60.0),
+        "grazing": scenes.CameraDesc(_look_at((3.3, 0.0, 6.0), (3.3, 0.0, -6.0)), fov_deg=50.0),
+        "inside": scenes.CameraDesc(scenes.transform12(None, (0.0, 0.0, 1.0)), fov_deg=90.0),
+        "behind": scenes.CameraDesc(_look_at((0.0, 0.0, 9.0), (0.0, 0.0, 20.0)), fov_deg=79.5),
+        "far": scenes.CameraDesc(scenes.transform12(None, (0.0, 0.0, 60.0)), fov_deg=30.0),
+        "narrow": scenes.CameraDesc(_look_at((8.0, 1.0, 8.0), (2.9, 2.0, 0.0)), fov_deg=8.0),
+    }
+    sc.camera = cams[view]
+    w, h, bounces, frames = 168, 96, 2, 2
+    cam = scenes.camera_block(sc.camera, w, h)
+    ref = oracle.build_scene(sc)
+    want, want_ldr, want_depth, cnt, _ = oracle.render(ref, cam, w, h, bounces, frames, 1, wire.ACCUM_HDR_F32)
+    ctx = host.Context(0)
+    try:
+        ctx.build_scene(sc, builder)
+        ctx.set_params(w, h, bounces, wire.ACCUM_HDR_F32)
+        ctx.set_camera(cam)
+        ctx.render(frames, 1, counted=True)
+        got, got_ldr, got_depth, st = ctx.read_accum(), ctx.read_ldr(), ctx.read_depth(), ctx.stats()
+    finally:
+        ctx.close()
+    assert st["rays"] == cnt["rays"]
+    if builder == capi.BUILD_REFERENCE_EXACT:
+        assert np.array_equal(got, want) and np.array_equal(got_ldr, want_ldr) and np.array_equal(got_depth, want_depth)
+        for k in ("blas_expand", "tri_tests", "tlas_expand", "inst_visits", "shaded_hits"):
+            assert st[k] == cnt[k], k
+    else:
+        assert rel_l2(got, want) <= 1e-4 and np.array_equal(got_depth == np.float32(want_depth.max()), want_depth == want_depth.max())
