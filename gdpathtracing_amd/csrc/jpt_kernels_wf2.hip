@@ -15,7 +15,10 @@
 //
 // Tracing kernels keep every lane busy: a lane whose ray is finished takes the next ray of the block's
 // segment (cursor in LDS) while its neighbours keep walking -- the wave never waits for its slowest ray.
-// Per-lane traversal stacks live in LDS (24 entries x 256 lanes, deeper levels spill to scratch).
+// Per-lane traversal stacks live in LDS (20 entries x 256 lanes, deeper levels spill to scratch).
+//
+// launch_wf2_render runs one render: a blocking render of many paths splits its frames into two groups that run
+// this pipeline concurrently on two streams; asynchronous renders are pipelined one level up (jpt_capi.hip).
 #include <cstdlib>
 
 #include "jpt_trace_core.h"
@@ -265,318 +268,6 @@ __global__ __launch_bounds__(kBlock, JPT_WAVES_PER_SIMD) void wf2_trace(WideScen
     if (COUNT) flush_counters(cnt, counters);
 }
 
-// ---- experimental: bounces >= 1 with a per-wave ray pool in LDS (JPT_TRACE_POOL=1) ---------------------------
-//
-// wf2_trace keeps one ray per lane in registers, so a turn of the node / triangle / instance code only serves the
-// lanes that happen to be in that state (28 / 13 / 18 of 64 on the demo scene).  Here a wave owns a pool of 128
-// rays whose state lives in LDS; every round it sorts the pool by state (ballot + prefix popcount into index
-// lists) and runs each state as dense 64-wide passes over its list.  One record per ray per round; every ray still
-// sees its own records in its own order, so results are unchanged.
-
-constexpr int kPoolRays = 128;
-constexpr int kPoolStack = 16;
-constexpr int kPoolMaxSegs = 8;            // segments one pool block may chain (grid >= kSegments / 8)
-enum : uint32_t { PS_EMPTY = 0, PS_NODE = 1, PS_LEAF = 2, PS_INST = 3, PS_EXIT = 4, PS_DONE = 5 };
-
-struct WavePool {
-    float ox[kPoolRays], oy[kPoolRays], oz[kPoolRays], dx[kPoolRays], dy[kPoolRays], dz[kPoolRays];
-    float rx[kPoolRays], ry[kPoolRays], rz[kPoolRays];
-    float t[kPoolRays], u[kPoolRays], v[kPoolRays];
-    uint32_t tri[kPoolRays], meta[kPoolRays];  // meta: best hit's instance id | front << 30
-    uint32_t level[kPoolRays];                 // instance being walked | in_blas << 31
-    uint32_t qidx[kPoolRays], state[kPoolRays];
-    int32_t cur[kPoolRays], sp[kPoolRays];
-    int32_t stack[kPoolStack][kPoolRays];
-    uint16_t list[4][kPoolRays];
-};
-
-__device__ __forceinline__ void wave_lds_sync()
-{
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-// after a record: take the next one off the ray's stack and classify it
-template <bool COUNT, bool W4>
-__device__ __forceinline__ void pool_advance(WavePool& P, int slot, Traversal<COUNT, W4>& tr,
-                                             const typename Traversal<COUNT, W4>::Stack& st)
-{
-    uint32_t state;
-    if (!tr.have) {
-        if (tr.sp == 0) {
-            state = PS_DONE;
-        } else {
-            const int32_t e = tr.pop(st);
-            if (e == kSentinel) {
-                state = PS_EXIT;
-            } else {
-                tr.cur = e;
-                tr.have = true;
-                state = tr.cur >= 0 ? PS_NODE : (tr.in_blas ? PS_LEAF : PS_INST);
-            }
-        }
-    } else {
-        state = tr.cur >= 0 ? PS_NODE : (tr.in_blas ? PS_LEAF : PS_INST);
-    }
-    P.cur[slot] = tr.cur;
-    P.sp[slot] = tr.sp;
-    P.state[slot] = state;
-}
-
-template <bool COUNT, bool W4>
-__global__ __launch_bounds__(kBlock, 2) void wf3_trace(WideSceneDev sc, Wf2Buffers wb, Wf2Dims dm, int bounce, WfTune tune,
-                                                       int32_t* __restrict__ spill_all, DevCounters* __restrict__ counters)
-{
-    __shared__ WavePool pools[kBlock / 64];
-    __shared__ uint32_t s_cursor;
-    __shared__ uint32_t s_prefix[kPoolMaxSegs + 1];  // this block's segments, flattened into one index space
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    // block b walks segments b, b + gridDim.x, ... as ONE stream of rays, so its pools stay full until the end
-    if (threadIdx.x == 0) {
-        s_cursor = 0;
-        uint32_t tot = 0;
-        int k = 0;
-        for (uint32_t sg = blockIdx.x; sg < kSegments && k < kPoolMaxSegs; sg += gridDim.x, k++) {
-            s_prefix[k] = tot;
-            tot += wb.qcount[(size_t)bounce * kSegments + sg];
-        }
-        for (; k <= kPoolMaxSegs; k++) s_prefix[k] = tot;
-    }
-    __syncthreads();
-    const uint32_t n = s_prefix[kPoolMaxSegs];
-    if (n == 0) return;
-    WavePool& P = pools[wave];
-    const float4* __restrict__ qo = wb.ray_o[bounce & 1];
-    const float4* __restrict__ qd = wb.ray_d[bounce & 1];
-    // flattened index -> position in the queue arrays
-    auto locate = [&](uint32_t g) -> uint32_t {
-        int k = 0;
-#pragma unroll
-        for (int j = 1; j < kPoolMaxSegs; j++) k += (g >= s_prefix[j]) ? 1 : 0;
-        const uint32_t sg = blockIdx.x + (uint32_t)k * gridDim.x;
-        return sg * dm.seg_cap + (g - s_prefix[k]);
-    };
-    int32_t* const spill_wave = spill_all + ((size_t)blockIdx.x * (kBlock / 64) + wave) * kPoolRays * kStackSpill;
-    using Tr = Traversal<COUNT, W4>;
-    auto stack_of = [&](int slot) { return typename Tr::Stack{&P.stack[0][slot], spill_wave + (size_t)slot * kStackSpill, kPoolRays, kPoolStack}; };
-    DevCounters cnt = {};
-    P.state[lane] = PS_EMPTY;
-    P.state[lane + 64] = PS_EMPTY;
-    wave_lds_sync();
-    bool exhausted = false;
-
-    for (;;) {
-        // ---- retire finished rays, count free slots
-        bool free_h[2];
-#pragma unroll
-        for (int h = 0; h < 2; h++) {
-            const int slot = lane + 64 * h;
-            uint32_t st = P.state[slot];
-            if (st == PS_DONE) {
-                const uint32_t q = P.qidx[slot], meta = P.meta[slot];
-                wb.hit_a[q] = make_float4(P.t[slot], P.u[slot], P.v[slot], __uint_as_float(P.tri[slot]));
-                wb.hit_b[q] = (meta & 0x00ffffffu) | ((meta & 0x40000000u) ? 0x80000000u : 0u);
-                st = PS_EMPTY;
-                P.state[slot] = PS_EMPTY;
-            }
-            free_h[h] = st == PS_EMPTY;
-        }
-        const unsigned long long f0 = __ballot(free_h[0]), f1 = __ballot(free_h[1]);
-        const int n_free = __popcll(f0) + __popcll(f1);
-        // ---- refill
-        if (!exhausted && n_free >= tune.refill_idle) {
-            uint32_t start = 0;
-            if (lane == 0) start = atomicAdd(&s_cursor, (uint32_t)n_free);
-            start = (uint32_t)__builtin_amdgcn_readfirstlane((int)start);
-            if (start + (uint32_t)n_free >= n) exhausted = true;
-#pragma unroll
-            for (int h = 0; h < 2; h++) {
-                const int slot = lane + 64 * h;
-                const uint32_t idx = start + (h ? (uint32_t)__popcll(f0) + lanes_below(f1, lane) : lanes_below(f0, lane));
-                if (free_h[h] && idx < n) {
-                    const uint32_t qpos = locate(idx);
-                    const float4 ro = qo[qpos], rd = qd[qpos];
-                    const f3 d = mk3(rd.x, rd.y, rd.z), r = rcp3(d);
-                    P.ox[slot] = ro.x; P.oy[slot] = ro.y; P.oz[slot] = ro.z;
-                    P.dx[slot] = d.x; P.dy[slot] = d.y; P.dz[slot] = d.z;
-                    P.rx[slot] = r.x; P.ry[slot] = r.y; P.rz[slot] = r.z;
-                    P.t[slot] = 1e9f;  // main.glsl:354
-                    P.u[slot] = 0.0f; P.v[slot] = 0.0f;
-                    P.tri[slot] = 0;
-                    P.meta[slot] = 0;
-                    P.level[slot] = 0;
-                    P.qidx[slot] = qpos;
-                    P.cur[slot] = sc.tlas_root;
-                    P.sp[slot] = 0;
-                    P.state[slot] = sc.n_instances == 0 ? PS_DONE : (sc.tlas_root >= 0 ? PS_NODE : PS_INST);
-                    free_h[h] = false;
-                }
-            }
-        }
-        wave_lds_sync();
-        // ---- sort the pool by state
-        int count[4] = {0, 0, 0, 0};
-#pragma unroll
-        for (int h = 0; h < 2; h++) {
-            const int slot = lane + 64 * h;
-            const uint32_t st = P.state[slot];
-#pragma unroll
-            for (int c = 0; c < 4; c++) {
-                const bool mine = st == (uint32_t)(PS_NODE + c);
-                const unsigned long long m = __ballot(mine);
-                if (mine) P.list[c][count[c] + (int)lanes_below(m, lane)] = (uint16_t)slot;
-                count[c] += __popcll(m);
-            }
-        }
-        const int busy = count[0] + count[1] + count[2] + count[3];
-        if (busy == 0) {
-            const int done_now = __popcll(__ballot(P.state[lane] == PS_DONE)) + __popcll(__ballot(P.state[lane + 64] == PS_DONE));
-            if (done_now == 0 && exhausted) break;
-            continue;
-        }
-        wave_lds_sync();
-        if (COUNT && lane == 0) cnt.phase[0]++;
-        // the states with few waiting rays are held back while the node list is long enough to fill a pass
-        const bool starving = count[0] < 32;
-
-        // ---- internal records: two list entries per lane per pass (their fetches overlap); a remainder of fewer
-        // than half a wave stays in the list for the next round unless the wave has little else to do
-        if (count[0] > 0) {
-            int todo = count[0];
-            if (todo > 64 && (todo & 63) < 32 && !starving) todo &= ~63;
-            for (int base = 0; base < todo; base += 128) {
-                const int i0 = base + lane, i1 = base + 64 + lane;
-                const bool a0 = i0 < todo, a1 = i1 < todo;
-                if (COUNT && lane == 0) {
-                    const int n0 = todo - base < 64 ? todo - base : 64;
-                    cnt.phase[1]++;
-                    cnt.phase[2] += (unsigned long long)n0;
-                    if (todo - base > 64) {
-                        cnt.phase[1]++;
-                        cnt.phase[2] += (unsigned long long)(todo - base - 64 < 64 ? todo - base - 64 : 64);
-                    }
-                }
-                const int s0 = a0 ? P.list[0][i0] : 0, s1 = a1 ? P.list[0][i1] : 0;
-                Tr t0, t1;
-                t0.have = t1.have = true;
-                if (a0) {
-                    t0.o = mk3(P.ox[s0], P.oy[s0], P.oz[s0]);
-                    t0.rD = mk3(P.rx[s0], P.ry[s0], P.rz[s0]);
-                    t0.hit.t = P.t[s0];
-                    t0.cur = P.cur[s0];
-                    t0.sp = P.sp[s0];
-                    t0.in_blas = (P.level[s0] >> 31) != 0u;
-                }
-                if (a1) {
-                    t1.o = mk3(P.ox[s1], P.oy[s1], P.oz[s1]);
-                    t1.rD = mk3(P.rx[s1], P.ry[s1], P.rz[s1]);
-                    t1.hit.t = P.t[s1];
-                    t1.cur = P.cur[s1];
-                    t1.sp = P.sp[s1];
-                    t1.in_blas = (P.level[s1] >> 31) != 0u;
-                }
-                typename Tr::NodeData n0, n1;
-                if (a0) n0 = t0.node_fetch(sc);
-                if (a1) n1 = t1.node_fetch(sc);
-                if (a0) {
-                    const typename Tr::Stack st = stack_of(s0);
-                    t0.node_apply(n0, st, cnt);
-                    pool_advance<COUNT, W4>(P, s0, t0, st);
-                }
-                if (a1) {
-                    const typename Tr::Stack st = stack_of(s1);
-                    t1.node_apply(n1, st, cnt);
-                    pool_advance<COUNT, W4>(P, s1, t1, st);
-                }
-            }
-        }
-        // ---- triangles: one per ray per round
-        if (count[1] > 0 && (count[1] >= tune.node_min_lanes || starving)) {
-            for (int base = 0; base < count[1]; base += 64) {
-                const int i = base + lane;
-                if (COUNT && lane == 0) {
-                    cnt.phase[3]++;
-                    cnt.phase[4] += (unsigned long long)(count[1] - base < 64 ? count[1] - base : 64);
-                }
-                if (i < count[1]) {
-                    const int slot = P.list[1][i];
-                    Tr tr;
-                    tr.o = mk3(P.ox[slot], P.oy[slot], P.oz[slot]);
-                    tr.d = mk3(P.dx[slot], P.dy[slot], P.dz[slot]);
-                    tr.hit.t = P.t[slot];
-                    tr.hit.tri = 0xffffffffu;
-                    tr.cur = P.cur[slot];
-                    tr.sp = P.sp[slot];
-                    tr.cur_inst = P.level[slot] & 0x00ffffffu;
-                    tr.in_blas = true;
-                    tr.have = true;
-                    tr.leaf_one(sc, cnt);
-                    if (tr.hit.tri != 0xffffffffu) {  // accepted (also on an exact tie, like main.glsl:247)
-                        P.t[slot] = tr.hit.t;
-                        P.u[slot] = tr.hit.u;
-                        P.v[slot] = tr.hit.v;
-                        P.tri[slot] = tr.hit.tri;
-                        P.meta[slot] = tr.cur_inst | (tr.hit.front ? 0x40000000u : 0u);
-                    }
-                    pool_advance<COUNT, W4>(P, slot, tr, stack_of(slot));
-                }
-            }
-        }
-        // ---- instance entries
-        if (count[2] > 0 && (count[2] >= tune.node_min_lanes || starving)) {
-            for (int base = 0; base < count[2]; base += 64) {
-                const int i = base + lane;
-                if (COUNT && lane == 0) {
-                    cnt.phase[5]++;
-                    cnt.phase[6] += (unsigned long long)(count[2] - base < 64 ? count[2] - base : 64);
-                }
-                if (i < count[2]) {
-                    const int slot = P.list[2][i];
-                    Tr tr;
-                    tr.wo = mk3(P.ox[slot], P.oy[slot], P.oz[slot]);  // at the TLAS level the pool holds the world ray
-                    tr.wd = mk3(P.dx[slot], P.dy[slot], P.dz[slot]);
-                    tr.cur = P.cur[slot];
-                    tr.sp = P.sp[slot];
-                    tr.in_blas = false;
-                    tr.have = true;
-                    const typename Tr::Stack st = stack_of(slot);
-                    tr.instance_step(sc, st, cnt);
-                    P.ox[slot] = tr.o.x; P.oy[slot] = tr.o.y; P.oz[slot] = tr.o.z;
-                    P.dx[slot] = tr.d.x; P.dy[slot] = tr.d.y; P.dz[slot] = tr.d.z;
-                    P.rx[slot] = tr.rD.x; P.ry[slot] = tr.rD.y; P.rz[slot] = tr.rD.z;
-                    P.level[slot] = 0x80000000u | tr.cur_inst;
-                    pool_advance<COUNT, W4>(P, slot, tr, st);
-                }
-            }
-        }
-        // ---- leaving an instance: the world ray comes back from the queue
-        if (count[3] > 0) {
-            for (int base = 0; base < count[3]; base += 64) {
-                const int i = base + lane;
-                if (i < count[3]) {
-                    const int slot = P.list[3][i];
-                    const uint32_t q = P.qidx[slot];
-                    const float4 ro = qo[q], rd = qd[q];
-                    const f3 d = mk3(rd.x, rd.y, rd.z), r = rcp3(d);
-                    P.ox[slot] = ro.x; P.oy[slot] = ro.y; P.oz[slot] = ro.z;
-                    P.dx[slot] = d.x; P.dy[slot] = d.y; P.dz[slot] = d.z;
-                    P.rx[slot] = r.x; P.ry[slot] = r.y; P.rz[slot] = r.z;
-                    P.level[slot] = 0u;
-                    Tr tr;
-                    tr.cur = 0;
-                    tr.sp = P.sp[slot];
-                    tr.in_blas = false;
-                    tr.have = false;
-                    pool_advance<COUNT, W4>(P, slot, tr, stack_of(slot));
-                }
-            }
-        }
-        wave_lds_sync();
-    }
-    if (COUNT) flush_counters(cnt, counters);
-}
-
 // ---- shading: one path vertex per queue entry (main.glsl:378-397) -------------------------------------------
 
 #ifndef JPT_SHADE_WAVES
@@ -724,16 +415,6 @@ Wf2Dims make_dims(int width, int local_rows, int n_frames)
 
 }  // namespace
 
-static bool pool_enabled()
-{
-    static const bool on = [] {
-        const char* e = getenv("JPT_TRACE_POOL");
-        return e && atoi(e) != 0;
-    }();
-    return on;
-}
-static size_t pool_spill_bytes() { return pool_enabled() ? (size_t)512 * (kBlock / 64) * kPoolRays * kStackSpill * sizeof(int32_t) : 0; }
-
 uint32_t wf2_segments() { return kSegments; }
 uint32_t trace_stack_capacity() { return (uint32_t)(kStackLds + kStackSpill); }
 
@@ -756,7 +437,7 @@ static int frame_groups(int n_frames, bool serial, size_t paths, size_t last_ray
         const int g = e ? atoi(e) : 0;
         return g < 0 ? 0 : (g > kMaxGroups ? kMaxGroups : g);
     }();
-    if (serial || pool_enabled() || n_frames < 2) return 1;
+    if (serial || n_frames < 2) return 1;
     // (a render of fewer paths that traced many segments last time -- every pixel on geometry -- qualifies too)
     const int wanted = forced ? forced : ((paths >= ((size_t)24 << 20) || last_rays >= ((size_t)24 << 20)) ? 2 : 1);
     return n_frames < wanted ? n_frames : wanted;
@@ -790,7 +471,6 @@ size_t wf2_workspace_bytes(int width, int local_rows, int n_frames, int max_boun
         const Wf2Dims all = make_dims(width, local_rows, n_frames);
         b += (size_t)all.slots_per_frame * (size_t)n_frames * sizeof(float4) + 256;  // rad: [frame][slot], shared by the groups
         b += (size_t)all.slots_per_frame * sizeof(float) + 256;
-        b += pool_spill_bytes();  // only touched by the experimental pool kernel
         worst = b > worst ? b : worst;
     }
     return worst + 17 * 256;
@@ -847,9 +527,6 @@ void launch_wf2_render(hipStream_t stream, const DeviceScene& ds, const FramePar
         gfp[g].n_frames = nf;
         gfp[g].depth_frame = (f0 + nf == fp.n_frames) ? nf - 1 : -1;  // the render's last frame writes the depth image
     }
-    const bool use_pool = pool_enabled();
-    const dim3 pgrid(512);  // 2 resident blocks per CU (75 KiB of LDS each); each chains kSegments / 512 segments
-    int32_t* pool_spill = use_pool ? (int32_t*)carve(pool_spill_bytes()) : nullptr;
 
     static const bool allow4 = [] {
         const char* e = getenv("JPT_BVH_WIDTH");
@@ -894,15 +571,7 @@ void launch_wf2_render(hipStream_t stream, const DeviceScene& ds, const FramePar
             else hipLaunchKernelGGL(wf2_shade<false>, sgrid, block, 0, st, sh, wb, dm, gp, cam, b, counters);
             if (b == gp.max_bounces) break;
             if (ev) (void)hipEventRecord(ev[2 * (b + 1)], st);
-            if (use_pool) {
-                if (counters) {
-                    if (w4) hipLaunchKernelGGL((wf3_trace<true, true>), pgrid, block, 0, st, sc, wb, dm, b + 1, tune, pool_spill, counters);
-                    else hipLaunchKernelGGL((wf3_trace<true, false>), pgrid, block, 0, st, sc, wb, dm, b + 1, tune, pool_spill, counters);
-                } else {
-                    if (w4) hipLaunchKernelGGL((wf3_trace<false, true>), pgrid, block, 0, st, sc, wb, dm, b + 1, tune, pool_spill, counters);
-                    else hipLaunchKernelGGL((wf3_trace<false, false>), pgrid, block, 0, st, sc, wb, dm, b + 1, tune, pool_spill, counters);
-                }
-            } else if (counters) {
+            if (counters) {
                 if (w4) hipLaunchKernelGGL((wf2_trace<true, true>), grid, block, 0, st, sc, wb, dm, b + 1, tune, counters);
                 else hipLaunchKernelGGL((wf2_trace<true, false>), grid, block, 0, st, sc, wb, dm, b + 1, tune, counters);
             } else {

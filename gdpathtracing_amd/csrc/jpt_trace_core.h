@@ -156,11 +156,6 @@ struct Traversal {
         }
         return nd;
     }
-    __device__ __forceinline__ void node_apply(const NodeData& nd, const Stack& st, DevCounters& cnt)
-    {
-        if (W4) node_apply4(nd, st, cnt);
-        else node_apply2(nd, st, cnt);
-    }
     __device__ __forceinline__ void node_step4(const WideSceneDev& sc, const Stack& st, DevCounters& cnt)
     {
         node_apply4(node_fetch(sc), st, cnt);
@@ -313,41 +308,6 @@ struct Traversal {
                 hit.front = dot3(cross3(edge1, edge2), d) > 0.0f;
             }
         }
-    }
-
-    // ONE triangle of the current leaf (same order as leaf_step: first, first+1, ...); the leaf reference in
-    // `cur` is rewritten to the remaining range, so no extra state is needed.
-    __device__ __forceinline__ void leaf_one(const WideSceneDev& sc, DevCounters& cnt)
-    {
-        const uint32_t bits = (uint32_t)~cur;
-        const uint32_t ti = bits & kLeafFirstMask;
-        const uint32_t rest = bits >> kLeafCountShift;  // triangles after this one
-        if (rest == 0) have = false;
-        else cur = (int32_t)~((ti + 1u) | ((rest - 1u) << kLeafCountShift));
-        const WideTri* tp = sc.tris + ti;
-        const float4 q0 = ld4(&tp->v0[0]);
-        const float4 q1 = ld4(&tp->e1[0]);
-        const float4 q2 = ld4(&tp->e2[0]);
-        if (COUNT) cnt.tri_tests++;
-        const f3 v0 = mk3(q0.x, q0.y, q0.z), edge1 = mk3(q1.x, q1.y, q1.z), edge2 = mk3(q2.x, q2.y, q2.z);
-        const f3 pvec = cross3(d, edge2);
-        const float det = dot3(edge1, pvec);
-        if (__builtin_fabsf(det) < 1e-5f) return;
-        const float invDet = 1.0f / det;
-        const f3 tvec = o - v0;
-        const float u = dot3(tvec, pvec) * invDet;
-        if (u < 0.0f || u > 1.0f) return;
-        const f3 qvec = cross3(tvec, edge1);
-        const float v = dot3(d, qvec) * invDet;
-        if (v < 0.0f || u + v > 1.0f) return;
-        const float t = dot3(edge2, qvec) * invDet;
-        if (t < 0.0f || t > hit.t) return;
-        hit.t = t;
-        hit.u = u;
-        hit.v = v;
-        hit.tri = ti;
-        hit.inst = cur_inst;
-        hit.front = dot3(cross3(edge1, edge2), d) > 0.0f;
     }
 
     // TLAS leaf: enter the instance (main.glsl:316-322)
