@@ -92,7 +92,7 @@ struct jpt_ctx {
     // render pipelining (jpt_render_async): consecutive asynchronous renders run their path kernels on two helper
     // streams with two workspaces, so one render's launch tails overlap the next render's kernels; the accumulation
     // kernels stay on the context's stream, in order
-    static constexpr int kPipeSlots = 3;
+    static constexpr int kPipeSlots = 4;
     DevBuf<char> d_workspace_more[kPipeSlots - 1];  // slot 0 is d_workspace
     hipStream_t pipe_stream[kPipeSlots] = {};
     uint64_t async_seq = 0;
@@ -539,11 +539,16 @@ int do_render_batch(jpt_ctx* c, int32_t n_frames, uint32_t first_frame_index, bo
                 const char* e = getenv("JPT_PIPELINE");
                 return !(e && atoi(e) == 0);
             }();
-            static const int pipe_slots = [] {
+            // renders in flight: a render is eleven dependent launches of >= 25-30 us each however little work it holds,
+            // so the smaller the render, the more of them are needed to fill the chip (1920x136x8 spp: 0.30 / 0.22 ms
+            // per render with 2 / 3 in flight; C3 gains nothing past 2).  JPT_PIPE_SLOTS overrides.
+            static const int forced_slots = [] {
                 const char* e = getenv("JPT_PIPE_SLOTS");
-                const int k = e ? atoi(e) : 2;
-                return k < 2 ? 2 : (k > jpt_ctx::kPipeSlots ? jpt_ctx::kPipeSlots : k);
+                const int k = e ? atoi(e) : 0;
+                return k <= 0 ? 0 : (k < 2 ? 2 : (k > jpt_ctx::kPipeSlots ? jpt_ctx::kPipeSlots : k));
             }();
+            const size_t render_paths = (size_t)c->width * (size_t)c->local_rows * (size_t)n_frames;
+            const int pipe_slots = forced_slots ? forced_slots : (render_paths >= ((size_t)12 << 20) ? 2 : (render_paths >= ((size_t)4 << 20) ? 3 : 4));
             if (wf2 && pipelining && !blocking && !counted && !need_ev && c->pipe_stream[jpt_ctx::kPipeSlots - 1]) {
                 // asynchronous render: path kernels on a helper stream + the other workspace; the accumulation on `s`
                 const int slot = (int)(c->async_seq % (uint64_t)pipe_slots);
@@ -761,7 +766,15 @@ const char* jpt_last_error(const jpt_ctx* c) { return c ? c->error.c_str() : g_c
 int jpt_set_stream(jpt_ctx* c, void* hip_stream)
 {
     if (!c || c->device < 0) return JPT_E_INVALID;
-    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    hipStream_t next = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    if (next != c->stream) {
+        // everything this context has queued is ordered by the old stream (uploads, accumulation kernels, the
+        // events its helper streams wait on): drain it before work starts appearing on another one
+        HIP_TRY(c, hipSetDevice(c->device));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        for (int k = 0; k < jpt_ctx::kPipeSlots; k++) c->acc_done_valid[k] = false;
+        c->stream = next;
+    }
     return JPT_OK;
 }
 

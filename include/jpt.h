@@ -108,7 +108,8 @@ const char *jpt_last_error(const jpt_ctx *ctx);   /* ctx may be NULL: error of t
 int jpt_abi_version(void);
 
 /* Run all work of this ctx on an existing HIP stream (hipStream_t as void*), e.g. torch's current
- * stream.  NULL restores the context's own stream.  No reference counterpart. */
+ * stream.  NULL restores the context's own stream.  Work already queued on the previous stream is waited for.
+ * No reference counterpart. */
 int jpt_set_stream(jpt_ctx *ctx, void *hip_stream);
 
 /* ---- scene ingest, route (i): reference layout ------------------------------------------------ */
