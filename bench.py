@@ -2,9 +2,12 @@
 """bench.py -- headline metric of BASELINE.json: Mrays/s at 1920x1080, 8 spp, 4 bounces.
 
 One "step" = one full render of the workload (accumulation reset, `spp` frames of the path-tracing
-kernels + accumulation, and -- for N > 1 -- the RCCL gather of the float4 pieces to rank 0 and their
-assembly).  Scene, camera and RNG streams are synthetic and deterministic (gdpathtracing_amd/scenes.py);
-the scene is resident in HBM before the timed region starts.
+kernels + accumulation, and -- for N > 1 -- the RCCL gather of every rank's finished rgba8 rows to rank 0
+and their assembly).  The K timed steps are queued with jpt_render_async and bracketed by barrier +
+torch.cuda.synchronize() on both sides; the library overlaps the launches of consecutive queued renders, so
+ms_per_step is the queued rate (the device time of one render on its own is reported as roofline.render_ms).
+Scene, camera and RNG streams are synthetic and deterministic (gdpathtracing_amd/scenes.py); the scene is
+resident in HBM before the timed region starts.
 
   python bench.py --gpus 1 --steps K --warmup W
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
