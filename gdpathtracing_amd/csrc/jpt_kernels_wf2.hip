@@ -98,18 +98,32 @@ struct Wf2Buffers {
     uint32_t* qcount;   // [max_bounces + 2][kSegments] queue sizes; row b = rays traced in bounce b (b >= 1)
 };
 
+// n / d for a divisor fixed per launch: one multiply-high with floor(2^32 / d) and one correction step (the
+// estimate is never too large and at most one too small for n < 2^31) instead of the ~35-instruction emulated divide.
+struct FastDiv {
+    uint32_t d, m;
+};
+inline FastDiv make_fastdiv(uint32_t d) { return FastDiv{d ? d : 1u, d > 1u ? (uint32_t)(0x100000000ull / d) : 0xffffffffu}; }
+__device__ __forceinline__ uint32_t fdiv(uint32_t n, const FastDiv& f)
+{
+    uint32_t q = __umulhi(n, f.m);
+    const uint32_t r = n - q * f.d;
+    return r >= f.d ? q + 1u : q;
+}
+
 struct Wf2Dims {
     int32_t tiles_x, tiles_y;
     uint32_t tiles_per_frame;
     uint32_t slots_per_frame;  // tiles_per_frame * 64
     uint32_t n_chunks;         // tiles_per_frame * n_frames
     uint32_t seg_cap;          // entries per segment
+    FastDiv by_tiles_x, by_tiles_per_frame, by_slots_per_frame;
 };
 
 __device__ __forceinline__ void slot_to_pixel(uint32_t slot, const Wf2Dims& dm, int& px, int& ly)
 {
     const uint32_t tile = slot >> 6, lane = slot & 63u;
-    const uint32_t ty = tile / (uint32_t)dm.tiles_x, tx = tile - ty * (uint32_t)dm.tiles_x;
+    const uint32_t ty = fdiv(tile, dm.by_tiles_x), tx = tile - ty * (uint32_t)dm.tiles_x;
     px = (int)(tx * 8u + (lane & 7u));
     ly = (int)(ty * 8u + (lane >> 3));
 }
@@ -157,7 +171,7 @@ __global__ __launch_bounds__(kBlock, JPT_PRIMARY_WAVES) void wf2_primary(WideSce
                 const uint32_t idx = start + lanes_below(idle, lane);
                 if (idx < n) {
                     const uint32_t chunk = seg + (idx >> 6) * kSegments;
-                    const uint32_t f = chunk / dm.tiles_per_frame, tile = chunk - f * dm.tiles_per_frame;
+                    const uint32_t f = fdiv(chunk, dm.by_tiles_per_frame), tile = chunk - f * dm.tiles_per_frame;
                     const uint32_t slot = tile * 64u + (idx & 63u);
                     int px, ly;
                     slot_to_pixel(slot, dm, px, ly);
@@ -192,7 +206,7 @@ __global__ __launch_bounds__(kBlock, JPT_PRIMARY_WAVES) void wf2_primary(WideSce
         {
             if (walk_round<COUNT, W4>(tr, active, sc, my_stack, cnt, tune.node_min_lanes, tune.leaf_min, tune.inst_min)) {
                 active = false;
-                const uint32_t f = path / dm.slots_per_frame;
+                const uint32_t f = fdiv(path, dm.by_slots_per_frame);
                 const bool last_frame = (int)f == fp.depth_frame;
                 if (tr.hit.t < 1e9f) {  // main.glsl:349: packed into the segment's bounce-0 queue
                     const uint32_t j = atomicAdd(&s_out, 1u);
@@ -299,7 +313,7 @@ __global__ __launch_bounds__(kBlock, JPT_SHADE_WAVES) void wf2_shade(SceneShadin
         const uint32_t hb = wb.hit_b[seg_base + i];
         f3 throughput, radiance;
         uint32_t sx, sy;
-        const uint32_t f = p / dm.slots_per_frame, slot = p - f * dm.slots_per_frame;
+        const uint32_t f = fdiv(p, dm.by_slots_per_frame), slot = p - f * dm.slots_per_frame;
         if (bounce == 0) {
             // fresh path: the seed after the jitter draw (main.glsl:409-411), recomputed from (x, y, frame)
             int px, ly;
@@ -412,6 +426,9 @@ Wf2Dims make_dims(int width, int local_rows, int n_frames)
     dm.slots_per_frame = dm.tiles_per_frame * 64u;
     dm.n_chunks = dm.tiles_per_frame * (uint32_t)n_frames;
     dm.seg_cap = ((dm.n_chunks + kSegments - 1u) / kSegments) * 64u;
+    dm.by_tiles_x = make_fastdiv((uint32_t)dm.tiles_x);
+    dm.by_tiles_per_frame = make_fastdiv(dm.tiles_per_frame);
+    dm.by_slots_per_frame = make_fastdiv(dm.slots_per_frame);
     return dm;
 }
 
