@@ -38,7 +38,6 @@ constexpr uint32_t kSegments = 256u * JPT_WAVES_PER_SIMD;  // persistent grid: o
 struct WfTune {
     int refill_idle;     // refill when at least this many lanes of a wave are idle
     int node_min_lanes;  // leave the node loop when fewer lanes than this still descend
-    int leaf_min, inst_min;  // hold leaf / instance turns back until this many lanes wait (unless the wave starves)
 };
 
 // One round of the walk for every active lane of the wave, "while-while" style so that lanes in different
@@ -46,8 +45,7 @@ struct WfTune {
 // leaf wait), (2) triangle leaves, (3) instance entries.  Returns true for lanes whose walk is complete.
 template <bool COUNT, bool W4>
 __device__ __forceinline__ bool walk_round(Traversal<COUNT, W4>& tr, bool active, const WideSceneDev& sc,
-                                           const typename Traversal<COUNT, W4>::Stack& st, DevCounters& cnt, int kNodeMinLanes,
-                                           int leaf_min, int inst_min)
+                                           const typename Traversal<COUNT, W4>::Stack& st, DevCounters& cnt, int kNodeMinLanes)
 {
     const bool lane0 = (threadIdx.x & 63) == 0;
     if (COUNT && lane0) cnt.phase[0]++;
@@ -62,28 +60,21 @@ __device__ __forceinline__ bool walk_round(Traversal<COUNT, W4>& tr, bool active
         }
         if (want) tr.node_step(sc, st, cnt);
     }
-    // leaf and instance turns cost the same whether 3 or 60 lanes take part: hold them back until enough lanes
-    // wait there, unless nothing else in the wave can move
     const bool wl = active && tr.wants_leaf();
     const bool wi = active && tr.wants_instance();
-    const unsigned long long ml = __ballot(wl), mi = __ballot(wi);
-    const int nl = __popcll(ml), ni = __popcll(mi);
-    const int nn = __popcll(__ballot(active && (tr.wants_node() || (!tr.have && tr.sp > 0))));
-    const bool starving = nn < kNodeMinLanes;  // the node loop has (almost) nothing left to do
-    const bool run_leaf = nl > 0 && (nl >= leaf_min || starving);
-    const bool run_inst = ni > 0 && (ni >= inst_min || starving);
-    if (COUNT && lane0) {
-        if (run_leaf) {
+    if (COUNT) {
+        const int nl = __popcll(__ballot(wl)), ni = __popcll(__ballot(wi));
+        if (lane0 && nl) {
             cnt.phase[3]++;
             cnt.phase[4] += (unsigned long long)nl;
         }
-        if (run_inst) {
+        if (lane0 && ni) {
             cnt.phase[5]++;
             cnt.phase[6] += (unsigned long long)ni;
         }
     }
-    if (run_leaf && wl) tr.leaf_step(sc, cnt);
-    if (run_inst && wi) tr.instance_step(sc, st, cnt);
+    if (wl) tr.leaf_step(sc, cnt);
+    if (wi) tr.instance_step(sc, st, cnt);
     return active && tr.finished();
 }
 
@@ -204,7 +195,7 @@ __global__ __launch_bounds__(kBlock, JPT_PRIMARY_WAVES) void wf2_primary(WideSce
             continue;
         }
         {
-            if (walk_round<COUNT, W4>(tr, active, sc, my_stack, cnt, tune.node_min_lanes, tune.leaf_min, tune.inst_min)) {
+            if (walk_round<COUNT, W4>(tr, active, sc, my_stack, cnt, tune.node_min_lanes)) {
                 active = false;
                 const uint32_t f = fdiv(path, dm.by_slots_per_frame);
                 const bool last_frame = (int)f == fp.depth_frame;
@@ -274,7 +265,7 @@ __global__ __launch_bounds__(kBlock, JPT_WAVES_PER_SIMD) void wf2_trace(WideScen
             continue;
         }
         {
-            if (walk_round<COUNT, W4>(tr, active, sc, my_stack, cnt, tune.node_min_lanes, tune.leaf_min, tune.inst_min)) {
+            if (walk_round<COUNT, W4>(tr, active, sc, my_stack, cnt, tune.node_min_lanes)) {
                 active = false;
                 wb.hit_a[seg_base + my_idx] = make_float4(tr.hit.t, tr.hit.u, tr.hit.v, __uint_as_float(tr.hit.tri));
                 wb.hit_b[seg_base + my_idx] = tr.hit.inst | (tr.hit.front ? 0x80000000u : 0u);
@@ -563,11 +554,9 @@ void launch_wf2_render(hipStream_t stream, const DeviceScene& ds, const FramePar
     const SceneShading sh = ds.shading();
     const dim3 grid(kSegments), block(kBlock);
     static const WfTune tune = [] {
-        WfTune t{32, 16, 1, 1};
+        WfTune t{32, 16};
         if (const char* e = getenv("JPT_REFILL_IDLE")) t.refill_idle = atoi(e);
         if (const char* e = getenv("JPT_NODE_MIN_LANES")) t.node_min_lanes = atoi(e);
-        if (const char* e = getenv("JPT_LEAF_MIN")) t.leaf_min = atoi(e);
-        if (const char* e = getenv("JPT_INST_MIN")) t.inst_min = atoi(e);
         return t;
     }();
 
