@@ -1,6 +1,7 @@
 #!/bin/bash
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
+export JPT_PIPELINE=0 JPT_GROUPS=1   # counters per kernel: launches one after another
 ARGS="bench.py --steps 3 --warmup 1 --no-cpu-baseline $*"
 mkdir -p gpurun_out/diag2
 i=0
