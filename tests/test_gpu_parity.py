@@ -83,9 +83,10 @@ def _moves_for(sc, seed, n):
             for i in rng.choice(np.arange(2, len(sc.instances)), size=n, replace=False)}
 
 
+@pytest.mark.parametrize("asynchronous", [False, True])
 @pytest.mark.parametrize("kernel", [capi.KERNEL_WAVEFRONT, capi.KERNEL_REFERENCE_LAYOUT])
 @pytest.mark.parametrize("builder", [capi.BUILD_REFERENCE_EXACT, capi.BUILD_SAH])
-def test_tlas_update_renders_like_a_fresh_build(oracle, hiplib, builder, kernel):
+def test_tlas_update_renders_like_a_fresh_build(oracle, hiplib, builder, kernel, asynchronous):
     """An animation step: render, move instances, jpt_scene_update_tlas, render again.  The second image must equal
     the oracle's image of the moved scene (reference-exact builder: bit for bit) and a fresh context's image."""
     sc = scenes.instanced_scene(n_side=6, n_unique=3, tris_per_mesh=128)
@@ -98,13 +99,20 @@ def test_tlas_update_renders_like_a_fresh_build(oracle, hiplib, builder, kernel)
         ctx.build_scene(sc, builder)
         ctx.set_params(w, h, bounces, wire.ACCUM_REF_LDR8)
         ctx.set_camera(cam)
-        ctx.render(frames, 1)
-        before = ctx.read_accum()
+        ctx.render(frames, 1, asynchronous=asynchronous)
+        if asynchronous:
+            # more queued work that still reads the old instance records when the update is requested
+            ctx.render(1, 3, asynchronous=True)
+            ctx.accum_reset()
+            ctx.render(frames, 1, asynchronous=True)
+        before = ctx.read_accum() if not asynchronous else None
         for i, t in moves.items():
             ctx.set_instance_transform(i, t)
-        ctx.update_tlas()
+        ctx.update_tlas()           # waits for the queued renders before the records move
+        if asynchronous:
+            before = ctx.read_accum()
         ctx.accum_reset()
-        ctx.render(frames, 1)
+        ctx.render(frames, 1, asynchronous=asynchronous)
         after, after_depth = ctx.read_accum(), ctx.read_depth()
     finally:
         ctx.close()
