@@ -199,15 +199,18 @@ def render(ref: RefLayoutScene, camera: np.ndarray, width: int, height: int, max
     return accum, ldr, depth, cnt.as_dict(), used
 
 
-def trace_frame(ref: RefLayoutScene, camera: np.ndarray, width: int, height: int, max_bounces: int = 4, flags: int = 0):
-    """One dispatch of main.glsl: float radiance (before the rgba8 store) + depth + counters."""
+def trace_frame(ref: RefLayoutScene, camera: np.ndarray, width: int, height: int, max_bounces: int = 4, flags: int = 0,
+                rows=None):
+    """One dispatch of main.glsl: float radiance (before the rgba8 store) + depth + counters.  rows = (y0, y1)
+    restricts it to those image rows (the arrays keep the full size; other rows stay zero)."""
     L = lib()
     cam = np.ascontiguousarray(camera, dtype=wire.CAMERA).reshape(1)
     rad = np.zeros((height, width, 4), dtype=np.float32)
     depth = np.zeros((height, width), dtype=np.float32)
     cnt = Counters()
     v = ref.view()
-    L.jpto_trace_frame(C.byref(v), _ptr(cam), width, height, max_bounces, flags, 0, height, _ptr(rad), _ptr(depth),
+    y0, y1 = (0, height) if rows is None else rows
+    L.jpto_trace_frame(C.byref(v), _ptr(cam), width, height, max_bounces, flags, y0, y1, _ptr(rad), _ptr(depth),
                        C.byref(cnt))
     return rad, depth, cnt.as_dict()
 
