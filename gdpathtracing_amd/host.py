@@ -11,7 +11,9 @@ linking into the addon, is described in INTEGRATION.md.
 """
 from __future__ import annotations
 
+import atexit
 import ctypes as C
+import weakref
 from typing import Optional
 
 import numpy as np
@@ -21,6 +23,20 @@ from . import capi, scenes, wire
 
 def _ptr(a):
     return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+_live_contexts = weakref.WeakSet()
+
+
+@atexit.register
+def _close_live_contexts():
+    # contexts the caller forgot to close are destroyed while the HIP runtime is still up (this handler is registered
+    # after torch's, so it runs before it), not from __del__ during interpreter teardown
+    for ctx in list(_live_contexts):
+        try:
+            ctx.close()
+        except Exception:
+            pass
 
 
 class Context:
@@ -36,6 +52,7 @@ class Context:
         self.h = h
         self.width = self.height = 0
         self._keep = []
+        _live_contexts.add(self)
 
     def close(self):
         if getattr(self, "h", None):
