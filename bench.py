@@ -276,7 +276,9 @@ def main():
                 "algorithmic_bytes": int(alg),
                 "ref_layout_algorithmic_bytes": int(alg_ref),
                 "ref_layout_achieved": round(alg_ref / (kernel_ms * 1e-3) / 1e9, 2),
-                "note": "scene is L2/Infinity-Cache resident; bytes are cache-served requests, not HBM traffic",
+                "note": "scene is L2/Infinity-Cache resident; bytes are cache-served requests, not HBM traffic. The launches are "
+                        "VALU-issue-bound: 1.2e8 wave-level VALU instructions per wf2_trace launch = 77 % of the SIMD cycles at "
+                        "29-37 % lane utilisation (rocprofv3 SQ counters, DESIGN.md section 4)",
             },
             "counters": total,
         }
