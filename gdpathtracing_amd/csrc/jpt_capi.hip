@@ -539,16 +539,20 @@ int do_render_batch(jpt_ctx* c, int32_t n_frames, uint32_t first_frame_index, bo
                 const char* e = getenv("JPT_PIPELINE");
                 return !(e && atoi(e) == 0);
             }();
-            // renders in flight: a render is eleven dependent launches of >= 25-30 us each however little work it holds,
-            // so the smaller the render, the more of them are needed to fill the chip (1920x136x8 spp: 0.30 / 0.22 ms
-            // per render with 2 / 3 in flight; C3 gains nothing past 2).  JPT_PIPE_SLOTS overrides.
+            // renders in flight (JPT_PIPE_SLOTS overrides): a render is eleven dependent launches of >= 25-30 us each
+            // however little work it holds, so several of them are needed to fill the chip
             static const int forced_slots = [] {
                 const char* e = getenv("JPT_PIPE_SLOTS");
                 const int k = e ? atoi(e) : 0;
                 return k <= 0 ? 0 : (k < 2 ? 2 : (k > jpt_ctx::kPipeSlots ? jpt_ctx::kPipeSlots : k));
             }();
-            const size_t render_paths = (size_t)c->width * (size_t)c->local_rows * (size_t)n_frames;
-            const int pipe_slots = forced_slots ? forced_slots : (render_paths >= ((size_t)12 << 20) ? 2 : (render_paths >= ((size_t)4 << 20) ? 3 : 4));
+            // Four renders in flight, each tracing with a quarter of the blocks (four consecutive segments per block: a
+            // deeper queue keeps a block's lanes refilled for a larger share of its launch) beat two renders of full-width
+            // launches on every size tried: C3 1.32 vs 1.45 ms, C2 0.36 vs 0.46, 1 frame 0.30 vs 0.37, 1920x136 0.185 vs
+            // 0.193, 4K x 16 spp 11.1 vs 11.1.  Renders whose workspace exceeds 24 GiB keep two slots and full-width launches.
+            const size_t one_workspace = wf2 ? wf2_workspace_bytes(c->width, c->local_rows, n_frames, c->max_bounces) : 0;
+            const bool huge = one_workspace > ((size_t)24 << 30);  // 4 x 24 GiB of workspaces is where this stops
+            const int pipe_slots = forced_slots ? forced_slots : (huge ? 2 : 4);
             if (wf2 && pipelining && !blocking && !counted && !need_ev && c->pipe_stream[jpt_ctx::kPipeSlots - 1]) {
                 // asynchronous render: path kernels on a helper stream + the other workspace; the accumulation on `s`
                 const int slot = (int)(c->async_seq % (uint64_t)pipe_slots);
@@ -566,6 +570,7 @@ int do_render_batch(jpt_ctx* c, int32_t n_frames, uint32_t first_frame_index, bo
                 // 3840x2160x16 spp 11.56 ms against 11.96 with two groups, instanced scene 3.80 against 4.05)
                 Wf2Async one_group = c->async;
                 one_group.aux_stream[0] = nullptr;
+                one_group.trace_chain = huge ? 1 : 4;
                 launch_wf2_render(ps, c->ds, fp, c->camera, ws.p, c->d_accum.p, c->d_ldr.p, c->d_depth.p, nullptr, nullptr, one_group, s,
                                   c->ev_paths_done[slot]);
                 HIP_TRY(c, hipEventRecord(c->ev_acc_done[slot], s));

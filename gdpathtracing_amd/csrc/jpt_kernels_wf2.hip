@@ -220,27 +220,37 @@ __global__ __launch_bounds__(kBlock, JPT_PRIMARY_WAVES) void wf2_primary(WideSce
 
 // ---- bounces >= 1: trace the segment's ray queue ----------------------------------------------------------
 
+// `chain` consecutive segments are one block's queue (entries of segment seg0, then seg0 + 1, ...): the grid is
+// kSegments / chain blocks.  A deeper queue per block keeps the lanes refilled for a larger share of the launch (at
+// bounce 4 of C3 a segment holds 1.7 rays per lane); the slots this leaves free are used by the launches of the
+// other renders in flight (render pipelining), so chain > 1 only pays when renders are queued.
+constexpr int kMaxChain = 4;
 template <bool COUNT, bool W4>
 __global__ __launch_bounds__(kBlock, JPT_WAVES_PER_SIMD) void wf2_trace(WideSceneDev sc, Wf2Buffers wb, Wf2Dims dm, int bounce, WfTune tune,
-                                                    DevCounters* __restrict__ counters)
+                                                    int chain, DevCounters* __restrict__ counters)
 {
     __shared__ int32_t stack[kStackLds * kBlock];
     __shared__ uint32_t s_cursor;
     const int lane = threadIdx.x & 63;
-    const uint32_t seg = blockIdx.x;
-    const uint32_t n = wb.qcount[(size_t)bounce * kSegments + seg];
+    const uint32_t seg0 = blockIdx.x * (uint32_t)chain;
+    // end[k] = entries in segments seg0 .. seg0 + k (wave-uniform, kept in scalars)
+    uint32_t end[kMaxChain];
+    uint32_t n = 0;
+    for (int k = 0; k < kMaxChain; k++) {
+        if (k < chain && seg0 + (uint32_t)k < kSegments) n += wb.qcount[(size_t)bounce * kSegments + seg0 + (uint32_t)k];
+        end[k] = n;
+    }
     if (n == 0) return;
     if (threadIdx.x == 0) s_cursor = 0;
     __syncthreads();
     int32_t spill[kStackSpill];
     const typename Traversal<COUNT, W4>::Stack my_stack{&stack[threadIdx.x], spill, kTraceBlock, kStackLds};
-    const size_t seg_base = (size_t)seg * dm.seg_cap;
-    const float4* __restrict__ qo = wb.ray_o[bounce & 1] + seg_base;
-    const float4* __restrict__ qd = wb.ray_d[bounce & 1] + seg_base;
+    const float4* __restrict__ qo = wb.ray_o[bounce & 1];
+    const float4* __restrict__ qd = wb.ray_d[bounce & 1];
     DevCounters cnt = {};
     Traversal<COUNT, W4> tr;
     bool active = false, exhausted = false;
-    uint32_t my_idx = 0;
+    size_t my_loc = 0;
 
     for (;;) {
         const unsigned long long idle = __ballot(!active);
@@ -253,9 +263,17 @@ __global__ __launch_bounds__(kBlock, JPT_WAVES_PER_SIMD) void wf2_trace(WideScen
             if (start < n && !active) {
                 const uint32_t idx = start + lanes_below(idle, lane);
                 if (idx < n) {
-                    const float4 ro = qo[idx], rd = qd[idx];
+                    // which of the chained segments holds entry idx
+                    uint32_t k = 0, first = 0;
+                    for (int j = 0; j < kMaxChain - 1; j++)
+                        if (idx >= end[j]) {
+                            k = (uint32_t)j + 1u;
+                            first = end[j];
+                        }
+                    const size_t loc = (size_t)(seg0 + k) * dm.seg_cap + (idx - first);
+                    const float4 ro = qo[loc], rd = qd[loc];
                     tr.begin(sc, mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z));
-                    my_idx = idx;
+                    my_loc = loc;
                     active = true;
                 }
             }
@@ -267,8 +285,8 @@ __global__ __launch_bounds__(kBlock, JPT_WAVES_PER_SIMD) void wf2_trace(WideScen
         {
             if (walk_round<COUNT, W4>(tr, active, sc, my_stack, cnt, tune.node_min_lanes)) {
                 active = false;
-                wb.hit_a[seg_base + my_idx] = make_float4(tr.hit.t, tr.hit.u, tr.hit.v, __uint_as_float(tr.hit.tri));
-                wb.hit_b[seg_base + my_idx] = tr.hit.inst | (tr.hit.front ? 0x80000000u : 0u);
+                wb.hit_a[my_loc] = make_float4(tr.hit.t, tr.hit.u, tr.hit.v, __uint_as_float(tr.hit.tri));
+                wb.hit_b[my_loc] = tr.hit.inst | (tr.hit.front ? 0x80000000u : 0u);
             }
         }
     }
@@ -552,7 +570,7 @@ void launch_wf2_render(hipStream_t stream, const DeviceScene& ds, const FramePar
     sc.tlas_root = w4 ? ds.tlas_root4 : ds.tlas_root;
     sc.n_instances = ds.n_instances;
     const SceneShading sh = ds.shading();
-    const dim3 grid(kSegments), block(kBlock);
+    const dim3 block(kBlock);
     static const WfTune tune = [] {
         WfTune t{32, 16};
         if (const char* e = getenv("JPT_REFILL_IDLE")) t.refill_idle = atoi(e);
@@ -560,6 +578,13 @@ void launch_wf2_render(hipStream_t stream, const DeviceScene& ds, const FramePar
         return t;
     }();
 
+    const int chain = [&] {  // JPT_TRACE_CHAIN overrides the caller's choice (tuning runs)
+        const char* e = getenv("JPT_TRACE_CHAIN");
+        const int c = e ? atoi(e) : async.trace_chain;
+        return c < 1 ? 1 : (c > kMaxChain ? kMaxChain : c);
+    }();
+    const dim3 tgrid((kSegments + (uint32_t)chain - 1u) / (uint32_t)chain);
+    const dim3 pgrid(kSegments);
     // the pipeline of one group on one stream
     auto run_group = [&](hipStream_t st, const Wf2Buffers& wb, const Wf2Dims& dm, const FrameParams& gp, hipEvent_t* ev) {
         // queue sizes of bounces >= 1 are accumulated with atomics by wf2_shade: start from zero
@@ -567,11 +592,11 @@ void launch_wf2_render(hipStream_t stream, const DeviceScene& ds, const FramePar
         const dim3 sgrid((dm.seg_cap + kBlock - 1) / kBlock, kSegments);
         if (ev) (void)hipEventRecord(ev[0], st);
         if (counters) {
-            if (w4) hipLaunchKernelGGL((wf2_primary<true, true>), grid, block, 0, st, sc, wb, dm, gp, cam, tune, async.cull, counters);
-            else hipLaunchKernelGGL((wf2_primary<true, false>), grid, block, 0, st, sc, wb, dm, gp, cam, tune, async.cull, counters);
+            if (w4) hipLaunchKernelGGL((wf2_primary<true, true>), pgrid, block, 0, st, sc, wb, dm, gp, cam, tune, async.cull, counters);
+            else hipLaunchKernelGGL((wf2_primary<true, false>), pgrid, block, 0, st, sc, wb, dm, gp, cam, tune, async.cull, counters);
         } else {
-            if (w4) hipLaunchKernelGGL((wf2_primary<false, true>), grid, block, 0, st, sc, wb, dm, gp, cam, tune, async.cull, counters);
-            else hipLaunchKernelGGL((wf2_primary<false, false>), grid, block, 0, st, sc, wb, dm, gp, cam, tune, async.cull, counters);
+            if (w4) hipLaunchKernelGGL((wf2_primary<false, true>), pgrid, block, 0, st, sc, wb, dm, gp, cam, tune, async.cull, counters);
+            else hipLaunchKernelGGL((wf2_primary<false, false>), pgrid, block, 0, st, sc, wb, dm, gp, cam, tune, async.cull, counters);
         }
         if (ev) (void)hipEventRecord(ev[1], st);
         for (int b = 0; b <= gp.max_bounces; b++) {
@@ -580,11 +605,11 @@ void launch_wf2_render(hipStream_t stream, const DeviceScene& ds, const FramePar
             if (b == gp.max_bounces) break;
             if (ev) (void)hipEventRecord(ev[2 * (b + 1)], st);
             if (counters) {
-                if (w4) hipLaunchKernelGGL((wf2_trace<true, true>), grid, block, 0, st, sc, wb, dm, b + 1, tune, counters);
-                else hipLaunchKernelGGL((wf2_trace<true, false>), grid, block, 0, st, sc, wb, dm, b + 1, tune, counters);
+                if (w4) hipLaunchKernelGGL((wf2_trace<true, true>), tgrid, block, 0, st, sc, wb, dm, b + 1, tune, chain, counters);
+                else hipLaunchKernelGGL((wf2_trace<true, false>), tgrid, block, 0, st, sc, wb, dm, b + 1, tune, chain, counters);
             } else {
-                if (w4) hipLaunchKernelGGL((wf2_trace<false, true>), grid, block, 0, st, sc, wb, dm, b + 1, tune, counters);
-                else hipLaunchKernelGGL((wf2_trace<false, false>), grid, block, 0, st, sc, wb, dm, b + 1, tune, counters);
+                if (w4) hipLaunchKernelGGL((wf2_trace<false, true>), tgrid, block, 0, st, sc, wb, dm, b + 1, tune, chain, counters);
+                else hipLaunchKernelGGL((wf2_trace<false, false>), tgrid, block, 0, st, sc, wb, dm, b + 1, tune, chain, counters);
             }
             if (ev) (void)hipEventRecord(ev[2 * (b + 1) + 1], st);
         }
