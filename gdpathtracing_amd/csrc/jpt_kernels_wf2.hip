@@ -454,9 +454,12 @@ uint32_t trace_stack_capacity() { return (uint32_t)(kStackLds + kStackSpill); }
 // frames of a render are split into groups, each group runs the pipeline on its own stream with its own queues,
 // and the hardware fills the slots one group's kernel frees with the blocks of the other group's next kernel.
 // Paths never cross groups and the per-pixel accumulation still reads the frames in order: results are unchanged.
-// Measured on one MI355X (ms per render, 1 / 2 / 3 / 4 groups): 3840x2160x16 spp 13.2 / 11.9 / 12.2 / 13.1;
-// 1920x1080x32 spp 5.92 / 5.38 / 5.75 / 6.18; x16 spp 3.13 / 2.98; x8 spp (C3, 22 M segments) 1.81 / 1.80 / 2.09 / 2.54; x8 spp close-up
-// (50 M segments) 6.88 / 6.41; x4 spp 1.17 / 1.31.  Every extra launch costs ~25 us, so two groups pay once a group still holds >= ~12 M paths.
+// Measured on one MI355X (ms per blocking render, 1 / 2 / 3 / 4 groups of full-width launches): 3840x2160x16 spp 13.2 /
+// 11.9 / 12.2 / 13.1; 1920x1080x32 spp 5.92 / 5.38 / 5.75 / 6.18; x8 spp (C3) 1.81 / 1.80 / 2.09 / 2.54; x4 spp 1.17 /
+// 1.31: every extra launch costs ~25 us.  Two groups whose tracing launches are HALF as wide (two chained segments per
+// block, wf2_trace) do better, because the two groups' launches then really run side by side: C3 1.76 -> 1.61,
+// close-up 6.89 -> 6.22, 16 spp 3.11 -> 2.82, instanced scene 4.56 -> 4.03; 1280x720x4 spp 0.69 -> 0.71 (not used
+// below 12 M paths).
 constexpr int kMaxGroups = 4;
 static int frame_groups(int n_frames, bool serial, size_t paths, size_t last_rays = 0)
 {
@@ -466,8 +469,8 @@ static int frame_groups(int n_frames, bool serial, size_t paths, size_t last_ray
         return g < 0 ? 0 : (g > kMaxGroups ? kMaxGroups : g);
     }();
     if (serial || n_frames < 2) return 1;
-    // (a render of fewer paths that traced many segments last time -- every pixel on geometry -- qualifies too)
-    const int wanted = forced ? forced : ((paths >= ((size_t)24 << 20) || last_rays >= ((size_t)24 << 20)) ? 2 : 1);
+    (void)last_rays;
+    const int wanted = forced ? forced : (paths >= ((size_t)12 << 20) ? 2 : 1);
     return n_frames < wanted ? n_frames : wanted;
 }
 static void group_frames(int n_frames, int groups, int g, int& first, int& count)
@@ -578,9 +581,9 @@ void launch_wf2_render(hipStream_t stream, const DeviceScene& ds, const FramePar
         return t;
     }();
 
-    const int chain = [&] {  // JPT_TRACE_CHAIN overrides the caller's choice (tuning runs)
+    const int chain = [&] {  // JPT_TRACE_CHAIN overrides (tuning runs); two frame groups share the chip: half-width launches
         const char* e = getenv("JPT_TRACE_CHAIN");
-        const int c = e ? atoi(e) : async.trace_chain;
+        const int c = e ? atoi(e) : (groups == 2 ? 2 : async.trace_chain);
         return c < 1 ? 1 : (c > kMaxChain ? kMaxChain : c);
     }();
     const dim3 tgrid((kSegments + (uint32_t)chain - 1u) / (uint32_t)chain);
