@@ -1,6 +1,6 @@
 """Multi-GPU path on CPU: 2 processes, gloo backend.  Each rank 'renders' its strips (with the oracle,
-which stands in for the device kernels here), the float4 pieces are gathered to rank 0 with the same
-helper bench.py uses, and the assembled image must be bit-identical to the single-process image."""
+which stands in for the device kernels here), the float4 pieces and the rgba8 display rows are gathered to
+rank 0 with the same helper bench.py uses, and the assembled image must be bit-identical to the single-process image."""
 import os
 import socket
 import sys
@@ -50,14 +50,18 @@ def _worker(rank, world, port, q):
         ref = ob.build_scene(sc)
         # the oracle renders whole images; a rank keeps only its strips (per-pixel RNG streams make the
         # rows independent, main.glsl:176-181)
-        full, _, _, _, _ = ob.render(ref, cam, w, h, 2, 2, 1, wire.ACCUM_REF_LDR8, n_threads=1)
+        full, full_ldr, _, _, _ = ob.render(ref, cam, w, h, 2, 2, 1, wire.ACCUM_REF_LDR8, n_threads=1)
         piece = torch.from_numpy(partition.extract_piece(full, rank, world))
         if rank != 0:
             piece = piece.clone()
         g = partition.gather_to_rank0(piece, dist, rank, world)
+        # what bench.py gathers by default: each rank's finished rgba8 rows, as one int32 per pixel
+        ldr_piece = torch.from_numpy(partition.extract_piece(full_ldr, rank, world).view(np.int32).copy())
+        gl = partition.gather_to_rank0(ldr_piece, dist, rank, world)
         if rank == 0:
             img = partition.assemble(g.numpy(), h, world)
-            q.put(("ok", bool(np.array_equal(img, full)), float(np.abs(img).sum())))
+            ldr = partition.assemble(gl.numpy().view(np.uint8).reshape(world, -1, w, 4), h, world)
+            q.put(("ok", bool(np.array_equal(img, full)) and bool(np.array_equal(ldr, full_ldr)), float(np.abs(img).sum())))
         dist.barrier()
     finally:
         dist.destroy_process_group()
