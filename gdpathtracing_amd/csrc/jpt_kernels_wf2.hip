@@ -19,6 +19,7 @@
 //
 // launch_wf2_render runs one render: a blocking render of many paths splits its frames into two groups that run
 // this pipeline concurrently on two streams; asynchronous renders are pipelined one level up (jpt_capi.hip).
+#include <algorithm>
 #include <cstdlib>
 
 #include "jpt_trace_core.h"
@@ -592,7 +593,11 @@ void launch_wf2_render(hipStream_t stream, const DeviceScene& ds, const FramePar
     auto run_group = [&](hipStream_t st, const Wf2Buffers& wb, const Wf2Dims& dm, const FrameParams& gp, hipEvent_t* ev) {
         // queue sizes of bounces >= 1 are accumulated with atomics by wf2_shade: start from zero
         (void)hipMemsetAsync(wb.qcount + kSegments, 0, (size_t)(nq - 1) * kSegments * sizeof(uint32_t), st);
-        const dim3 sgrid((dm.seg_cap + kBlock - 1) / kBlock, kSegments);
+        // Blocks go to the 8 XCDs round-robin by linear index (y * grid.x + x), and the chunks of a segment are far from
+        // alike (the first ones are full, the last ones empty): with grid.x a multiple of 8 every XCD would always get
+        // the same chunk position.  An odd grid.x deals every position to every XCD (capping C3's grid.x from 37 to 8
+        // cost 9 %).
+        const dim3 sgrid(((dm.seg_cap + kBlock - 1) / kBlock) | 1u, kSegments);
         if (ev) (void)hipEventRecord(ev[0], st);
         if (counters) {
             if (w4) hipLaunchKernelGGL((wf2_primary<true, true>), pgrid, block, 0, st, sc, wb, dm, gp, cam, tune, async.cull, counters);
