@@ -66,3 +66,40 @@ def load_obj(text: str) -> Mesh:
     surfaces = [Surface(np.asarray(g["v"], np.float32), np.asarray(g["n"], np.float32), np.asarray(g["t"], np.float32),
                         np.asarray(g["idx"], np.int32)) for g in (groups[n] for n in order) if g["idx"]]
     return Mesh(surfaces)
+
+
+def pack_texture_array(images, resolution: int) -> np.ndarray:
+    """The texture-array packing of GeometryGroup3D::build (geometry_group3d.cpp:294-300): every albedo image becomes
+    one RGBA8 layer of `resolution` x `resolution` (the reference: clear_mipmaps, decompress, Image::resize).  Returns
+    (layers, resolution, resolution, 4) uint8 for Scene.textures / jpt_scene_set_textures; an empty list gives the one
+    blank layer the reference creates (:301-303).
+
+    The resampling is a plain bilinear filter over pixel centres.  Godot's Image::resize is engine code (absent here),
+    so a layer made from an image of another size is NOT claimed to match the reference's texel for texel; images
+    that already have the array's resolution pass through unchanged."""
+    if not images:
+        return np.zeros((1, resolution, resolution, 4), dtype=np.uint8)
+    layers = []
+    for img in images:
+        a = np.asarray(img)
+        if a.ndim == 2:
+            a = a[..., None]
+        if a.shape[-1] == 1:
+            a = np.repeat(a, 3, axis=-1)
+        if a.shape[-1] == 3:
+            a = np.concatenate([a, np.full(a.shape[:2] + (1,), 255, dtype=a.dtype)], axis=-1)
+        a = a[..., :4].astype(np.uint8)
+        h, w = a.shape[:2]
+        if (h, w) != (resolution, resolution):
+            ys = (np.arange(resolution) + 0.5) * h / resolution - 0.5
+            xs = (np.arange(resolution) + 0.5) * w / resolution - 0.5
+            y0 = np.clip(np.floor(ys).astype(np.int64), 0, h - 1); y1 = np.clip(y0 + 1, 0, h - 1)
+            x0 = np.clip(np.floor(xs).astype(np.int64), 0, w - 1); x1 = np.clip(x0 + 1, 0, w - 1)
+            fy = np.clip(ys - np.floor(ys), 0.0, 1.0)[:, None, None]
+            fx = np.clip(xs - np.floor(xs), 0.0, 1.0)[None, :, None]
+            f = a.astype(np.float64)
+            top = f[y0][:, x0] * (1.0 - fx) + f[y0][:, x1] * fx
+            bot = f[y1][:, x0] * (1.0 - fx) + f[y1][:, x1] * fx
+            a = np.clip(np.floor(top * (1.0 - fy) + bot * fy + 0.5), 0, 255).astype(np.uint8)
+        layers.append(a)
+    return np.stack(layers)

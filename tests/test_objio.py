@@ -57,3 +57,20 @@ def test_obj_without_normals_or_uvs_gets_face_normals():
     m = objio.load_obj("v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2 3\n")
     s = m.surfaces[0]
     assert len(s.indices) == 3 and np.allclose(s.normals, [[0, 0, 1]] * 3) and (s.uvs == 0).all()
+
+
+def test_pack_texture_array():
+    from gdpathtracing_amd.objio import pack_texture_array
+    assert pack_texture_array([], 16).shape == (1, 16, 16, 4) and not pack_texture_array([], 16).any()
+    rng = np.random.RandomState(0)
+    same = rng.randint(0, 256, size=(8, 8, 4)).astype(np.uint8)
+    grey = rng.randint(0, 256, size=(5, 3)).astype(np.uint8)
+    rgb = np.zeros((4, 4, 3), np.uint8); rgb[:, 2:] = (200, 100, 50)
+    t = pack_texture_array([same, grey, rgb], 8)
+    assert t.shape == (3, 8, 8, 4) and t.dtype == np.uint8
+    assert np.array_equal(t[0], same)                                  # already the array's resolution: untouched
+    assert (t[1][..., 0] == t[1][..., 1]).all() and (t[1][..., 3] == 255).all()   # grey -> rgb, opaque
+    assert tuple(t[2][0, 0]) == (0, 0, 0, 255) and tuple(t[2][0, 7]) == (200, 100, 50, 255)
+    assert 0 < t[2][0, 3, 0] < 200 or 0 < t[2][0, 4, 0] < 200          # the edge is filtered, not replicated
+    flat = np.full((2, 2, 4), 77, np.uint8)
+    assert (pack_texture_array([flat], 16) == 77).all()                # a constant image stays constant
