@@ -281,11 +281,14 @@ struct Traversal {
                 const bool out = (__builtin_fabsf(det) < 1e-5f) | (u < 0.0f) | (u > 1.0f) | (v < 0.0f) | (u + v > 1.0f) |
                                  (t < 0.0f) | (t > hit.t);
                 const bool front = dot3(cross3(edge1, edge2), d) > 0.0f;
+                // hitInfo.blas follows `if (hitInfo.t < minT)` after the instance's walk (main.glsl:324-327): a hit that
+                // only TIES the distance found in an earlier instance replaces the triangle but not the instance
+                const bool closer = t < hit.t;
+                hit.inst = (out || !closer) ? hit.inst : cur_inst;
                 hit.t = out ? hit.t : t;
                 hit.u = out ? hit.u : u;
                 hit.v = out ? hit.v : v;
                 hit.tri = out ? hit.tri : ti;
-                hit.inst = out ? hit.inst : cur_inst;
                 hit.front = out ? hit.front : front;
             } else {
                 const f3 pvec = cross3(d, edge2);
@@ -300,11 +303,11 @@ struct Traversal {
                 if (v < 0.0f || u + v > 1.0f) continue;
                 const float t = dot3(edge2, qvec) * invDet;
                 if (t < 0.0f || t > hit.t) continue;
+                if (t < hit.t) hit.inst = cur_inst;  // main.glsl:324-327, see above
                 hit.t = t;
                 hit.u = u;
                 hit.v = v;
                 hit.tri = ti;
-                hit.inst = cur_inst;
                 hit.front = dot3(cross3(edge1, edge2), d) > 0.0f;
             }
         }

@@ -197,3 +197,39 @@ def test_sky_cull_is_exact(oracle, hiplib, view, builder):
             assert st[k] == cnt[k], k
     else:
         assert rel_l2(got, want) <= 1e-4 and np.array_equal(got_depth == np.float32(want_depth.max()), want_depth == want_depth.max())
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_duplicated_instance_keeps_the_first_visited_one(oracle, hiplib, kernel):
+    """Two instances of one mesh with the SAME transform and different override materials: every ray finds the same
+    triangle at the same distance in both.  The reference replaces the triangle on a tie (`t > hitInfo.t` rejects,
+    main.glsl:247) but moves hitInfo.blas only on a strictly smaller distance (main.glsl:324-327), so the instance
+    visited first supplies the material.  Reference-tree routes must reproduce that, bit for bit."""
+    import copy
+    sc = scenes.cornell_scene()
+    dup = copy.deepcopy(sc.instances[2])
+    dup.material_ids = [4 if sc.instances[2].material_ids[0] != 4 else 3]
+    sc.instances.append(dup)
+    tall = copy.deepcopy(sc.instances[3])
+    tall.material_ids = [6]                       # and a metallic twin of the tall block, inserted before its original
+    sc.instances.insert(1, tall)
+    w, h, bounces, frames = 128, 96, 3, 2
+    cam = scenes.camera_block(sc.camera, w, h)
+    ref = oracle.build_scene(sc)
+    want, want_ldr, want_depth, cnt, _ = oracle.render(ref, cam, w, h, bounces, frames, 1, wire.ACCUM_HDR_F32)
+    for route in ("upload", "exact"):
+        ctx = host.Context(0)
+        try:
+            ctx.set_kernel(kernel)
+            if route == "upload":
+                ctx.upload_reference_layout(ref.tri_geom, ref.tri_data, ref.materials, ref.bvh_nodes, ref.instances, ref.tlas_nodes)
+            else:
+                ctx.build_scene(sc, capi.BUILD_REFERENCE_EXACT)
+            ctx.set_params(w, h, bounces, wire.ACCUM_HDR_F32)
+            ctx.set_camera(cam)
+            ctx.render(frames, 1, counted=True)
+            got, st = ctx.read_accum(), ctx.stats()
+        finally:
+            ctx.close()
+        assert np.array_equal(got, want), route
+        assert st["shaded_hits"] == cnt["shaded_hits"] and st["tri_tests"] == cnt["tri_tests"]
