@@ -22,6 +22,12 @@ import time
 
 import numpy as np
 
+# The HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4); streams that share
+# a queue run in submission order.  The library keeps four renders in flight on four streams plus the context's
+# stream, so it wants more than four queues (gdpathtracing_amd/csrc/jpt_capi.hip).  Read at
+# runtime start-up: set before torch is imported.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -461,6 +461,47 @@ int do_render(jpt_ctx* c, int32_t n_frames, uint32_t first_frame_index, bool cou
     return JPT_OK;
 }
 
+// Helper streams and events are made on first use: most contexts (tests, tools, one-off renders) never queue renders
+// or render enough paths to split them.  NOTE on hardware queues: the HIP runtime multiplexes all streams of a
+// process onto GPU_MAX_HW_QUEUES hardware queues (default 4) in creation order, and two streams that share a queue
+// execute in submission order.  Four pipeline slots + the context's stream need five queues to be independent; with
+// the default of four the rate of queued renders depends on which streams happen to share (C3: 1.32 ms per render
+// with the most fortunate order, 1.60 and 2.39 with others), with GPU_MAX_HW_QUEUES >= 8 it does not (1.29-1.30).
+// The variable is read when the runtime starts, i.e. it has to be in the environment of the process (bench.py sets it).
+// frame groups: `groups - 1` helper streams (launch_wf2_render); false = not available, renders run serially
+bool ensure_group_streams(jpt_ctx* c, int groups)
+{
+    if (!c->async.fork && hipEventCreateWithFlags(&c->async.fork, hipEventDisableTiming) != hipSuccess) {
+        c->async.fork = nullptr;
+        (void)hipGetLastError();
+        return false;
+    }
+    for (int k = 0; k + 1 < groups && k < 3; k++) {
+        if (!c->async.aux_stream[k] && hipStreamCreateWithFlags(&c->async.aux_stream[k], hipStreamNonBlocking) != hipSuccess) {
+            c->async.aux_stream[k] = nullptr;
+            (void)hipGetLastError();
+            return false;
+        }
+        if (!c->async.join[k] && hipEventCreateWithFlags(&c->async.join[k], hipEventDisableTiming) != hipSuccess) {
+            c->async.join[k] = nullptr;
+            (void)hipGetLastError();
+            return false;
+        }
+    }
+    return true;
+}
+// render pipelining: stream + two events of slot `slot`
+bool ensure_pipe_slot(jpt_ctx* c, int slot)
+{
+    if (c->pipe_stream[slot] && c->ev_paths_done[slot] && c->ev_acc_done[slot]) return true;
+    bool ok = true;
+    if (!c->pipe_stream[slot]) ok = hipStreamCreateWithFlags(&c->pipe_stream[slot], hipStreamNonBlocking) == hipSuccess;
+    if (ok && !c->ev_paths_done[slot]) ok = hipEventCreateWithFlags(&c->ev_paths_done[slot], hipEventDisableTiming) == hipSuccess;
+    if (ok && !c->ev_acc_done[slot]) ok = hipEventCreateWithFlags(&c->ev_acc_done[slot], hipEventDisableTiming) == hipSuccess;
+    if (!ok) (void)hipGetLastError();
+    return ok;
+}
+
 int do_render_batch(jpt_ctx* c, int32_t n_frames, uint32_t first_frame_index, bool counted, bool blocking)
 {
     if (!c) return JPT_E_INVALID;
@@ -553,9 +594,9 @@ int do_render_batch(jpt_ctx* c, int32_t n_frames, uint32_t first_frame_index, bo
             const size_t one_workspace = wf2 ? wf2_workspace_bytes(c->width, c->local_rows, n_frames, c->max_bounces) : 0;
             const bool huge = one_workspace > ((size_t)24 << 30);  // 4 x 24 GiB of workspaces is where this stops
             const int pipe_slots = forced_slots ? forced_slots : (huge ? 2 : 4);
-            if (wf2 && pipelining && !blocking && !counted && !need_ev && c->pipe_stream[jpt_ctx::kPipeSlots - 1]) {
+            const int slot = (int)(c->async_seq % (uint64_t)pipe_slots);
+            if (wf2 && pipelining && !blocking && !counted && !need_ev && ensure_pipe_slot(c, slot)) {
                 // asynchronous render: path kernels on a helper stream + the other workspace; the accumulation on `s`
-                const int slot = (int)(c->async_seq % (uint64_t)pipe_slots);
                 hipStream_t ps = c->pipe_stream[slot];
                 DevBuf<char>& ws = slot ? c->d_workspace_more[slot - 1] : c->d_workspace;
                 const size_t need = wf2_workspace_bytes(c->width, c->local_rows, n_frames, c->max_bounces);
@@ -564,8 +605,11 @@ int do_render_batch(jpt_ctx* c, int32_t n_frames, uint32_t first_frame_index, bo
                     HIP_TRY(c, ws.resize(need));
                     c->acc_done_valid[slot] = false;
                 }
-                // this workspace was last read by the accumulation of the render `pipe_slots` renders ago
-                if (c->acc_done_valid[slot]) HIP_TRY(c, hipStreamWaitEvent(ps, c->ev_acc_done[slot], 0));
+                // this workspace was last read by the accumulation of the render `pipe_slots` renders ago; when that is
+                // not on record (first use of the slot, or renders that went through `s` itself since), wait for
+                // whatever `s` holds now
+                if (!c->acc_done_valid[slot]) HIP_TRY(c, hipEventRecord(c->ev_acc_done[slot], s));
+                HIP_TRY(c, hipStreamWaitEvent(ps, c->ev_acc_done[slot], 0));
                 // (one frame group: overlapping with the neighbouring render does what groups do, without extra launches:
                 // 3840x2160x16 spp 11.56 ms against 11.96 with two groups, instanced scene 3.80 against 4.05)
                 Wf2Async one_group = c->async;
@@ -577,9 +621,13 @@ int do_render_batch(jpt_ctx* c, int32_t n_frames, uint32_t first_frame_index, bo
                 c->acc_done_valid[slot] = true;
                 c->async_seq++;
                 pipelined = true;
-            } else if (wf2)
+            } else if (wf2) {
+                // (launch_wf2_render splits the frames into groups only if the helper streams exist)
+                const int want_groups = wf2_wanted_groups(n_frames, (size_t)c->width * (size_t)c->local_rows * (size_t)n_frames);
+                if (want_groups > 1 && !need_ev && !counted) (void)ensure_group_streams(c, want_groups);
                 launch_wf2_render(s, c->ds, fp, c->camera, c->d_workspace.p, c->d_accum.p, c->d_ldr.p, c->d_depth.p, cnt,
                                   need_ev ? c->trace_events.data() : nullptr, c->async);
+            }
             else
                 launch_wide_render(s, c->ds, fp, c->camera, c->d_workspace.p, c->d_accum.p, c->d_ldr.p, c->d_depth.p, cnt,
                                    need_ev ? c->trace_events.data() : nullptr);
@@ -601,11 +649,7 @@ int do_render_batch(jpt_ctx* c, int32_t n_frames, uint32_t first_frame_index, bo
         HIP_TRY(c, hipGetLastError());
     }
     HIP_TRY(c, hipEventRecord(c->ev1, s));
-    if (wavefront && !pipelined && c->ev_acc_done[0]) {
-        // a render that went through d_workspace on `s` itself: the next pipelined render into that workspace waits for it
-        HIP_TRY(c, hipEventRecord(c->ev_acc_done[0], s));
-        c->acc_done_valid[0] = true;
-    }
+    if (wavefront && !pipelined) c->acc_done_valid[0] = false;  // d_workspace was used on `s` itself: see the pipelined branch
     c->frame_count += (uint32_t)n_frames;
     c->stats.frames = c->frame_count;
     if (blocking || counted) {
@@ -706,28 +750,6 @@ int jpt_create(int device_id, jpt_ctx** out)
         return JPT_E_DEVICE;
     }
     c->stream = c->own_stream;
-    // helper streams of the frame groups; without them (creation failed) renders simply run serially
-    bool ok = hipEventCreateWithFlags(&c->async.fork, hipEventDisableTiming) == hipSuccess;
-    for (int k = 0; k < 3 && ok; k++)
-        ok = hipStreamCreateWithFlags(&c->async.aux_stream[k], hipStreamNonBlocking) == hipSuccess &&
-             hipEventCreateWithFlags(&c->async.join[k], hipEventDisableTiming) == hipSuccess;
-    for (int k = 0; k < jpt_ctx::kPipeSlots && ok; k++)
-        ok = hipStreamCreateWithFlags(&c->pipe_stream[k], hipStreamNonBlocking) == hipSuccess &&
-             hipEventCreateWithFlags(&c->ev_paths_done[k], hipEventDisableTiming) == hipSuccess &&
-             hipEventCreateWithFlags(&c->ev_acc_done[k], hipEventDisableTiming) == hipSuccess;
-    if (!ok) {
-        (void)hipGetLastError();
-        for (int k = 0; k < 3; k++) {
-            if (c->async.aux_stream[k]) (void)hipStreamDestroy(c->async.aux_stream[k]);
-            if (c->async.join[k]) (void)hipEventDestroy(c->async.join[k]);
-            c->async.aux_stream[k] = nullptr;
-            c->async.join[k] = nullptr;
-        }
-        for (int k = 0; k < jpt_ctx::kPipeSlots; k++) {
-            if (c->pipe_stream[k]) (void)hipStreamDestroy(c->pipe_stream[k]);
-            c->pipe_stream[k] = nullptr;
-        }
-    }
     *out = c;
     return JPT_OK;
 }

@@ -160,6 +160,8 @@ void launch_wf2_render(hipStream_t stream, const DeviceScene& ds, const FramePar
 void launch_temporal(hipStream_t stream, const RefTemporalParams& tp, uint32_t* screen, const float* depth, float4* hist1,
                      float4* hist2);
 
+int wf2_wanted_groups(int n_frames, size_t paths);
+
 // rank-major gathered strips -> full framebuffer (multi-GPU assemble)
 void launch_assemble(hipStream_t stream, const float4* gathered, int world, int width, int height, int max_local_rows,
                      float4* accum_full, uint32_t* ldr_full, uint32_t frame_count);

@@ -656,4 +656,7 @@ void launch_wf2_render(hipStream_t stream, const DeviceScene& ds, const FramePar
     hipLaunchKernelGGL(wf2_accumulate, dim3(ablocks), block, 0, acc_stream, wb_all, dm_all, fp, cam, accum, ldr, depth);
 }
 
+// the number of frame groups a blocking render of this size wants (helper streams permitting)
+int wf2_wanted_groups(int n_frames, size_t paths) { return frame_groups(n_frames, false, paths); }
+
 }  // namespace jpt
