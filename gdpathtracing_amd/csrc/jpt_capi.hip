@@ -815,6 +815,7 @@ int jpt_scene_upload_reference_layout(jpt_ctx* c, const void* tri_geometry, uint
         (n_instances && !blas_instances) || (n_tlas_nodes && !tlas_nodes))
         return fail(c, JPT_E_INVALID, "null buffer with non-zero count");
     if (n_tlas_nodes > 65536) return fail(c, JPT_E_LIMIT, "TLAS has more nodes than 16-bit child indices address (bvh.h:59)");
+    if (n_instances > 32767) return fail(c, JPT_E_LIMIT, "more instances than a TLAS with 16-bit child indices can hold (bvh.h:59; 32 767)");
     const auto t0 = std::chrono::steady_clock::now();
     c->scene_ready = c->host_scene_ready = false;
     RefScene& r = c->ref;

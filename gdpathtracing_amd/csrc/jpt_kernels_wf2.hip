@@ -353,9 +353,10 @@ __global__ __launch_bounds__(kBlock, JPT_SHADE_WAVES) void wf2_shade(SceneShadin
             h.u = ha.y;
             h.v = ha.z;
             h.tri = __float_as_uint(ha.w);
-            h.inst = hb & 0x7fffffffu;
+            h.inst = hb & kInstMask;                               // hitInfo.blas
+            const uint32_t found_in = (hb >> kInstBits) & kInstMask;   // the instance whose local ray found the triangle
             // the hit instance's local ray: the expression ray_trace_tlas evaluates (main.glsl:319-320)
-            const RefInstance& b = sh.instances[h.inst];
+            const RefInstance& b = sh.instances[found_in];
             h.lo = xform_point(b.inverse_transform, ray.o);
             h.ld = xform_dir(b.inverse_transform, ray.d);
             const Shading s = get_shading_data(sh, h, (hb >> 31) != 0u);

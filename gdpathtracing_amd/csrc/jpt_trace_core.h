@@ -62,6 +62,13 @@ __device__ __forceinline__ float slab_entry(const f3& o, const f3& rD, float mnx
     return tmin;
 }
 
+// TraceHit::inst holds two instance ids (a TLAS addresses at most 32 767 instances, bvh.h:59): bits 0..14 the
+// instance hitInfo.blas names -- it moves only on a strictly smaller distance -- and bits 15..29 the instance whose
+// local ray found the triangle kept, which is where hitInfo.position and hitInfo.out_dir come from (main.glsl:
+// 246-252).  The two differ only after a tie between instances.
+constexpr int kInstBits = 15;
+constexpr uint32_t kInstMask = (1u << kInstBits) - 1u;
+
 struct TraceHit {
     float t, u, v;
     uint32_t tri, inst;
@@ -284,7 +291,7 @@ struct Traversal {
                 // hitInfo.blas follows `if (hitInfo.t < minT)` after the instance's walk (main.glsl:324-327): a hit that
                 // only TIES the distance found in an earlier instance replaces the triangle but not the instance
                 const bool closer = t < hit.t;
-                hit.inst = (out || !closer) ? hit.inst : cur_inst;
+                hit.inst = out ? hit.inst : (((closer ? cur_inst : hit.inst) & kInstMask) | (cur_inst << kInstBits));
                 hit.t = out ? hit.t : t;
                 hit.u = out ? hit.u : u;
                 hit.v = out ? hit.v : v;
@@ -303,7 +310,7 @@ struct Traversal {
                 if (v < 0.0f || u + v > 1.0f) continue;
                 const float t = dot3(edge2, qvec) * invDet;
                 if (t < 0.0f || t > hit.t) continue;
-                if (t < hit.t) hit.inst = cur_inst;  // main.glsl:324-327, see above
+                hit.inst = (((t < hit.t) ? cur_inst : hit.inst) & kInstMask) | (cur_inst << kInstBits);  // main.glsl:324-327, see above
                 hit.t = t;
                 hit.u = u;
                 hit.v = v;

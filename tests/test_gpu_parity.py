@@ -233,3 +233,40 @@ def test_duplicated_instance_keeps_the_first_visited_one(oracle, hiplib, kernel)
             ctx.close()
         assert np.array_equal(got, want), route
         assert st["shaded_hits"] == cnt["shaded_hits"] and st["tri_tests"] == cnt["tri_tests"]
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_tie_between_instances_with_different_transforms(oracle, hiplib, kernel):
+    """Two instances of a plane mesh that cover each other exactly, one mirrored (x -> -x): many rays find bit-identical
+    distances in both.  The reference then shades the later triangle with the earlier instance's transform and
+    materials AND keeps the later instance's local hit position and outgoing direction (main.glsl:246-252, 324-327).
+    Every device route must land on the same picture as the oracle, which restates exactly that."""
+    floor = scenes.plane_mesh()
+    mats = np.stack([scenes.material(), scenes.material(albedo=(0.9, 0.2, 0.2), metallic=1.0, roughness=0.1),
+                     scenes.material(albedo=(0.2, 0.9, 0.2), metallic=1.0, roughness=0.25),
+                     scenes.material(emission=(1.0, 0.9, 0.8), energy=6.0)])
+    inst = [scenes.Instance(0, scenes.transform12(np.diag([3.0, 1.0, 3.0]), (0, -1.0, 0)), [1]),
+            scenes.Instance(0, scenes.transform12(np.diag([-3.0, 1.0, 3.0]), (0, -1.0, 0)), [2]),
+            scenes.Instance(0, scenes.transform12([[1.5, 0, 0], [0, -1, 0], [0, 0, -1.5]], (0.3, 2.5, -0.2)), [3])]
+    cam = scenes.CameraDesc(_look_at((0.4, 2.0, 5.0), (0.0, -1.0, 0.0)), fov_deg=60.0)
+    sc = scenes.Scene("ties", [floor], inst, mats, cam)
+    w, h, bounces, frames = 128, 96, 3, 2
+    camb = scenes.camera_block(sc.camera, w, h)
+    ref = oracle.build_scene(sc)
+    want, want_ldr, want_depth, cnt, _ = oracle.render(ref, camb, w, h, bounces, frames, 1, wire.ACCUM_HDR_F32)
+    for route in ("upload", "exact"):
+        ctx = host.Context(0)
+        try:
+            ctx.set_kernel(kernel)
+            if route == "upload":
+                ctx.upload_reference_layout(ref.tri_geom, ref.tri_data, ref.materials, ref.bvh_nodes, ref.instances, ref.tlas_nodes)
+            else:
+                ctx.build_scene(sc, capi.BUILD_REFERENCE_EXACT)
+            ctx.set_params(w, h, bounces, wire.ACCUM_HDR_F32)
+            ctx.set_camera(camb)
+            ctx.render(frames, 1)
+            got, got_depth = ctx.read_accum(), ctx.read_depth()
+        finally:
+            ctx.close()
+        assert np.array_equal(got, want), route
+        assert np.array_equal(got_depth, want_depth)
