@@ -26,7 +26,8 @@ import numpy as np
 # a queue run in submission order.  The library keeps four renders in flight on four streams plus the context's
 # stream, so it wants more than four queues (gdpathtracing_amd/csrc/jpt_capi.hip).  Read at
 # runtime start-up: set before torch is imported.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+if os.environ.get("JPT_BENCH_BACKEND", "nccl") == "nccl":   # (the gloo rehearsal puts several ranks on ONE GPU: their queues add up)
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
