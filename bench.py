@@ -2,7 +2,7 @@
 """bench.py -- headline metric of BASELINE.json: Mrays/s at 1920x1080, 8 spp, 4 bounces.
 
 One "step" = one full render of the workload (accumulation reset, `spp` frames of the path-tracing
-kernels + accumulation, and -- for N > 1 -- the RCCL gather of every rank's finished rgba8 rows to rank 0
+kernels + accumulation, and -- for N > 1 -- the RCCL gather of every rank's finished float4 rows to rank 0
 and their assembly).  The K timed steps are queued with jpt_render_async and bracketed by barrier +
 torch.cuda.synchronize() on both sides; the library overlaps the launches of consecutive queued renders, so
 ms_per_step is the queued rate (the device time of one render on its own is reported as roofline.render_ms).
@@ -69,9 +69,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--verify", action="store_true",
                     help="after the timed region, rank 0 re-renders the whole image alone and checks the assembled one bit for bit")
-    ap.add_argument("--gather", choices=["ldr", "accum"], default="ldr",
-                    help="N > 1: what crosses the links each render -- the rgba8 display rows (4 B/pixel, what the reference reads "
-                         "back) or the float4 accumulation rows (16 B/pixel)")
+    ap.add_argument("--gather", choices=["ldr", "accum"], default="accum",
+                    help="N > 1: what crosses the links each render -- the float4 accumulation rows (16 B/pixel: the exchange "
+                         "BASELINE.json's north_star names, the default) or only the rgba8 display rows (4 B/pixel, what the "
+                         "reference reads back)")
     ap.add_argument("--cpu-sample", default="auto")
     ap.add_argument("--pmc-json", default=os.path.join(ROOT, "profiles", "current_pmc.json"),
                     help="per-launch HBM bytes of each kernel from the committed rocprofv3 --pmc passes (tools/pmc.sh)")
