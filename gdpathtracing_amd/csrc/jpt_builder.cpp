@@ -909,7 +909,10 @@ bool flatten(const RefScene& ref, WideScene& out, std::string& err)
         t.v0[0] = g.vertices[0].x; t.v0[1] = g.vertices[0].y; t.v0[2] = g.vertices[0].z;
         t.e1[0] = g.vertices[1].x - g.vertices[0].x; t.e1[1] = g.vertices[1].y - g.vertices[0].y; t.e1[2] = g.vertices[1].z - g.vertices[0].z;
         t.e2[0] = g.vertices[2].x - g.vertices[0].x; t.e2[1] = g.vertices[2].y - g.vertices[0].y; t.e2[2] = g.vertices[2].z - g.vertices[0].z;
-        t.src_index = (uint32_t)i;
+        // cross(e1, e2), each product and difference rounded on its own like the shader's (no contraction: Makefile)
+        t.nx = t.e1[1] * t.e2[2] - t.e1[2] * t.e2[1];
+        t.ny = t.e1[2] * t.e2[0] - t.e1[0] * t.e2[2];
+        t.nz = t.e1[0] * t.e2[1] - t.e1[1] * t.e2[0];
     }
     // one BLAS tree per distinct root referenced by an instance
     std::vector<std::pair<uint32_t, int32_t>> root_refs;

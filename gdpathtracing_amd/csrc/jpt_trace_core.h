@@ -287,7 +287,7 @@ struct Traversal {
                 const float t = dot3(edge2, qvec) * invDet;
                 const bool out = (__builtin_fabsf(det) < 1e-5f) | (u < 0.0f) | (u > 1.0f) | (v < 0.0f) | (u + v > 1.0f) |
                                  (t < 0.0f) | (t > hit.t);
-                const bool front = dot3(cross3(edge1, edge2), d) > 0.0f;
+                const bool front = dot3(mk3(q0.w, q1.w, q2.w), d) > 0.0f;  // the record carries cross(edge1, edge2)
                 // hitInfo.blas follows `if (hitInfo.t < minT)` after the instance's walk (main.glsl:324-327): a hit that
                 // only TIES the distance found in an earlier instance replaces the triangle but not the instance
                 const bool closer = t < hit.t;

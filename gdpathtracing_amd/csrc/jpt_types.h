@@ -129,13 +129,16 @@ constexpr int32_t kEmptyChild = (int32_t)0x80000000;  // ~0x7fffffff: never a va
 
 // 48-byte triangle record: v0 and the two Moller-Trumbore edges, precomputed with the same float
 // subtractions intersectTriangle performs (main.glsl:231-232), so t,u,v are bit-identical.
+// The fourth words hold cross(e1, e2) (main.glsl:253's geometric normal, the same three float expressions), so the
+// front/back test of a triangle test is one dot product.  Records are in reference order: triangle i of the
+// shading arrays (tri_data) is record i.
 struct alignas(16) WideTri {
     float v0[3];
-    uint32_t src_index;  // index into the reference-order shading arrays (tri_data)
+    float nx;
     float e1[3];
-    uint32_t _p1;
+    float ny;
     float e2[3];
-    uint32_t _p2;
+    float nz;
 };
 static_assert(sizeof(WideTri) == 48, "WideTri");
 
