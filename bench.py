@@ -22,12 +22,14 @@ import time
 
 import numpy as np
 
-# The HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4); streams that share
-# a queue run in submission order.  The library keeps four renders in flight on four streams plus the context's
-# stream, so it wants more than four queues (gdpathtracing_amd/csrc/jpt_capi.hip).  Read at
-# runtime start-up: set before torch is imported.
+# The HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4), dealt in the
+# order the streams are first used; streams that share a queue run in submission order.  The library keeps four
+# renders in flight on four streams plus the context's stream, so it wants more than four queues, and it wants to
+# stay off the LAST queue of the pool (a render stream that lands there costs 23 %: 1.58 instead of 1.28 ms on C3,
+# whatever the pool size -- DESIGN.md section 4).  Sixteen leaves room for the streams RCCL and torch use first.
+# Read at runtime start-up: set before torch is imported.
 if os.environ.get("JPT_BENCH_BACKEND", "nccl") == "nccl":   # (the gloo rehearsal puts several ranks on ONE GPU: their queues add up)
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -124,10 +126,12 @@ def main():
     ctx.set_params(W, H, bounces, accum_mode)
     ctx.set_camera(cam)
     ctx.set_kernel({"wavefront": capi.KERNEL_WAVEFRONT, "ref": capi.KERNEL_REFERENCE_LAYOUT, "wavefront_v1": capi.KERNEL_WAVEFRONT_V1}[args.kernel])
-    # one explicit (non-null) stream carries the kernels, the timing events and the collective
-    stream = torch.cuda.Stream()
+    # One explicit (non-null) stream carries the renders, the timing events and the collective: the context's own,
+    # made torch's current stream.  (Not a stream from torch's pool: the pool is 32 streams created at once, the HIP
+    # runtime deals streams to its hardware queues round-robin in creation order, and the library's slot streams,
+    # created next, would land on the very queue the pool stream sits on -- one frame per render 0.40 instead of 0.31 ms.)
+    stream = torch.cuda.ExternalStream(ctx.get_stream(), device=torch.device("cuda", local_rank))
     torch.cuda.set_stream(stream)
-    ctx.set_stream(stream.cuda_stream)
     ctx.set_kernel_timing(False)   # per-launch HIP events serialise the frame groups: they are collected after the timed region
 
     # gather plumbing (N > 1): the local piece (rgba8 display rows, or float4 sums) viewed as a torch tensor, no copy

@@ -22,7 +22,7 @@ BUF_TRI_GEOMETRY, BUF_TRI_DATA, BUF_MATERIALS, BUF_BVH_NODES, BUF_INSTANCES, BUF
 
 # every symbol include/jpt.h declares
 SYMBOLS = [
-    "jpt_abi_version", "jpt_create", "jpt_destroy", "jpt_last_error", "jpt_set_stream",
+    "jpt_abi_version", "jpt_create", "jpt_destroy", "jpt_last_error", "jpt_set_stream", "jpt_get_stream",
     "jpt_scene_upload_reference_layout", "jpt_scene_begin", "jpt_scene_add_mesh", "jpt_scene_add_instance",
     "jpt_scene_set_materials", "jpt_scene_set_textures", "jpt_scene_commit", "jpt_scene_get_reference_buffer",
     "jpt_scene_set_instance_transform", "jpt_scene_update_tlas", "jpt_scene_update_reference_tlas",
@@ -92,6 +92,7 @@ def lib():
     L.jpt_last_error.argtypes = [vp]
     L.jpt_last_error.restype = C.c_char_p
     L.jpt_set_stream.argtypes = [vp, vp]
+    L.jpt_get_stream.argtypes = [vp, C.POINTER(vp)]
     L.jpt_scene_upload_reference_layout.argtypes = [vp, vp, u32, vp, vp, u32, vp, u32, vp, u32, vp, u32, vp, i32, i32]
     L.jpt_scene_begin.argtypes = [vp]
     L.jpt_scene_add_mesh.argtypes = [vp, C.POINTER(Surface), i32, C.POINTER(u32)]

@@ -463,11 +463,12 @@ int do_render(jpt_ctx* c, int32_t n_frames, uint32_t first_frame_index, bool cou
 
 // Helper streams and events are made on first use: most contexts (tests, tools, one-off renders) never queue renders
 // or render enough paths to split them.  NOTE on hardware queues: the HIP runtime multiplexes all streams of a
-// process onto GPU_MAX_HW_QUEUES hardware queues (default 4) in creation order, and two streams that share a queue
-// execute in submission order.  Four pipeline slots + the context's stream need five queues to be independent; with
-// the default of four the rate of queued renders depends on which streams happen to share (C3: 1.32 ms per render
-// with the most fortunate order, 1.60 and 2.39 with others), with GPU_MAX_HW_QUEUES >= 8 it does not (1.29-1.30).
-// The variable is read when the runtime starts, i.e. it has to be in the environment of the process (bench.py sets it).
+// process onto GPU_MAX_HW_QUEUES hardware queues (default 4) in the order of their first use, and two streams that
+// share a queue execute in submission order.  Four pipeline slots + the context's stream need five queues to be
+// independent; with the default of four the rate of queued renders depends on which streams happen to share (C3: 1.32
+// ms per render with the most fortunate order, 1.60 and 2.39 with others), with GPU_MAX_HW_QUEUES >= 8 it does not
+// (1.27-1.29) -- unless a slot's stream lands on the LAST queue of the pool (1.58).  The variable
+// is read when the runtime starts, i.e. it has to be in the environment of the process (bench.py sets it to 16).
 // frame groups: `groups - 1` helper streams (launch_wf2_render); false = not available, renders run serially
 bool ensure_group_streams(jpt_ctx* c, int groups)
 {
@@ -628,9 +629,25 @@ int do_render_batch(jpt_ctx* c, int32_t n_frames, uint32_t first_frame_index, bo
                 Wf2Async one_group = c->async;
                 one_group.aux_stream[0] = nullptr;
                 one_group.trace_chain = huge ? 1 : 4;
-                launch_wf2_render(ps, c->ds, fp, c->camera, ws.p, c->d_accum.p, c->d_ldr.p, c->d_depth.p, nullptr, nullptr, one_group, s,
-                                  c->ev_paths_done[slot]);
-                HIP_TRY(c, hipEventRecord(c->ev_acc_done[slot], s));
+                static const bool acc_on_slot = [] {
+                    const char* e = getenv("JPT_ACC_ON_SLOT");
+                    return !(e && atoi(e) == 0);
+                }();
+                if (acc_on_slot) {
+                    // The accumulation runs on the slot's stream too, after whatever `s` holds now (the previous render's
+                    // accumulation, an upload, a read-back), and `s` then waits for it: the results are those of serial
+                    // execution, and `s` itself carries no kernels of a render -- the hardware runs four queues side by
+                    // side, and four slots plus a busy `s` were five (C3 1.287 -> 1.265 ms, a GPU's eighth of C3 329 -> 306 us)
+                    HIP_TRY(c, hipEventRecord(c->ev_paths_done[slot], s));
+                    one_group.before_acc = c->ev_paths_done[slot];
+                    launch_wf2_render(ps, c->ds, fp, c->camera, ws.p, c->d_accum.p, c->d_ldr.p, c->d_depth.p, nullptr, nullptr, one_group);
+                    HIP_TRY(c, hipEventRecord(c->ev_acc_done[slot], ps));
+                    HIP_TRY(c, hipStreamWaitEvent(s, c->ev_acc_done[slot], 0));
+                } else {
+                    launch_wf2_render(ps, c->ds, fp, c->camera, ws.p, c->d_accum.p, c->d_ldr.p, c->d_depth.p, nullptr, nullptr, one_group, s,
+                                      c->ev_paths_done[slot]);
+                    HIP_TRY(c, hipEventRecord(c->ev_acc_done[slot], s));
+                }
                 c->acc_done_valid[slot] = true;
                 c->async_seq++;
                 pipelined = true;
@@ -815,6 +832,14 @@ int jpt_set_stream(jpt_ctx* c, void* hip_stream)
         for (int k = 0; k < jpt_ctx::kPipeSlots; k++) c->acc_done_valid[k] = false;
         c->stream = next;
     }
+    return JPT_OK;
+}
+
+int jpt_get_stream(jpt_ctx* c, void** hip_stream)
+{
+    if (!c || !hip_stream) return JPT_E_INVALID;
+    if (c->device < 0) return fail(c, JPT_E_DEVICE, "host-only context has no stream");
+    *hip_stream = (void*)c->stream;
     return JPT_OK;
 }
 

@@ -150,6 +150,7 @@ struct Wf2Async {
     size_t last_rays = 0;  // ray segments of this context's previous render of the same size (0: unknown)
     SkyCull cull;          // for the primary launch of this render
     int trace_chain = 1;   // wf2_trace: consecutive segments per block (1: lowest latency; 4 when renders are queued)
+    hipEvent_t before_acc = nullptr;  // the accumulation kernel waits for this event (whatever its stream)
 };
 void launch_wf2_render(hipStream_t stream, const DeviceScene& ds, const FrameParams& fp, const RefCamera& cam, void* workspace,
                        float4* accum, uint32_t* ldr, float* depth, DevCounters* counters, hipEvent_t* trace_events,

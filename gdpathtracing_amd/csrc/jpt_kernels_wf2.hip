@@ -225,7 +225,10 @@ __global__ __launch_bounds__(kBlock, JPT_PRIMARY_WAVES) void wf2_primary(WideSce
 // kSegments / chain blocks.  A deeper queue per block keeps the lanes refilled for a larger share of the launch (at
 // bounce 4 of C3 a segment holds 1.7 rays per lane); the slots this leaves free are used by the launches of the
 // other renders in flight (render pipelining), so chain > 1 only pays when renders are queued.
-constexpr int kMaxChain = 4;
+#ifndef JPT_MAX_CHAIN
+#define JPT_MAX_CHAIN 4
+#endif
+constexpr int kMaxChain = JPT_MAX_CHAIN;
 template <bool COUNT, bool W4>
 __global__ __launch_bounds__(kBlock, JPT_WAVES_PER_SIMD) void wf2_trace(WideSceneDev sc, Wf2Buffers wb, Wf2Dims dm, int bounce, WfTune tune,
                                                     int chain, DevCounters* __restrict__ counters)
@@ -653,6 +656,7 @@ void launch_wf2_render(hipStream_t stream, const DeviceScene& ds, const FramePar
     } else {
         acc_stream = stream;
     }
+    if (async.before_acc) (void)hipStreamWaitEvent(acc_stream, async.before_acc, 0);
     const uint32_t ablocks = (dm_all.slots_per_frame + kBlock - 1) / kBlock;
     hipLaunchKernelGGL(wf2_accumulate, dim3(ablocks), block, 0, acc_stream, wb_all, dm_all, fp, cam, accum, ldr, depth);
 }

@@ -141,6 +141,11 @@ class Context:
     def set_stream(self, hip_stream: Optional[int]):
         self._ck(self._lib.jpt_set_stream(self.h, hip_stream), "jpt_set_stream")
 
+    def get_stream(self) -> int:
+        out = C.c_void_p()
+        self._ck(self._lib.jpt_get_stream(self.h, C.byref(out)), "jpt_get_stream")
+        return int(out.value or 0)
+
     def render(self, n_frames=1, first_frame_index=1, counted=False, asynchronous=False):
         fn = self._lib.jpt_render_counted if counted else (self._lib.jpt_render_async if asynchronous else self._lib.jpt_render)
         self._ck(fn(self.h, n_frames, first_frame_index), "jpt_render")

@@ -111,6 +111,10 @@ int jpt_abi_version(void);
  * stream.  NULL restores the context's own stream.  Work already queued on the previous stream is waited for.
  * No reference counterpart. */
 int jpt_set_stream(jpt_ctx *ctx, void *hip_stream);
+/* The stream this ctx orders its work on (its own one unless jpt_set_stream replaced it), as hipStream_t: lets a
+ * framework queue its own work -- a collective on the finished rows -- behind the renders (bench.py wraps it in
+ * torch.cuda.ExternalStream).  No reference counterpart. */
+int jpt_get_stream(jpt_ctx *ctx, void **hip_stream);
 
 /* ---- scene ingest, route (i): reference layout ------------------------------------------------ */
 
@@ -197,8 +201,9 @@ int jpt_render(jpt_ctx *ctx, int32_t n_frames, uint32_t first_frame_index);
 /* Same result, kernels compiled with event counters; fills the jpt_stats counter fields. */
 int jpt_render_counted(jpt_ctx *ctx, int32_t n_frames, uint32_t first_frame_index);
 /* Asynchronous form: enqueue and return; jpt_sync() or a jpt_read_* waits.  Consecutive asynchronous renders are
- * pipelined: their path kernels run on alternating internal streams with separate workspaces (one render's launch
- * tails overlap the next render's kernels), the accumulation kernels run in call order on the ctx stream, so the
+ * pipelined: their kernels run on alternating internal streams with separate workspaces (one render's launch
+ * tails overlap the next render's kernels), the accumulation kernels run in call order (chained by events through
+ * the ctx stream, which waits for each of them: work queued on the ctx stream afterwards sees the result), so the
  * framebuffers hold exactly what serial execution would leave (C3: 1.82 -> 1.31 ms per render when queued; up to four
  * renders are in flight, each with its own workspace). */
 int jpt_render_async(jpt_ctx *ctx, int32_t n_frames, uint32_t first_frame_index);
