@@ -477,3 +477,42 @@ def test_asynchronous_renders_pipeline_in_order(oracle, hiplib):
     ref = oracle.build_scene(sc)
     want, want_ldr, _, _, _ = oracle.render(ref, cam, w, h, bounces, 3, 7, wire.ACCUM_REF_LDR8)   # frames 7, 8, 9 after the reset
     assert np.array_equal(a[1][0], want) and np.array_equal(a[1][1], want_ldr)
+
+
+def test_foreign_work_on_the_context_stream_sees_each_queued_render(hiplib):
+    """jpt_get_stream: work a framework queues on the context's stream between asynchronous renders (bench.py's
+    gather) is ordered after the render before it and before the render after it -- although the renders' kernels,
+    the accumulation included, run on the library's own streams."""
+    import torch
+    sc = scenes.demo_scene(2500)
+    w, h, bounces = 320, 180, 3
+    ctx = make_ctx(sc, w, h, bounces, wire.ACCUM_HDR_F32)
+    s = ctx.get_stream()
+    assert s != 0
+    stream = torch.cuda.ExternalStream(s, device=torch.device("cuda", 0))
+    ptr, nbytes = ctx.device_accum()
+
+    class _View:
+        __cuda_array_interface__ = {"shape": (nbytes // 4,), "typestr": "<f4", "data": (ptr, False), "version": 2}
+
+    accum = torch.as_tensor(_View(), device=torch.device("cuda", 0))
+    snaps = []
+    with torch.cuda.stream(stream):
+        for k in range(6):
+            ctx.accum_reset()
+            ctx.render(2, 1 + 2 * k, asynchronous=True)
+            snaps.append(accum.clone())          # queued on the context's stream right behind render k
+        stream.synchronize()
+    ctx.sync()
+    solo = make_ctx(sc, w, h, bounces, wire.ACCUM_HDR_F32)
+    for k in range(6):
+        solo.accum_reset()
+        solo.render(2, 1 + 2 * k)
+        assert np.array_equal(snaps[k].cpu().numpy().reshape(h, w, 4), solo.read_accum()), k
+    # replacing the stream and restoring it: the getter follows
+    other = torch.cuda.Stream()
+    ctx.set_stream(other.cuda_stream)
+    assert ctx.get_stream() == other.cuda_stream
+    ctx.set_stream(None)
+    assert ctx.get_stream() == s
+    ctx.close(); solo.close()
