@@ -17,7 +17,8 @@ ctx.sync()
 best = 1e9
 for rep in range(3):
     t0 = time.perf_counter()
-    for _ in range(n): ctx.accum_reset(); ctx.render(spp, 1, asynchronous=True)
+    blocking = bool(os.environ.get('RATE_BLOCKING'))   # one render at a time: the latency of a render
+    for _ in range(n): ctx.accum_reset(); ctx.render(spp, 1, asynchronous=not blocking)
     ctx.sync(); best = min(best, (time.perf_counter() - t0) / n * 1e6)
 print("%dx%dx%d /%d %s: %.1f us/step" % (w, h, spp, world, " ".join("%s=%s" % (k, v) for k, v in os.environ.items() if k.startswith(("JPT_", "RATE_"))), best))
 ctx.close()
