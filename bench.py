@@ -197,8 +197,9 @@ def main():
     barrier()
     # Timed region.  Steps are queued back to back and the closing barrier waits for all of them: the library runs
     # the path kernels of consecutive asynchronous renders on its pipeline slots' streams (four workspaces), so one
-    # render's launch tails overlap the next renders' kernels; the accumulation kernels run in order on the context's
-    # stream.  (A queue of K renders takes K x rate + the latency of the last one, ~3 ms: small K reads lower.)
+    # render's launch tails overlap the next renders' kernels; the accumulation kernels run in call order, chained
+    # through the context's stream.  (A queue of K renders takes K x rate + the latency of the last one, ~3 ms: small
+    # K reads lower.)
     t0 = time.perf_counter()
     for i in range(args.steps):
         ctx.accum_reset()
@@ -305,7 +306,9 @@ def main():
             out["verified_bit_identical_to_one_context"] = verified
         if world == 1 and not args.no_cpu_baseline:
             from oracle import binding as ob
-            ref = ob.build_scene(sc)
+            t0 = time.perf_counter()
+            ref = ob.build_scene(sc)   # the reference's BVH / TLAS builder restated (src/bvh/bvh.cpp), one thread
+            cpu_build_s = time.perf_counter() - t0
             # probe the host's rate on a small image, then size the sample for ~5-20 s of wall time
             # (the whole workload if the host is fast enough)
             pw, ph = 240, 135
@@ -325,6 +328,7 @@ def main():
             dt = time.perf_counter() - t0
             out["cpu_baseline"] = {
                 "value": round(cnt["rays"] / dt / 1e6, 3), "unit": "Mrays/s", "cores": used, "kind": "port",
+                "bvh_build_s": round(cpu_build_s, 4), "bvh_build_cores": 1,
                 "sample": "same scene/camera/seeds at %dx%d, %d spp, %d bounces (%.1f s, %d rays); oracle = C restatement "
                           "of main.glsl over the reference-layout BVH, pthreads" % (sw, sh, spp, bounces, dt, cnt["rays"]),
             }

@@ -451,7 +451,7 @@ def test_frame_groups_on_concurrent_streams(oracle, hiplib, monkeypatch, groups)
 
 def test_asynchronous_renders_pipeline_in_order(oracle, hiplib):
     """jpt_render_async: consecutive asynchronous renders run their path kernels on alternating helper streams and
-    workspaces while the accumulation stays in order on the context's stream.  Five queued renders (continuing one
+    workspaces while the accumulation kernels stay in call order (chained through the context's stream).  Five queued renders (continuing one
     accumulation, then a reset, then a blocking render in between) give exactly what the same calls give one by one."""
     sc = scenes.demo_scene(2500)
     w, h, bounces = 176, 100, 3
