@@ -25,7 +25,7 @@ SYMBOLS = [
     "jpt_abi_version", "jpt_create", "jpt_destroy", "jpt_last_error", "jpt_set_stream", "jpt_get_stream",
     "jpt_scene_upload_reference_layout", "jpt_scene_begin", "jpt_scene_add_mesh", "jpt_scene_add_instance",
     "jpt_scene_set_materials", "jpt_scene_set_textures", "jpt_scene_commit", "jpt_scene_get_reference_buffer",
-    "jpt_scene_set_instance_transform", "jpt_scene_update_tlas", "jpt_scene_update_reference_tlas",
+    "jpt_scene_set_instance_transform", "jpt_scene_update_tlas", "jpt_scene_refit_tlas", "jpt_scene_update_reference_tlas",
     "jpt_set_params", "jpt_set_kernel", "jpt_set_kernel_timing", "jpt_set_partition", "jpt_set_camera", "jpt_render", "jpt_render_counted", "jpt_render_async",
     "jpt_sync", "jpt_accum_reset", "jpt_set_denoising_mode", "jpt_set_temporal_params", "jpt_read_ldr_rgba8", "jpt_readback_ldr_begin", "jpt_readback_ldr_end", "jpt_read_accum_f32", "jpt_read_depth_f32",
     "jpt_device_accum", "jpt_assemble_from_ranks", "jpt_device_ldr", "jpt_assemble_ldr_from_ranks", "jpt_local_rows", "jpt_get_stats",
@@ -103,6 +103,7 @@ def lib():
     L.jpt_scene_get_reference_buffer.argtypes = [vp, i32, vp, C.c_size_t, C.POINTER(C.c_size_t)]
     L.jpt_scene_set_instance_transform.argtypes = [vp, u32, vp]
     L.jpt_scene_update_tlas.argtypes = [vp]
+    L.jpt_scene_refit_tlas.argtypes = [vp, vp, u32]
     L.jpt_scene_update_reference_tlas.argtypes = [vp, vp, u32, vp, u32]
     L.jpt_set_params.argtypes = [vp, i32, i32, i32, i32, i32]
     L.jpt_set_partition.argtypes = [vp, i32, i32]

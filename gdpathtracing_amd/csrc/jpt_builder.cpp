@@ -1,5 +1,6 @@
 // jpt_builder.cpp -- see jpt_builder.h.  Host C++ only (no device code).
 #include "jpt_builder.h"
+#include "jpt_instance_math.h"
 
 #include <algorithm>
 #include <cfloat>
@@ -375,20 +376,7 @@ struct SahBlasBuilder {
     }
 };
 
-// Utils::transform_to_float (utils.h:15-37)
-void transform12_to_mat16(const float* t, float* m)
-{
-    for (int c = 0; c < 3; c++) {
-        m[c * 4 + 0] = t[0 * 3 + c];
-        m[c * 4 + 1] = t[1 * 3 + c];
-        m[c * 4 + 2] = t[2 * 3 + c];
-        m[c * 4 + 3] = 0.0f;
-    }
-    m[12] = t[9];
-    m[13] = t[10];
-    m[14] = t[11];
-    m[15] = 1.0f;
-}
+// (Utils::transform_to_float, utils.h:15-37, is transform12_to_mat16 in jpt_instance_math.h)
 
 // TLAS::FindBestMatch (bvh.cpp:319-340)
 int nearest_partner(const std::vector<RefTlasNode>& nodes, const std::vector<int>& list, int n, int a)
@@ -583,27 +571,6 @@ bool build_tlas_sah(const std::vector<RefInstance>& inst, std::vector<RefTlasNod
 
 }  // namespace
 
-// godot Basis::invert (cofactors) + Transform3D::affine_inverse, float.  godot-cpp (branch 4.3) is an
-// absent submodule; this is its published algorithm.  Runs before the path: it only fills the matrices
-// of the BLASInstance record.
-void affine_inverse12(const float* t, float* o)
-{
-    auto R = [&](int r, int c) { return t[r * 3 + c]; };
-    auto cof = [&](int r1, int c1, int r2, int c2) { return R(r1, c1) * R(r2, c2) - R(r1, c2) * R(r2, c1); };
-    const float co0 = cof(1, 1, 2, 2), co1 = cof(1, 2, 2, 0), co2 = cof(1, 0, 2, 1);
-    const float det = R(0, 0) * co0 + R(0, 1) * co1 + R(0, 2) * co2;
-    const float s = 1.0f / det;
-    float m[9];
-    m[0] = co0 * s; m[1] = cof(0, 2, 2, 1) * s; m[2] = cof(0, 1, 1, 2) * s;
-    m[3] = co1 * s; m[4] = cof(0, 0, 2, 2) * s; m[5] = cof(0, 2, 1, 0) * s;
-    m[6] = co2 * s; m[7] = cof(0, 1, 2, 0) * s; m[8] = cof(0, 0, 1, 1) * s;
-    for (int k = 0; k < 9; k++) o[k] = m[k];
-    const float nx = -t[9], ny = -t[10], nz = -t[11];
-    o[9] = m[0] * nx + m[1] * ny + m[2] * nz;
-    o[10] = m[3] * nx + m[4] * ny + m[5] * nz;
-    o[11] = m[6] * nx + m[7] * ny + m[8] * nz;
-}
-
 void SceneBuilder::begin()
 {
     meshes_.clear();
@@ -671,35 +638,8 @@ bool SceneBuilder::rebuild_instances(BuildMode mode, RefScene& out, std::string&
         std::memset(&inst, 0, sizeof inst);
         inst.blas_index = out.mesh_roots[pi.mesh];
         for (int k = 0; k < 3; k++) inst.material[k] = pi.mats[k];
-        float inv12[12];
-        affine_inverse12(pi.t12, inv12);
-        transform12_to_mat16(pi.t12, inst.transform);
-        transform12_to_mat16(inv12, inst.inverse_transform);
-        // BLASInstance::update_aabb (bvh.h:90-115)
         const RefBvhNode& root = out.bvh_nodes[inst.blas_index];
-        inst.aabbMin = Vec4{1e34f, 1e34f, 1e34f, 1.0f};
-        inst.aabbMax = Vec4{-1e34f, -1e34f, -1e34f, 1.0f};
-        for (int i = 0; i < 8; i++) {
-            const float corner[4] = {(i & 1) ? root.aabbMax.x : root.aabbMin.x, (i & 2) ? root.aabbMax.y : root.aabbMin.y,
-                                     (i & 4) ? root.aabbMax.z : root.aabbMin.z, 1.0f};
-            float tc[4] = {0.0f, 0.0f, 0.0f, 1.0f};
-            for (int j = 0; j < 4; j++)
-                for (int k = 0; k < 4; k++) tc[j] += inst.transform[k * 4 + j] * corner[k];
-            const float s = 2.0f / tc[3];
-            const Vec4 c{tc[0] * s, tc[1] * s, tc[2] * s, tc[3] * s};
-            inst.aabbMin = Vec4{lo_(inst.aabbMin.x, c.x), lo_(inst.aabbMin.y, c.y), lo_(inst.aabbMin.z, c.z), lo_(inst.aabbMin.w, c.w)};
-            inst.aabbMax = Vec4{hi_(inst.aabbMax.x, c.x), hi_(inst.aabbMax.y, c.y), hi_(inst.aabbMax.z, c.z), hi_(inst.aabbMax.w, c.w)};
-        }
-        if (mode == BuildMode::Sah) {
-            // pad the world box like the BLAS boxes (the affine map of the corners rounds)
-            float m = 0.0f;
-            const float* lo = &inst.aabbMin.x;
-            const float* hi = &inst.aabbMax.x;
-            for (int k = 0; k < 3; k++) m = std::max(m, std::max(std::fabs(lo[k]), std::fabs(hi[k])));
-            const float pad = m * 2e-6f;
-            inst.aabbMin = Vec4{lo[0] - pad, lo[1] - pad, lo[2] - pad, 1.0f};
-            inst.aabbMax = Vec4{hi[0] + pad, hi[1] + pad, hi[2] + pad, 1.0f};
-        }
+        instance_record(pi.t12, root.aabbMin, root.aabbMax, mode == BuildMode::Sah, inst);  // jpt_instance_math.h
         out.instances.push_back(inst);
     }
     if (mode == BuildMode::Sah ? !build_tlas_sah(out.instances, out.tlas_nodes, err) : !build_tlas(out.instances, out.tlas_nodes, err))
@@ -1084,6 +1024,31 @@ uint32_t need4(const std::vector<WideNode4>& nodes, int32_t ref, std::vector<int
 }
 
 }  // namespace
+
+void tlas4_refit_schedule(const WideScene& w, std::vector<uint32_t>& order, std::vector<uint32_t>& level_start)
+{
+    order.clear();
+    level_start.clear();
+    level_start.push_back(0);
+    const size_t n = w.tlas_nodes4.size();
+    if (w.tlas_root4 < 0 || (size_t)w.tlas_root4 >= n) return;  // no record: the root is an instance (or nothing)
+    // breadth first from the root: the levels, shallowest first; a record has one parent, so each appears once
+    std::vector<std::vector<uint32_t>> levels;
+    levels.push_back({(uint32_t)w.tlas_root4});
+    for (size_t l = 0; l < levels.size() && l <= n; l++) {
+        std::vector<uint32_t> next;
+        for (uint32_t ni : levels[l])
+            for (int k = 0; k < 4; k++) {
+                const int32_t c = w.tlas_nodes4[ni].child[k];
+                if (c >= 0 && (size_t)c < n) next.push_back((uint32_t)c);
+            }
+        if (!next.empty()) levels.push_back(std::move(next));
+    }
+    for (size_t l = levels.size(); l-- > 0;) {
+        order.insert(order.end(), levels[l].begin(), levels[l].end());
+        level_start.push_back((uint32_t)order.size());
+    }
+}
 
 void compute_stack_need(WideScene& out)
 {

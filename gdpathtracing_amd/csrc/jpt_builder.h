@@ -83,8 +83,11 @@ class SceneBuilder {
     std::vector<PendingInstance> instances_;
 };
 
-// godot Transform3D::affine_inverse restated in float (godot-cpp is absent; published algorithm)
-void affine_inverse12(const float* t12, float* out12);
+// (godot Transform3D::affine_inverse restated in float: affine_inverse12 in jpt_instance_math.h)
+
+// Bottom-up schedule of the four-child TLAS records for a refit on the device (jpt_kernels_post.hip): `order` lists the
+// records of w.tlas_nodes4 deepest level first, level l is order[level_start[l] .. level_start[l + 1]).
+void tlas4_refit_schedule(const WideScene& w, std::vector<uint32_t>& order, std::vector<uint32_t>& level_start);
 
 // Reference layout -> flattened layout.  Keeps topology, boxes and child order, so traversal visits the
 // same nodes in the same order as main.glsl:270-350 does on the reference arrays.

@@ -122,6 +122,15 @@ struct jpt_ctx {
     float4* hist_written = nullptr;    // the one the last temporal pass wrote
 
     // pinned staging for the split read-back
+    // device refit of the instance level (jpt_scene_refit_tlas)
+    static constexpr int kRefitStages = 4;   // refits the host may queue before it has to wait for a copy to leave its buffer
+    float* h_refit_t12[kRefitStages] = {};   // pinned staging for the transforms
+    size_t h_refit_floats[kRefitStages] = {};
+    hipEvent_t ev_refit_copied[kRefitStages] = {};
+    uint64_t refit_seq = 0;
+    DevBuf<uint32_t> d_tlas4_order, d_tlas4_levels;
+    uint32_t n_tlas4_levels = 0;
+    bool refit_active = false;         // the device's instance level is ahead of the host mirrors (and of the other kernels' arrays)
     uint32_t* h_ldr_pinned = nullptr;
     size_t h_ldr_pinned_px = 0;
     hipEvent_t ev_readback = nullptr;
@@ -214,6 +223,15 @@ int upload_nodes4(jpt_ctx* c, bool tlas_only)
     HIP_TRY(c, hipStreamSynchronize(s));  // `tail` is pageable host memory
     c->ds.nodes4 = c->d_nodes4.p;
     c->ds.tlas_root4 = w.tlas_root4 >= 0 ? w.tlas_root4 + (int32_t)nb : w.tlas_root4;
+    {
+        // bottom-up schedule of the TLAS records, for refits on the device
+        std::vector<uint32_t> order, levels;
+        tlas4_refit_schedule(w, order, levels);
+        HIP_TRY(c, c->d_tlas4_order.upload(order, s));
+        HIP_TRY(c, c->d_tlas4_levels.upload(levels, s));
+        HIP_TRY(c, hipStreamSynchronize(s));  // pageable host vectors
+        c->n_tlas4_levels = (uint32_t)levels.size() - 1u;
+    }
     return JPT_OK;
 }
 
@@ -242,6 +260,7 @@ int upload_scene(jpt_ctx* c)
     }
     c->host_scene_ready = true;
     c->tlas_dirty = false;
+    c->refit_active = false;
     if (c->device < 0) return JPT_OK;  // host-only context: arrays stay on the host, nothing can be rendered
     HIP_TRY(c, hipSetDevice(c->device));
     hipStream_t s = c->stream;
@@ -322,6 +341,7 @@ void compute_sky_cull(const jpt_ctx* c, SkyCull& out)
         return !(e && atoi(e) == 0);
     }();
     if (!enabled || c->width <= 0 || c->height <= 0) return;
+    if (c->refit_active) return;  // the root's boxes were last refitted on the device: the host copy is stale
     // the boxes: children of the TLAS root record in the layout the kernels walk
     double lo[4][3], hi[4][3];
     int n = 0;
@@ -511,6 +531,8 @@ int do_render_batch(jpt_ctx* c, int32_t n_frames, uint32_t first_frame_index, bo
     if (!c->params_set) return fail(c, JPT_E_STATE, "jpt_set_params not called");
     if (!c->camera_set) return fail(c, JPT_E_STATE, "jpt_set_camera not called");
     if (n_frames < 0) return fail(c, JPT_E_INVALID, "n_frames < 0");
+    if (c->refit_active && c->kernel_variant != JPT_KERNEL_WAVEFRONT)
+        return fail(c, JPT_E_STATE, "jpt_scene_refit_tlas refits the default kernel's records only: call jpt_scene_update_tlas before rendering with another kernel");
     HIP_TRY(c, hipSetDevice(c->device));
     hipStream_t s = c->stream;
     c->assembled = c->assembled_ldr = false;
@@ -798,6 +820,10 @@ void jpt_destroy(jpt_ctx* c)
     for (hipEvent_t e : c->trace_events) (void)hipEventDestroy(e);
     if (c->ev_readback) (void)hipEventDestroy(c->ev_readback);
     if (c->h_ldr_pinned) (void)hipHostFree(c->h_ldr_pinned);
+    for (int k = 0; k < jpt_ctx::kRefitStages; k++) {
+        if (c->h_refit_t12[k]) (void)hipHostFree(c->h_refit_t12[k]);
+        if (c->ev_refit_copied[k]) (void)hipEventDestroy(c->ev_refit_copied[k]);
+    }
     for (int k = 0; k < 3; k++) {
         if (c->async.aux_stream[k]) {
             (void)hipStreamSynchronize(c->async.aux_stream[k]);
@@ -997,6 +1023,7 @@ int upload_tlas_update(jpt_ctx* c)
         const int rc4 = upload_nodes4(c, true);
         if (rc4 != JPT_OK) return rc4;
     }
+    c->refit_active = false;
     DeviceScene& d = c->ds;
     d.ref_instances = c->d_instances.p;
     d.ref_tlas = c->d_tlas.p;
@@ -1040,6 +1067,55 @@ int jpt_scene_update_tlas(jpt_ctx* c)
     return rc;
 }
 
+int jpt_scene_refit_tlas(jpt_ctx* c, const float* transforms12, uint32_t n_instances)
+{
+    if (!c) return JPT_E_INVALID;
+    if (!c->host_scene_ready || c->building || !c->native_tree)
+        return fail(c, JPT_E_STATE, "jpt_scene_refit_tlas needs a scene made by jpt_scene_commit with the native builder");
+    if (!transforms12 && n_instances) return fail(c, JPT_E_INVALID, "null transforms");
+    if (n_instances != c->ref.instances.size()) return fail(c, JPT_E_INVALID, "one transform per instance of the committed scene");
+    if (c->device < 0) return fail(c, JPT_E_DEVICE, "host-only context: the refit runs on the device (jpt_scene_update_tlas is the host route)");
+    // the host keeps the transforms (a later jpt_scene_update_tlas rebuilds from them); its arrays are stale from here on
+    for (uint32_t i = 0; i < n_instances; i++) (void)c->builder.set_instance_transform(i, transforms12 + (size_t)i * 12);
+    c->tlas_dirty = true;
+    static const bool width2 = [] {
+        const char* e = getenv("JPT_BVH_WIDTH");
+        return e && atoi(e) == 2;
+    }();
+    if (width2 || !c->ds.use4 || !c->scene_ready) return jpt_scene_update_tlas(c);  // no four-child records to refit
+    if (n_instances == 0) return JPT_OK;
+    const auto t0 = std::chrono::steady_clock::now();
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    const size_t floats = (size_t)n_instances * 12;
+    // a ring of pinned staging buffers, so that the host can queue refits ahead of the device
+    const int st = (int)(c->refit_seq++ % (uint64_t)jpt_ctx::kRefitStages);
+    if (!c->ev_refit_copied[st]) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_refit_copied[st], hipEventDisableTiming));
+    else HIP_TRY(c, hipEventSynchronize(c->ev_refit_copied[st]));  // the refit that used this stage last has run
+    if (c->h_refit_floats[st] < floats) {
+        if (c->h_refit_t12[st]) (void)hipHostFree(c->h_refit_t12[st]);
+        c->h_refit_t12[st] = nullptr;
+        c->h_refit_floats[st] = 0;
+        HIP_TRY(c, hipHostMalloc((void**)&c->h_refit_t12[st], floats * sizeof(float), hipHostMallocDefault));
+        c->h_refit_floats[st] = floats;
+    }
+    std::memcpy(c->h_refit_t12[st], transforms12, floats * sizeof(float));
+    // The kernel reads the transforms straight from the pinned buffer (48 B per instance over the host link: no
+    // copy to queue).  Everything below is queued on the context's stream: behind the renders already queued (the
+    // stream waits for each of them), ahead of the next ones (their slots' streams wait for the stream's tail:
+    // acc_done_valid).
+    float* dev_view = nullptr;
+    HIP_TRY(c, hipHostGetDevicePointer((void**)&dev_view, c->h_refit_t12[st], 0));
+    launch_tlas4_refit(s, dev_view, n_instances, c->d_bvh.p, c->d_instances.p, c->d_winst.p, c->d_winst4.p, c->d_nodes4.p,
+                       (uint32_t)c->wide.blas_nodes4.size(), c->d_tlas4_order.p, c->d_tlas4_levels.p, c->n_tlas4_levels);
+    HIP_TRY(c, hipEventRecord(c->ev_refit_copied[st], s));
+    HIP_TRY(c, hipGetLastError());
+    for (int k = 0; k < jpt_ctx::kPipeSlots; k++) c->acc_done_valid[k] = false;
+    c->refit_active = true;
+    c->stats.last_build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return JPT_OK;
+}
+
 int jpt_scene_update_reference_tlas(jpt_ctx* c, const void* blas_instances, uint32_t n_instances, const void* tlas_nodes,
                                     uint32_t n_tlas_nodes)
 {
@@ -1080,6 +1156,11 @@ int jpt_scene_update_reference_tlas(jpt_ctx* c, const void* blas_instances, uint
 int jpt_scene_get_reference_buffer(jpt_ctx* c, int32_t which, void* out, size_t capacity, size_t* size_out)
 {
     if (!c) return JPT_E_INVALID;
+    if (c->refit_active && (which == JPT_BUF_INSTANCES || which == JPT_BUF_TLAS_NODES)) {
+        // the instance level was last refitted on the device: bring the host mirrors (and the device) to a fresh build
+        const int rc = jpt_scene_update_tlas(c);
+        if (rc != JPT_OK) return rc;
+    }
     const void* src = nullptr;
     size_t bytes = 0;
     const RefScene& r = c->ref;

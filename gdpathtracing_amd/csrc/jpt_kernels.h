@@ -156,6 +156,13 @@ void launch_wf2_render(hipStream_t stream, const DeviceScene& ds, const FramePar
                        float4* accum, uint32_t* ldr, float* depth, DevCounters* counters, hipEvent_t* trace_events,
                        const Wf2Async& async, hipStream_t acc_stream = nullptr, hipEvent_t paths_done = nullptr);
 
+// Moving instances without the host (jpt_scene_refit_tlas): instance records from new transforms, then the boxes of the
+// four-child TLAS records bottom-up over the unchanged topology.  transforms12: n x 12 floats on the device; bvh: the
+// reference-layout BLAS nodes (root boxes); order / level_start: tlas4_refit_schedule, on the device.
+void launch_tlas4_refit(hipStream_t stream, const float* transforms12, uint32_t n_instances, const RefBvhNode* bvh,
+                        RefInstance* ref_instances, WideInstance* wide_instances, WideInstance* wide_instances4, WideNode4* nodes4,
+                        uint32_t n_blas_records, const uint32_t* order, const uint32_t* level_start, uint32_t n_levels);
+
 // one dispatch of temporal_reprojection.glsl over a whole image (jpt_kernels_post.hip): screen rgba8 in/out, depth
 // read-only, hist1 / hist2 the two rgba32f history images
 void launch_temporal(hipStream_t stream, const RefTemporalParams& tp, uint32_t* screen, const float* depth, float4* hist1,

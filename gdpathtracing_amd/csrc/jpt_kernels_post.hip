@@ -3,6 +3,7 @@
 // scattered back to image rows, and the display image (ACES of the mean, progressive_rendering.glsl:39-45)
 // is re-derived from the assembled sums.  No reference counterpart (the reference is single-device).
 #include "jpt_kernels.h"
+#include "jpt_instance_math.h"
 
 namespace jpt {
 
@@ -80,6 +81,83 @@ __global__ __launch_bounds__(256) void temporal_kernel(RefTemporalParams tp, uin
     next[i] = make_float4(blended.x, blended.y, blended.z, 1.0f);  // :66
     const f3 col = aces_film(blended);                             // :68-70
     screen[i] = unorm8(col.x) | (unorm8(col.y) << 8) | (unorm8(col.z) << 16) | 0xFF000000u;
+}
+
+// ---- device-side refit of the instance level (jpt_scene_refit_tlas) -------------------------------------------------
+
+// one thread per instance: the BLASInstance record (jpt_instance_math.h, the host builder's own code) and the hot
+// traversal records' inverse matrices
+__global__ __launch_bounds__(256) void instance_refit_kernel(const float* __restrict__ t12, uint32_t n, const RefBvhNode* __restrict__ bvh,
+                                                             RefInstance* __restrict__ ref_inst, WideInstance* __restrict__ winst,
+                                                             WideInstance* __restrict__ winst4)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    RefInstance inst = ref_inst[i];  // blas_index and materials stay
+    float t[12];
+    for (int k = 0; k < 12; k++) t[k] = t12[(size_t)i * 12 + k];
+    const RefBvhNode root = bvh[inst.blas_index];
+    instance_record(t, root.aabbMin, root.aabbMax, true, inst);
+    ref_inst[i] = inst;
+    for (int c = 0; c < 4; c++)
+        for (int r = 0; r < 3; r++) {
+            const float v = inst.inverse_transform[c * 4 + r];
+            if (winst) winst[i].inv[c * 3 + r] = v;
+            if (winst4) winst4[i].inv[c * 3 + r] = v;
+        }
+}
+
+// One block walks the levels of the TLAS deepest first: the box of a child slot is the instance's world box, or the
+// union of the boxes of the record below (min / max are exact, so these are the boxes a host build of the same
+// topology stores).  A level only reads records of deeper levels; __syncthreads orders the levels.
+__global__ __launch_bounds__(1024) void tlas4_refit_kernel(WideNode4* __restrict__ nodes4, uint32_t nb, const uint32_t* __restrict__ order,
+                                                           const uint32_t* __restrict__ level_start, uint32_t n_levels,
+                                                           const RefInstance* __restrict__ inst)
+{
+    for (uint32_t l = 0; l < n_levels; l++) {
+        for (uint32_t i = level_start[l] + threadIdx.x; i < level_start[l + 1]; i += blockDim.x) {
+            WideNode4* node = nodes4 + nb + order[i];
+            for (int k = 0; k < 4; k++) {
+                const int32_t c = node->child[k];
+                if (c == kEmptyChild) continue;
+                float lo[3], hi[3];
+                if (c < 0) {
+                    const RefInstance& in = inst[(uint32_t)~c];
+                    lo[0] = in.aabbMin.x; lo[1] = in.aabbMin.y; lo[2] = in.aabbMin.z;
+                    hi[0] = in.aabbMax.x; hi[1] = in.aabbMax.y; hi[2] = in.aabbMax.z;
+                } else {
+                    const WideNode4* below = nodes4 + c;  // (internal references already count from the array's start)
+                    bool any = false;
+                    for (int j = 0; j < 4; j++) {
+                        if (below->child[j] == kEmptyChild) continue;
+                        const float bl[3] = {below->lo_x[j], below->lo_y[j], below->lo_z[j]};
+                        const float bh[3] = {below->hi_x[j], below->hi_y[j], below->hi_z[j]};
+                        for (int a = 0; a < 3; a++) {
+                            lo[a] = any ? imin_(lo[a], bl[a]) : bl[a];
+                            hi[a] = any ? imax_(hi[a], bh[a]) : bh[a];
+                        }
+                        any = true;
+                    }
+                    if (!any) continue;
+                }
+                node->lo_x[k] = lo[0]; node->lo_y[k] = lo[1]; node->lo_z[k] = lo[2];
+                node->hi_x[k] = hi[0]; node->hi_y[k] = hi[1]; node->hi_z[k] = hi[2];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+void launch_tlas4_refit(hipStream_t stream, const float* transforms12, uint32_t n_instances, const RefBvhNode* bvh,
+                        RefInstance* ref_instances, WideInstance* wide_instances, WideInstance* wide_instances4, WideNode4* nodes4,
+                        uint32_t n_blas_records, const uint32_t* order, const uint32_t* level_start, uint32_t n_levels)
+{
+    if (n_instances == 0) return;
+    hipLaunchKernelGGL(instance_refit_kernel, dim3((n_instances + 255) / 256), dim3(256), 0, stream, transforms12, n_instances, bvh,
+                       ref_instances, wide_instances, wide_instances4);
+    if (n_levels)
+        hipLaunchKernelGGL(tlas4_refit_kernel, dim3(1), dim3(1024), 0, stream, nodes4, n_blas_records, order, level_start, n_levels,
+                           ref_instances);
 }
 
 void launch_temporal(hipStream_t stream, const RefTemporalParams& tp, uint32_t* screen, const float* depth, float4* hist1,

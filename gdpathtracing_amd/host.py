@@ -108,6 +108,12 @@ class Context:
     def update_tlas(self):
         self._ck(self._lib.jpt_scene_update_tlas(self.h), "jpt_scene_update_tlas")
 
+    def refit_tlas(self, transforms12):
+        """All instance transforms at once, instance records + TLAS boxes recomputed on the device (no host rebuild,
+        no synchronisation); transforms12: [n_instances, 12] float32."""
+        t = np.ascontiguousarray(transforms12, dtype=np.float32).reshape(-1, 12)
+        self._ck(self._lib.jpt_scene_refit_tlas(self.h, _ptr(t), t.shape[0]), "jpt_scene_refit_tlas")
+
     def update_reference_tlas(self, instances, tlas_nodes):
         a, b = np.ascontiguousarray(instances), np.ascontiguousarray(tlas_nodes)
         self._ck(self._lib.jpt_scene_update_reference_tlas(self.h, _ptr(a), len(a), _ptr(b), len(b)), "jpt_scene_update_reference_tlas")
@@ -226,9 +232,10 @@ class GeometryGroup3D:
         ctx.build_scene(self.scene, self.builder)
         self._built = [np.array(i.transform, dtype=np.float32) for i in self.scene.instances]
 
-    def update_transforms(self) -> int:
+    def update_transforms(self, refit: bool = False) -> int:
         """Moving nodes without build() again (the reference has no such call; README.md:39-40 wants one): hands
-        the changed instance transforms to the library, which redoes BLASInstance records + TLAS only."""
+        the changed instance transforms to the library, which redoes BLASInstance records + TLAS only -- on the host
+        (rebuild, the default) or, with refit=True, on the device over the topology of the last build."""
         moved = 0
         for i, inst in enumerate(self.scene.instances):
             now = np.asarray(inst.transform, dtype=np.float32)
@@ -237,7 +244,10 @@ class GeometryGroup3D:
                 self._built[i] = now.copy()
                 moved += 1
         if moved:
-            self.ctx.update_tlas()
+            if refit:
+                self.ctx.refit_tlas(np.stack(self._built))
+            else:
+                self.ctx.update_tlas()
         return moved
 
     def get_triangles_geometry_buffer(self):            # geometry_group3d.cpp:40

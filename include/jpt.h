@@ -159,6 +159,16 @@ int jpt_scene_get_reference_buffer(jpt_ctx *ctx, int32_t which, void *out, size_
 int jpt_scene_set_instance_transform(jpt_ctx *ctx, uint32_t instance, const float *transform12);
 /*   ... then one call that rebuilds instance records + TLAS with the builder of the last commit */
 int jpt_scene_update_tlas(jpt_ctx *ctx);
+/*   route (ii), on the device: ALL instance transforms at once (n_instances x 12 floats, jpt_scene_add_instance
+ *   order).  Nothing is rebuilt on the host: the transforms are copied to the device, one kernel recomputes the
+ *   BLASInstance records (the host builder's own arithmetic, bit for bit) and one refits the boxes of the TLAS
+ *   records bottom-up over the topology of the last build -- all queued on the ctx stream behind the renders already
+ *   queued and ahead of the next ones, with no synchronisation (jpt_scene_update_tlas drains the stream).  Scenes
+ *   committed with JPT_BUILD_SAH only; renders with the default kernel (the other kernels' arrays and
+ *   jpt_scene_get_reference_buffer's host mirrors are refreshed by the next jpt_scene_update_tlas, which also
+ *   re-optimises the topology: call it now and then when instances travel far).  The closest hit does not depend on
+ *   the topology, so the image equals a fresh commit of the moved scene except at exact distance ties. */
+int jpt_scene_refit_tlas(jpt_ctx *ctx, const float *transforms12, uint32_t n_instances);
 /*   route (i): the caller re-ran BLASInstance::set_transform / TLAS::build itself; same instance count and
  *   the same blas_index per instance as the uploaded scene (otherwise: JPT_E_INVALID, upload the whole scene) */
 int jpt_scene_update_reference_tlas(jpt_ctx *ctx, const void *blas_instances, uint32_t n_instances,

@@ -306,7 +306,9 @@ class GeometryGroup3D {
     // Returns the number of instances that moved.
     MeshInstance3D& get_child(size_t i) { return children.at(i); }
     size_t get_child_count() const { return children.size(); }
-    int update_transforms()
+    // refit_on_device: instance records + TLAS boxes recomputed by two kernels over the topology of the last build
+    // (jpt_scene_refit_tlas: no host rebuild, no stall); default: host rebuild (jpt_scene_update_tlas)
+    int update_transforms(bool refit_on_device = false)
     {
         if (!ctx_) throw std::runtime_error("GeometryGroup3D::update_transforms before build");
         int moved = 0;
@@ -323,7 +325,16 @@ class GeometryGroup3D {
             }
             instance++;
         }
-        if (moved) check(ctx_, jpt_scene_update_tlas(ctx_), "jpt_scene_update_tlas");
+        if (moved) {
+            if (refit_on_device) {
+                std::vector<float> all;
+                all.reserve(built_transforms_.size() * 12);
+                for (const auto& t : built_transforms_) all.insert(all.end(), t.begin(), t.end());
+                check(ctx_, jpt_scene_refit_tlas(ctx_, all.data(), (uint32_t)built_transforms_.size()), "jpt_scene_refit_tlas");
+            } else {
+                check(ctx_, jpt_scene_update_tlas(ctx_), "jpt_scene_update_tlas");
+            }
+        }
         return moved;
     }
 

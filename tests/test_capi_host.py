@@ -138,3 +138,17 @@ def test_too_deep_tree_is_rejected_at_upload(hiplib, oracle):
     shallow[2 * 40]["first_tri_index"], shallow[2 * 40]["tri_count"] = 40, 1
     ctx.upload_reference_layout(tri, dat, ref.materials, shallow, inst, tlas)
     ctx.close()
+
+
+def test_device_refit_is_refused_without_a_device(hiplib):
+    """jpt_scene_refit_tlas runs on the device: a host-only context reports that instead of doing anything else."""
+    from gdpathtracing_amd import scenes
+    ctx = host.Context(-1)
+    sc = scenes.instanced_scene(n_side=3, n_unique=2, tris_per_mesh=32)
+    ctx.build_scene(sc, capi.BUILD_SAH)
+    t = np.stack([np.asarray(i.transform, dtype=np.float32) for i in sc.instances])
+    with pytest.raises(capi.JptError, match="host-only"):
+        ctx.refit_tlas(t)
+    with pytest.raises(capi.JptError, match="one transform per instance"):
+        ctx.refit_tlas(t[:-1])
+    ctx.close()

@@ -126,6 +126,86 @@ def test_tlas_update_renders_like_a_fresh_build(oracle, hiplib, builder, kernel,
         assert np.array_equal(after, want) and np.array_equal(after_depth, want_depth)
 
 
+@pytest.mark.parametrize("asynchronous", [False, True])
+def test_device_refit_renders_like_a_fresh_build(oracle, hiplib, asynchronous):
+    """jpt_scene_refit_tlas: all transforms at once, instance records and TLAS boxes recomputed by kernels queued on
+    the context's stream (no host rebuild, no stall).  Three animation steps with renders queued around them; every
+    image equals a fresh context's image of the moved scene, and the instance records on the device equal the host
+    builder's records of the moved scene byte for byte (read back through the host mirrors after the final
+    jpt_scene_update_tlas, and compared with the oracle's)."""
+    sc = scenes.instanced_scene(n_side=6, n_unique=3, tris_per_mesh=128)
+    w, h, bounces, frames = 160, 96, 3, 2
+    cam = scenes.camera_block(sc.camera, w, h)
+    ctx = host.Context(0)
+    try:
+        ctx.build_scene(sc, capi.BUILD_SAH)
+        ctx.set_params(w, h, bounces, wire.ACCUM_REF_LDR8)
+        ctx.set_camera(cam)
+        cur = sc
+        for step in range(3):
+            ctx.accum_reset()
+            ctx.render(frames, 1, asynchronous=asynchronous)      # still reads the records of the previous step
+            moves = _moves_for(cur, 11 + 7 * step, 5 + step)
+            cur = _moved(cur, moves)
+            ctx.refit_tlas(np.stack([np.asarray(i.transform, dtype=np.float32) for i in cur.instances]))
+            ctx.accum_reset()
+            ctx.render(frames, 1, asynchronous=asynchronous)
+            if asynchronous:
+                ctx.render(1, 3, asynchronous=True)               # a second render in flight behind the refit
+                ctx.accum_reset()
+                ctx.render(frames, 1, asynchronous=True)
+            after, after_depth = ctx.read_accum(), ctx.read_depth()
+            fresh, _, fresh_depth = _render_hip(cur, cam, w, h, bounces, frames, wire.ACCUM_REF_LDR8, builder=capi.BUILD_SAH)
+            assert np.array_equal(after, fresh) and np.array_equal(after_depth, fresh_depth), step
+        # the other kernels' arrays were not refitted: they refuse until the host route has caught up
+        ctx.set_kernel(capi.KERNEL_REFERENCE_LAYOUT)
+        with pytest.raises(capi.JptError, match="jpt_scene_update_tlas"):
+            ctx.render(1, 1)
+        ctx.update_tlas()
+        ctx.accum_reset()
+        ctx.render(frames, 1)
+        audit = ctx.read_accum()
+        ref = oracle.build_scene(cur)
+        want, _, _, _, _ = oracle.render(ref, cam, w, h, bounces, frames, 1, wire.ACCUM_REF_LDR8)
+        assert rel_l2(audit, want) <= 1e-4
+    finally:
+        ctx.close()
+
+
+def test_device_refit_records_equal_the_host_builders(hiplib):
+    """Sheared, mirrored and non-uniformly scaled instances, every one of them perturbed twice: the refitted scene
+    renders exactly like a fresh commit of the same transforms (sums and depth)."""
+    sc = scenes.random_scene(5, coincident=False)   # (exact distance ties are decided by the visit order, i.e. by the tree)
+    w, h = 128, 96
+    cam = scenes.camera_block(sc.camera, w, h)
+    rng = np.random.default_rng(3)
+    ctx = host.Context(0)
+    try:
+        ctx.build_scene(sc, capi.BUILD_SAH)
+        ctx.set_params(w, h, 2, wire.ACCUM_HDR_F32)
+        ctx.set_camera(cam)
+        moved = sc
+        for step in range(2):
+            ts = []
+            for inst in moved.instances:
+                t = np.array(inst.transform, dtype=np.float32).copy()
+                t[:9] += rng.normal(0.0, 0.05, 9).astype(np.float32)      # shear / scale a little
+                t[9:12] += rng.normal(0.0, 0.1, 3).astype(np.float32)
+                ts.append(t)
+            moved = _moved(moved, {i: t for i, t in enumerate(ts)})
+            ctx.refit_tlas(np.stack(ts))
+            ctx.accum_reset()
+            ctx.render(2, 1)
+            got, got_depth = ctx.read_accum(), ctx.read_depth()
+            fresh, _, fresh_depth = _render_hip(moved, cam, w, h, 2, 2, wire.ACCUM_HDR_F32, builder=capi.BUILD_SAH)
+            # (bit patterns: such soups produce NaN pixels, which compare unequal to themselves)
+            bad = int(np.count_nonzero(got.view(np.uint32) != fresh.view(np.uint32)))
+            bad_depth = int(np.count_nonzero(got_depth.view(np.uint32) != fresh_depth.view(np.uint32)))
+            assert bad == 0 and bad_depth == 0, (step, bad, bad_depth)
+    finally:
+        ctx.close()
+
+
 def test_reference_tlas_update_route(oracle, hiplib):
     """Route (i): the addon keeps its own builder and hands over new BLASInstance[] + TLASNode[] only."""
     sc = scenes.instanced_scene(n_side=5, n_unique=2, tris_per_mesh=96)
