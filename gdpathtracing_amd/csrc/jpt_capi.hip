@@ -128,6 +128,18 @@ struct jpt_ctx {
     size_t h_refit_floats[kRefitStages] = {};
     hipEvent_t ev_refit_copied[kRefitStages] = {};
     uint64_t refit_seq = 0;
+    // Several copies of the instance level (RefInstance + WideInstance arrays, TLAS tail of d_nodes4): a refit writes
+    // a copy the renders in flight do NOT read, so the renders after a refit overlap with the renders before it.
+    static constexpr int kInstanceSets = 4;   // as many as renders in flight: a queue of animation steps stays pipelined
+    DevBuf<RefInstance> d_instances_more[kInstanceSets - 1];
+    DevBuf<WideInstance> d_winst4_more[kInstanceSets - 1];
+    size_t tlas4_cap = 0;              // records reserved per TLAS tail
+    int cur_set = 0;                   // which copy new renders read
+    bool set_b_ready = false;          // copies 1.. exist and mirror the last host upload
+    hipStream_t refit_stream = nullptr;
+    hipEvent_t ev_set_retired[kInstanceSets] = {}, ev_refit_done = nullptr;
+    bool set_retired_valid[kInstanceSets] = {};
+    uint64_t refit_wait_seq = 0, slot_refit_seen[4] = {};
     DevBuf<uint32_t> d_tlas4_order, d_tlas4_levels;
     uint32_t n_tlas4_levels = 0;
     bool refit_active = false;         // the device's instance level is ahead of the host mirrors (and of the other kernels' arrays)
@@ -204,7 +216,8 @@ int upload_nodes4(jpt_ctx* c, bool tlas_only)
 {
     const WideScene& w = c->wide;
     const size_t nb = w.blas_nodes4.size(), nt = w.tlas_nodes4.size();
-    const size_t cap = nb + std::max<size_t>(w.instances4.size(), std::max<size_t>(nt, 1));
+    const size_t cap_t = std::max<size_t>(w.instances4.size(), std::max<size_t>(nt, 1));
+    const size_t cap = nb + (size_t)jpt_ctx::kInstanceSets * cap_t;  // one TLAS tail per copy of the instance level (jpt_scene_refit_tlas)
     hipStream_t s = c->stream;
     if (w.instances4.empty() && nb == 0) {
         c->ds.nodes4 = nullptr;
@@ -215,12 +228,19 @@ int upload_nodes4(jpt_ctx* c, bool tlas_only)
         HIP_TRY(c, c->d_nodes4.resize(cap));
         if (nb) HIP_TRY(c, hipMemcpyAsync(c->d_nodes4.p, w.blas_nodes4.data(), nb * sizeof(WideNode4), hipMemcpyHostToDevice, s));
     }
-    std::vector<WideNode4> tail(w.tlas_nodes4);
-    for (WideNode4& n : tail)
-        for (int k = 0; k < 4; k++)
-            if (n.child[k] >= 0) n.child[k] += (int32_t)nb;
-    if (nt) HIP_TRY(c, hipMemcpyAsync(c->d_nodes4.p + nb, tail.data(), nt * sizeof(WideNode4), hipMemcpyHostToDevice, s));
-    HIP_TRY(c, hipStreamSynchronize(s));  // `tail` is pageable host memory
+    for (int copy = 0; copy < jpt_ctx::kInstanceSets; copy++) {
+        const size_t base = nb + (size_t)copy * cap_t;
+        std::vector<WideNode4> tail(w.tlas_nodes4);
+        for (WideNode4& n : tail)
+            for (int k = 0; k < 4; k++)
+                if (n.child[k] >= 0) n.child[k] += (int32_t)base;
+        if (nt) HIP_TRY(c, hipMemcpyAsync(c->d_nodes4.p + base, tail.data(), nt * sizeof(WideNode4), hipMemcpyHostToDevice, s));
+        HIP_TRY(c, hipStreamSynchronize(s));  // `tail` is pageable host memory
+    }
+    c->tlas4_cap = cap_t;
+    c->cur_set = 0;
+    c->set_b_ready = false;  // the instance arrays of the other copies are made (again) by the next refit
+    for (int k = 0; k < jpt_ctx::kInstanceSets; k++) c->set_retired_valid[k] = false;
     c->ds.nodes4 = c->d_nodes4.p;
     c->ds.tlas_root4 = w.tlas_root4 >= 0 ? w.tlas_root4 + (int32_t)nb : w.tlas_root4;
     {
@@ -646,6 +666,11 @@ int do_render_batch(jpt_ctx* c, int32_t n_frames, uint32_t first_frame_index, bo
                 // whatever `s` holds now
                 if (!c->acc_done_valid[slot]) HIP_TRY(c, hipEventRecord(c->ev_acc_done[slot], s));
                 HIP_TRY(c, hipStreamWaitEvent(ps, c->ev_acc_done[slot], 0));
+                if (c->slot_refit_seen[slot] != c->refit_wait_seq) {
+                    // the instance level this render reads was refitted on the refit stream (jpt_scene_refit_tlas)
+                    HIP_TRY(c, hipStreamWaitEvent(ps, c->ev_refit_done, 0));
+                    c->slot_refit_seen[slot] = c->refit_wait_seq;
+                }
                 // (one frame group: overlapping with the neighbouring render does what groups do, without extra launches:
                 // 3840x2160x16 spp 11.56 ms against 11.96 with two groups, instanced scene 3.80 against 4.05)
                 Wf2Async one_group = c->async;
@@ -820,6 +845,9 @@ void jpt_destroy(jpt_ctx* c)
     for (hipEvent_t e : c->trace_events) (void)hipEventDestroy(e);
     if (c->ev_readback) (void)hipEventDestroy(c->ev_readback);
     if (c->h_ldr_pinned) (void)hipHostFree(c->h_ldr_pinned);
+    if (c->refit_stream) { (void)hipStreamSynchronize(c->refit_stream); (void)hipStreamDestroy(c->refit_stream); }
+    for (int k = 0; k < jpt_ctx::kInstanceSets; k++) if (c->ev_set_retired[k]) (void)hipEventDestroy(c->ev_set_retired[k]);
+    if (c->ev_refit_done) (void)hipEventDestroy(c->ev_refit_done);
     for (int k = 0; k < jpt_ctx::kRefitStages; k++) {
         if (c->h_refit_t12[k]) (void)hipHostFree(c->h_refit_t12[k]);
         if (c->ev_refit_copied[k]) (void)hipEventDestroy(c->ev_refit_copied[k]);
@@ -1100,17 +1128,51 @@ int jpt_scene_refit_tlas(jpt_ctx* c, const float* transforms12, uint32_t n_insta
         c->h_refit_floats[st] = floats;
     }
     std::memcpy(c->h_refit_t12[st], transforms12, floats * sizeof(float));
-    // The kernel reads the transforms straight from the pinned buffer (48 B per instance over the host link: no
-    // copy to queue).  Everything below is queued on the context's stream: behind the renders already queued (the
-    // stream waits for each of them), ahead of the next ones (their slots' streams wait for the stream's tail:
-    // acc_done_valid).
+    // the kernel reads the transforms straight from the pinned buffer (48 B per instance over the host link)
     float* dev_view = nullptr;
     HIP_TRY(c, hipHostGetDevicePointer((void**)&dev_view, c->h_refit_t12[st], 0));
-    launch_tlas4_refit(s, dev_view, n_instances, c->d_bvh.p, c->d_instances.p, c->d_winst.p, c->d_winst4.p, c->d_nodes4.p,
-                       (uint32_t)c->wide.blas_nodes4.size(), c->d_tlas4_order.p, c->d_tlas4_levels.p, c->n_tlas4_levels);
-    HIP_TRY(c, hipEventRecord(c->ev_refit_copied[st], s));
+    if (!c->refit_stream) HIP_TRY(c, hipStreamCreateWithFlags(&c->refit_stream, hipStreamNonBlocking));
+    for (int k = 0; k < jpt_ctx::kInstanceSets; k++)
+        if (!c->ev_set_retired[k]) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_set_retired[k], hipEventDisableTiming));
+    if (!c->ev_refit_done) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_refit_done, hipEventDisableTiming));
+    if (!c->set_b_ready) {
+        // first refit since the last host upload: the other copies of the instance arrays start as copies of copy 0
+        // (the TLAS tails were all uploaded).  Once per upload, so the drain does not matter.
+        HIP_TRY(c, hipStreamSynchronize(s));
+        for (int k = 0; k + 1 < jpt_ctx::kInstanceSets; k++) {
+            HIP_TRY(c, c->d_instances_more[k].resize(c->d_instances.n));
+            HIP_TRY(c, c->d_winst4_more[k].resize(c->d_winst4.n));
+            HIP_TRY(c, hipMemcpyAsync(c->d_instances_more[k].p, c->d_instances.p, c->d_instances.n * sizeof(RefInstance), hipMemcpyDeviceToDevice, s));
+            HIP_TRY(c, hipMemcpyAsync(c->d_winst4_more[k].p, c->d_winst4.p, c->d_winst4.n * sizeof(WideInstance), hipMemcpyDeviceToDevice, s));
+        }
+        HIP_TRY(c, hipStreamSynchronize(s));
+        c->set_b_ready = true;
+        for (int k = 0; k < jpt_ctx::kInstanceSets; k++) c->set_retired_valid[k] = false;
+    }
+    // The refit writes the copy that new renders do not read yet (`next`); its last readers are the renders queued
+    // before the refit that retired it, i.e. before ev_set_retired[next] was recorded on the context's stream (which
+    // waits for every render).  The renders queued since read the current copy and keep running meanwhile.
+    const int next = (c->cur_set + 1) % jpt_ctx::kInstanceSets;
+    HIP_TRY(c, hipEventRecord(c->ev_set_retired[c->cur_set], s));
+    c->set_retired_valid[c->cur_set] = true;
+    hipStream_t rs = c->refit_stream;
+    if (c->set_retired_valid[next]) HIP_TRY(c, hipStreamWaitEvent(rs, c->ev_set_retired[next], 0));
+    RefInstance* inst_next = next ? c->d_instances_more[next - 1].p : c->d_instances.p;
+    WideInstance* winst4_next = next ? c->d_winst4_more[next - 1].p : c->d_winst4.p;
+    const uint32_t tail_base = (uint32_t)(c->wide.blas_nodes4.size() + (size_t)next * c->tlas4_cap);
+    launch_tlas4_refit(rs, dev_view, n_instances, c->d_bvh.p, inst_next, nullptr, winst4_next, c->d_nodes4.p, tail_base,
+                       c->d_tlas4_order.p, c->d_tlas4_levels.p, c->n_tlas4_levels);
     HIP_TRY(c, hipGetLastError());
-    for (int k = 0; k < jpt_ctx::kPipeSlots; k++) c->acc_done_valid[k] = false;
+    HIP_TRY(c, hipEventRecord(c->ev_refit_copied[st], rs));
+    HIP_TRY(c, hipEventRecord(c->ev_refit_done, rs));
+    // the context's stream (blocking renders, read-backs, uploads, foreign work) is ordered after the refit; queued
+    // renders wait for it on their own streams (do_render_batch), not through the context's stream
+    HIP_TRY(c, hipStreamWaitEvent(s, c->ev_refit_done, 0));
+    c->refit_wait_seq++;
+    c->cur_set = next;
+    c->ds.ref_instances = inst_next;
+    c->ds.wide_instances4 = winst4_next;
+    if (c->wide.tlas_root4 >= 0) c->ds.tlas_root4 = c->wide.tlas_root4 + (int32_t)tail_base;
     c->refit_active = true;
     c->stats.last_build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return JPT_OK;

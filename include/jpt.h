@@ -160,12 +160,13 @@ int jpt_scene_set_instance_transform(jpt_ctx *ctx, uint32_t instance, const floa
 /*   ... then one call that rebuilds instance records + TLAS with the builder of the last commit */
 int jpt_scene_update_tlas(jpt_ctx *ctx);
 /*   route (ii), on the device: ALL instance transforms at once (n_instances x 12 floats, jpt_scene_add_instance
- *   order).  Nothing is rebuilt on the host: the transforms are copied to the device, one kernel recomputes the
- *   BLASInstance records (the host builder's own arithmetic, bit for bit) and one refits the boxes of the TLAS
- *   records bottom-up over the topology of the last build -- all queued on the ctx stream behind the renders already
- *   queued and ahead of the next ones, with no synchronisation (jpt_scene_update_tlas drains the stream).  Scenes
- *   committed with JPT_BUILD_SAH only; renders with the default kernel (the other kernels' arrays and
- *   jpt_scene_get_reference_buffer's host mirrors are refreshed by the next jpt_scene_update_tlas, which also
+ *   order).  Nothing is rebuilt on the host: one kernel recomputes the BLASInstance records from the transforms (the
+ *   host builder's own arithmetic, bit for bit) and one refits the boxes of the TLAS records bottom-up over the
+ *   topology of the last build.  They run on a stream of their own and write a COPY of the instance level that no
+ *   render in flight reads (four copies: as many as renders in flight), so a queue of "refit, render" steps stays
+ *   pipelined and the host never waits (jpt_scene_update_tlas drains the stream); the ctx stream is ordered after
+ *   the refit.  Scenes committed with JPT_BUILD_SAH only; renders with the default kernel (the other kernels' arrays
+ *   and jpt_scene_get_reference_buffer's host mirrors are refreshed by the next jpt_scene_update_tlas, which also
  *   re-optimises the topology: call it now and then when instances travel far).  The closest hit does not depend on
  *   the topology, so the image equals a fresh commit of the moved scene except at exact distance ties. */
 int jpt_scene_refit_tlas(jpt_ctx *ctx, const float *transforms12, uint32_t n_instances);

@@ -172,6 +172,50 @@ def test_device_refit_renders_like_a_fresh_build(oracle, hiplib, asynchronous):
         ctx.close()
 
 
+def test_queue_of_animation_steps_stays_correct(hiplib):
+    """Ten animation steps queued without ever waiting: refit, render, and a device-side snapshot of the sums queued on
+    the context's stream behind each render.  More steps than copies of the instance level and than pipeline slots, so
+    every reuse path runs; each snapshot equals a fresh commit of that step's scene."""
+    import torch
+    sc = scenes.instanced_scene(n_side=6, n_unique=3, tris_per_mesh=128)
+    w, h, bounces, frames = 480, 270, 3, 3      # large enough for consecutive renders to really overlap
+    cam = scenes.camera_block(sc.camera, w, h)
+    ctx = host.Context(0)
+    try:
+        ctx.build_scene(sc, capi.BUILD_SAH)
+        ctx.set_params(w, h, bounces, wire.ACCUM_HDR_F32)
+        ctx.set_camera(cam)
+        stream = torch.cuda.ExternalStream(ctx.get_stream(), device=torch.device("cuda", 0))
+        ptr, nbytes = ctx.device_accum()
+
+        class _View:
+            __cuda_array_interface__ = {"shape": (nbytes // 4,), "typestr": "<f4", "data": (ptr, False), "version": 2}
+
+        accum = torch.as_tensor(_View(), device=torch.device("cuda", 0))
+        cur, steps, snaps = sc, [], []
+        with torch.cuda.stream(stream):
+            for k in range(10):
+                cur = _moved(cur, _moves_for(cur, 100 + k, 6))
+                steps.append(cur)
+                ctx.refit_tlas(np.stack([np.asarray(i.transform, dtype=np.float32) for i in cur.instances]))
+                ctx.accum_reset()
+                ctx.render(frames, 1 + k, asynchronous=True)
+                snaps.append(accum.clone())
+            stream.synchronize()
+        ctx.sync()
+    finally:
+        ctx.close()
+    for k, scene_k in enumerate(steps):
+        ref = host.Context(0)
+        ref.build_scene(scene_k, capi.BUILD_SAH)
+        ref.set_params(w, h, bounces, wire.ACCUM_HDR_F32)
+        ref.set_camera(cam)
+        ref.render(frames, 1 + k)
+        want = ref.read_accum()
+        ref.close()
+        assert np.array_equal(snaps[k].cpu().numpy().reshape(h, w, 4), want), k
+
+
 def test_device_refit_records_equal_the_host_builders(hiplib):
     """Sheared, mirrored and non-uniformly scaled instances, every one of them perturbed twice: the refitted scene
     renders exactly like a fresh commit of the same transforms (sums and depth)."""
