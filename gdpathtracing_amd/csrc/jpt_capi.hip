@@ -13,6 +13,7 @@
 
 #include "jpt_builder.h"
 #include "jpt_kernels.h"
+#include "jpt_instance_math.h"
 
 using namespace jpt;
 
@@ -143,6 +144,8 @@ struct jpt_ctx {
     DevBuf<uint32_t> d_tlas4_order, d_tlas4_levels;
     uint32_t n_tlas4_levels = 0;
     bool refit_active = false;         // the device's instance level is ahead of the host mirrors (and of the other kernels' arrays)
+    bool cull_boxes_current = true;    // c->wide.tlas_nodes4 holds the boxes of the copy new renders read (sky cull)
+    std::vector<uint32_t> tlas4_order_h, tlas4_levels_h;   // the refit schedule, host copy
     uint32_t* h_ldr_pinned = nullptr;
     size_t h_ldr_pinned_px = 0;
     hipEvent_t ev_readback = nullptr;
@@ -245,12 +248,13 @@ int upload_nodes4(jpt_ctx* c, bool tlas_only)
     c->ds.tlas_root4 = w.tlas_root4 >= 0 ? w.tlas_root4 + (int32_t)nb : w.tlas_root4;
     {
         // bottom-up schedule of the TLAS records, for refits on the device
-        std::vector<uint32_t> order, levels;
+        std::vector<uint32_t>&order = c->tlas4_order_h, &levels = c->tlas4_levels_h;
         tlas4_refit_schedule(w, order, levels);
         HIP_TRY(c, c->d_tlas4_order.upload(order, s));
         HIP_TRY(c, c->d_tlas4_levels.upload(levels, s));
         HIP_TRY(c, hipStreamSynchronize(s));  // pageable host vectors
         c->n_tlas4_levels = (uint32_t)levels.size() - 1u;
+        c->cull_boxes_current = true;
     }
     return JPT_OK;
 }
@@ -361,7 +365,7 @@ void compute_sky_cull(const jpt_ctx* c, SkyCull& out)
         return !(e && atoi(e) == 0);
     }();
     if (!enabled || c->width <= 0 || c->height <= 0) return;
-    if (c->refit_active) return;  // the root's boxes were last refitted on the device: the host copy is stale
+    if (!c->cull_boxes_current) return;  // the root's boxes were last refitted on the device only: the host copy is stale
     // the boxes: children of the TLAS root record in the layout the kernels walk
     double lo[4][3], hi[4][3];
     int n = 0;
@@ -1173,6 +1177,50 @@ int jpt_scene_refit_tlas(jpt_ctx* c, const float* transforms12, uint32_t n_insta
     c->ds.ref_instances = inst_next;
     c->ds.wide_instances4 = winst4_next;
     if (c->wide.tlas_root4 >= 0) c->ds.tlas_root4 = c->wide.tlas_root4 + (int32_t)tail_base;
+    // The sky cull (compute_sky_cull) projects the boxes the TLAS root offers, on the host.  For a modest number of
+    // instances the host repeats the refit on its own copy of the four-child TLAS records (same arithmetic, same
+    // schedule: ~0.1 us per instance); beyond that the cull is off until the next jpt_scene_update_tlas.
+    if (n_instances <= 4096u && !c->tlas4_levels_h.empty()) {
+        WideScene& w = c->wide;
+        std::vector<RefInstance> boxes(n_instances);
+        for (uint32_t i = 0; i < n_instances; i++) {
+            const RefBvhNode& root = c->ref.bvh_nodes[c->ref.instances[i].blas_index];
+            instance_record(transforms12 + (size_t)i * 12, root.aabbMin, root.aabbMax, true, boxes[i]);
+        }
+        for (size_t l = 0; l + 1 < c->tlas4_levels_h.size(); l++)
+            for (uint32_t k = c->tlas4_levels_h[l]; k < c->tlas4_levels_h[l + 1]; k++) {
+                WideNode4& node = w.tlas_nodes4[c->tlas4_order_h[k]];
+                for (int slot = 0; slot < 4; slot++) {
+                    const int32_t ch = node.child[slot];
+                    if (ch == kEmptyChild) continue;
+                    float lo[3], hi[3];
+                    if (ch < 0) {
+                        const RefInstance& in = boxes[(uint32_t)~ch];
+                        lo[0] = in.aabbMin.x; lo[1] = in.aabbMin.y; lo[2] = in.aabbMin.z;
+                        hi[0] = in.aabbMax.x; hi[1] = in.aabbMax.y; hi[2] = in.aabbMax.z;
+                    } else {
+                        const WideNode4& below = w.tlas_nodes4[(size_t)ch];
+                        bool any = false;
+                        for (int j = 0; j < 4; j++) {
+                            if (below.child[j] == kEmptyChild) continue;
+                            const float bl[3] = {below.lo_x[j], below.lo_y[j], below.lo_z[j]};
+                            const float bh[3] = {below.hi_x[j], below.hi_y[j], below.hi_z[j]};
+                            for (int a = 0; a < 3; a++) {
+                                lo[a] = any ? imin_(lo[a], bl[a]) : bl[a];
+                                hi[a] = any ? imax_(hi[a], bh[a]) : bh[a];
+                            }
+                            any = true;
+                        }
+                        if (!any) continue;
+                    }
+                    node.lo_x[slot] = lo[0]; node.lo_y[slot] = lo[1]; node.lo_z[slot] = lo[2];
+                    node.hi_x[slot] = hi[0]; node.hi_y[slot] = hi[1]; node.hi_z[slot] = hi[2];
+                }
+            }
+        c->cull_boxes_current = true;
+    } else {
+        c->cull_boxes_current = false;
+    }
     c->refit_active = true;
     c->stats.last_build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return JPT_OK;

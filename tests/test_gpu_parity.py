@@ -172,6 +172,40 @@ def test_device_refit_renders_like_a_fresh_build(oracle, hiplib, asynchronous):
         ctx.close()
 
 
+def test_device_refit_keeps_the_sky_cull_exact(hiplib):
+    """The demo scene leaves most of the frame to the sky, so the primary launch culls by the screen rectangles of the
+    TLAS root's boxes -- which a refit moves.  The host repeats the refit on its copy of the records for that purpose;
+    the image (sums, depth) and the ray count equal a fresh commit's, with the cull and without."""
+    sc = scenes.demo_scene(2500)
+    w, h, bounces, frames = 320, 180, 3, 2
+    cam = scenes.camera_block(sc.camera, w, h)
+    ctx = host.Context(0)
+    try:
+        ctx.build_scene(sc, capi.BUILD_SAH)
+        ctx.set_params(w, h, bounces, wire.ACCUM_REF_LDR8)
+        ctx.set_camera(cam)
+        ctx.render(1, 1)
+        cur = sc
+        for step in range(3):
+            moves = {2: scenes.transform12(scenes.rot_y(40.0 * (step + 1)) * 1.2, np.asarray(sc.instances[2].transform[9:12]) + np.array([0.6 * (step + 1), 0.2, 0.0])),
+                     3: scenes.transform12(scenes.rot_y(-25.0 * (step + 1)) * 0.8, np.asarray(sc.instances[3].transform[9:12]) + np.array([-0.9 * (step + 1), 0.0, 0.3]))}
+            cur = _moved(cur, moves)
+            ctx.refit_tlas(np.stack([np.asarray(i.transform, dtype=np.float32) for i in cur.instances]))
+            ctx.accum_reset()
+            ctx.render(frames, 1, counted=True)
+            got, got_depth, rays = ctx.read_accum(), ctx.read_depth(), ctx.stats()["rays"]
+            fresh = host.Context(0)
+            fresh.build_scene(cur, capi.BUILD_SAH)
+            fresh.set_params(w, h, bounces, wire.ACCUM_REF_LDR8)
+            fresh.set_camera(cam)
+            fresh.render(frames, 1, counted=True)
+            want, want_depth, want_rays = fresh.read_accum(), fresh.read_depth(), fresh.stats()["rays"]
+            fresh.close()
+            assert np.array_equal(got, want) and np.array_equal(got_depth, want_depth) and rays == want_rays, step
+    finally:
+        ctx.close()
+
+
 def test_queue_of_animation_steps_stays_correct(hiplib):
     """Ten animation steps queued without ever waiting: refit, render, and a device-side snapshot of the sums queued on
     the context's stream behind each render.  More steps than copies of the instance level and than pipeline slots, so
