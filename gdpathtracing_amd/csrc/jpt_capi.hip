@@ -153,7 +153,6 @@ struct jpt_ctx {
     bool readback_full = false;  // the read-back in flight copies the assembled image (else: this context's rows)
 
     jpt_stats stats;
-    int32_t stats_frames = 0;  // n_frames of the render stats.rays belongs to
 };
 
 namespace {
@@ -621,7 +620,6 @@ int do_render_batch(jpt_ctx* c, int32_t n_frames, uint32_t first_frame_index, bo
                 c->trace_events.push_back(e);
             }
             c->trace_events_used = (int32_t)need_ev;
-            if (wf2) c->async.last_rays = (c->stats_frames == n_frames) ? (size_t)c->stats.rays : 0;
             if (wf2) compute_sky_cull(c, c->async.cull);
             static const bool pipelining = [] {
                 const char* e = getenv("JPT_PIPELINE");
@@ -757,7 +755,6 @@ int do_render_batch(jpt_ctx* c, int32_t n_frames, uint32_t first_frame_index, bo
             for (int b = 1; b <= c->max_bounces; b++)
                 for (size_t k = 0; k < per_row; k++) rays += c->h_qcount[(size_t)b * per_row + k];
             c->stats.rays = rays;
-            c->stats_frames = n_frames;
         }
         if (counted) {
             DevCounters h;

@@ -147,7 +147,6 @@ struct SkyCull {
 struct Wf2Async {
     hipStream_t aux_stream[3] = {nullptr, nullptr, nullptr};
     hipEvent_t fork = nullptr, join[3] = {nullptr, nullptr, nullptr};
-    size_t last_rays = 0;  // ray segments of this context's previous render of the same size (0: unknown)
     SkyCull cull;          // for the primary launch of this render
     int trace_chain = 1;   // wf2_trace: consecutive segments per block (1: lowest latency; 4 when renders are queued)
     hipEvent_t before_acc = nullptr;  // the accumulation kernel waits for this event (whatever its stream)

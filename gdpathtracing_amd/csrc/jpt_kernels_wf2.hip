@@ -466,7 +466,7 @@ uint32_t trace_stack_capacity() { return (uint32_t)(kStackLds + kStackSpill); }
 // close-up 6.89 -> 6.22, 16 spp 3.11 -> 2.82, instanced scene 4.56 -> 4.03; 1280x720x4 spp 0.69 -> 0.71 (not used
 // below 12 M paths).
 constexpr int kMaxGroups = 4;
-static int frame_groups(int n_frames, bool serial, size_t paths, size_t last_rays = 0)
+static int frame_groups(int n_frames, bool serial, size_t paths)
 {
     const int forced = [] {  // JPT_GROUPS=n overrides the rule (tuning runs, tests); read on every render
         const char* e = getenv("JPT_GROUPS");
@@ -474,7 +474,6 @@ static int frame_groups(int n_frames, bool serial, size_t paths, size_t last_ray
         return g < 0 ? 0 : (g > kMaxGroups ? kMaxGroups : g);
     }();
     if (serial || n_frames < 2) return 1;
-    (void)last_rays;
     const int wanted = forced ? forced : (paths >= ((size_t)12 << 20) ? 2 : 1);
     return n_frames < wanted ? n_frames : wanted;
 }
@@ -535,7 +534,7 @@ void launch_wf2_render(hipStream_t stream, const DeviceScene& ds, const FramePar
     const int nq = fp.max_bounces + 2;
     // per-launch events and event counters want the launches one after another
     const int groups = frame_groups(fp.n_frames, trace_events != nullptr || counters != nullptr || !async.aux_stream[0],
-                                    (size_t)fp.width * (size_t)fp.local_rows * (size_t)fp.n_frames, async.last_rays);
+                                    (size_t)fp.width * (size_t)fp.local_rows * (size_t)fp.n_frames);
     Wf2Buffers gb[kMaxGroups];
     Wf2Dims gdm[kMaxGroups];
     FrameParams gfp[kMaxGroups];
