@@ -6,6 +6,7 @@
 //   host_demo buffers <scene.bin> <prefix>                      host-only context, REFERENCE_EXACT, dumps get_*_buffer()
 //   host_demo render  <scene.bin> <prefix> <w> <h> <frames> <builder> <accum_mode> [denoising_mode] [overlapped]   GPU 0
 //   host_demo moved   <scene.bin> <prefix>                      host-only context, update_transforms()
+//   host_demo animate <scene.bin> <prefix> <w> <h> <steps> <refit>   GPU 0: move, update_transforms(refit), render, repeat
 #include <jpt_host.hpp>
 
 #include <cstdio>
@@ -161,6 +162,34 @@ int main(int argc, char** argv)
             dump(prefix + "_camera.bin", &cam.camera, sizeof(Camera));
             std::printf("rendered %d frames, frame_index %u, frame_count %u\n", frames, cam.camera.frame_index,
                         cam.progressive_renderer.frame_count);
+            return 0;
+        }
+        if (mode == "animate" && argc >= 8) {
+            // moving nodes on the GPU: every step shifts child i by (0.25 i, 0, -0.125 i), update_transforms(refit),
+            // one frame in the NONE mode (the screen is that frame alone); the last screen is dumped
+            const int w = std::atoi(argv[4]), h = std::atoi(argv[5]), steps = std::atoi(argv[6]);
+            const bool refit = std::atoi(argv[7]) != 0;
+            PathTracingCamera cam(0);
+            group.builder = JPT_BUILD_SAH;
+            cam.set_fov(fov);
+            cam.set_geometry_group(&group);
+            cam.set_global_transform(cam_t);
+            cam.camera.frame_index = 0;
+            cam.set_denoising_mode(PathTracingCamera::NONE);
+            cam.init(w, h);
+            PackedByteArray screen;
+            int moved_total = 0;
+            for (int k = 0; k < steps; k++) {
+                for (size_t i = 1; i < group.get_child_count(); i++) {
+                    group.get_child(i).global_transform.origin.x += 0.25f * (float)i;
+                    group.get_child(i).global_transform.origin.z -= 0.125f * (float)i;
+                }
+                moved_total += group.update_transforms(refit);
+                screen = cam.render();
+            }
+            dump(prefix + "_ldr.bin", screen.data(), screen.size());
+            dump(prefix + "_camera.bin", &cam.camera, sizeof(Camera));
+            std::printf("animated %d steps, %d moves, frame_index %u\n", steps, moved_total, cam.camera.frame_index);
             return 0;
         }
         std::fprintf(stderr, "bad mode\n");

@@ -6,7 +6,7 @@ import subprocess
 import numpy as np
 import pytest
 
-from gdpathtracing_amd import capi, scenes, wire
+from gdpathtracing_amd import capi, host, scenes, wire
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -214,3 +214,36 @@ def test_gdcs_adapter_other_denoising_modes(oracle, gdcs_test, denoise):
     out = subprocess.run([exe, path, pre, str(w), str(h), str(frames), str(denoise)], capture_output=True, text=True)
     assert out.returncode == 0, out.stderr
     _check_other_modes(oracle, pre, sc, w, h, frames, denoise)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("refit", [0, 1])
+def test_cpp_moving_nodes_on_the_gpu(host_demo, refit):
+    """GeometryGroup3D::update_transforms between PathTracingCamera::render() calls -- host rebuild (0) or device
+    refit (1): after three animation steps the screen equals a fresh context's render of the moved scene."""
+    import copy
+    exe, d = host_demo
+    sc = scenes.instanced_scene(n_side=4, n_unique=2, tris_per_mesh=64)
+    path = os.path.join(d, "a.jpts")
+    scenes.write_scene_file(sc, path)
+    w, h, steps = 160, 90, 3
+    pre = os.path.join(d, "a%d" % refit)
+    out = subprocess.run([exe, "animate", path, pre, str(w), str(h), str(steps), str(refit)], capture_output=True, text=True, check=True).stdout
+    assert "animated %d steps, %d moves, frame_index %d" % (steps, steps * (len(sc.instances) - 1), steps) in out
+    got = np.frombuffer(open(pre + "_ldr.bin", "rb").read(), dtype=np.uint8).reshape(h, w, 4)
+    moved = copy.deepcopy(sc)
+    for i in range(1, len(moved.instances)):
+        t = moved.instances[i].transform.astype(np.float32).copy()
+        for _ in range(steps):
+            t[9] = np.float32(t[9]) + np.float32(0.25) * np.float32(i)
+            t[11] = np.float32(t[11]) - np.float32(0.125) * np.float32(i)
+        moved.instances[i].transform = t
+    ctx = host.Context(0)
+    ctx.build_scene(moved, capi.BUILD_SAH)
+    ctx.set_params(w, h, 4, wire.ACCUM_REF_LDR8)
+    ctx.set_camera(np.frombuffer(open(pre + "_camera.bin", "rb").read(), dtype=wire.CAMERA)[0])   # the C++ layer's float camera block
+    ctx.set_denoising_mode(capi.DENOISE_NONE)
+    ctx.render(1, steps)
+    want = ctx.read_ldr()
+    ctx.close()
+    assert np.array_equal(got, want)
