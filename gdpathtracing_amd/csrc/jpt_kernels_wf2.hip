@@ -109,6 +109,7 @@ struct Wf2Dims {
     uint32_t slots_per_frame;  // tiles_per_frame * 64
     uint32_t n_chunks;         // tiles_per_frame * n_frames
     uint32_t seg_cap;          // entries per segment
+    uint32_t run_shift;        // a segment is dealt runs of 2^run_shift consecutive chunks (neighbouring tiles of one frame)
     FastDiv by_tiles_x, by_tiles_per_frame, by_slots_per_frame;
 };
 
@@ -136,8 +137,11 @@ __global__ __launch_bounds__(kBlock, JPT_PRIMARY_WAVES) void wf2_primary(WideSce
     const int lane = threadIdx.x & 63;
     const uint32_t seg = blockIdx.x;
     // chunks seg, seg + G, seg + 2G, ... belong to this block
-    const uint32_t my_chunks = seg < dm.n_chunks ? (dm.n_chunks - seg + kSegments - 1u) / kSegments : 0u;
-    const uint32_t n = my_chunks * 64u;
+    // runs seg, seg + G, seg + 2G, ... of 2^run_shift consecutive chunks belong to this block
+    const uint32_t run_mask = (1u << dm.run_shift) - 1u;
+    const uint32_t n_runs = (dm.n_chunks + run_mask) >> dm.run_shift;
+    const uint32_t my_runs = seg < n_runs ? (n_runs - seg + kSegments - 1u) / kSegments : 0u;
+    const uint32_t n = (my_runs << dm.run_shift) * 64u;  // (the last run of the image may be short: checked per entry)
     if (threadIdx.x == 0) {
         s_cursor = 0;
         s_out = 0;
@@ -162,12 +166,13 @@ __global__ __launch_bounds__(kBlock, JPT_PRIMARY_WAVES) void wf2_primary(WideSce
             if (start < n && !active) {
                 const uint32_t idx = start + lanes_below(idle, lane);
                 if (idx < n) {
-                    const uint32_t chunk = seg + (idx >> 6) * kSegments;
+                    const uint32_t j = idx >> 6;  // local chunk number: run j >> run_shift, position j & run_mask
+                    const uint32_t chunk = ((seg + (j >> dm.run_shift) * kSegments) << dm.run_shift) + (j & run_mask);
                     const uint32_t f = fdiv(chunk, dm.by_tiles_per_frame), tile = chunk - f * dm.tiles_per_frame;
                     const uint32_t slot = tile * 64u + (idx & 63u);
                     int px, ly;
                     slot_to_pixel(slot, dm, px, ly);
-                    if (px < fp.width && ly < fp.local_rows) {
+                    if (chunk < dm.n_chunks && px < fp.width && ly < fp.local_rows) {
                         const int py = local_to_global_row(ly, fp);
                         uint32_t sx, sy;
                         const Ray ray = primary_ray(cam, fp.width, fp.height, px, py, fp.frame_index + f, sx, sy);
@@ -439,7 +444,22 @@ Wf2Dims make_dims(int width, int local_rows, int n_frames)
     dm.tiles_per_frame = (uint32_t)dm.tiles_x * (uint32_t)dm.tiles_y;
     dm.slots_per_frame = dm.tiles_per_frame * 64u;
     dm.n_chunks = dm.tiles_per_frame * (uint32_t)n_frames;
-    dm.seg_cap = ((dm.n_chunks + kSegments - 1u) / kSegments) * 64u;
+    // Chunks are dealt to the segments in runs of 1, 2 or 4 neighbouring tiles of a frame: a wave refills its idle
+    // lanes from consecutive entries, and neighbouring tiles keep its rays alike for longer (record steps of the
+    // primary launch at 49 of 64 lanes instead of 37).  Longer runs start to unbalance the segments, and so do runs
+    // at all when a segment has few chunks (ms per queued render with runs of 1 / 2 / 4 / 8: C3 1.261 / 1.242 / 1.240 /
+    // 1.300, 1920x1080x16 2.417 / 2.374 / 2.358 / 2.369, 3840x2160x16 9.34 / 9.04 / 8.94 / 9.02, 1280x720x4 0.440 / 0.421 /
+    // 0.424 / 0.495; 1920x1080x2 0.431 / 0.444 / 0.452, one frame 0.331 / 0.367 / 0.376).  JPT_RUN_SHIFT overrides.
+    static const int forced_shift = [] {
+        const char* e = getenv("JPT_RUN_SHIFT");
+        const int v = e ? atoi(e) : -1;
+        return v > 8 ? 8 : v;
+    }();
+    const uint32_t per_segment = dm.n_chunks / kSegments;
+    const uint32_t run_shift = forced_shift >= 0 ? (uint32_t)forced_shift : (n_frames < 4 || per_segment < 32u ? 0u : (per_segment < 64u ? 1u : 2u));
+    dm.run_shift = run_shift;
+    const uint32_t n_runs = (dm.n_chunks + (1u << run_shift) - 1u) >> run_shift;
+    dm.seg_cap = (((n_runs + kSegments - 1u) / kSegments) << run_shift) * 64u;
     dm.by_tiles_x = make_fastdiv((uint32_t)dm.tiles_x);
     dm.by_tiles_per_frame = make_fastdiv(dm.tiles_per_frame);
     dm.by_slots_per_frame = make_fastdiv(dm.slots_per_frame);
