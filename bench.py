@@ -296,9 +296,9 @@ def main():
                 "ref_layout_algorithmic_bytes": int(alg_ref),
                 "ref_layout_achieved": round(alg_ref / (kernel_ms * 1e-3) / 1e9, 2),
                 "note": "scene is L2/Infinity-Cache resident; bytes are cache-served requests, not HBM traffic. The kernels are "
-                        "VALU-issue-bound: 7.9e8 wave-level VALU instructions per C3 render x 4 cycles / (1024 SIMDs x 2.4 GHz) = "
-                        "1.29 ms, which is what ms_per_step (renders queued, four in flight) reaches; lane utilisation of wf2_trace "
-                        "is 29 % (rocprofv3 SQ counters, profiles/r01/r01f_sq_counters.txt, DESIGN.md section 4)",
+                        "VALU-issue-bound: 7.6e8 wave-level VALU instructions per C3 render x 4 cycles / (1024 SIMDs x 2.4 GHz) = "
+                        "1.24 ms, against which ms_per_step (renders queued, four in flight) is to be read; lane utilisation of "
+                        "wf2_trace is 30 % (rocprofv3 SQ counters, profiles/r01/r01h_sq_counters.txt, DESIGN.md section 4)",
             },
             "counters": total,
         }
