@@ -516,3 +516,39 @@ def test_foreign_work_on_the_context_stream_sees_each_queued_render(hiplib):
     ctx.set_stream(None)
     assert ctx.get_stream() == s
     ctx.close(); solo.close()
+
+
+def test_c4_device_refit_at_full_size(hiplib):
+    """The instanced scene of config C4 (1 026 instances, a TLAS ten records deep) at 1920x1080: every instance moves,
+    jpt_scene_refit_tlas, queued renders; sums, depth and ray count equal a fresh commit of the moved scene.  Then the
+    host route (jpt_scene_update_tlas) on top of the refitted state gives the same image again."""
+    sc = scenes.instanced_scene()
+    w, h, bounces, frames = 1920, 1080, 4, 2
+    cam = scenes.camera_block(sc.camera, w, h)
+    rng = np.random.RandomState(11)
+    ctx = make_ctx(sc, w, h, bounces, wire.ACCUM_REF_LDR8)
+    ctx.render(1, 1, asynchronous=True)
+    import copy
+    moved = copy.deepcopy(sc)
+    for step in range(2):
+        for i in range(2, len(moved.instances)):
+            t = np.asarray(moved.instances[i].transform, dtype=np.float32).copy()
+            t[9:12] += rng.uniform(-0.4, 0.4, size=3).astype(np.float32)
+            moved.instances[i].transform = t
+        ctx.refit_tlas(np.stack([np.asarray(i.transform, dtype=np.float32) for i in moved.instances]))
+        ctx.accum_reset()
+        ctx.render(frames, 1, asynchronous=True)
+    got, got_depth = ctx.read_accum(), ctx.read_depth()
+    fresh = make_ctx(moved, w, h, bounces, wire.ACCUM_REF_LDR8)
+    fresh.render(frames, 1, counted=True)
+    want, want_depth, want_rays = fresh.read_accum(), fresh.read_depth(), fresh.stats()["rays"]
+    fresh.close()
+    assert np.array_equal(got, want) and np.array_equal(got_depth, want_depth)
+    ctx.accum_reset()
+    ctx.render(frames, 1, counted=True)          # counted renders run serially on the context's stream: same records
+    assert ctx.stats()["rays"] == want_rays and np.array_equal(ctx.read_accum(), want)
+    ctx.update_tlas()                            # host rebuild from the same transforms: new topology, same image
+    ctx.accum_reset()
+    ctx.render(frames, 1)
+    assert np.array_equal(ctx.read_accum(), want) and np.array_equal(ctx.read_depth(), want_depth)
+    ctx.close()
