@@ -215,7 +215,7 @@ int jpt_render_counted(jpt_ctx *ctx, int32_t n_frames, uint32_t first_frame_inde
  * pipelined: their kernels run on alternating internal streams with separate workspaces (one render's launch
  * tails overlap the next render's kernels), the accumulation kernels run in call order (chained by events through
  * the ctx stream, which waits for each of them: work queued on the ctx stream afterwards sees the result), so the
- * framebuffers hold exactly what serial execution would leave (C3: 1.82 -> 1.31 ms per render when queued; up to four
+ * framebuffers hold exactly what serial execution would leave (C3: 1.78 -> 1.28 ms per render when queued; up to four
  * renders are in flight, each with its own workspace). */
 int jpt_render_async(jpt_ctx *ctx, int32_t n_frames, uint32_t first_frame_index);
 int jpt_sync(jpt_ctx *ctx);
