@@ -293,6 +293,9 @@ def main():
                 "render_ms": round(float(np.mean(render_ms)), 4),
                 "render_ms_note": "one render alone, launches serialised (kernel timing on); ms_per_step is the pipelined rate",
                 "algorithmic_bytes": int(alg),
+                # what a render must move through HBM whatever the caches do -- the framebuffers it leaves
+                # behind (float4 sums, rgba8 screen, r32f depth), per render, not per launch
+                "compulsory_framebuffer_bytes_per_render": int(n_pixels * (16 + 4 + 4)),
                 "ref_layout_algorithmic_bytes": int(alg_ref),
                 "ref_layout_achieved": round(alg_ref / (kernel_ms * 1e-3) / 1e9, 2),
                 "note": "scene is L2/Infinity-Cache resident; bytes are cache-served requests, not HBM traffic. The kernels are "
