@@ -64,7 +64,7 @@ def main():
     ap.add_argument("--scene", default="demo", choices=["demo", "cornell", "inst"])
     ap.add_argument("--builder", default="sah", choices=["sah", "exact"])
     ap.add_argument("--accum", default="ldr8", choices=["ldr8", "hdr"])
-    ap.add_argument("--kernel", default="wavefront", choices=["wavefront", "ref", "wavefront_v1"])
+    ap.add_argument("--kernel", default="wavefront", choices=["wavefront", "ref"])
     ap.add_argument("--camera", default="demo", choices=["demo", "closeup"],
                     help="demo = demo.tscn's camera (the box covers ~1/6 of the frame); closeup = camera at the box opening "
                          "(every pixel sees geometry; not the headline config)")
@@ -125,7 +125,7 @@ def main():
     ctx.set_partition(rank, world)
     ctx.set_params(W, H, bounces, accum_mode)
     ctx.set_camera(cam)
-    ctx.set_kernel({"wavefront": capi.KERNEL_WAVEFRONT, "ref": capi.KERNEL_REFERENCE_LAYOUT, "wavefront_v1": capi.KERNEL_WAVEFRONT_V1}[args.kernel])
+    ctx.set_kernel({"wavefront": capi.KERNEL_WAVEFRONT, "ref": capi.KERNEL_REFERENCE_LAYOUT}[args.kernel])
     # One explicit (non-null) stream carries the renders, the timing events and the collective: the context's own,
     # made torch's current stream.  (Not a stream from torch's pool: the pool is 32 streams created at once, the HIP
     # runtime deals streams to its hardware queues round-robin in creation order, and the library's slot streams,

@@ -16,7 +16,7 @@ CSRC = os.path.join(_HERE, "csrc")
 OK = 0
 ACCUM_REF_LDR8, ACCUM_HDR_F32 = 0, 1
 BUILD_REFERENCE_EXACT, BUILD_SAH = 0, 1
-KERNEL_WAVEFRONT, KERNEL_REFERENCE_LAYOUT, KERNEL_WAVEFRONT_V1 = 0, 1, 2
+KERNEL_WAVEFRONT, KERNEL_REFERENCE_LAYOUT = 0, 1
 DENOISE_PROGRESSIVE, DENOISE_TEMPORAL, DENOISE_NONE = 0, 1, 2
 BUF_TRI_GEOMETRY, BUF_TRI_DATA, BUF_MATERIALS, BUF_BVH_NODES, BUF_INSTANCES, BUF_TLAS_NODES, BUF_TRIANGLES = range(7)
 

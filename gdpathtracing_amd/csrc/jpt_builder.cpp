@@ -1,6 +1,7 @@
 // jpt_builder.cpp -- see jpt_builder.h.  Host C++ only (no device code).
 #include "jpt_builder.h"
 #include "jpt_instance_math.h"
+#include "jpt_tuning.h"
 
 #include <algorithm>
 #include <cfloat>
@@ -199,15 +200,7 @@ struct SahBlasBuilder {
 
     static constexpr int kBins = 16;
     // largest leaf the builder keeps without a split that pays (JPT_MAX_LEAF overrides, for tuning runs)
-    static int max_leaf()
-    {
-        static const int v = [] {
-            const char* e = getenv("JPT_MAX_LEAF");
-            const int k = e ? atoi(e) : 2;
-            return k < 1 ? 1 : (k > 16 ? 16 : k);
-        }();
-        return v;
-    }
+    static int max_leaf() { return tuning().max_leaf; }
 
     void prepare(int start, int end)
     {
@@ -716,6 +709,12 @@ struct Flattener {
             err = "BVH child index out of range";
             return ~0;
         }
+        // uploaded arrays are only range-checked: a cycle (or a chain deeper than any builder makes) must not
+        // overflow the host stack.  A tree over n nodes is at most n deep.
+        if (depth > 4096u || depth > ref.bvh_nodes.size() + 1u) {
+            err = "BVH is cyclic or deeper than 4096 levels";
+            return ~0;
+        }
         out.max_blas_depth = std::max(out.max_blas_depth, depth);
         const RefBvhNode& n = ref.bvh_nodes[ni];
         if (n.tri_count > 0 || (n.left_child == 0 && n.right_child == 0)) {
@@ -727,18 +726,21 @@ struct Flattener {
             }
             if (count <= (uint32_t)kMaxLeafTris) return leaf_ref(first, count);
             // oversized leaf (the reference makes them when all three SAH axes are rejected): chain of
-            // records whose two boxes both equal the leaf box
+            // records whose two boxes both equal the leaf box.  With equal entry distances the walk takes the
+            // else branch of main.glsl:293-299 and visits the RIGHT child first, so the first 64 triangles go
+            // right and the rest left: the triangles are tested in index order, as the leaf loop of
+            // main.glsl:280-283 does (ties, t == hitInfo.t, go to the later triangle)
             const int32_t self = (int32_t)out.blas_nodes.size();
             out.blas_nodes.emplace_back();
             WideNode w;
             std::memset(&w, 0, sizeof w);
             set_box(w.lmin, w.lmax, n);
             set_box(w.rmin, w.rmax, n);
-            w.left = leaf_ref(first, kMaxLeafTris);
+            w.right = leaf_ref(first, kMaxLeafTris);
             RefBvhNode rest = n;
             rest.first_tri_index = first + kMaxLeafTris;
             rest.tri_count = count - kMaxLeafTris;
-            w.right = oversized_rest(rest);
+            w.left = oversized_rest(rest);
             out.blas_nodes[self] = w;
             return self;
         }
@@ -782,11 +784,11 @@ struct Flattener {
         std::memset(&w, 0, sizeof w);
         set_box(w.lmin, w.lmax, n);
         set_box(w.rmin, w.rmax, n);
-        w.left = leaf_ref(n.first_tri_index, kMaxLeafTris);
+        w.right = leaf_ref(n.first_tri_index, kMaxLeafTris);   // visited first (see blas_child)
         RefBvhNode rest = n;
         rest.first_tri_index += kMaxLeafTris;
         rest.tri_count -= kMaxLeafTris;
-        w.right = oversized_rest(rest);
+        w.left = oversized_rest(rest);
         out.blas_nodes[self] = w;
         return self;
     }

@@ -14,12 +14,23 @@
 #include "jpt_builder.h"
 #include "jpt_kernels.h"
 #include "jpt_instance_math.h"
+#include "jpt_tuning.h"
 
 using namespace jpt;
 
 namespace {
 
 thread_local std::string g_create_error;
+
+// Hardware queues.  The HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4),
+// dealt in the order the streams are first used; streams that share a queue run in submission order.  Queued renders
+// use four pipeline-slot streams plus the context's stream, so the library asks for a pool of 16 itself: the variable is
+// read when the HIP runtime initialises (first HIP call of the process), and this runs when the library is loaded --
+// before main() of a program that links it, at dlopen()/ctypes time otherwise.  A value the host has set is kept;
+// jpt_create reports one that is too small (and cannot know about a runtime that was initialised before the load).
+struct HwQueueRequest {
+    HwQueueRequest() { (void)setenv("GPU_MAX_HW_QUEUES", "16", /*overwrite*/ 0); }
+} g_hw_queue_request;
 
 template <typename T>
 struct DevBuf {
@@ -359,11 +370,7 @@ int validate_ref_scene(jpt_ctx* c)
 void compute_sky_cull(const jpt_ctx* c, SkyCull& out)
 {
     out.n = -1;
-    static const bool enabled = [] {
-        const char* e = getenv("JPT_SKY_CULL");
-        return !(e && atoi(e) == 0);
-    }();
-    if (!enabled || c->width <= 0 || c->height <= 0) return;
+    if (!tuning().sky_cull || c->width <= 0 || c->height <= 0) return;
     if (!c->cull_boxes_current) return;  // the root's boxes were last refitted on the device only: the host copy is stale
     // the boxes: children of the TLAS root record in the layout the kernels walk
     double lo[4][3], hi[4][3];
@@ -459,10 +466,7 @@ int do_render_batch(jpt_ctx* c, int32_t n_frames, uint32_t first_frame_index, bo
 // frames of one wavefront render that fit the workspace budget (all frames of a batch are in flight at once)
 int32_t frames_per_batch(const jpt_ctx* c, int32_t n_frames)
 {
-    static const size_t budget = [] {
-        const char* e = getenv("JPT_WORKSPACE_BUDGET_MB");
-        return (size_t)(e ? atoll(e) : 16384) << 20;
-    }();
+    const size_t budget = (size_t)tuning().workspace_budget_mb << 20;
     if (c->kernel_variant == JPT_KERNEL_REFERENCE_LAYOUT || n_frames <= 1) return n_frames;
     const size_t one = wf2_workspace_bytes(c->width, c->local_rows, 1, c->max_bounces);
     const size_t fit = std::max<size_t>(1, budget / std::max<size_t>(one, 1));
@@ -585,12 +589,11 @@ int do_render_batch(jpt_ctx* c, int32_t n_frames, uint32_t first_frame_index, bo
         cnt = c->d_counters.p;
         HIP_TRY(c, hipMemsetAsync(cnt, 0, sizeof(DevCounters), s));
     }
-    const bool wavefront = c->kernel_variant == JPT_KERNEL_WAVEFRONT || c->kernel_variant == JPT_KERNEL_WAVEFRONT_V1;
-    const bool wf2 = c->kernel_variant == JPT_KERNEL_WAVEFRONT;
+    const bool wavefront = c->kernel_variant == JPT_KERNEL_WAVEFRONT;
+    const bool wf2 = wavefront;
     const int nq = c->max_bounces + 2;
     if (wavefront && c->local_rows > 0 && c->width > 0 && n_frames > 0) {
-        const size_t need = wf2 ? wf2_workspace_bytes(c->width, c->local_rows, n_frames, c->max_bounces)
-                                : wide_workspace_bytes(c->width, c->local_rows, n_frames, c->max_bounces);
+        const size_t need = wf2_workspace_bytes(c->width, c->local_rows, n_frames, c->max_bounces);
         if (c->d_workspace.n < need) {
             HIP_TRY(c, hipStreamSynchronize(s));
             HIP_TRY(c, c->d_workspace.resize(need));
@@ -621,15 +624,11 @@ int do_render_batch(jpt_ctx* c, int32_t n_frames, uint32_t first_frame_index, bo
             }
             c->trace_events_used = (int32_t)need_ev;
             if (wf2) compute_sky_cull(c, c->async.cull);
-            static const bool pipelining = [] {
-                const char* e = getenv("JPT_PIPELINE");
-                return !(e && atoi(e) == 0);
-            }();
+            const bool pipelining = tuning().pipelining;
             // renders in flight (JPT_PIPE_SLOTS overrides): a render is eleven dependent launches of >= 25-30 us each
             // however little work it holds, so several of them are needed to fill the chip
-            static const int forced_slots = [] {
-                const char* e = getenv("JPT_PIPE_SLOTS");
-                const int k = e ? atoi(e) : 0;
+            const int forced_slots = [] {
+                const int k = tuning().pipe_slots;
                 return k <= 0 ? 0 : (k < 2 ? 2 : (k > jpt_ctx::kPipeSlots ? jpt_ctx::kPipeSlots : k));
             }();
             // Four renders in flight, each tracing with a quarter of the blocks (four consecutive segments per block: a
@@ -678,10 +677,7 @@ int do_render_batch(jpt_ctx* c, int32_t n_frames, uint32_t first_frame_index, bo
                 Wf2Async one_group = c->async;
                 one_group.aux_stream[0] = nullptr;
                 one_group.trace_chain = huge ? 1 : 4;
-                static const bool acc_on_slot = [] {
-                    const char* e = getenv("JPT_ACC_ON_SLOT");
-                    return !(e && atoi(e) == 0);
-                }();
+                const bool acc_on_slot = tuning().acc_on_slot;
                 if (acc_on_slot) {
                     // The accumulation runs on the slot's stream too, after whatever `s` holds now (the previous render's
                     // accumulation, an upload, a read-back), and `s` then waits for it: the results are those of serial
@@ -707,9 +703,6 @@ int do_render_batch(jpt_ctx* c, int32_t n_frames, uint32_t first_frame_index, bo
                 launch_wf2_render(s, c->ds, fp, c->camera, c->d_workspace.p, c->d_accum.p, c->d_ldr.p, c->d_depth.p, cnt,
                                   need_ev ? c->trace_events.data() : nullptr, c->async);
             }
-            else
-                launch_wide_render(s, c->ds, fp, c->camera, c->d_workspace.p, c->d_accum.p, c->d_ldr.p, c->d_depth.p, cnt,
-                                   need_ev ? c->trace_events.data() : nullptr);
         } else {
             for (int32_t f = 0; f < n_frames; f++) {
                 fp.frame_index = first_frame_index + (uint32_t)f;
@@ -828,6 +821,11 @@ int jpt_create(int device_id, jpt_ctx** out)
         return JPT_E_DEVICE;
     }
     c->stream = c->own_stream;
+    (void)tuning();  // environment switches are read here, once per process
+    if (const char* q = getenv("GPU_MAX_HW_QUEUES"))
+        if (atoi(q) < 6)
+            c->error = std::string("note: GPU_MAX_HW_QUEUES=") + q + " -- queued renders (jpt_render_async) use five streams; with fewer "
+                       "hardware queues they share queues and the queued rate drops by up to 2x (DESIGN.md section 4)";
     *out = c;
     return JPT_OK;
 }
@@ -1107,10 +1105,7 @@ int jpt_scene_refit_tlas(jpt_ctx* c, const float* transforms12, uint32_t n_insta
     // the host keeps the transforms (a later jpt_scene_update_tlas rebuilds from them); its arrays are stale from here on
     for (uint32_t i = 0; i < n_instances; i++) (void)c->builder.set_instance_transform(i, transforms12 + (size_t)i * 12);
     c->tlas_dirty = true;
-    static const bool width2 = [] {
-        const char* e = getenv("JPT_BVH_WIDTH");
-        return e && atoi(e) == 2;
-    }();
+    const bool width2 = tuning().bvh_width == 2;
     if (width2 || !c->ds.use4 || !c->scene_ready) return jpt_scene_update_tlas(c);  // no four-child records to refit
     if (n_instances == 0) return JPT_OK;
     const auto t0 = std::chrono::steady_clock::now();
@@ -1295,7 +1290,7 @@ int jpt_set_params(jpt_ctx* c, int32_t width, int32_t height, int32_t max_bounce
     if (width < 0 || height < 0 || width > 65536 || height > 65536) return fail(c, JPT_E_INVALID, "bad resolution");
     if (max_bounces < 0 || max_bounces > 64) return fail(c, JPT_E_INVALID, "max_bounces must be in [0,64]");
     if (accum_mode != JPT_ACCUM_REF_LDR8 && accum_mode != JPT_ACCUM_HDR_F32) return fail(c, JPT_E_INVALID, "unknown accum_mode");
-    if (sampler_mode != JPT_SAMPLER_NEAREST_CLAMP) return fail(c, JPT_E_INVALID, "unknown sampler_mode");
+    if (sampler_mode < JPT_SAMPLER_NEAREST_CLAMP || sampler_mode > JPT_SAMPLER_LINEAR_REPEAT) return fail(c, JPT_E_INVALID, "unknown sampler_mode");
     if (c->device < 0) return fail(c, JPT_E_DEVICE, "host-only context has no framebuffers");
     HIP_TRY(c, hipSetDevice(c->device));
     c->width = width;
@@ -1303,6 +1298,7 @@ int jpt_set_params(jpt_ctx* c, int32_t width, int32_t height, int32_t max_bounce
     c->max_bounces = max_bounces;
     c->accum_mode = accum_mode;
     c->sampler_mode = sampler_mode;
+    c->ds.sampler_mode = sampler_mode;
     c->params_set = true;
     return alloc_framebuffers(c);
 }
@@ -1353,7 +1349,7 @@ int jpt_sync(jpt_ctx* c)
 int jpt_set_kernel(jpt_ctx* c, int32_t variant)
 {
     if (!c) return JPT_E_INVALID;
-    if (variant != JPT_KERNEL_WAVEFRONT && variant != JPT_KERNEL_REFERENCE_LAYOUT && variant != JPT_KERNEL_WAVEFRONT_V1) return fail(c, JPT_E_INVALID, "unknown kernel variant");
+    if (variant != JPT_KERNEL_WAVEFRONT && variant != JPT_KERNEL_REFERENCE_LAYOUT) return fail(c, JPT_E_INVALID, "unknown kernel variant");
     c->kernel_variant = variant;
     return JPT_OK;
 }

@@ -45,6 +45,7 @@ struct DeviceScene {
     const uint8_t* tex = nullptr;
     uint32_t n_tris = 0, n_materials = 0, n_ref_bvh = 0, n_instances = 0, n_ref_tlas = 0;
     int32_t tex_res = 0, n_layers = 0;
+    int32_t sampler_mode = 0;  // JPT_SAMPLER_* (jpt_set_params)
     // flattened layout (native route)
     const WideNode* blas_nodes = nullptr;
     const WideTri* wide_tris = nullptr;
@@ -66,6 +67,8 @@ struct DeviceScene {
         s.materials = ref_materials;
         s.tex = tex;
         s.n_materials = n_materials;
+        s.n_instances = n_instances;
+        s.sampler_mode = sampler_mode;
         s.tex_res = tex_res;
         s.n_layers = n_layers;
         return s;
@@ -121,15 +124,8 @@ __device__ __forceinline__ void flush_counters(const DevCounters& c, DevCounters
 void launch_ref_frame(hipStream_t stream, const DeviceScene& ds, const FrameParams& fp, const RefCamera& cam, float4* accum,
                       uint32_t* ldr, float* depth, DevCounters* counters);
 
-// one render of fp.n_frames frames over the flattened layout (jpt_kernels_wide.hip).  fp.frame_index /
-// fp.frame_count are those of the FIRST frame.  The first (max_bounces + 2) u32 of `workspace` are the
-// per-bounce queue sizes afterwards (their sum = ray segments traced).  trace_events (may be null):
-// 2 * (max_bounces + 1) events recorded around each wf_trace launch.
-size_t wide_workspace_bytes(int width, int local_rows, int n_frames, int max_bounces);
-void launch_wide_render(hipStream_t stream, const DeviceScene& ds, const FrameParams& fp, const RefCamera& cam, void* workspace,
-                        float4* accum, uint32_t* ldr, float* depth, DevCounters* counters, hipEvent_t* trace_events);
-
-// the persistent-block pipeline (jpt_kernels_wf2.hip): same contract.  The first (max_bounces + 2) *
+// The persistent-block pipeline (jpt_kernels_wf2.hip): one render of fp.n_frames frames over the flattened layout;
+// fp.frame_index / fp.frame_count are those of the FIRST frame.  The first (max_bounces + 2) *
 // wf2_segments() u32 of `workspace` are per-bounce, per-segment queue sizes afterwards; rows 1..max_bounces
 // sum to the secondary ray segments traced.  trace_events: pairs around wf2_primary and each wf2_trace.
 uint32_t wf2_segments();

@@ -23,6 +23,7 @@
 #include <cstdlib>
 
 #include "jpt_trace_core.h"
+#include "jpt_tuning.h"
 
 // the primary kernel carries the ray set-up and the sky-cull test besides the walk: at 72 VGPRs it spills 48 bytes,
 // at 80 (6 waves/SIMD) it does not, and the queued render rate is 2 % better (1.48 vs 1.51 ms on C3)
@@ -450,11 +451,7 @@ Wf2Dims make_dims(int width, int local_rows, int n_frames)
     // at all when a segment has few chunks (ms per queued render with runs of 1 / 2 / 4 / 8: C3 1.261 / 1.242 / 1.240 /
     // 1.300, 1920x1080x16 2.417 / 2.374 / 2.358 / 2.369, 3840x2160x16 9.34 / 9.04 / 8.94 / 9.02, 1280x720x4 0.440 / 0.421 /
     // 0.424 / 0.495; 1920x1080x2 0.431 / 0.444 / 0.452, one frame 0.331 / 0.367 / 0.376).  JPT_RUN_SHIFT overrides.
-    static const int forced_shift = [] {
-        const char* e = getenv("JPT_RUN_SHIFT");
-        const int v = e ? atoi(e) : -1;
-        return v > 8 ? 8 : v;
-    }();
+    const int forced_shift = tuning().run_shift;
     const uint32_t per_segment = dm.n_chunks / kSegments;
     const uint32_t run_shift = forced_shift >= 0 ? (uint32_t)forced_shift : (n_frames < 4 || per_segment < 32u ? 0u : (per_segment < 64u ? 1u : 2u));
     dm.run_shift = run_shift;
@@ -488,9 +485,8 @@ uint32_t trace_stack_capacity() { return (uint32_t)(kStackLds + kStackSpill); }
 constexpr int kMaxGroups = 4;
 static int frame_groups(int n_frames, bool serial, size_t paths)
 {
-    const int forced = [] {  // JPT_GROUPS=n overrides the rule (tuning runs, tests); read on every render
-        const char* e = getenv("JPT_GROUPS");
-        const int g = e ? atoi(e) : 0;
+    const int forced = [] {  // JPT_GROUPS=n overrides the rule (tuning runs, tests)
+        const int g = tuning().groups;
         return g < 0 ? 0 : (g > kMaxGroups ? kMaxGroups : g);
     }();
     if (serial || n_frames < 2) return 1;
@@ -583,11 +579,7 @@ void launch_wf2_render(hipStream_t stream, const DeviceScene& ds, const FramePar
         gfp[g].depth_frame = (f0 + nf == fp.n_frames) ? nf - 1 : -1;  // the render's last frame writes the depth image
     }
 
-    static const bool allow4 = [] {
-        const char* e = getenv("JPT_BVH_WIDTH");
-        return !(e && atoi(e) == 2);
-    }();
-    const bool w4 = allow4 && ds.use4;
+    const bool w4 = tuning().bvh_width == 4 && ds.use4;
     WideSceneDev sc;
     sc.blas_nodes = ds.blas_nodes;
     sc.tlas_nodes = ds.tlas_nodes;
@@ -598,16 +590,10 @@ void launch_wf2_render(hipStream_t stream, const DeviceScene& ds, const FramePar
     sc.n_instances = ds.n_instances;
     const SceneShading sh = ds.shading();
     const dim3 block(kBlock);
-    static const WfTune tune = [] {
-        WfTune t{32, 16};
-        if (const char* e = getenv("JPT_REFILL_IDLE")) t.refill_idle = atoi(e);
-        if (const char* e = getenv("JPT_NODE_MIN_LANES")) t.node_min_lanes = atoi(e);
-        return t;
-    }();
+    const WfTune tune{tuning().refill_idle, tuning().node_min_lanes};
 
     const int chain = [&] {  // JPT_TRACE_CHAIN overrides (tuning runs); two frame groups share the chip: half-width launches
-        const char* e = getenv("JPT_TRACE_CHAIN");
-        const int c = e ? atoi(e) : (groups == 2 ? 2 : async.trace_chain);
+        const int c = tuning().trace_chain > 0 ? tuning().trace_chain : (groups == 2 ? 2 : async.trace_chain);
         return c < 1 ? 1 : (c > kMaxChain ? kMaxChain : c);
     }();
     const dim3 tgrid((kSegments + (uint32_t)chain - 1u) / (uint32_t)chain);

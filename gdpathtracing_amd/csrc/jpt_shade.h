@@ -35,8 +35,9 @@ struct SceneShading {  // cold, once-per-hit data: kept in the reference layout
     const RefInstance* __restrict__ instances;
     const RefMaterial* __restrict__ materials;
     const uint8_t* __restrict__ tex;
-    uint32_t n_materials;
+    uint32_t n_materials, n_instances;
     int32_t tex_res, n_layers;
+    int32_t sampler_mode;  // JPT_SAMPLER_*: bit 0 repeat, bit 1 linear
 };
 
 // ---- RNG (main.glsl:163-181) -----------------------------------------------------------------
@@ -105,17 +106,44 @@ __device__ __forceinline__ f3 sample_sky(f3 d)  // main.glsl:189-192
     return mk3(mix_(0.95f, 0.9f, t) * 1.0f, mix_(0.95f, 0.94f, t) * 1.0f, mix_(0.95f, 1.0f, t) * 1.0f);
 }
 
-// texture(textureArray, vec3(uv, layer)) (main.glsl:214): nearest + clamp-to-edge
+// texture(textureArray, vec3(uv, layer)) (main.glsl:214).  The sampler state is a parameter (jpt_set_params); what
+// each mode computes is pinned in oracle/oracle_trace.c::sample_texture (Vulkan texel addressing: nearest floor(u*res),
+// linear around u*res - 0.5, clamp-to-edge or non-negative modulo, mix() of the four UNORM8 texels, no sRGB decode).
+__device__ __forceinline__ int tex_index(float f, int res, bool repeat)
+{
+    if (f != f || f >= 1073741824.0f || f <= -1073741824.0f) return 0;
+    int i = (int)f;
+    if (repeat) {
+        i %= res;
+        return i < 0 ? i + res : i;
+    }
+    return i < 0 ? 0 : (i > res - 1 ? res - 1 : i);
+}
+__device__ __forceinline__ f3 texel(const SceneShading& sc, int layer, int ix, int iy)
+{
+    const uint32_t p = reinterpret_cast<const uint32_t*>(sc.tex)[((size_t)layer * sc.tex_res + iy) * sc.tex_res + ix];
+    return mk3(from_unorm8(p & 255u), from_unorm8((p >> 8) & 255u), from_unorm8((p >> 16) & 255u));
+}
 __device__ __forceinline__ f3 sample_texture(const SceneShading& sc, float u, float v, int layer)
 {
     if (!sc.tex || sc.n_layers <= 0 || sc.tex_res <= 0) return mk3(0.0f, 0.0f, 0.0f);
     if (layer >= sc.n_layers) layer = sc.n_layers - 1;
     const int res = sc.tex_res;
-    const float fx = __builtin_floorf(u * (float)res), fy = __builtin_floorf(v * (float)res);
-    const int ix = (fx < 0.0f || fx != fx) ? 0 : (fx > (float)(res - 1) ? res - 1 : (int)fx);
-    const int iy = (fy < 0.0f || fy != fy) ? 0 : (fy > (float)(res - 1) ? res - 1 : (int)fy);
-    const uint8_t* p = sc.tex + (((size_t)layer * res + iy) * res + ix) * 4;
-    return mk3(from_unorm8(p[0]), from_unorm8(p[1]), from_unorm8(p[2]));
+    const bool repeat = (sc.sampler_mode & 1) != 0, linear = (sc.sampler_mode & 2) != 0;
+    const float x = u * (float)res, y = v * (float)res;
+    if (!linear) return texel(sc, layer, tex_index(__builtin_floorf(x), res, repeat), tex_index(__builtin_floorf(y), res, repeat));
+    const float xs = x - 0.5f, ys = y - 0.5f;
+    const float fx = __builtin_floorf(xs), fy = __builtin_floorf(ys);
+    float a = xs - fx, b = ys - fy;
+    if (a != a) a = 0.0f;
+    if (b != b) b = 0.0f;
+    const int x0 = tex_index(fx, res, repeat), x1 = tex_index(fx + 1.0f, res, repeat);
+    const int y0 = tex_index(fy, res, repeat), y1 = tex_index(fy + 1.0f, res, repeat);
+    const f3 t00 = texel(sc, layer, x0, y0), t10 = texel(sc, layer, x1, y0);
+    const f3 t01 = texel(sc, layer, x0, y1), t11 = texel(sc, layer, x1, y1);
+    const f3 r0 = mk3(mix_(t00.x, t10.x, a), mix_(t00.y, t10.y, a), mix_(t00.z, t10.z, a));
+    const f3 r1 = mk3(mix_(t01.x, t11.x, a), mix_(t01.y, t11.y, a), mix_(t01.z, t11.z, a));
+    return mk3(mix_(r0.x, r1.x, b), mix_(r0.y, r1.y, b), mix_(r0.z, r1.z, b));
 }
 
 // ---- shading record (main.glsl:194-222) -------------------------------------------------------
@@ -126,8 +154,11 @@ __device__ __forceinline__ Shading get_shading_data(const SceneShading& sc, cons
     const RefTriData& tri = sc.tri_data[h.tri];
     const RefInstance& b = sc.instances[h.inst];
     const uint32_t slot = tri.material_index;
-    // b.materials[tri.materialIndex] is unchecked in the reference (main.glsl:198): slots past 2 read on
-    uint32_t mat_id = (slot < 3) ? b.material[slot] : reinterpret_cast<const uint32_t*>(&b + 1)[slot - 3];
+    // b.materials[tri.materialIndex] is unchecked in the reference (main.glsl:198): slots past 2 read on into the next
+    // instance's record; a read past the END of the instance buffer returns 0 (Vulkan robust buffer access; the same
+    // pin as the oracle's), so no uploaded material_index can make the kernel read outside the array
+    const unsigned long long word = (unsigned long long)h.inst * 44ull + 41ull + (unsigned long long)slot;
+    uint32_t mat_id = word < (unsigned long long)sc.n_instances * 44ull ? reinterpret_cast<const uint32_t*>(sc.instances)[word] : 0u;
     if (mat_id >= sc.n_materials) mat_id = 0;
     const RefMaterial& material = sc.materials[mat_id];
 

@@ -1,0 +1,53 @@
+// jpt_tuning.h -- the library's environment switches, read ONCE per process (first use, normally the first jpt_create).
+// They exist for tuning runs and tests; the defaults are the measured optima.  Nothing on the
+// render path calls getenv.
+#pragma once
+
+#include <cstdlib>
+
+namespace jpt {
+
+struct Tuning {
+    bool sky_cull = true;          // JPT_SKY_CULL=0: trace every primary ray
+    long workspace_budget_mb = 16384;  // JPT_WORKSPACE_BUDGET_MB: frames in flight per launch set
+    bool pipelining = true;        // JPT_PIPELINE=0: asynchronous renders run one after another
+    int pipe_slots = 0;            // JPT_PIPE_SLOTS=2..4: renders in flight (0: the library's rule)
+    bool acc_on_slot = true;       // JPT_ACC_ON_SLOT=0: accumulation kernels on the context's stream
+    int bvh_width = 4;             // JPT_BVH_WIDTH=2: two-child records on the native tree
+    int run_shift = -1;            // JPT_RUN_SHIFT: tiles dealt to a segment in runs of 2^n (-1: the library's rule)
+    int groups = 0;                // JPT_GROUPS=1..4: frame groups of a blocking render (0: the library's rule)
+    int refill_idle = 32;          // JPT_REFILL_IDLE: a wave refills when this many lanes are idle
+    int node_min_lanes = 16;       // JPT_NODE_MIN_LANES: leave the record loop below this many descending lanes
+    int trace_chain = 0;           // JPT_TRACE_CHAIN=1..4: segments per block of the tracing launches (0: the library's rule)
+    int max_leaf = 2;              // JPT_MAX_LEAF: native builder leaf size
+};
+
+inline const Tuning& tuning()
+{
+    static const Tuning t = [] {
+        Tuning v;
+        auto geti = [](const char* name, int dflt) {
+            const char* e = std::getenv(name);
+            return e ? std::atoi(e) : dflt;
+        };
+        v.sky_cull = geti("JPT_SKY_CULL", 1) != 0;
+        if (const char* e = std::getenv("JPT_WORKSPACE_BUDGET_MB")) v.workspace_budget_mb = std::atol(e);
+        v.pipelining = geti("JPT_PIPELINE", 1) != 0;
+        v.pipe_slots = geti("JPT_PIPE_SLOTS", 0);
+        v.acc_on_slot = geti("JPT_ACC_ON_SLOT", 1) != 0;
+        v.bvh_width = geti("JPT_BVH_WIDTH", 4) == 2 ? 2 : 4;
+        v.run_shift = geti("JPT_RUN_SHIFT", -1);
+        if (v.run_shift > 8) v.run_shift = 8;
+        v.groups = geti("JPT_GROUPS", 0);
+        v.refill_idle = geti("JPT_REFILL_IDLE", 32);
+        v.node_min_lanes = geti("JPT_NODE_MIN_LANES", 16);
+        v.trace_chain = geti("JPT_TRACE_CHAIN", 0);
+        v.max_leaf = geti("JPT_MAX_LEAF", 2);
+        if (v.max_leaf < 1) v.max_leaf = 1;
+        if (v.max_leaf > 16) v.max_leaf = 16;
+        return v;
+    }();
+    return t;
+}
+
+}  // namespace jpt

@@ -11,7 +11,6 @@ from __future__ import annotations
 import numpy as np
 
 STRIP_ROWS = 8  # == jpt::kStripRows
-_GATHER_OK = True
 
 
 def rows_of_rank(height: int, rank: int, world: int) -> np.ndarray:
@@ -48,19 +47,13 @@ def assemble(pieces, height: int, world: int) -> np.ndarray:
 
 def gather_to_rank0(piece, dist, rank: int, world: int, gathered=None):
     """One exchange per render: every rank's piece to rank 0 (torch tensors; RCCL on GPUs, gloo on CPU).
-    Each peer's piece travels point-to-point to rank 0 -- on MI355X that is one xGMI link per peer."""
+    Each peer's piece travels point-to-point to rank 0 -- on MI355X that is one xGMI link per peer.  There is no
+    fallback: a backend that cannot gather raises (an all_gather in its place would put 8x the bytes on every link
+    without anybody noticing)."""
     import torch
     if world == 1:
         return piece.unsqueeze(0)
     if rank == 0 and gathered is None:
         gathered = torch.empty((world,) + tuple(piece.shape), dtype=piece.dtype, device=piece.device)
-    global _GATHER_OK
-    if _GATHER_OK:
-        try:
-            dist.gather(piece, list(gathered.unbind(0)) if rank == 0 else None, dst=0)
-            return gathered if rank == 0 else None
-        except (RuntimeError, NotImplementedError):
-            _GATHER_OK = False   # backend without gather: fall through to all_gather (same on every rank)
-    everyone = gathered if rank == 0 else torch.empty((world,) + tuple(piece.shape), dtype=piece.dtype, device=piece.device)
-    dist.all_gather_into_tensor(everyone.view(-1), piece.contiguous().view(-1))
-    return everyone if rank == 0 else None
+    dist.gather(piece, list(gathered.unbind(0)) if rank == 0 else None, dst=0)
+    return gathered if rank == 0 else None

@@ -41,8 +41,17 @@ enum {
     JPT_ACCUM_HDR_F32 = 1    /* pure float sum of radiance */
 };
 
-/* texture sampler (state lives in absent gdcs; parity unpinned) */
-enum { JPT_SAMPLER_NEAREST_CLAMP = 0 };
+/* Sampler of texture(textureArray, vec3(uv, layer)) (main.glsl:213-214).  The reference sets the sampler state inside
+ * the absent gdcs (format set up at path_tracing_camera.cpp:178-184), so it is a parameter here;
+ * bit 0 = repeat instead of clamp-to-edge, bit 1 = linear instead of nearest.  What each mode computes is pinned in
+ * oracle/oracle_trace.c::sample_texture (Vulkan texel addressing, UNORM8 texels, no sRGB decode, no mipmaps:
+ * geometry_group3d.cpp:294-300). */
+enum {
+    JPT_SAMPLER_NEAREST_CLAMP = 0,   /* default: Godot's RDSamplerState defaults */
+    JPT_SAMPLER_NEAREST_REPEAT = 1,
+    JPT_SAMPLER_LINEAR_CLAMP = 2,
+    JPT_SAMPLER_LINEAR_REPEAT = 3
+};
 
 /* post-processing after the path-tracing pass: PathTracingCamera::Denoising (path_tracing_camera.h:30-34,
  * the switch at path_tracing_camera.cpp:207-225) */
@@ -187,8 +196,7 @@ int jpt_set_params(jpt_ctx *ctx, int32_t width, int32_t height, int32_t max_boun
  *   WAVEFRONT          queue-based path tracer over the flattened 64-byte-node layout (default, fast);
  *   REFERENCE_LAYOUT   one thread per pixel straight over the six reference-layout buffers, node for node
  *                      as main.glsl:270-350 (audit route). */
-enum { JPT_KERNEL_WAVEFRONT = 0, JPT_KERNEL_REFERENCE_LAYOUT = 1,
-       JPT_KERNEL_WAVEFRONT_V1 = 2 /* earlier wavefront pipeline without lane refill, kept for A/B timing */ };
+enum { JPT_KERNEL_WAVEFRONT = 0, JPT_KERNEL_REFERENCE_LAYOUT = 1 };
 int jpt_set_kernel(jpt_ctx *ctx, int32_t variant);
 
 /* Per-launch timing of the traversal kernels (HIP events recorded around each launch on the context's stream;

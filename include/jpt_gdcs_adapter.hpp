@@ -1,45 +1,56 @@
-// jpt_gdcs_adapter.hpp -- a `ComputeShader`-shaped adapter over the C ABI, so that PathTracingCamera and
-// ProgressiveRendering of the reference compile UNCHANGED against it.
+// jpt_gdcs_adapter.hpp -- a `ComputeShader`-shaped adapter over the C ABI, so that PathTracingCamera,
+// ProgressiveRendering and TemporalReprojection of the reference compile against it with their call sites AS WRITTEN
+// (SURVEY.md 8(f)-2).
 //
 // The reference drives its GPU work through `gdcs::ComputeShader` (submodule src/gdcs, absent).  Its contract is
-// recoverable from the call sites:
+// recoverable from the call sites; every method below has the parameter list of the call it serves:
 //
 //   ComputeShader(res_path, RenderingDevice*, std::vector<String> defines = {})   path_tracing_camera.cpp:139, progressive_rendering.cpp:25
 //   RID  create_storage_buffer_uniform(PackedByteArray, binding, set)            path_tracing_camera.cpp:142-143,170-175
-//   Ref<RDTextureFormat> create_texture_format(w, h, DataFormat)                 :148,163,182
-//   RID  create_image_uniform(Ref<Image>, format, Ref<RDTextureView>, binding, set)          :158,165
-//   RID  create_layered_image_uniform(std::vector<Ref<Image>>, format, view, binding, set)   :183
-//   void add_existing_buffer(RID, UniformType, binding, set)                     progressive_rendering.cpp:30
+//   Ref<RDTextureFormat> create_texture_format(w, h, RenderingDevice::DataFormat)  :148,163,182; progressive_rendering.cpp:35
+//   RID  create_image_uniform(Ref<Image>, Ref<RDTextureFormat>, Ref<RDTextureView>, binding, set)          :158,165
+//   RID  create_layered_image_uniform(std::vector<Ref<Image>>, format, view, binding, set)                 :183
+//   void add_existing_buffer(RID, RenderingDevice::UniformType, binding, set)    progressive_rendering.cpp:30
 //   void finish_create_uniforms()                                                :186
 //   bool check_ready()                                                           :195
 //   void update_storage_buffer_uniform(RID, PackedByteArray)                     :200
 //   void compute({gx, gy, gz})                                                   :204
 //   PackedByteArray get_image_uniform_buffer(RID)                                :229
 //
-// The adapter is a template over a small traits struct so it needs no Godot header: with godot-cpp the traits
-// map to godot::PackedByteArray / godot::RID / godot::String; the repository's test
-// (tests/cpp/gdcs_adapter_test.cpp) instantiates it with std:: types.  Descriptor roles are taken from the
-// shader's layout (main.glsl:98-155, progressive_rendering.glsl:5-16):
+// The adapter is a template over a traits struct so it needs no Godot header: with godot-cpp the traits map to
+// godot::PackedByteArray / RID / String / Ref<Image> / Ref<RDTextureFormat> / Ref<RDTextureView> / RenderingDevice
+// (INTEGRATION.md section 4); the repository's test (tests/cpp/gdcs_adapter_test.cpp) instantiates it with small
+// stand-ins of those types and replays the reference's init()/render() bodies call for call.  Descriptor roles are
+// taken from the shaders' layouts (main.glsl:98-155, progressive_rendering.glsl:5-16):
 //   main.glsl          set 0: b0 rgba8 out, b1 r32f depth, b2 Params, b3 Camera;  set 1: b0..b5 scene buffers;
 //                      set 2: b0 texture array
 //   progressive.glsl   set 0: b0 Params{w,h,frame_count}, b1 screen image (shared), b2 rgba32f frame buffer
 //   temporal_reprojection.glsl  set 0: b0 RenderParameters (88 B), b1 screen image (shared), b2 depth image (shared),
 //                      b3 / b4 the two rgba32f history images (temporal_reprojection.cpp:32-49)
+//
+// All ComputeShaders created on one RenderingDevice share one jpt context (the reference creates the three of them on
+// the camera's local RenderingDevice, path_tracing_camera.cpp:114,139,211,218): the context hangs off the device
+// pointer in a registry kept by this header and is destroyed with the last ComputeShader that uses it.
+//
+// Two optional `defines` strings are understood (anything else is ignored, like the reference's "#define TESTe"):
+//   "#define JPT_MAX_BOUNCES n"   path length (default 4 = the literal 5 of main.glsl:377)
+//   "#define JPT_SAMPLER n"       JPT_SAMPLER_* of jpt.h for texture(textureArray, ...) (default NEAREST_CLAMP)
 #pragma once
 
 #include <jpt.h>
 
 #include <array>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
+#include <map>
 #include <memory>
 #include <string>
 #include <vector>
 
 namespace jpt_gdcs {
 
-// One jpt context shared by the main pass and the progressive pass that add_existing_buffer()s its image
-// (both ComputeShaders are created on the same RenderingDevice in the reference, path_tracing_camera.cpp:114,211).
+// One jpt context shared by the main pass and the post-processing passes that add_existing_buffer() its images.
 struct SharedDevice {
     jpt_ctx* ctx = nullptr;
     int width = 0, height = 0;
@@ -50,46 +61,80 @@ struct SharedDevice {
     ~SharedDevice() { jpt_destroy(ctx); }
 };
 
+// device pointer -> context; weak, so the context goes with the last ComputeShader on that device
+inline std::shared_ptr<SharedDevice> shared_device_of(const void* rendering_device)
+{
+    static std::map<const void*, std::weak_ptr<SharedDevice>> registry;
+    std::shared_ptr<SharedDevice> d = registry[rendering_device].lock();
+    if (!d) {
+        d = std::make_shared<SharedDevice>();
+        registry[rendering_device] = d;
+    }
+    return d;
+}
+
 template <class Traits>
 class ComputeShader {
   public:
-    using Bytes = typename Traits::Bytes;    // PackedByteArray-like: size(), ptr(), resize(), ptrw()
-    using RID = typename Traits::RID;        // integer-like handle
+    using Bytes = typename Traits::Bytes;                  // PackedByteArray
+    using RID = typename Traits::RID;
     using String = typename Traits::String;
+    using Device = typename Traits::Device;                // RenderingDevice
+    using ImageRef = typename Traits::ImageRef;            // Ref<Image>
+    using TextureFormatRef = typename Traits::TextureFormatRef;  // Ref<RDTextureFormat>
+    using TextureViewRef = typename Traits::TextureViewRef;      // Ref<RDTextureView>
+    using DataFormat = typename Traits::DataFormat;        // RenderingDevice::DataFormat
+    using UniformType = typename Traits::UniformType;      // RenderingDevice::UniformType
 
-    ComputeShader(const String& res_path, std::shared_ptr<SharedDevice> device, const std::vector<String>& /*defines*/ = {})
-        : dev_(std::move(device)),
+    ComputeShader(const String& res_path, Device* rd, const std::vector<String>& defines = {})
+        : dev_(shared_device_of(rd)),
           progressive_(Traits::contains(res_path, "progressive_rendering")),
           temporal_(Traits::contains(res_path, "temporal_reprojection"))
     {
+        for (const String& d : defines) {
+            const std::string s = Traits::to_std(d);
+            read_define(s, "JPT_MAX_BOUNCES", max_bounces_);
+            read_define(s, "JPT_SAMPLER", sampler_);
+        }
         if (!dev_->ctx && jpt_create(0, &dev_->ctx) != JPT_OK) error_ = jpt_last_error(nullptr);
     }
 
     RID create_storage_buffer_uniform(const Bytes& data, int binding, int set)
     {
-        const RID id = next_rid_++;
+        const uint64_t id = next_id_++;
         Slot s{set, binding, std::vector<uint8_t>(Traits::ptr(data), Traits::ptr(data) + Traits::size(data))};
         slots_.emplace_back(id, std::move(s));
-        return id;
+        return Traits::make_rid(id);
     }
-    // images: only their size matters here (the library owns the device images)
-    RID create_image_uniform(int width, int height, int binding, int set)
+    TextureFormatRef create_texture_format(int width, int height, DataFormat format)
     {
-        if (!progressive_ && set == 0 && binding == 0) {
-            dev_->width = width;
-            dev_->height = height;
+        return Traits::make_texture_format(width, height, format);
+    }
+    // images: the library owns the device images; what matters is the size of main.glsl's output image
+    RID create_image_uniform(const ImageRef& image, const TextureFormatRef& format, const TextureViewRef& /*view*/, int binding, int set)
+    {
+        if (!progressive_ && !temporal_ && set == 0 && binding == 0) {
+            dev_->width = Traits::format_width(format);
+            dev_->height = Traits::format_height(format);
+            if (Traits::image_width(image) != dev_->width || Traits::image_height(image) != dev_->height)
+                error_ = "output image and its texture format differ in size";
         }
-        return next_rid_++;
+        return Traits::make_rid(next_id_++);
     }
-    RID create_layered_image_uniform(const std::vector<Bytes>& layers, int resolution, int /*binding*/, int /*set*/)
+    RID create_layered_image_uniform(const std::vector<ImageRef>& layers, const TextureFormatRef& format, const TextureViewRef& /*view*/,
+                                     int /*binding*/, int /*set*/)
     {
-        tex_res_ = resolution;
+        tex_res_ = Traits::format_width(format);
         tex_layers_ = (int)layers.size();
         tex_.clear();
-        for (const Bytes& l : layers) tex_.insert(tex_.end(), Traits::ptr(l), Traits::ptr(l) + Traits::size(l));
-        return next_rid_++;
+        for (const ImageRef& l : layers) {
+            const Bytes b = Traits::image_data(l);
+            if ((int)Traits::size(b) != tex_res_ * tex_res_ * 4) error_ = "texture layer is not res x res RGBA8";
+            tex_.insert(tex_.end(), Traits::ptr(b), Traits::ptr(b) + Traits::size(b));
+        }
+        return Traits::make_rid(next_id_++);
     }
-    void add_existing_buffer(RID, int /*uniform_type*/, int /*binding*/, int /*set*/) {}
+    void add_existing_buffer(const RID&, UniformType, int /*binding*/, int /*set*/) {}
 
     void finish_create_uniforms()
     {
@@ -114,9 +159,7 @@ class ComputeShader {
                                                    (uint32_t)(b[4]->bytes.size() / 176), b[5]->bytes.data(),
                                                    (uint32_t)(b[5]->bytes.size() / 32), tex_.empty() ? nullptr : tex_.data(),
                                                    tex_res_, tex_layers_);
-        if (rc == JPT_OK)
-            rc = jpt_set_params(dev_->ctx, dev_->width, dev_->height, 4 /* the literal 5 of main.glsl:377 */, JPT_ACCUM_REF_LDR8,
-                                JPT_SAMPLER_NEAREST_CLAMP);
+        if (rc == JPT_OK) rc = jpt_set_params(dev_->ctx, dev_->width, dev_->height, max_bounces_, JPT_ACCUM_REF_LDR8, sampler_);
         if (rc != JPT_OK) {
             error_ = jpt_last_error(dev_->ctx);
             return;
@@ -129,11 +172,13 @@ class ComputeShader {
 
     bool check_ready() const { return ready_; }
     const std::string& last_error() const { return error_; }
+    jpt_ctx* context() const { return dev_->ctx; }   // for callers that want the float sums (jpt_read_accum_f32) as well
 
-    void update_storage_buffer_uniform(RID rid, const Bytes& data)
+    void update_storage_buffer_uniform(const RID& rid, const Bytes& data)
     {
+        const uint64_t id = Traits::rid_id(rid);
         for (auto& kv : slots_)
-            if (kv.first == rid) {
+            if (kv.first == id) {
                 kv.second.bytes.assign(Traits::ptr(data), Traits::ptr(data) + Traits::size(data));
                 if (!progressive_ && !temporal_ && kv.second.set == 0 && kv.second.binding == 3) upload_camera(kv.second.bytes);
                 if (progressive_ && kv.second.set == 0 && kv.second.binding == 0 && kv.second.bytes.size() >= 12) {
@@ -174,7 +219,7 @@ class ComputeShader {
         dev_->frame_pending = false;
     }
     // denoising_mode == NONE: no progressive pass follows; the caller reads the image right after compute()
-    Bytes get_image_uniform_buffer(RID)
+    Bytes get_image_uniform_buffer(const RID&)
     {
         Bytes out;
         Traits::resize(out, (size_t)dev_->width * dev_->height * 4);
@@ -193,6 +238,15 @@ class ComputeShader {
         int set, binding;
         std::vector<uint8_t> bytes;
     };
+    static void read_define(const std::string& s, const char* name, int& value)
+    {
+        const size_t at = s.find(name);
+        if (at == std::string::npos) return;
+        const char* p = s.c_str() + at + std::strlen(name);
+        char* end = nullptr;
+        const long v = std::strtol(p, &end, 10);
+        if (end != p) value = (int)v;
+    }
     void upload_camera(const std::vector<uint8_t>& bytes)
     {
         if (bytes.size() < 160 || !dev_->params_ready) return;
@@ -202,10 +256,11 @@ class ComputeShader {
     std::shared_ptr<SharedDevice> dev_;
     bool progressive_, temporal_;
     bool ready_ = false;
-    std::vector<std::pair<RID, Slot>> slots_;
+    int max_bounces_ = 4, sampler_ = 0;
+    std::vector<std::pair<uint64_t, Slot>> slots_;
     std::vector<uint8_t> tex_;
     int tex_res_ = 0, tex_layers_ = 0;
-    RID next_rid_ = 1;
+    uint64_t next_id_ = 1;
     std::string error_;
 };
 

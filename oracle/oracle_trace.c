@@ -272,17 +272,52 @@ static v3 sample_sky(v3 direction)
     return v3_make(p_mix(0.95f, 0.9f, t) * 1.0f, p_mix(0.95f, 0.94f, t) * 1.0f, p_mix(0.95f, 1.0f, t) * 1.0f);
 }
 
-/* texture(textureArray, vec3(uv, layer)) (M:214): pinned nearest + clamp-to-edge */
+/* texture(textureArray, vec3(uv, layer)) (M:214).  The sampler state lives in the absent gdcs, so the mode is a
+ * parameter (sampler_mode: bit 0 = repeat instead of clamp-to-edge, bit 1 = linear instead of nearest); what each
+ * mode computes is pinned here after the Vulkan texel-addressing rules:
+ *   unnormalised coordinate  x = u * res                        (one float multiply)
+ *   nearest                  i = floor(x)
+ *   linear                   i0 = floor(x - 0.5), i1 = i0 + 1, weight a = (x - 0.5) - floor(x - 0.5)
+ *   clamp-to-edge            i = clamp(i, 0, res - 1);     repeat   i = i mod res (non-negative remainder)
+ *   NaN or |floor| >= 2^30   index 0 (weight 0)
+ *   filter                   mix(mix(t00, t10, a), mix(t01, t11, a), b) per channel, mix = a*(1-t) + b*t (oracle_pins.h);
+ *                            texels are UNORM8 -> float by p_from_unorm8, no sRGB decode (path_tracing_camera.cpp:182) */
+static int32_t tex_index(float f, int32_t res, int repeat)
+{
+    if (f != f || f >= 1073741824.0f || f <= -1073741824.0f) return 0;
+    int32_t i = (int32_t)f;   /* f is integral */
+    if (repeat) {
+        i %= res;
+        return i < 0 ? i + res : i;
+    }
+    return i < 0 ? 0 : (i > res - 1 ? res - 1 : i);
+}
+static v3 texel(const jpto_scene_view *sc, int32_t layer, int32_t ix, int32_t iy)
+{
+    const int32_t res = sc->tex_res;
+    const uint8_t *p = sc->tex_rgba8 + (((size_t)layer * res + iy) * res + ix) * 4;
+    return v3_make(p_from_unorm8(p[0]), p_from_unorm8(p[1]), p_from_unorm8(p[2]));
+}
 static v3 sample_texture(const jpto_scene_view *sc, float u, float v, int32_t layer)
 {
     if (!sc->tex_rgba8 || sc->n_layers <= 0 || sc->tex_res <= 0) return v3_make(0.0f, 0.0f, 0.0f);
     if (layer >= sc->n_layers) layer = sc->n_layers - 1;
-    int32_t res = sc->tex_res;
-    float fx = floorf(u * (float)res), fy = floorf(v * (float)res);
-    int32_t ix = (fx < 0.0f || fx != fx) ? 0 : (fx > (float)(res - 1) ? res - 1 : (int32_t)fx);
-    int32_t iy = (fy < 0.0f || fy != fy) ? 0 : (fy > (float)(res - 1) ? res - 1 : (int32_t)fy);
-    const uint8_t *p = sc->tex_rgba8 + (((size_t)layer * res + iy) * res + ix) * 4;
-    return v3_make(p_from_unorm8(p[0]), p_from_unorm8(p[1]), p_from_unorm8(p[2]));
+    const int32_t res = sc->tex_res;
+    const int repeat = sc->sampler_mode & 1, linear = (sc->sampler_mode >> 1) & 1;
+    const float x = u * (float)res, y = v * (float)res;
+    if (!linear) return texel(sc, layer, tex_index(floorf(x), res, repeat), tex_index(floorf(y), res, repeat));
+    const float xs = x - 0.5f, ys = y - 0.5f;
+    const float fx = floorf(xs), fy = floorf(ys);
+    float a = xs - fx, b = ys - fy;
+    if (a != a) a = 0.0f;
+    if (b != b) b = 0.0f;
+    const int32_t x0 = tex_index(fx, res, repeat), x1 = tex_index(fx + 1.0f, res, repeat);
+    const int32_t y0 = tex_index(fy, res, repeat), y1 = tex_index(fy + 1.0f, res, repeat);
+    const v3 t00 = texel(sc, layer, x0, y0), t10 = texel(sc, layer, x1, y0);
+    const v3 t01 = texel(sc, layer, x0, y1), t11 = texel(sc, layer, x1, y1);
+    const v3 r0 = v3_make(p_mix(t00.x, t10.x, a), p_mix(t00.y, t10.y, a), p_mix(t00.z, t10.z, a));
+    const v3 r1 = v3_make(p_mix(t01.x, t11.x, a), p_mix(t01.y, t11.y, a), p_mix(t01.z, t11.z, a));
+    return v3_make(p_mix(r0.x, r1.x, b), p_mix(r0.y, r1.y, b), p_mix(r0.z, r1.z, b));
 }
 
 /* M:194-222 */
@@ -292,10 +327,12 @@ static void get_shading_data(ctx_t *cx, const hit_t *h, shading_t *s)
     cx->cnt.shaded_hits++;
     const jpto_tri_data *tri = &sc->tri_data[h->triangle];
     const jpto_blas_instance *b = &sc->instances[h->blas];
-    /* b.materials[tri.materialIndex] has no bounds check in the reference (M:198);
-     * indices past 2 read the words that follow in the 176-B record. */
+    /* b.materials[tri.materialIndex] has no bounds check in the reference (M:198): indices past 2 read the words
+     * that follow in the blas_instances buffer (the next instance's transform).  Pinned: a read past the END of
+     * that buffer returns 0, the robust-buffer-access rule of Vulkan storage buffers. */
     uint32_t mslot = tri->material_index;
-    uint32_t mat_id = (mslot < 3) ? b->material[mslot] : ((const uint32_t *)(b + 1))[mslot - 3];
+    uint64_t word = (uint64_t)h->blas * 44u + 41u + (uint64_t)mslot;   /* 176 B = 44 words; material[] starts at word 41 */
+    uint32_t mat_id = word < (uint64_t)sc->n_inst * 44u ? ((const uint32_t *)sc->instances)[word] : 0u;
     if (mat_id >= sc->n_mat) mat_id = 0;
     const jpto_material *material = &sc->materials[mat_id];
 

@@ -10,7 +10,7 @@ from gdpathtracing_amd import capi, host, scenes, wire
 
 pytestmark = pytest.mark.gpu
 
-KERNELS = [capi.KERNEL_WAVEFRONT, capi.KERNEL_REFERENCE_LAYOUT, capi.KERNEL_WAVEFRONT_V1]
+KERNELS = [capi.KERNEL_WAVEFRONT, capi.KERNEL_REFERENCE_LAYOUT]
 
 
 def _cam_with_index(sc, w, h, frame_index):

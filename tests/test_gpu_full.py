@@ -11,7 +11,7 @@ from gdpathtracing_amd import capi, host, partition, scenes, wire
 
 pytestmark = pytest.mark.gpu
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-KERNELS = [capi.KERNEL_WAVEFRONT, capi.KERNEL_REFERENCE_LAYOUT, capi.KERNEL_WAVEFRONT_V1]
+KERNELS = [capi.KERNEL_WAVEFRONT, capi.KERNEL_REFERENCE_LAYOUT]
 
 
 def rel_l2(a, b):

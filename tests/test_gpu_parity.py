@@ -30,7 +30,7 @@ def _render_hip(sc, cam, w, h, bounces, frames, mode, builder=None, ref=None, fi
         ctx.close()
 
 
-KERNELS = [capi.KERNEL_WAVEFRONT, capi.KERNEL_REFERENCE_LAYOUT, capi.KERNEL_WAVEFRONT_V1]
+KERNELS = [capi.KERNEL_WAVEFRONT, capi.KERNEL_REFERENCE_LAYOUT]
 
 
 @pytest.mark.parametrize("kernel", KERNELS)
