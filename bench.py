@@ -62,7 +62,7 @@ def main():
     ap.add_argument("--bounces", type=int, default=4)
     ap.add_argument("--tris", type=int, default=51200)
     ap.add_argument("--scene", default="demo", choices=["demo", "cornell", "inst"])
-    ap.add_argument("--builder", default="sah", choices=["sah", "exact"])
+    ap.add_argument("--builder", default="sah", choices=["sah", "exact", "watertight"])
     ap.add_argument("--accum", default="ldr8", choices=["ldr8", "hdr"])
     ap.add_argument("--kernel", default="wavefront", choices=["wavefront", "ref"])
     ap.add_argument("--camera", default="demo", choices=["demo", "closeup"],
@@ -120,7 +120,7 @@ def main():
 
     ctx = host.Context(local_rank)
     t0 = time.time()
-    ctx.build_scene(sc, capi.BUILD_SAH if args.builder == "sah" else capi.BUILD_REFERENCE_EXACT)
+    ctx.build_scene(sc, {"sah": capi.BUILD_SAH, "exact": capi.BUILD_REFERENCE_EXACT, "watertight": capi.BUILD_SAH_WATERTIGHT}[args.builder])
     build_s = time.time() - t0
     ctx.set_partition(rank, world)
     ctx.set_params(W, H, bounces, accum_mode)
@@ -216,7 +216,7 @@ def main():
     if args.verify and rank == 0:
         got = ctx.read_ldr() if (world > 1 and args.gather == "ldr") else ctx.read_accum()
         solo = host.Context(local_rank)
-        solo.build_scene(sc, capi.BUILD_SAH if args.builder == "sah" else capi.BUILD_REFERENCE_EXACT)
+        solo.build_scene(sc, {"sah": capi.BUILD_SAH, "exact": capi.BUILD_REFERENCE_EXACT, "watertight": capi.BUILD_SAH_WATERTIGHT}[args.builder])
         solo.set_params(W, H, bounces, accum_mode)
         solo.set_camera(cam)
         solo.render(spp, 1)
@@ -244,7 +244,7 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         mrays = rays * args.steps / elapsed / 1e6
         # roofline of the dominant kernel (this rank's share of the events ~ total / world)
-        table = WIDE4_BYTES if (args.builder == "sah" and args.kernel == "wavefront") else WIDE_BYTES
+        table = WIDE4_BYTES if (args.builder != "exact" and args.kernel == "wavefront") else WIDE_BYTES
         alg = algorithmic_bytes(total, table) / world / n_trace_launches               # per launch
         alg_ref = (algorithmic_bytes(total, REF_BYTES) + n_pixels * spp * 48) / world / n_trace_launches
         achieved = alg / (kernel_ms * 1e-3) / 1e9

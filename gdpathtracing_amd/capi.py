@@ -15,8 +15,9 @@ CSRC = os.path.join(_HERE, "csrc")
 
 OK = 0
 ACCUM_REF_LDR8, ACCUM_HDR_F32 = 0, 1
-BUILD_REFERENCE_EXACT, BUILD_SAH = 0, 1
+BUILD_REFERENCE_EXACT, BUILD_SAH, BUILD_SAH_WATERTIGHT = 0, 1, 2
 KERNEL_WAVEFRONT, KERNEL_REFERENCE_LAYOUT = 0, 1
+SAMPLER_NEAREST_CLAMP, SAMPLER_NEAREST_REPEAT, SAMPLER_LINEAR_CLAMP, SAMPLER_LINEAR_REPEAT = 0, 1, 2, 3
 DENOISE_PROGRESSIVE, DENOISE_TEMPORAL, DENOISE_NONE = 0, 1, 2
 BUF_TRI_GEOMETRY, BUF_TRI_DATA, BUF_MATERIALS, BUF_BVH_NODES, BUF_INSTANCES, BUF_TLAS_NODES, BUF_TRIANGLES = range(7)
 

@@ -22,6 +22,9 @@ void RefScene::clear()
     instances.clear();
     tlas_nodes.clear();
     mesh_roots.clear();
+    reach_tri.clear();
+    reach_inst.clear();
+    mesh_ref_root.clear();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -163,6 +166,33 @@ struct ExactBlasBuilder {
         return self;
     }
 };
+
+// The reference's builder on a copy of one mesh: by_original[i] = box of the reference leaf that ends up holding
+// triangle i of the mesh (`always` when that leaf is the root), root = the reference root's box.
+void reference_leaf_boxes(const std::vector<RefTriangle>& mesh_tris, std::vector<ReachTri>& by_original, ReachInst& root)
+{
+    std::vector<RefTriangle> copy(mesh_tris);
+    for (size_t i = 0; i < copy.size(); i++) copy[i]._pad = (uint32_t)i;  // travels with the triangle through the partition swaps
+    std::vector<RefBvhNode> nodes;
+    nodes.reserve(copy.size());
+    ExactBlasBuilder eb{nodes, copy};
+    (void)eb.build(0, (int)copy.size());
+    by_original.assign(copy.size(), ReachTri{});
+    std::memset(&root, 0, sizeof root);
+    if (nodes.empty()) return;
+    root.root_lo[0] = nodes[0].aabbMin.x; root.root_lo[1] = nodes[0].aabbMin.y; root.root_lo[2] = nodes[0].aabbMin.z;
+    root.root_hi[0] = nodes[0].aabbMax.x; root.root_hi[1] = nodes[0].aabbMax.y; root.root_hi[2] = nodes[0].aabbMax.z;
+    for (size_t ni = 0; ni < nodes.size(); ni++) {
+        const RefBvhNode& n = nodes[ni];
+        if (n.tri_count == 0) continue;
+        ReachTri r;
+        r.lo[0] = n.aabbMin.x; r.lo[1] = n.aabbMin.y; r.lo[2] = n.aabbMin.z;
+        r.hi[0] = n.aabbMax.x; r.hi[1] = n.aabbMax.y; r.hi[2] = n.aabbMax.z;
+        r.always = ni == 0 ? 1u : 0u;
+        r._pad = 0;
+        for (uint32_t k = 0; k < n.tri_count; k++) by_original[copy[n.first_tri_index + k]._pad] = r;
+    }
+}
 
 // ---- native binned-SAH BLAS build -----------------------------------------------------------------
 
@@ -617,6 +647,20 @@ bool SceneBuilder::set_instance_transform(uint32_t instance, const float* transf
     return true;
 }
 
+// the world box BLASInstance::update_aabb (bvh.h:90-115) gives an instance whose BLAS root has the reference's box
+ReachInst reach_instance(const float* t12, const ReachInst& mesh_root)
+{
+    ReachInst r = mesh_root;
+    RefInstance tmp;
+    std::memset(&tmp, 0, sizeof tmp);
+    const Vec4 lo{mesh_root.root_lo[0], mesh_root.root_lo[1], mesh_root.root_lo[2], 1.0f};
+    const Vec4 hi{mesh_root.root_hi[0], mesh_root.root_hi[1], mesh_root.root_hi[2], 1.0f};
+    instance_record(t12, lo, hi, /*pad_box*/ false, tmp);
+    r.lo[0] = tmp.aabbMin.x; r.lo[1] = tmp.aabbMin.y; r.lo[2] = tmp.aabbMin.z;
+    r.hi[0] = tmp.aabbMax.x; r.hi[1] = tmp.aabbMax.y; r.hi[2] = tmp.aabbMax.z;
+    return r;
+}
+
 // instances (geometry_group3d.cpp:322-341) and TLAS::build (bvh.cpp:264-317) over the BLASes already in `out`
 bool SceneBuilder::rebuild_instances(BuildMode mode, RefScene& out, std::string& err)
 {
@@ -632,10 +676,13 @@ bool SceneBuilder::rebuild_instances(BuildMode mode, RefScene& out, std::string&
         inst.blas_index = out.mesh_roots[pi.mesh];
         for (int k = 0; k < 3; k++) inst.material[k] = pi.mats[k];
         const RefBvhNode& root = out.bvh_nodes[inst.blas_index];
-        instance_record(pi.t12, root.aabbMin, root.aabbMax, mode == BuildMode::Sah, inst);  // jpt_instance_math.h
+        instance_record(pi.t12, root.aabbMin, root.aabbMax, is_native(mode), inst);  // jpt_instance_math.h
         out.instances.push_back(inst);
     }
-    if (mode == BuildMode::Sah ? !build_tlas_sah(out.instances, out.tlas_nodes, err) : !build_tlas(out.instances, out.tlas_nodes, err))
+    out.reach_inst.clear();
+    if (mode == BuildMode::Sah && out.mesh_ref_root.size() == meshes_.size())
+        for (const PendingInstance& pi : instances_) out.reach_inst.push_back(reach_instance(pi.t12, out.mesh_ref_root[pi.mesh]));
+    if (is_native(mode) ? !build_tlas_sah(out.instances, out.tlas_nodes, err) : !build_tlas(out.instances, out.tlas_nodes, err))
         return false;
     return true;
 }
@@ -654,12 +701,30 @@ bool SceneBuilder::commit(BuildMode mode, RefScene& out, std::string& err)
                 ExactBlasBuilder b{out.bvh_nodes, out.triangles};
                 root = b.build(start, end);
             } else {
+                // reach records: the reference's own builder runs on a copy of the mesh (beside the native build), only
+                // to learn which leaf box holds which triangle and what the root box is
+                std::vector<ReachTri> by_original;
+                ReachInst ref_root;
+                std::future<void> reach;
+                if (mode == BuildMode::Sah)
+                    reach = std::async(std::launch::async, [&] { reference_leaf_boxes(pm.tris, by_original, ref_root); });
                 SahBlasBuilder b{out.bvh_nodes, out.triangles};
                 b.prepare(start, end);
                 root = b.build(0, end - start);
                 b.apply_order(start, end);
+                if (mode == BuildMode::Sah) {
+                    reach.get();
+                    out.reach_tri.resize((size_t)end);
+                    for (int i = 0; i < end - start; i++) out.reach_tri[(size_t)(start + i)] = by_original[b.order[(size_t)i]];
+                    out.mesh_ref_root.resize(out.mesh_roots.size() + 1);
+                    out.mesh_ref_root.back() = ref_root;
+                }
             }
         } else {
+            if (mode == BuildMode::Sah) {
+                out.mesh_ref_root.resize(out.mesh_roots.size() + 1);
+                std::memset(&out.mesh_ref_root.back(), 0, sizeof(ReachInst));
+            }
             // BuildBVH on an empty mesh returns 0 (bvh.cpp:111-112); keep a valid empty leaf instead
             root = (uint32_t)out.bvh_nodes.size();
             RefBvhNode n;

@@ -38,6 +38,11 @@ struct RefScene {
     std::vector<uint8_t> textures;
     int32_t tex_res = 0, n_layers = 0;
     std::vector<uint32_t> mesh_roots;         // BuildBVH return values, one per unique mesh
+    // reach records (jpt_types.h; BuildMode::Sah only, else empty): per triangle the box of its reference leaf, per
+    // mesh the box of the reference root, per instance the world box the reference computes from it
+    std::vector<ReachTri> reach_tri;
+    std::vector<ReachInst> reach_inst;
+    std::vector<ReachInst> mesh_ref_root;     // root_lo / root_hi filled; one per unique mesh
     void clear();
 };
 
@@ -58,7 +63,12 @@ struct WideScene {
     uint32_t stack_need2 = 0, stack_need4 = 0;
 };
 
-enum class BuildMode { ReferenceExact = 0, Sah = 1 };
+enum class BuildMode {
+    ReferenceExact = 0,
+    Sah = 1,            // native tree + reach records (one extra run of the reference's builder per mesh)
+    SahWatertight = 2   // native tree alone: every Moller-Trumbore hit is found, the reference's cracks are not reproduced
+};
+inline bool is_native(BuildMode m) { return m != BuildMode::ReferenceExact; }
 
 class SceneBuilder {
   public:
@@ -84,6 +94,9 @@ class SceneBuilder {
 };
 
 // (godot Transform3D::affine_inverse restated in float: affine_inverse12 in jpt_instance_math.h)
+
+// reach record of one instance: mesh_root (root_lo / root_hi) + the world box the reference computes for this transform
+ReachInst reach_instance(const float* transform12, const ReachInst& mesh_root);
 
 // Bottom-up schedule of the four-child TLAS records for a refit on the device (jpt_kernels_post.hip): `order` lists the
 // records of w.tlas_nodes4 deepest level first, level l is order[level_start[l] .. level_start[l + 1]).

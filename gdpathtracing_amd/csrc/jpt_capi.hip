@@ -91,6 +91,9 @@ struct jpt_ctx {
     DevBuf<WideTri> d_wtris;
     DevBuf<WideInstance> d_winst, d_winst4;
     DevBuf<WideNode4> d_nodes4;   // four-child records: BLAS part, then room for the TLAS part (one index space)
+    DevBuf<ReachTri> d_reach_tri;   // reach records (JPT_BUILD_SAH): per triangle / per instance (one per copy of the instance level)
+    DevBuf<ReachInst> d_reach_inst;
+    BuildMode build_mode = BuildMode::ReferenceExact;
     DeviceScene ds;
 
     // per-render state
@@ -145,6 +148,7 @@ struct jpt_ctx {
     static constexpr int kInstanceSets = 4;   // as many as renders in flight: a queue of animation steps stays pipelined
     DevBuf<RefInstance> d_instances_more[kInstanceSets - 1];
     DevBuf<WideInstance> d_winst4_more[kInstanceSets - 1];
+    DevBuf<ReachInst> d_reach_inst_more[kInstanceSets - 1];
     size_t tlas4_cap = 0;              // records reserved per TLAS tail
     int cur_set = 0;                   // which copy new renders read
     bool set_b_ready = false;          // copies 1.. exist and mirror the last host upload
@@ -310,12 +314,18 @@ int upload_scene(jpt_ctx* c)
     HIP_TRY(c, c->d_wtris.upload(c->wide.tris, s));
     HIP_TRY(c, c->d_winst.upload(c->wide.instances, s));
     HIP_TRY(c, c->d_winst4.upload(c->wide.instances4, s));
+    HIP_TRY(c, c->d_reach_tri.upload(c->ref.reach_tri, s));
+    HIP_TRY(c, c->d_reach_inst.upload(c->ref.reach_inst, s));
     HIP_TRY(c, hipStreamSynchronize(s));
     {
         const int rc4 = upload_nodes4(c, false);
         if (rc4 != JPT_OK) return rc4;
     }
     DeviceScene& d = c->ds;
+    const bool reach = !c->ref.reach_tri.empty() && c->ref.reach_tri.size() == c->ref.tri_geom.size() &&
+                       c->ref.reach_inst.size() == c->ref.instances.size();
+    d.reach_tri = reach ? c->d_reach_tri.p : nullptr;
+    d.reach_inst = reach ? c->d_reach_inst.p : nullptr;
     d.ref_tri_geom = c->d_tri_geom.p;
     d.ref_tri_data = c->d_tri_data.p;
     d.ref_materials = c->d_materials.p;
@@ -931,6 +941,10 @@ int jpt_scene_upload_reference_layout(jpt_ctx* c, const void* tri_geometry, uint
     }
     c->ref_is_exact = false;
     c->native_tree = false;  // uploaded trees are walked as given
+    c->build_mode = BuildMode::ReferenceExact;
+    r.reach_tri.clear();
+    r.reach_inst.clear();
+    r.mesh_ref_root.clear();
     int rc = validate_ref_scene(c);
     if (rc != JPT_OK) return rc;
     rc = upload_scene(c);
@@ -1001,18 +1015,20 @@ int jpt_scene_set_textures(jpt_ctx* c, const uint8_t* tex, int32_t tex_res, int3
 int jpt_scene_commit(jpt_ctx* c, int32_t builder)
 {
     if (!c || !c->building) return fail(c, JPT_E_STATE, "jpt_scene_begin not called");
-    if (builder != JPT_BUILD_REFERENCE_EXACT && builder != JPT_BUILD_SAH) return fail(c, JPT_E_INVALID, "unknown builder");
+    if (builder != JPT_BUILD_REFERENCE_EXACT && builder != JPT_BUILD_SAH && builder != JPT_BUILD_SAH_WATERTIGHT)
+        return fail(c, JPT_E_INVALID, "unknown builder");
+    c->build_mode = builder == JPT_BUILD_SAH ? BuildMode::Sah : (builder == JPT_BUILD_SAH_WATERTIGHT ? BuildMode::SahWatertight : BuildMode::ReferenceExact);
     const auto t0 = std::chrono::steady_clock::now();
     c->scene_ready = c->host_scene_ready = false;
     std::string err;
-    if (!c->builder.commit(builder == JPT_BUILD_SAH ? BuildMode::Sah : BuildMode::ReferenceExact, c->ref, err))
+    if (!c->builder.commit(c->build_mode, c->ref, err))
         return fail(c, JPT_E_LIMIT, err);
     c->ref.materials = c->pending_materials;
     c->ref.textures = c->pending_tex;
     c->ref.tex_res = c->pending_tex_res;
     c->ref.n_layers = c->pending_layers;
     c->ref_is_exact = (builder == JPT_BUILD_REFERENCE_EXACT);
-    c->native_tree = (builder == JPT_BUILD_SAH);
+    c->native_tree = is_native(c->build_mode);
     int rc = validate_ref_scene(c);
     if (rc != JPT_OK) return rc;
     rc = upload_scene(c);
@@ -1045,11 +1061,13 @@ int upload_tlas_update(jpt_ctx* c)
     HIP_TRY(c, c->d_wtlas.upload(c->wide.tlas_nodes, s));
     HIP_TRY(c, c->d_winst.upload(c->wide.instances, s));
     HIP_TRY(c, c->d_winst4.upload(c->wide.instances4, s));
+    HIP_TRY(c, c->d_reach_inst.upload(c->ref.reach_inst, s));
     HIP_TRY(c, hipStreamSynchronize(s));
     {
         const int rc4 = upload_nodes4(c, true);
         if (rc4 != JPT_OK) return rc4;
     }
+    if (c->ds.reach_tri) c->ds.reach_inst = c->d_reach_inst.p;
     c->refit_active = false;
     DeviceScene& d = c->ds;
     d.ref_instances = c->d_instances.p;
@@ -1084,7 +1102,7 @@ int jpt_scene_update_tlas(jpt_ctx* c)
     if (!c->tlas_dirty) return JPT_OK;
     const auto t0 = std::chrono::steady_clock::now();
     std::string err;
-    if (!c->builder.rebuild_instances(c->native_tree ? BuildMode::Sah : BuildMode::ReferenceExact, c->ref, err)) {
+    if (!c->builder.rebuild_instances(c->build_mode, c->ref, err)) {
         c->scene_ready = c->host_scene_ready = false;
         return fail(c, JPT_E_LIMIT, err);
     }
@@ -1140,6 +1158,9 @@ int jpt_scene_refit_tlas(jpt_ctx* c, const float* transforms12, uint32_t n_insta
             HIP_TRY(c, c->d_winst4_more[k].resize(c->d_winst4.n));
             HIP_TRY(c, hipMemcpyAsync(c->d_instances_more[k].p, c->d_instances.p, c->d_instances.n * sizeof(RefInstance), hipMemcpyDeviceToDevice, s));
             HIP_TRY(c, hipMemcpyAsync(c->d_winst4_more[k].p, c->d_winst4.p, c->d_winst4.n * sizeof(WideInstance), hipMemcpyDeviceToDevice, s));
+            HIP_TRY(c, c->d_reach_inst_more[k].resize(c->d_reach_inst.n));
+            if (c->d_reach_inst.n)
+                HIP_TRY(c, hipMemcpyAsync(c->d_reach_inst_more[k].p, c->d_reach_inst.p, c->d_reach_inst.n * sizeof(ReachInst), hipMemcpyDeviceToDevice, s));
         }
         HIP_TRY(c, hipStreamSynchronize(s));
         c->set_b_ready = true;
@@ -1156,8 +1177,9 @@ int jpt_scene_refit_tlas(jpt_ctx* c, const float* transforms12, uint32_t n_insta
     RefInstance* inst_next = next ? c->d_instances_more[next - 1].p : c->d_instances.p;
     WideInstance* winst4_next = next ? c->d_winst4_more[next - 1].p : c->d_winst4.p;
     const uint32_t tail_base = (uint32_t)(c->wide.blas_nodes4.size() + (size_t)next * c->tlas4_cap);
+    ReachInst* reach_next = c->ds.reach_tri ? (next ? c->d_reach_inst_more[next - 1].p : c->d_reach_inst.p) : nullptr;
     launch_tlas4_refit(rs, dev_view, n_instances, c->d_bvh.p, inst_next, nullptr, winst4_next, c->d_nodes4.p, tail_base,
-                       c->d_tlas4_order.p, c->d_tlas4_levels.p, c->n_tlas4_levels);
+                       c->d_tlas4_order.p, c->d_tlas4_levels.p, c->n_tlas4_levels, reach_next);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipEventRecord(c->ev_refit_copied[st], rs));
     HIP_TRY(c, hipEventRecord(c->ev_refit_done, rs));
@@ -1168,6 +1190,7 @@ int jpt_scene_refit_tlas(jpt_ctx* c, const float* transforms12, uint32_t n_insta
     c->cur_set = next;
     c->ds.ref_instances = inst_next;
     c->ds.wide_instances4 = winst4_next;
+    if (reach_next) c->ds.reach_inst = reach_next;
     if (c->wide.tlas_root4 >= 0) c->ds.tlas_root4 = c->wide.tlas_root4 + (int32_t)tail_base;
     // The sky cull (compute_sky_cull) projects the boxes the TLAS root offers, on the host.  For a modest number of
     // instances the host repeats the refit on its own copy of the four-child TLAS records (same arithmetic, same

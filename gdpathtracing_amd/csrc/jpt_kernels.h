@@ -58,6 +58,9 @@ struct DeviceScene {
     const WideNode4* nodes4 = nullptr;       // BLAS records followed by the TLAS records, one index space
     const WideInstance* wide_instances4 = nullptr;
     int32_t tlas_root4 = 0;
+    // reach records (jpt_types.h): null unless the scene was committed with JPT_BUILD_SAH
+    const ReachTri* reach_tri = nullptr;
+    const ReachInst* reach_inst = nullptr;
 
     SceneShading shading() const
     {
@@ -69,6 +72,8 @@ struct DeviceScene {
         s.n_materials = n_materials;
         s.n_instances = n_instances;
         s.sampler_mode = sampler_mode;
+        s.reach_tri = reach_tri;
+        s.reach_inst = reach_inst;
         s.tex_res = tex_res;
         s.n_layers = n_layers;
         return s;
@@ -156,7 +161,8 @@ void launch_wf2_render(hipStream_t stream, const DeviceScene& ds, const FramePar
 // reference-layout BLAS nodes (root boxes); order / level_start: tlas4_refit_schedule, on the device.
 void launch_tlas4_refit(hipStream_t stream, const float* transforms12, uint32_t n_instances, const RefBvhNode* bvh,
                         RefInstance* ref_instances, WideInstance* wide_instances, WideInstance* wide_instances4, WideNode4* nodes4,
-                        uint32_t n_blas_records, const uint32_t* order, const uint32_t* level_start, uint32_t n_levels);
+                        uint32_t n_blas_records, const uint32_t* order, const uint32_t* level_start, uint32_t n_levels,
+                        ReachInst* reach_instances /* may be null */);
 
 // one dispatch of temporal_reprojection.glsl over a whole image (jpt_kernels_post.hip): screen rgba8 in/out, depth
 // read-only, hist1 / hist2 the two rgba32f history images

@@ -89,7 +89,7 @@ __global__ __launch_bounds__(256) void temporal_kernel(RefTemporalParams tp, uin
 // traversal records' inverse matrices
 __global__ __launch_bounds__(256) void instance_refit_kernel(const float* __restrict__ t12, uint32_t n, const RefBvhNode* __restrict__ bvh,
                                                              RefInstance* __restrict__ ref_inst, WideInstance* __restrict__ winst,
-                                                             WideInstance* __restrict__ winst4)
+                                                             WideInstance* __restrict__ winst4, ReachInst* __restrict__ reach)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -97,6 +97,15 @@ __global__ __launch_bounds__(256) void instance_refit_kernel(const float* __rest
     float t[12];
     for (int k = 0; k < 12; k++) t[k] = t12[(size_t)i * 12 + k];
     const RefBvhNode root = bvh[inst.blas_index];
+    if (reach) {
+        // the world box the reference computes from ITS root box (reach records, jpt_types.h): same code as the host's
+        ReachInst r = reach[i];
+        RefInstance tmp = inst;
+        instance_record(t, Vec4{r.root_lo[0], r.root_lo[1], r.root_lo[2], 1.0f}, Vec4{r.root_hi[0], r.root_hi[1], r.root_hi[2], 1.0f}, false, tmp);
+        r.lo[0] = tmp.aabbMin.x; r.lo[1] = tmp.aabbMin.y; r.lo[2] = tmp.aabbMin.z;
+        r.hi[0] = tmp.aabbMax.x; r.hi[1] = tmp.aabbMax.y; r.hi[2] = tmp.aabbMax.z;
+        reach[i] = r;
+    }
     instance_record(t, root.aabbMin, root.aabbMax, true, inst);
     ref_inst[i] = inst;
     for (int c = 0; c < 4; c++)
@@ -150,11 +159,11 @@ __global__ __launch_bounds__(1024) void tlas4_refit_kernel(WideNode4* __restrict
 
 void launch_tlas4_refit(hipStream_t stream, const float* transforms12, uint32_t n_instances, const RefBvhNode* bvh,
                         RefInstance* ref_instances, WideInstance* wide_instances, WideInstance* wide_instances4, WideNode4* nodes4,
-                        uint32_t n_blas_records, const uint32_t* order, const uint32_t* level_start, uint32_t n_levels)
+                        uint32_t n_blas_records, const uint32_t* order, const uint32_t* level_start, uint32_t n_levels, ReachInst* reach)
 {
     if (n_instances == 0) return;
     hipLaunchKernelGGL(instance_refit_kernel, dim3((n_instances + 255) / 256), dim3(256), 0, stream, transforms12, n_instances, bvh,
-                       ref_instances, wide_instances, wide_instances4);
+                       ref_instances, wide_instances, wide_instances4, reach);
     if (n_levels)
         hipLaunchKernelGGL(tlas4_refit_kernel, dim3(1), dim3(1024), 0, stream, nodes4, n_blas_records, order, level_start, n_levels,
                            ref_instances);

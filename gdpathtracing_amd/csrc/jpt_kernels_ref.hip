@@ -13,6 +13,10 @@ struct RefSceneDev {
     const RefInstance* __restrict__ instances;
     const RefTlasNode* __restrict__ tlas;
     uint32_t n_instances, n_tlas;
+    // reach records (jpt_types.h), null unless the scene is a native tree committed with JPT_BUILD_SAH: then this kernel
+    // walks the native tree in reference layout and applies the reference's two reachability tests itself
+    const ReachTri* __restrict__ reach_tri;
+    const ReachInst* __restrict__ reach_inst;
 };
 
 struct RefHit {
@@ -58,6 +62,10 @@ __device__ __forceinline__ void intersect_triangle(const RefSceneDev& sc, const 
     if (v < 0.0f || u + v > 1.0f) return;
     const float t = dot3(edge2, qvec) * invDet;
     if (t < 0.0f || t > hit.t) return;
+    if (sc.reach_tri) {
+        const ReachTri& r = sc.reach_tri[tri_index];
+        if (!r.always && !(intersect_aabb(ray, mk3(r.lo[0], r.lo[1], r.lo[2]), mk3(r.hi[0], r.hi[1], r.hi[2])) < 1e30f)) return;
+    }
     hit.t = t;
     hit.tri = tri_index;
     hit.u = u;
@@ -118,6 +126,10 @@ __device__ __forceinline__ bool ray_trace_tlas(const RefSceneDev& sc, const Ray&
         if (lr == 0) {
             if (COUNT) cnt.inst_visits++;
             const uint32_t inst = node.blas;
+            if (sc.reach_inst && sc.n_instances > 1u) {
+                const ReachInst& r = sc.reach_inst[inst];
+                if (!(intersect_aabb(ray, mk3(r.lo[0], r.lo[1], r.lo[2]), mk3(r.hi[0], r.hi[1], r.hi[2])) < 1e30f)) continue;
+            }
             const RefInstance& b = sc.instances[inst];
             Ray b_ray;
             b_ray.o = xform_point(b.inverse_transform, ray.o);
@@ -212,6 +224,8 @@ void launch_ref_frame(hipStream_t stream, const DeviceScene& ds, const FramePara
     sc.tlas = ds.ref_tlas;
     sc.n_instances = ds.n_instances;
     sc.n_tlas = ds.n_ref_tlas;
+    sc.reach_tri = ds.reach_tri;
+    sc.reach_inst = ds.reach_inst;
     const SceneShading sh = ds.shading();
     dim3 grid((fp.width + 31) / 32, (fp.local_rows + 7) / 8), block(256);
     if (counters)

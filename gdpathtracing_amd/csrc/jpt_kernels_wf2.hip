@@ -89,6 +89,8 @@ struct Wf2Buffers {
     float4* rad;        // per path: radiance.xyz,   w = seed.y bits  ([frame][slot]: also the per-frame output)
     float* first_depth; // per slot of the LAST frame: distance of the first hit (or far)
     uint32_t* qcount;   // [max_bounces + 2][kSegments] queue sizes; row b = rays traced in bounce b (b >= 1)
+    uint32_t* redo_count;  // [0]: paths set aside because the reference cannot reach their hit (wf2_finish) ...
+    float4* redo_rec;      // ... two float4 each: the vertex's ray, origin.w = bounce bits, direction.w = path id bits
 };
 
 // n / d for a divisor fixed per launch: one multiply-high with floor(2^32 / d) and one correction step (the
@@ -308,9 +310,91 @@ __global__ __launch_bounds__(kBlock, JPT_WAVES_PER_SIMD) void wf2_trace(WideScen
 #ifndef JPT_SHADE_WAVES
 #define JPT_SHADE_WAVES 1
 #endif
+// One path vertex (main.glsl:378-397): the queue entry's ray and closest hit in, radiance / throughput / seeds of the path
+// updated, returns true when the path goes on (no / nd = its next ray).  With reach records (JPT_BUILD_SAH) and
+// check_reach, a hit the reference's own traversal could not have reached -- the world ray fails the world box the
+// reference gives the instance, or the local ray fails the box of the triangle's reference leaf (jpt_types.h) -- is
+// not shaded: `unreachable` comes back true and nothing has been written; the path leaves the wavefront and is finished by wf2_finish.
 template <bool COUNT>
-__global__ __launch_bounds__(kBlock, JPT_SHADE_WAVES) void wf2_shade(SceneShading sh, Wf2Buffers wb, Wf2Dims dm, FrameParams fp, RefCamera cam,
-                                                    int bounce, DevCounters* __restrict__ counters)
+__device__ __forceinline__ bool shade_entry(const SceneShading& sh, const Wf2Buffers& wb, const Wf2Dims& dm, const FrameParams& fp, float cam_far,
+                                            int bounce, const float4 ro, const float4 rd, const float4 ha, const uint32_t hb, bool check_reach,
+                                            bool& unreachable, float4& no, float4& nd, DevCounters& cnt)
+{
+    unreachable = false;
+    const uint32_t p = __float_as_uint(rd.w);
+    f3 throughput, radiance;
+    uint32_t sx, sy;
+    const uint32_t f = fdiv(p, dm.by_slots_per_frame), slot = p - f * dm.slots_per_frame;
+    Ray ray;
+    ray.o = mk3(ro.x, ro.y, ro.z);
+    ray.d = mk3(rd.x, rd.y, rd.z);
+    const bool is_hit = ha.x < 1e9f;  // main.glsl:349
+    Hit h;
+    uint32_t found_in = 0;
+    if (is_hit) {
+        h.t = ha.x;
+        h.u = ha.y;
+        h.v = ha.z;
+        h.tri = __float_as_uint(ha.w);
+        h.inst = hb & kInstMask;                   // hitInfo.blas
+        found_in = (hb >> kInstBits) & kInstMask;  // the instance whose local ray found the triangle
+        // the hit instance's local ray: the expression ray_trace_tlas evaluates (main.glsl:319-320)
+        const RefInstance& b = sh.instances[found_in];
+        h.lo = xform_point(b.inverse_transform, ray.o);
+        h.ld = xform_dir(b.inverse_transform, ray.d);
+        if (check_reach && sh.reach_tri) {
+            const float4 ta = ld4(&sh.reach_tri[h.tri].lo[0]), tb = ld4(&sh.reach_tri[h.tri].hi[0]);
+            bool reached = __float_as_uint(ta.w) != 0u || slab(h.lo, rcp3(h.ld), ta.x, ta.y, ta.z, tb.x, tb.y, tb.z) < 1e30f;
+            if (reached && sh.n_instances > 1u) {
+                const float4 ia = ld4(&sh.reach_inst[found_in].lo[0]), ib = ld4(&sh.reach_inst[found_in].hi[0]);
+                reached = slab(ray.o, rcp3(ray.d), ia.x, ia.y, ia.z, ib.x, ib.y, ib.z) < 1e30f;
+            }
+            if (!reached) {
+                unreachable = true;
+                return false;
+            }
+        }
+    }
+    if (bounce == 0) {
+        // fresh path: the seed after the jitter draw (main.glsl:409-411), recomputed from (x, y, frame)
+        int px, ly;
+        slot_to_pixel(slot, dm, px, ly);
+        prng_seed((uint32_t)px, (uint32_t)local_to_global_row(ly, fp), fp.frame_index + f, sx, sy);
+        float r0, r1;
+        pcg2d(sx, sy, r0, r1);
+        throughput = mk3(1.0f, 1.0f, 1.0f);
+        radiance = mk3(0.0f, 0.0f, 0.0f);
+    } else {
+        const float4 t4 = wb.thr[p], r4 = wb.rad[p];
+        throughput = mk3(t4.x, t4.y, t4.z);
+        radiance = mk3(r4.x, r4.y, r4.z);
+        sx = __float_as_uint(t4.w);
+        sy = __float_as_uint(r4.w);
+    }
+    if (COUNT && bounce > 0) cnt.rays++;
+    bool alive = false;
+    if (!is_hit) {
+        radiance = radiance + throughput * sample_sky(ray.d);
+        if (bounce == 0 && (int)f == fp.depth_frame) wb.first_depth[slot] = cam_far;  // (only a redone primary hit can turn into a miss here)
+    } else {
+        if (COUNT) cnt.shaded_hits++;
+        const Shading s = get_shading_data(sh, h, (hb >> 31) != 0u);
+        radiance = radiance + throughput * s.emission;
+        if (bounce == 0 && (int)f == fp.depth_frame) wb.first_depth[slot] = length3(s.position - ray.o);
+        if (bounce < fp.max_bounces) alive = bounce_step(s, sx, sy, ray, throughput);
+    }
+    wb.rad[p] = make_float4(radiance.x, radiance.y, radiance.z, __uint_as_float(sy));
+    if (alive) {
+        wb.thr[p] = make_float4(throughput.x, throughput.y, throughput.z, __uint_as_float(sx));
+        no = make_float4(ray.o.x, ray.o.y, ray.o.z, 0.0f);
+        nd = make_float4(ray.d.x, ray.d.y, ray.d.z, __uint_as_float(p));
+    }
+    return alive;
+}
+
+template <bool COUNT>
+__global__ __launch_bounds__(kBlock, JPT_SHADE_WAVES) void wf2_shade(SceneShading sh, Wf2Buffers wb, Wf2Dims dm, FrameParams fp, float cam_far, int bounce,
+                                                    DevCounters* __restrict__ counters)
 {
     // grid = (chunks per segment, segments): every 256-entry chunk of every segment is its own block, so the
     // launch is balanced however unevenly the segments are filled; blocks past a segment's end exit at once.
@@ -327,57 +411,14 @@ __global__ __launch_bounds__(kBlock, JPT_SHADE_WAVES) void wf2_shade(SceneShadin
     float4 no, nd;
     if (i < n) {
         const float4 ro = wb.ray_o[in][seg_base + i], rd = wb.ray_d[in][seg_base + i];
-        const uint32_t p = __float_as_uint(rd.w);
         const float4 ha = wb.hit_a[seg_base + i];
         const uint32_t hb = wb.hit_b[seg_base + i];
-        f3 throughput, radiance;
-        uint32_t sx, sy;
-        const uint32_t f = fdiv(p, dm.by_slots_per_frame), slot = p - f * dm.slots_per_frame;
-        if (bounce == 0) {
-            // fresh path: the seed after the jitter draw (main.glsl:409-411), recomputed from (x, y, frame)
-            int px, ly;
-            slot_to_pixel(slot, dm, px, ly);
-            prng_seed((uint32_t)px, (uint32_t)local_to_global_row(ly, fp), fp.frame_index + f, sx, sy);
-            float r0, r1;
-            pcg2d(sx, sy, r0, r1);
-            throughput = mk3(1.0f, 1.0f, 1.0f);
-            radiance = mk3(0.0f, 0.0f, 0.0f);
-        } else {
-            const float4 t4 = wb.thr[p], r4 = wb.rad[p];
-            throughput = mk3(t4.x, t4.y, t4.z);
-            radiance = mk3(r4.x, r4.y, r4.z);
-            sx = __float_as_uint(t4.w);
-            sy = __float_as_uint(r4.w);
-        }
-        Ray ray;
-        ray.o = mk3(ro.x, ro.y, ro.z);
-        ray.d = mk3(rd.x, rd.y, rd.z);
-        if (COUNT && bounce > 0) cnt.rays++;
-        if (!(ha.x < 1e9f)) {  // main.glsl:349
-            radiance = radiance + throughput * sample_sky(ray.d);
-        } else {
-            if (COUNT) cnt.shaded_hits++;
-            Hit h;
-            h.t = ha.x;
-            h.u = ha.y;
-            h.v = ha.z;
-            h.tri = __float_as_uint(ha.w);
-            h.inst = hb & kInstMask;                               // hitInfo.blas
-            const uint32_t found_in = (hb >> kInstBits) & kInstMask;   // the instance whose local ray found the triangle
-            // the hit instance's local ray: the expression ray_trace_tlas evaluates (main.glsl:319-320)
-            const RefInstance& b = sh.instances[found_in];
-            h.lo = xform_point(b.inverse_transform, ray.o);
-            h.ld = xform_dir(b.inverse_transform, ray.d);
-            const Shading s = get_shading_data(sh, h, (hb >> 31) != 0u);
-            radiance = radiance + throughput * s.emission;
-            if (bounce == 0 && (int)f == fp.depth_frame) wb.first_depth[slot] = length3(s.position - ray.o);
-            if (bounce < fp.max_bounces) alive = bounce_step(s, sx, sy, ray, throughput);
-        }
-        wb.rad[p] = make_float4(radiance.x, radiance.y, radiance.z, __uint_as_float(sy));
-        if (alive) {
-            wb.thr[p] = make_float4(throughput.x, throughput.y, throughput.z, __uint_as_float(sx));
-            no = make_float4(ray.o.x, ray.o.y, ray.o.z, 0.0f);
-            nd = make_float4(ray.d.x, ray.d.y, ray.d.z, __uint_as_float(p));
+        bool unreachable;
+        alive = shade_entry<COUNT>(sh, wb, dm, fp, cam_far, bounce, ro, rd, ha, hb, true, unreachable, no, nd, cnt);
+        if (unreachable) {  // a few paths in 10^7: they leave the wavefront here and are finished, exactly, by wf2_finish
+            const size_t k = atomicAdd(&wb.redo_count[0], 1u);
+            wb.redo_rec[2 * k] = make_float4(ro.x, ro.y, ro.z, __uint_as_float((uint32_t)bounce));
+            wb.redo_rec[2 * k + 1] = rd;
         }
     }
     // active-ray packing: wave ballot + prefix popcount, one atomic per wave on the SEGMENT's counter (1792
@@ -391,6 +432,44 @@ __global__ __launch_bounds__(kBlock, JPT_SHADE_WAVES) void wf2_shade(SceneShadin
             const size_t j = seg_base + wbase + lanes_below(m, lane);
             wb.ray_o[out][j] = no;
             wb.ray_d[out][j] = nd;
+        }
+    }
+    if (COUNT) flush_counters(cnt, counters);
+}
+
+// The paths wf2_shade set aside: their hit is one the reference's traversal cannot reach.  Each is finished here, after
+// the render's last bounce launch and before the accumulation: from the vertex where it left the wavefront the path is
+// traced with the reach tests applied to every instance entry and every accepted triangle (Traversal<.., REACH = true>:
+// the closest hit among the triangles the reference can reach, i.e. the reference's answer) and shaded bounce after
+// bounce by the same shade_entry, its state passing through the path's own thr / rad words.  A handful of paths per
+// render, so one small grid of single-wave blocks with the whole stack in scratch; one launch per render.
+template <bool COUNT, bool W4>
+__global__ __launch_bounds__(64) void wf2_finish(WideSceneDev sc, SceneShading sh, Wf2Buffers wb, Wf2Dims dm, FrameParams fp, float cam_far,
+                                                 DevCounters* __restrict__ counters)
+{
+    const uint32_t n = wb.redo_count[0];
+    if (blockIdx.x * 64u >= n) return;
+    constexpr int kDepth = kStackLds + kStackSpill;
+    int32_t stack_mem[kDepth];
+    const typename Traversal<COUNT, W4, true>::Stack st{nullptr, stack_mem, 0, 0, kDepth};
+    DevCounters cnt = {};
+    for (uint32_t k = blockIdx.x * 64u + threadIdx.x; k < n; k += gridDim.x * 64u) {
+        float4 ro = wb.redo_rec[2 * (size_t)k], rd = wb.redo_rec[2 * (size_t)k + 1];
+        const int first = (int)__float_as_uint(ro.w);
+        for (int bounce = first;; bounce++) {
+            Traversal<COUNT, W4, true> tr;
+            tr.begin(sc, mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z));
+            while (tr.step(sc, st, cnt)) {
+            }
+            // (the ray-segment count the host reads is the sum of the queue sizes: this path's later segments are in no queue)
+            if (bounce > first) atomicAdd(&wb.qcount[(size_t)bounce * kSegments], 1u);
+            const float4 ha = make_float4(tr.hit.t, tr.hit.u, tr.hit.v, __uint_as_float(tr.hit.tri));
+            const uint32_t hb = tr.hit.inst | (tr.hit.front ? 0x80000000u : 0u);
+            bool unreachable;
+            float4 no, nd;
+            if (!shade_entry<COUNT>(sh, wb, dm, fp, cam_far, bounce, ro, rd, ha, hb, false, unreachable, no, nd, cnt)) break;
+            ro = no;
+            rd = nd;
         }
     }
     if (COUNT) flush_counters(cnt, counters);
@@ -517,7 +596,8 @@ size_t wf2_workspace_bytes(int width, int local_rows, int n_frames, int max_boun
             b += q * sizeof(float4) + 256;            // hit_a
             b += q * sizeof(uint32_t) + 256;          // hit_b
             b += paths * sizeof(float4) + 256;        // thr
-            b += (size_t)(max_bounces + 2) * kSegments * sizeof(uint32_t) + 256;
+            b += ((size_t)(max_bounces + 2) * kSegments + 64) * sizeof(uint32_t) + 256;   // queue sizes + the set-aside count
+            b += paths * 2 * sizeof(float4) + 256;    // set-aside records (a path is set aside at most once)
         }
         const Wf2Dims all = make_dims(width, local_rows, n_frames);
         b += (size_t)all.slots_per_frame * (size_t)n_frames * sizeof(float4) + 256;  // rad: [frame][slot], shared by the groups
@@ -554,7 +634,10 @@ void launch_wf2_render(hipStream_t stream, const DeviceScene& ds, const FramePar
     Wf2Buffers gb[kMaxGroups];
     Wf2Dims gdm[kMaxGroups];
     FrameParams gfp[kMaxGroups];
-    for (int g = 0; g < groups; g++) gb[g].qcount = (uint32_t*)carve((size_t)nq * kSegments * sizeof(uint32_t));  // group 0 first: the host reads it
+    for (int g = 0; g < groups; g++) {  // group 0 first: the host reads it
+        gb[g].qcount = (uint32_t*)carve(((size_t)nq * kSegments + 64) * sizeof(uint32_t));
+        gb[g].redo_count = gb[g].qcount + (size_t)nq * kSegments;
+    }
     float4* rad_all = (float4*)carve((size_t)dm_all.slots_per_frame * (size_t)fp.n_frames * sizeof(float4));
     float* first_depth = (float*)carve((size_t)dm_all.slots_per_frame * sizeof(float));
     for (int g = 0; g < groups; g++) {
@@ -570,6 +653,7 @@ void launch_wf2_render(hipStream_t stream, const DeviceScene& ds, const FramePar
         wb.ray_d[1] = (float4*)carve(q * sizeof(float4));
         wb.hit_a = (float4*)carve(q * sizeof(float4));
         wb.hit_b = (uint32_t*)carve(q * sizeof(uint32_t));
+        wb.redo_rec = (float4*)carve(paths * 2 * sizeof(float4));
         wb.thr = (float4*)carve(paths * sizeof(float4));
         wb.rad = rad_all + (size_t)f0 * dm_all.slots_per_frame;  // this group's frames of the [frame][slot] array
         wb.first_depth = first_depth;
@@ -588,7 +672,10 @@ void launch_wf2_render(hipStream_t stream, const DeviceScene& ds, const FramePar
     sc.instances = w4 ? ds.wide_instances4 : ds.wide_instances;
     sc.tlas_root = w4 ? ds.tlas_root4 : ds.tlas_root;
     sc.n_instances = ds.n_instances;
-    const SceneShading sh = ds.shading();
+    sc.reach_tri = ds.reach_tri;
+    sc.reach_inst = ds.reach_inst;
+    SceneShading sh = ds.shading();
+    if (tuning().reach == 0) sh.reach_tri = nullptr;
     const dim3 block(kBlock);
     const WfTune tune{tuning().refill_idle, tuning().node_min_lanes};
 
@@ -601,7 +688,7 @@ void launch_wf2_render(hipStream_t stream, const DeviceScene& ds, const FramePar
     // the pipeline of one group on one stream
     auto run_group = [&](hipStream_t st, const Wf2Buffers& wb, const Wf2Dims& dm, const FrameParams& gp, hipEvent_t* ev) {
         // queue sizes of bounces >= 1 are accumulated with atomics by wf2_shade: start from zero
-        (void)hipMemsetAsync(wb.qcount + kSegments, 0, (size_t)(nq - 1) * kSegments * sizeof(uint32_t), st);
+        (void)hipMemsetAsync(wb.qcount + kSegments, 0, ((size_t)(nq - 1) * kSegments + 64) * sizeof(uint32_t), st);  // (and the set-aside count behind them)
         // Blocks go to the 8 XCDs round-robin by linear index (y * grid.x + x), and the chunks of a segment are far from
         // alike (the first ones are full, the last ones empty): with grid.x a multiple of 8 every XCD would always get
         // the same chunk position.  An odd grid.x deals every position to every XCD (capping C3's grid.x from 37 to 8
@@ -617,8 +704,8 @@ void launch_wf2_render(hipStream_t stream, const DeviceScene& ds, const FramePar
         }
         if (ev) (void)hipEventRecord(ev[1], st);
         for (int b = 0; b <= gp.max_bounces; b++) {
-            if (counters) hipLaunchKernelGGL(wf2_shade<true>, sgrid, block, 0, st, sh, wb, dm, gp, cam, b, counters);
-            else hipLaunchKernelGGL(wf2_shade<false>, sgrid, block, 0, st, sh, wb, dm, gp, cam, b, counters);
+            if (counters) hipLaunchKernelGGL(wf2_shade<true>, sgrid, block, 0, st, sh, wb, dm, gp, cam.far_, b, counters);
+            else hipLaunchKernelGGL(wf2_shade<false>, sgrid, block, 0, st, sh, wb, dm, gp, cam.far_, b, counters);
             if (b == gp.max_bounces) break;
             if (ev) (void)hipEventRecord(ev[2 * (b + 1)], st);
             if (counters) {
@@ -629,6 +716,16 @@ void launch_wf2_render(hipStream_t stream, const DeviceScene& ds, const FramePar
                 else hipLaunchKernelGGL((wf2_trace<false, false>), tgrid, block, 0, st, sc, wb, dm, b + 1, tune, chain, counters);
             }
             if (ev) (void)hipEventRecord(ev[2 * (b + 1) + 1], st);
+        }
+        if (sh.reach_tri && tuning().reach == 2) {  // the paths set aside because the reference cannot reach their hit: finished exactly
+            const dim3 rgrid(16), rblock(64);
+            if (counters) {
+                if (w4) hipLaunchKernelGGL((wf2_finish<true, true>), rgrid, rblock, 0, st, sc, sh, wb, dm, gp, cam.far_, counters);
+                else hipLaunchKernelGGL((wf2_finish<true, false>), rgrid, rblock, 0, st, sc, sh, wb, dm, gp, cam.far_, counters);
+            } else {
+                if (w4) hipLaunchKernelGGL((wf2_finish<false, true>), rgrid, rblock, 0, st, sc, sh, wb, dm, gp, cam.far_, counters);
+                else hipLaunchKernelGGL((wf2_finish<false, false>), rgrid, rblock, 0, st, sc, sh, wb, dm, gp, cam.far_, counters);
+            }
         }
     };
 

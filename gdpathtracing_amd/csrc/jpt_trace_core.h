@@ -32,6 +32,8 @@ struct WideSceneDev {
     const WideInstance* __restrict__ instances;  // roots refer to the record kind in use
     int32_t tlas_root;
     uint32_t n_instances;
+    const ReachTri* __restrict__ reach_tri;      // reach records (jpt_types.h); read by Traversal<.., REACH = true> only
+    const ReachInst* __restrict__ reach_inst;
 };
 
 __device__ __forceinline__ float4 ld4(const void* p) { return *reinterpret_cast<const float4*>(p); }
@@ -75,7 +77,11 @@ struct TraceHit {
     bool front;
 };
 
-template <bool COUNT, bool W4 = false>
+// REACH = true is the slow, exact form used to re-trace the few rays whose hit the reference's own traversal could not
+// have reached (wf2_redo, jpt_kernels_wf2.hip): an instance is entered only if the world ray passes the world box the
+// reference gives it, and a triangle is accepted only if the local ray passes the box of its reference leaf -- the two
+// tests that decide reachability in main.glsl:270-350 (jpt_types.h, reach records).
+template <bool COUNT, bool W4 = false, bool REACH = false>
 struct Traversal {
     f3 wo, wd, wrD;   // world ray and its reciprocal direction (kept so leaving an instance costs no divisions)
     f3 o, d, rD;      // current-level ray (world at TLAS level, instance-local below)
@@ -87,35 +93,33 @@ struct Traversal {
 
     // The stack: entries 0..kStackLds-1 in LDS (`lds` = this lane's column), deeper ones in `spill`, a
     // per-lane scratch array owned by the kernel (kept OUT of this struct so the struct stays in registers).
+    // Capacity: lds_entries + spill_entries.  A push past it is dropped and the matching pop returns the sentinel, i.e. a
+    // too-deep walk would silently lose subtrees -- which cannot happen: every upload and TLAS update computes the worst
+    // case for the tree at hand (compute_stack_need) and refuses a scene that needs more than trace_stack_capacity(),
+    // and jpt_scene_refit_tlas keeps the topology (only boxes move), so the bound of the last build still holds.
     struct Stack {
         int32_t* __restrict__ lds;    // entry k of this ray at lds[k * stride]
-        int32_t* __restrict__ spill;  // entries past kStackLds (scratch or global)
+        int32_t* __restrict__ spill;  // entries past lds_entries (scratch)
         int stride = kTraceBlock;
         int lds_entries = kStackLds;
+        int spill_entries = kStackSpill;
     };
 
     __device__ __forceinline__ void push(const Stack& st, int32_t v)
     {
-#ifdef JPT_NO_SPILL  // experiment only: valid when the scene's stack depth never exceeds kStackLds
-        st.lds[sp * kTraceBlock] = v;
-#else
         if (sp < st.lds_entries) st.lds[sp * st.stride] = v;
-        else if (sp < st.lds_entries + kStackSpill) st.spill[sp - st.lds_entries] = v;
-#endif
+        else if (sp < st.lds_entries + st.spill_entries) st.spill[sp - st.lds_entries] = v;
         sp++;
     }
     __device__ __forceinline__ int32_t pop(const Stack& st)
     {
         sp--;
-#ifdef JPT_NO_SPILL
-        return st.lds[sp * kTraceBlock];
-#else
+        if (st.lds_entries <= 0) return sp < st.spill_entries ? st.spill[sp] : kSentinel;  // (all-scratch stack: wf2_redo)
         // the LDS read is issued unconditionally (row clamped); only a walk deeper than the LDS part branches
         const int row = sp < st.lds_entries ? sp : st.lds_entries - 1;
         int32_t v = st.lds[row * st.stride];
-        if (__builtin_expect(sp >= st.lds_entries, 0)) v = sp < st.lds_entries + kStackSpill ? st.spill[sp - st.lds_entries] : kSentinel;
+        if (__builtin_expect(sp >= st.lds_entries, 0)) v = sp < st.lds_entries + st.spill_entries ? st.spill[sp - st.lds_entries] : kSentinel;
         return v;
-#endif
     }
 
     __device__ __forceinline__ void begin(const WideSceneDev& sc, f3 ro, f3 rd)
@@ -285,8 +289,11 @@ struct Traversal {
                 const f3 qvec = cross3(tvec, edge1);
                 const float v = dot3(d, qvec) * invDet;
                 const float t = dot3(edge2, qvec) * invDet;
-                const bool out = (__builtin_fabsf(det) < 1e-5f) | (u < 0.0f) | (u > 1.0f) | (v < 0.0f) | (u + v > 1.0f) |
-                                 (t < 0.0f) | (t > hit.t);
+                bool out = (__builtin_fabsf(det) < 1e-5f) | (u < 0.0f) | (u > 1.0f) | (v < 0.0f) | (u + v > 1.0f) |
+                           (t < 0.0f) | (t > hit.t);
+                if (REACH) {
+                    if (!out && !reaches_triangle(sc, ti)) out = true;
+                }
                 const bool front = dot3(mk3(q0.w, q1.w, q2.w), d) > 0.0f;  // the record carries cross(edge1, edge2)
                 // hitInfo.blas follows `if (hitInfo.t < minT)` after the instance's walk (main.glsl:324-327): a hit that
                 // only TIES the distance found in an earlier instance replaces the triangle but not the instance
@@ -310,6 +317,9 @@ struct Traversal {
                 if (v < 0.0f || u + v > 1.0f) continue;
                 const float t = dot3(edge2, qvec) * invDet;
                 if (t < 0.0f || t > hit.t) continue;
+                if (REACH) {
+                    if (!reaches_triangle(sc, ti)) continue;
+                }
                 hit.inst = (((t < hit.t) ? cur_inst : hit.inst) & kInstMask) | (cur_inst << kInstBits);  // main.glsl:324-327, see above
                 hit.t = t;
                 hit.u = u;
@@ -320,10 +330,28 @@ struct Traversal {
         }
     }
 
+    // the local ray against the box of the reference leaf that holds triangle ti (REACH)
+    __device__ __forceinline__ bool reaches_triangle(const WideSceneDev& sc, uint32_t ti) const
+    {
+        const float4 a = ld4(&sc.reach_tri[ti].lo[0]), b = ld4(&sc.reach_tri[ti].hi[0]);
+        if (__float_as_uint(a.w) != 0u) return true;  // the reference's BLAS root is this leaf: no box test on the way
+        return slab(o, rD, a.x, a.y, a.z, b.x, b.y, b.z) < 1e30f;
+    }
+
     // TLAS leaf: enter the instance (main.glsl:316-322)
     __device__ __forceinline__ void instance_step(const WideSceneDev& sc, const Stack& st, DevCounters& cnt)
     {
         cur_inst = (uint32_t)~cur;
+        if (REACH) {
+            // the reference enters the instance only through its TLAS leaf's box (no test when the TLAS is one leaf)
+            if (sc.n_instances > 1u) {
+                const float4 a = ld4(&sc.reach_inst[cur_inst].lo[0]), b = ld4(&sc.reach_inst[cur_inst].hi[0]);
+                if (!(slab(wo, wrD, a.x, a.y, a.z, b.x, b.y, b.z) < 1e30f)) {
+                    have = false;
+                    return;
+                }
+            }
+        }
         const WideInstance* ip = sc.instances + cur_inst;
         const float4 m0 = ld4(&ip->inv[0]);
         const float4 m1 = ld4(&ip->inv[4]);

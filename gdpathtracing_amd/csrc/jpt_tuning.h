@@ -20,6 +20,7 @@ struct Tuning {
     int node_min_lanes = 16;       // JPT_NODE_MIN_LANES: leave the record loop below this many descending lanes
     int trace_chain = 0;           // JPT_TRACE_CHAIN=1..4: segments per block of the tracing launches (0: the library's rule)
     int max_leaf = 2;              // JPT_MAX_LEAF: native builder leaf size
+    int reach = 2;                 // JPT_REACH=0: ignore the reach records; 1: check but never redo (timing experiments only)
 };
 
 inline const Tuning& tuning()
@@ -43,6 +44,7 @@ inline const Tuning& tuning()
         v.node_min_lanes = geti("JPT_NODE_MIN_LANES", 16);
         v.trace_chain = geti("JPT_TRACE_CHAIN", 0);
         v.max_leaf = geti("JPT_MAX_LEAF", 2);
+        v.reach = geti("JPT_REACH", 2);
         if (v.max_leaf < 1) v.max_leaf = 1;
         if (v.max_leaf > 16) v.max_leaf = 16;
         return v;

@@ -150,6 +150,35 @@ struct alignas(64) WideInstance {
 };
 static_assert(sizeof(WideInstance) == 64, "WideInstance");
 
+// ---- reach records: which triangles can the REFERENCE's own traversal reach? ---------------------------------
+//
+// The boxes of the reference's trees are nested (a node's box is the exact min/max over a superset of its child's
+// vertices, bvh.cpp:19-37,299-303) and every operation of intersectAABB (main.glsl:259-268) is monotone in the box
+// planes, so a ray that passes a leaf's box passes every ancestor's box: ray_trace_tlas / ray_trace_blas test triangle
+// T of instance I if and only if the world ray passes I's world box (the TLAS leaf) and the local ray passes the box
+// of the BLAS leaf that holds T (oracle/jpt_oracle.h, JPTO_FLAG_REACH_ONLY; up to the `d < hitInfo.t` culls).  Float
+// rounding makes those tests fail for a few rays in 10^7 whose triangle test succeeds ("cracks": the reference's ray
+// goes through).  The native builder records the two boxes, so that a hit found on ITS tree can be checked against
+// what the reference would have reached, and the image equals the reference's, cracks included.
+struct alignas(16) ReachTri {   // per triangle (device order): the box of the reference BLAS leaf that holds it
+    float lo[3];
+    uint32_t always;            // 1: the reference's BLAS root is this leaf -- never box-tested (main.glsl:272-283)
+    float hi[3];
+    uint32_t _pad;
+};
+static_assert(sizeof(ReachTri) == 32, "ReachTri");
+struct alignas(64) ReachInst {  // per instance
+    float lo[3];                // world box the reference's BLASInstance::update_aabb computes (bvh.h:90-115) ...
+    uint32_t _p0;
+    float hi[3];
+    uint32_t _p1;
+    float root_lo[3];           // ... from the box of the reference BLAS root (kept for refits on the device)
+    uint32_t _p2;
+    float root_hi[3];
+    uint32_t _p3;
+};
+static_assert(sizeof(ReachInst) == 64, "ReachInst");
+
 constexpr int kLeafCountShift = 25;
 constexpr uint32_t kLeafFirstMask = (1u << kLeafCountShift) - 1u;
 constexpr int kMaxLeafTris = 64;

@@ -65,7 +65,15 @@ enum {
 enum {
     JPT_BUILD_REFERENCE_EXACT = 0, /* reproduces src/bvh/bvh.cpp node-for-node (incl. its default-box quirk);
                                       kernels traverse the same tree in the same order */
-    JPT_BUILD_SAH = 1              /* native binned-SAH builder, flattened wide-fetch layout (fast path) */
+    JPT_BUILD_SAH = 1,             /* native binned-SAH builder, flattened wide-fetch layout (fast path).  Also runs the
+                                      reference's builder once per mesh to record which leaf box holds each triangle
+                                      ("reach records"): a hit found on the native tree is checked against the two box
+                                      tests that decide whether the reference's traversal reaches that triangle at all
+                                      (main.glsl:259-350), so the image equals the reference's even where float rounding
+                                      lets a reference ray slip through its own boxes */
+    JPT_BUILD_SAH_WATERTIGHT = 2   /* the native builder alone (half the build time): every triangle hit is found; differs
+                                      from the reference's image in the few pixels per 10^7 paths where the reference's
+                                      tree has such a crack */
 };
 
 /* which reference-layout buffer (GeometryGroup3D::get_*_buffer, geometry_group3d.cpp:40-68) */

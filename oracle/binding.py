@@ -104,6 +104,7 @@ def lib():
         L.jpto_unorm8.argtypes = [C.c_float]
         L.jpto_unorm8.restype = C.c_uint8
         L.jpto_aces.argtypes = [C.c_void_p, C.c_void_p]
+        L.jpto_sample_texture.argtypes = [C.POINTER(SceneView), C.c_float, C.c_float, C.c_int32, C.c_void_p]
         _lib = L
     return _lib
 

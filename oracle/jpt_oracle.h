@@ -115,7 +115,7 @@ typedef struct {
     const uint8_t            *tex_rgba8;  /* n_layers * res * res * 4, may be NULL */
     int32_t tex_res;
     int32_t n_layers;
-    int32_t sampler_mode;                 /* 0 = nearest + clamp-to-edge (pinned default) */
+    int32_t sampler_mode;                 /* bit 0: repeat (else clamp-to-edge), bit 1: linear (else nearest); 0 = default */
 } jpto_scene_view;
 
 /* exact event counters, SURVEY.md 8(d) */
@@ -130,7 +130,19 @@ typedef struct {
 } jpto_counters;
 
 enum { JPTO_ACCUM_REF_LDR8 = 0, JPTO_ACCUM_HDR_F32 = 1 };
-enum { JPTO_FLAG_NO_CULL = 1 };  /* every box test passes: BVH-independent closest hit */
+enum {
+    JPTO_FLAG_NO_CULL = 1,     /* every box test passes: BVH-independent closest hit */
+    /* Which triangles can the reference's traversal reach at all?  The boxes of a reference tree are nested (a node's
+     * box is the exact min/max over a superset of its child's vertices, bvh.cpp:19-37,299-303) and every operation of
+     * intersectAABB (main.glsl:259-268) is monotone in the box planes, so a ray that passes a LEAF's box passes every
+     * ancestor's box: ray_trace_tlas / ray_trace_blas test triangle T of instance I if and only if the world ray passes
+     * I's world box (the TLAS leaf; no test when the TLAS is a single leaf) and the local ray passes the box of T's BLAS
+     * leaf (no test when the BLAS root is the leaf) -- up to the distance culls `d < hitInfo.t` and NaN corner cases.
+     * With this flag the walk ignores every internal box and every distance cull and applies exactly those two tests:
+     * the image must equal the normal walk's (tests/test_oracle_render.py), which is what lets a DIFFERENT tree
+     * reproduce the reference's image, "cracks" included (gdpathtracing_amd/csrc: reach records). */
+    JPTO_FLAG_REACH_ONLY = 2
+};
 
 /* ---- builder (oracle_bvh.c) ---- */
 
@@ -223,6 +235,8 @@ void  jpto_brdf(const jpto_shading *s, const float l[3], float out[3]);
 void  jpto_sample_brdf(const jpto_shading *s, const float xi[2], float out[3]);
 float jpto_brdf_density(const jpto_shading *s, const float l[3]);
 uint8_t jpto_unorm8(float x);
+/* texture(textureArray, vec3(u, v, layer)) (main.glsl:214) under scene->sampler_mode (bit 0 repeat, bit 1 linear) */
+void  jpto_sample_texture(const jpto_scene_view *scene, float u, float v, int32_t layer, float out[3]);
 void  jpto_aces(const float in[3], float out[3]);                                       /* progressive_rendering.glsl:19-26 */
 
 #ifdef __cplusplus

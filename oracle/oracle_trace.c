@@ -422,6 +422,7 @@ static int ray_trace_blas(ctx_t *cx, uint32_t root, const ray_t *ray, hit_t *hit
 {
     const jpto_bvh_node *bvh = cx->sc->bvh_nodes;
     const int no_cull = (cx->flags & JPTO_FLAG_NO_CULL) != 0;
+    const int reach_only = (cx->flags & JPTO_FLAG_REACH_ONLY) != 0;
     uint32_t stack[STACK_MAX];
     uint32_t sp = 0;
     stack[sp++] = root;
@@ -441,6 +442,10 @@ static int ray_trace_blas(ctx_t *cx, uint32_t root, const ray_t *ray, hit_t *hit
         float d2 = intersect_aabb(ray, v4xyz(childR->aabbMin), v4xyz(childR->aabbMax));
         int leftValid = no_cull || (d1 < hit->t);
         int rightValid = no_cull || (d2 < hit->t);
+        if (reach_only) { /* see JPTO_FLAG_REACH_ONLY: only a LEAF's own box decides */
+            leftValid = childL->tri_count > 0 ? d1 < 1e30f : 1;
+            rightValid = childR->tri_count > 0 ? d2 < 1e30f : 1;
+        }
 
         if (d1 < d2) {
             if (rightValid) PUSH(stack, sp, node->right_child);
@@ -458,6 +463,7 @@ static int ray_trace_tlas(ctx_t *cx, const ray_t *ray, hit_t *hit)
 {
     const jpto_tlas_node *tlas = cx->sc->tlas_nodes;
     const int no_cull = (cx->flags & JPTO_FLAG_NO_CULL) != 0;
+    const int reach_only = (cx->flags & JPTO_FLAG_REACH_ONLY) != 0;
     uint32_t stack[STACK_MAX];
     uint32_t sp = 0;
     stack[sp++] = 0;
@@ -492,6 +498,10 @@ static int ray_trace_tlas(ctx_t *cx, const ray_t *ray, hit_t *hit)
                                   v3_make(childR->aabbMax[0], childR->aabbMax[1], childR->aabbMax[2]));
         int leftValid = no_cull || (d1 < hit->t);
         int rightValid = no_cull || (d2 < hit->t);
+        if (reach_only) {
+            leftValid = childL->leftRight == 0 ? d1 < 1e30f : 1;
+            rightValid = childR->leftRight == 0 ? d2 < 1e30f : 1;
+        }
 
         if (d1 < d2) {
             if (rightValid) PUSH(stack, sp, right);
@@ -867,6 +877,12 @@ float jpto_brdf_density(const jpto_shading *in, const float l[3])
 }
 
 uint8_t jpto_unorm8(float x) { return p_unorm8(x); }
+
+void jpto_sample_texture(const jpto_scene_view *scene, float u, float v, int32_t layer, float out[3])
+{
+    v3 t = sample_texture(scene, u, v, layer);
+    out[0] = t.x; out[1] = t.y; out[2] = t.z;
+}
 
 void jpto_aces(const float in[3], float out[3])
 {

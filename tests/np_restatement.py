@@ -216,3 +216,28 @@ def temporal_reproject(delta_colmajor, frame_count, screen_u8, depth, fb1, fb2):
     out[..., :3] = np.floor(col * f(255.0) + f(0.5)).astype(np.uint8)
     out[..., 3] = 255
     return out, hist, which
+
+
+def sample_texture(tex, u, v, layer, mode):
+    """texture(sampler2DArray, vec3(u, v, layer)) after the Vulkan texel-addressing rules (the pin written down in
+    oracle/oracle_trace.c), in float64: mode bit 0 = repeat (else clamp-to-edge), bit 1 = linear (else nearest).
+    tex: [layers, res, res, 4] uint8, UNORM, no sRGB decode.  Returns rgb in [0, 1]."""
+    res = tex.shape[1]
+    repeat, linear = bool(mode & 1), bool(mode & 2)
+
+    def wrap(i):
+        return int(i) % res if repeat else min(max(int(i), 0), res - 1)
+
+    def texel(ix, iy):
+        return tex[layer, iy, ix, :3].astype(np.float64) / 255.0
+
+    x, y = float(np.float32(u) * np.float32(res)), float(np.float32(v) * np.float32(res))   # one float32 multiply, as pinned
+    if not linear:
+        return texel(wrap(np.floor(x)), wrap(np.floor(y)))
+    xs, ys = x - 0.5, y - 0.5
+    fx, fy = np.floor(xs), np.floor(ys)
+    a, b = xs - fx, ys - fy
+    x0, x1, y0, y1 = wrap(fx), wrap(fx + 1), wrap(fy), wrap(fy + 1)
+    r0 = texel(x0, y0) * (1 - a) + texel(x1, y0) * a
+    r1 = texel(x0, y1) * (1 - a) + texel(x1, y1) * a
+    return r0 * (1 - b) + r1 * b

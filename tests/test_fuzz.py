@@ -83,7 +83,7 @@ def test_native_tree_matches_the_tree_independent_answer(oracle, hiplib, seed):
     want, _, _, _, _ = oracle.render(ref, cam, w, h, bounces, frames, 1, wire.ACCUM_HDR_F32, flags=1)
     ctx = host.Context(0)
     try:
-        ctx.build_scene(sc, capi.BUILD_SAH)
+        ctx.build_scene(sc, capi.BUILD_SAH_WATERTIGHT)
         ctx.set_params(w, h, bounces, wire.ACCUM_HDR_F32)
         ctx.set_camera(cam)
         ctx.render(frames, 1)
@@ -99,3 +99,39 @@ def test_native_tree_matches_the_tree_independent_answer(oracle, hiplib, seed):
     print("fuzz", seed, "differing pixels", ndiff, "rel_l2", err, "nan pixels", int(nan_got.sum()), int(nan_want.sum()))
     assert np.array_equal(nan_got, nan_want)
     assert err <= 1e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kernel", [capi.KERNEL_WAVEFRONT, capi.KERNEL_REFERENCE_LAYOUT])
+@pytest.mark.parametrize("seed", SEEDS)
+def test_native_tree_with_reach_records_answers_like_the_reference(oracle, hiplib, seed, kernel):
+    """JPT_BUILD_SAH = native tree + reach records: a triangle counts only if the reference's traversal can reach it (the
+    world ray passes the instance's reference world box, the local ray passes the box of the triangle's reference leaf).
+    Checked against the oracle's statement of exactly that rule on the REFERENCE arrays (JPTO_FLAG_REACH_ONLY: no internal
+    box, no distance cull, so no tree order is involved) bit for bit, and against the oracle's normal walk of the
+    reference tree within the north-star tolerance.  Soups without coincident triangles (exact ties depend on the order)."""
+    sc = scenes.random_scene(seed, coincident=False)
+    w, h, bounces, frames = 96, 64, 3, 2
+    cam = scenes.camera_block(sc.camera, w, h)
+    ref = oracle.build_scene(sc)
+    want, _, _, _, _ = oracle.render(ref, cam, w, h, bounces, frames, 1, wire.ACCUM_HDR_F32, flags=2)
+    walk, _, _, _, _ = oracle.render(ref, cam, w, h, bounces, frames, 1, wire.ACCUM_HDR_F32)
+    ctx = host.Context(0)
+    try:
+        ctx.set_kernel(kernel)
+        ctx.build_scene(sc, capi.BUILD_SAH)
+        ctx.set_params(w, h, bounces, wire.ACCUM_HDR_F32)
+        ctx.set_camera(cam)
+        ctx.render(frames, 1)
+        got = ctx.read_accum()
+    finally:
+        ctx.close()
+    nan_got, nan_want = np.isnan(got).any(axis=-1), np.isnan(want).any(axis=-1)
+    ok = ~(nan_got | nan_want)
+    ndiff = int((got[ok] != want[ok]).any(axis=-1).sum())
+    ok2 = ok & ~np.isnan(walk).any(axis=-1)
+    print("fuzz reach", seed, "vs REACH_ONLY: differing pixels", ndiff, "rel_l2", rel_l2(got[ok], want[ok]),
+          "| vs the reference walk: differing pixels", int((got[ok2] != walk[ok2]).any(axis=-1).sum()), "rel_l2", rel_l2(got[ok2], walk[ok2]))
+    assert np.array_equal(nan_got, nan_want)
+    assert ndiff == 0
+    assert rel_l2(got[ok2], walk[ok2]) <= 1e-4

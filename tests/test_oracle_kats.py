@@ -217,3 +217,35 @@ def test_unorm8_and_aces(oracle):
         out = (C.c_float * 3)()
         L.jpto_aces(_f3(*x), out)
         assert np.allclose(tuple(out), npr.aces(x), atol=2e-6)
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2, 3])
+def test_sampler_modes_match_the_numpy_restatement(oracle, mode):
+    """texture(textureArray, ...) in the four sampler modes (nearest / linear x clamp-to-edge / repeat, jpt.h JPT_SAMPLER_*):
+    the oracle against an independent float64 restatement of the Vulkan addressing rules, inside and far outside
+    [0, 1], plus the exact cases (texel centres reproduce the texel in every mode; repeat has period 1)."""
+    L = oracle.lib()
+    rng = np.random.RandomState(5)
+    tex = rng.randint(0, 256, size=(2, 8, 8, 4)).astype(np.uint8)
+    ref = oracle.RefLayoutScene(*(np.zeros(0, d) for d in (wire.TRIANGLE, wire.TRI_GEOMETRY, wire.TRI_DATA, wire.MATERIAL,
+                                                            wire.BVH_NODE, wire.BLAS_INSTANCE, wire.TLAS_NODE)), textures=tex)
+    view = ref.view(mode)
+
+    def sample(u, v, layer):
+        out = (C.c_float * 3)()
+        L.jpto_sample_texture(C.byref(view), float(u), float(v), layer, out)
+        return np.array(out[:], dtype=np.float64)
+
+    for u, v in rng.uniform(-2.5, 3.5, size=(300, 2)):
+        for layer in (0, 1):
+            assert np.allclose(sample(u, v, layer), npr.sample_texture(tex, u, v, layer, mode), rtol=0, atol=2e-6), (u, v, mode)
+    for ix in range(8):
+        for iy in range(8):
+            want = tex[1, iy, ix, :3].astype(np.float32) / np.float32(255)
+            got = sample((ix + 0.5) / 8.0, (iy + 0.5) / 8.0, 1)
+            assert np.array_equal(got.astype(np.float32), want), (ix, iy, mode)
+    if mode & 1:   # repeat: whole texture periods are exact in float for these coordinates
+        for u, v in ((0.3125, 0.6875), (0.03125, 0.96875)):
+            assert np.array_equal(sample(u, v, 0), sample(u + 2.0, v - 1.0, 0))
+    else:          # clamp-to-edge: everything beyond the edge texel centre is the edge texel
+        assert np.array_equal(sample(-3.0, 0.5, 0), sample(0.01, 0.5, 0)) and np.array_equal(sample(7.0, 0.5, 0), sample(0.99, 0.5, 0))

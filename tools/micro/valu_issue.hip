@@ -2,11 +2,14 @@
 //
 // The question behind DESIGN.md's issue-rate accounting: MI355X_MICROARCH.md says "SIMD-32, 2 cycles per wave64
 // instruction with >= 2 waves per SIMD, 4 for a wave alone"; the SQ counters of round 1 (SQ_ACTIVE_INST_VALU /
-// SQ_INSTS_VALU = 1.0 quad-cycle) read 4.  This program measures it directly: every wave runs a loop of 16
-// INDEPENDENT instructions of one kind (16 accumulators, inline asm so nothing is folded), with 1, 2, 4 or 8 waves
-// resident per SIMD (blocks of 256 threads = one wave per SIMD, `w` blocks per CU), and reports
-//     cycles per instruction per SIMD = wave cycles (s_memtime) / (waves per SIMD x instructions per wave)
-// from the median wave, plus the same figure from wall time at the clock the chip held (s_memrealtime).
+// SQ_INSTS_VALU = 1.0 quad-cycle) read 4.  This program measures it directly.  Every wave runs a loop whose body is
+// 64 INDEPENDENT instructions of one kind (16 accumulators x 4, inline asm so nothing is folded).  Residency is
+// pinned, not hoped for: a workgroup of 256 * min(w, 4) threads puts min(w, 4) waves on each SIMD of its CU, and a
+// dynamic LDS allocation of more than half (w <= 4) or just under half (w = 8) of the CU's 160 KiB makes exactly one
+// or two workgroups fit per CU; the grid is one (two) workgroups per CU.  Reported:
+//     cycles per instruction per SIMD = median wave's s_memtime cycles / (w x instructions per wave)
+// and the same from the launch's wall time at the clock the chip held (s_memtime / s_memrealtime); the two agree when
+// all waves really ran side by side.
 //
 //   hipcc --offload-arch=gfx950 -O2 -o valu_issue valu_issue.hip && ./valu_issue
 #include <hip/hip_runtime.h>
@@ -17,16 +20,21 @@
 #include <vector>
 
 #define REP16(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15)
+#define REP64(X) REP16(X) REP16(X) REP16(X) REP16(X)
 
-enum Kind { FMA = 0, MUL, MIN, MAX3, CNDMASK, PK_FMA, PK_MUL, RCP, FMA_DEP, FMA_16LANES, MIX_SALU, N_KINDS };
-static const char* kKindName[N_KINDS] = {"v_fma_f32", "v_mul_f32", "v_min_f32", "v_max3_f32", "v_cndmask_b32", "v_pk_fma_f32",
-                                         "v_pk_mul_f32", "v_rcp_f32", "v_fma_f32 (one dependent chain)", "v_fma_f32, 16 of 64 lanes enabled",
-                                         "v_fma_f32 + s_add_u32 interleaved (VALU count only)"};
+enum Kind { FMA = 0, MUL, ADD, MIN, MAX3, PK_FMA, PK_MUL, RCP, FMA_DEP, FMA_16LANES, SUB, FMAC, CNDMASK, CMP_F32, CMP_U32, AND, OR, LSHL, ADD_U32, MOV, MIN_U32, MED3, MIN3, AND_OR, BFE, CVT_F32_U32, MUL_LO_U32, MAD_U32_U24, MOV_DPP, SQRT, N_KINDS };
+static const char* kKindName[N_KINDS] = {"v_fma_f32", "v_mul_f32", "v_add_f32", "v_min_f32", "v_max3_f32", "v_pk_fma_f32", "v_pk_mul_f32",
+                                         "v_rcp_f32", "v_fma_f32, ONE dependent chain", "v_fma_f32, 16 of 64 lanes enabled",
+                                         "v_sub_f32", "v_fmac_f32", "v_cndmask_b32 (sgpr mask)", "v_cmp_lt_f32 -> sgpr pair", "v_cmp_lt_u32 -> sgpr pair",
+                                         "v_and_b32", "v_or_b32", "v_lshlrev_b32", "v_add_u32", "v_mov_b32", "v_min_u32", "v_med3_f32", "v_min3_f32",
+                                         "v_and_or_b32", "v_bfe_u32", "v_cvt_f32_u32", "v_mul_lo_u32", "v_mad_u32_u24", "v_mov_b32 dpp quad_perm",
+                                         "v_sqrt_f32"};
 
 template <int KIND>
-__global__ __launch_bounds__(256) void issue_loop(float* __restrict__ out, unsigned long long* __restrict__ cycles,
-                                                  unsigned long long* __restrict__ realtime, int iters)
+__global__ __launch_bounds__(1024) void issue_loop(float* __restrict__ out, unsigned long long* __restrict__ cycles,
+                                                   unsigned long long* __restrict__ realtime, int iters)
 {
+    extern __shared__ float lds[];
     float a[16];
     float2 p[16];
     for (int k = 0; k < 16; k++) {
@@ -35,8 +43,9 @@ __global__ __launch_bounds__(256) void issue_loop(float* __restrict__ out, unsig
     }
     float b = 1.0001f, c = 1e-6f;
     float2 pb = make_float2(1.0001f, 0.9999f), pc = make_float2(1e-6f, 2e-6f);
-    unsigned int s = 0;
+    unsigned long long msk = 0x5555555555555555ull + (unsigned long long)iters, mo[4] = {0, 0, 0, 0};
     const bool on = KIND != FMA_16LANES || (threadIdx.x & 63) < 16;
+    if (threadIdx.x == 0) lds[0] = 0.0f;
     __syncthreads();
     const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
@@ -44,113 +53,223 @@ __global__ __launch_bounds__(256) void issue_loop(float* __restrict__ out, unsig
         for (int i = 0; i < iters; i++) {
             if (KIND == FMA || KIND == FMA_16LANES) {
 #define X(k) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[k]) : "v"(b), "v"(c));
-                REP16(X)
+                REP64(X)
 #undef X
             } else if (KIND == MUL) {
 #define X(k) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(a[k]) : "v"(b));
-                REP16(X)
+                REP64(X)
+#undef X
+            } else if (KIND == ADD) {
+#define X(k) asm volatile("v_add_f32 %0, %0, %1" : "+v"(a[k]) : "v"(c));
+                REP64(X)
 #undef X
             } else if (KIND == MIN) {
 #define X(k) asm volatile("v_min_f32 %0, %0, %1" : "+v"(a[k]) : "v"(b));
-                REP16(X)
+                REP64(X)
 #undef X
             } else if (KIND == MAX3) {
 #define X(k) asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(a[k]) : "v"(b), "v"(c));
-                REP16(X)
-#undef X
-            } else if (KIND == CNDMASK) {
-#define X(k) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[k]) : "v"(b) : );
-                REP16(X)
+                REP64(X)
 #undef X
             } else if (KIND == PK_FMA) {
 #define X(k) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(p[k]) : "v"(pb), "v"(pc));
-                REP16(X)
+                REP64(X)
 #undef X
             } else if (KIND == PK_MUL) {
 #define X(k) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(p[k]) : "v"(pb));
-                REP16(X)
+                REP64(X)
 #undef X
             } else if (KIND == RCP) {
 #define X(k) asm volatile("v_rcp_f32 %0, %0" : "+v"(a[k]));
-                REP16(X)
+                REP64(X)
+#undef X
+            } else if (KIND == SUB) {
+#define X(k) asm volatile("v_sub_f32 %0, %0, %1" : "+v"(a[k]) : "v"(c));
+                REP64(X)
+#undef X
+            } else if (KIND == FMAC) {
+#define X(k) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(a[k]) : "v"(b), "v"(c));
+                REP64(X)
+#undef X
+            } else if (KIND == CNDMASK) {
+#define X(k) asm volatile("v_cndmask_b32 %0, %0, %1, %2" : "+v"(a[k]) : "v"(b), "s"(msk));
+                REP64(X)
+#undef X
+            } else if (KIND == CMP_F32) {
+#define X(k) asm volatile("v_cmp_lt_f32 %0, %1, %2" : "=s"(mo[k & 3]) : "v"(a[k]), "v"(b));
+                REP64(X)
+#undef X
+            } else if (KIND == CMP_U32) {
+#define X(k) asm volatile("v_cmp_lt_u32 %0, %1, %2" : "=s"(mo[k & 3]) : "v"(a[k]), "v"(b));
+                REP64(X)
+#undef X
+            } else if (KIND == AND) {
+#define X(k) asm volatile("v_and_b32 %0, %0, %1" : "+v"(a[k]) : "v"(b));
+                REP64(X)
+#undef X
+            } else if (KIND == OR) {
+#define X(k) asm volatile("v_or_b32 %0, %0, %1" : "+v"(a[k]) : "v"(b));
+                REP64(X)
+#undef X
+            } else if (KIND == LSHL) {
+#define X(k) asm volatile("v_lshlrev_b32 %0, 1, %0" : "+v"(a[k]));
+                REP64(X)
+#undef X
+            } else if (KIND == ADD_U32) {
+#define X(k) asm volatile("v_add_u32 %0, %0, %1" : "+v"(a[k]) : "v"(b));
+                REP64(X)
+#undef X
+            } else if (KIND == MOV) {
+#define X(k) asm volatile("v_mov_b32 %0, %1" : "=v"(a[k]) : "v"(b));
+                REP64(X)
+#undef X
+            } else if (KIND == MIN_U32) {
+#define X(k) asm volatile("v_min_u32 %0, %0, %1" : "+v"(a[k]) : "v"(b));
+                REP64(X)
+#undef X
+            } else if (KIND == MED3) {
+#define X(k) asm volatile("v_med3_f32 %0, %0, %1, %2" : "+v"(a[k]) : "v"(b), "v"(c));
+                REP64(X)
+#undef X
+            } else if (KIND == MIN3) {
+#define X(k) asm volatile("v_min3_f32 %0, %0, %1, %2" : "+v"(a[k]) : "v"(b), "v"(c));
+                REP64(X)
+#undef X
+            } else if (KIND == AND_OR) {
+#define X(k) asm volatile("v_and_or_b32 %0, %0, %1, %2" : "+v"(a[k]) : "v"(b), "v"(c));
+                REP64(X)
+#undef X
+            } else if (KIND == BFE) {
+#define X(k) asm volatile("v_bfe_u32 %0, %0, %1, 8" : "+v"(a[k]) : "v"(b));
+                REP64(X)
+#undef X
+            } else if (KIND == CVT_F32_U32) {
+#define X(k) asm volatile("v_cvt_f32_u32 %0, %0" : "+v"(a[k]));
+                REP64(X)
+#undef X
+            } else if (KIND == MUL_LO_U32) {
+#define X(k) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(a[k]) : "v"(b));
+                REP64(X)
+#undef X
+            } else if (KIND == MAD_U32_U24) {
+#define X(k) asm volatile("v_mad_u32_u24 %0, %0, %1, %2" : "+v"(a[k]) : "v"(b), "v"(c));
+                REP64(X)
+#undef X
+            } else if (KIND == MOV_DPP) {
+#define X(k) asm volatile("v_mov_b32_dpp %0, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "=v"(a[k]) : "v"(b));
+                REP64(X)
+#undef X
+            } else if (KIND == SQRT) {
+#define X(k) asm volatile("v_sqrt_f32 %0, %0" : "+v"(a[k]));
+                REP64(X)
 #undef X
             } else if (KIND == FMA_DEP) {
 #define X(k) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[0]) : "v"(b), "v"(c));
-                REP16(X)
-#undef X
-            } else if (KIND == MIX_SALU) {
-#define X(k) asm volatile("v_fma_f32 %0, %0, %2, %3\n\ts_add_u32 %1, %1, 1" : "+v"(a[k]), "+s"(s) : "v"(b), "v"(c));
-                REP16(X)
+                REP64(X)
 #undef X
             }
         }
     }
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
     const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
-    float sum = (float)s;
+    float sum = lds[0] + (float)(mo[0] ^ mo[1] ^ mo[2] ^ mo[3]);
     for (int k = 0; k < 16; k++) sum += a[k] + p[k].x + p[k].y;
-    out[blockIdx.x * blockDim.x + threadIdx.x] = sum;
+    out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = sum;
     if ((threadIdx.x & 63) == 0) {
-        const size_t w = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+        const size_t w = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
         cycles[w] = t1 - t0;
         realtime[w] = r1 - r0;
     }
 }
 
+#define CK(x)                                                                          \
+    do {                                                                               \
+        hipError_t e_ = (x);                                                           \
+        if (e_ != hipSuccess) {                                                        \
+            std::printf("%s: %s\n", #x, hipGetErrorString(e_));                        \
+            std::exit(1);                                                              \
+        }                                                                              \
+    } while (0)
+
 template <int KIND>
 static void run_kind(float* out, unsigned long long* d_cyc, unsigned long long* d_rt, int n_cu)
 {
-    const int iters = 20000;
-    for (int w : {1, 2, 4, 8}) {
-        const int blocks = n_cu * w;
-        hipLaunchKernelGGL(issue_loop<KIND>, dim3(blocks), dim3(256), 0, 0, out, d_cyc, d_rt, 200);  // warm-up
+    const int iters = 4000;
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(issue_loop<KIND>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
+    for (int w : {(KIND <= FMA_16LANES ? 1 : 4), 2, 4, 8}) {
+        if (KIND > FMA_16LANES && w == 2) continue;   // the later kinds: 4 and 8 waves per SIMD only
+        const int threads = 256 * (w < 4 ? w : 4);
+        const int per_cu = w > 4 ? 2 : 1;
+        const size_t lds_bytes = per_cu == 2 ? 72 * 1024 : 100 * 1024;  // two fit / only one fits in 160 KiB
+        const int blocks = n_cu * per_cu;
+        hipLaunchKernelGGL(issue_loop<KIND>, dim3(blocks), dim3(threads), lds_bytes, 0, out, d_cyc, d_rt, 50);  // warm-up
         hipEvent_t e0, e1;
-        hipEventCreate(&e0);
-        hipEventCreate(&e1);
-        hipEventRecord(e0);
-        hipLaunchKernelGGL(issue_loop<KIND>, dim3(blocks), dim3(256), 0, 0, out, d_cyc, d_rt, iters);
-        hipEventRecord(e1);
-        hipEventSynchronize(e1);
+        CK(hipEventCreate(&e0));
+        CK(hipEventCreate(&e1));
+        CK(hipEventRecord(e0));
+        hipLaunchKernelGGL(issue_loop<KIND>, dim3(blocks), dim3(threads), lds_bytes, 0, out, d_cyc, d_rt, iters);
+        CK(hipEventRecord(e1));
+        CK(hipEventSynchronize(e1));
         float ms = 0;
-        hipEventElapsedTime(&ms, e0, e1);
-        std::vector<unsigned long long> cyc((size_t)blocks * 4), rt((size_t)blocks * 4);
-        hipMemcpy(cyc.data(), d_cyc, cyc.size() * 8, hipMemcpyDeviceToHost);
-        hipMemcpy(rt.data(), d_rt, rt.size() * 8, hipMemcpyDeviceToHost);
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        const size_t n_waves = (size_t)blocks * (threads / 64);
+        std::vector<unsigned long long> cyc(n_waves), rt(n_waves);
+        CK(hipMemcpy(cyc.data(), d_cyc, n_waves * 8, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(rt.data(), d_rt, n_waves * 8, hipMemcpyDeviceToHost));
         std::sort(cyc.begin(), cyc.end());
         std::sort(rt.begin(), rt.end());
-        const double med = (double)cyc[cyc.size() / 2], med_rt = (double)rt[rt.size() / 2];
-        const double n_inst = (double)iters * 16.0;
+        const double med = (double)cyc[n_waves / 2], med_rt = (double)rt[n_waves / 2];
+        const double n_inst = (double)iters * 64.0;
         const double clock_ghz = med / (med_rt * 10.0);  // s_memrealtime ticks at 100 MHz
-        std::printf("%-52s waves/SIMD %d: %6.3f cycles per instruction per SIMD (median wave %.0f cycles, in-kernel clock %.2f GHz, "
-                    "launch %.3f ms => %.3f from wall time)\n",
-                    kKindName[KIND], w, med / ((double)w * n_inst), med, clock_ghz, ms,
+        std::printf("%-36s waves/SIMD %d: %6.3f cycles per instruction per SIMD (median wave %.0f cycles, min %.0f, max %.0f; in-kernel clock "
+                    "%.2f GHz; launch %.3f ms => %.3f from wall time)\n",
+                    kKindName[KIND], w, med / ((double)w * n_inst), med, (double)cyc.front(), (double)cyc.back(), clock_ghz, ms,
                     (double)ms * 1e-3 * clock_ghz * 1e9 / ((double)w * n_inst));
-        hipEventDestroy(e0);
-        hipEventDestroy(e1);
+        CK(hipEventDestroy(e0));
+        CK(hipEventDestroy(e1));
     }
 }
 
 int main()
 {
     hipDeviceProp_t prop;
-    hipGetDeviceProperties(&prop, 0);
+    CK(hipGetDeviceProperties(&prop, 0));
     const int n_cu = prop.multiProcessorCount;
     std::printf("%s, %d CUs, %d MHz\n", prop.gcnArchName, n_cu, prop.clockRate / 1000);
     float* out;
     unsigned long long *d_cyc, *d_rt;
-    hipMalloc(&out, (size_t)n_cu * 8 * 256 * sizeof(float));
-    hipMalloc(&d_cyc, (size_t)n_cu * 8 * 4 * 8);
-    hipMalloc(&d_rt, (size_t)n_cu * 8 * 4 * 8);
+    CK(hipMalloc(&out, (size_t)n_cu * 2 * 1024 * sizeof(float)));
+    CK(hipMalloc(&d_cyc, (size_t)n_cu * 2 * 16 * 8));
+    CK(hipMalloc(&d_rt, (size_t)n_cu * 2 * 16 * 8));
     run_kind<FMA>(out, d_cyc, d_rt, n_cu);
     run_kind<MUL>(out, d_cyc, d_rt, n_cu);
+    run_kind<ADD>(out, d_cyc, d_rt, n_cu);
     run_kind<MIN>(out, d_cyc, d_rt, n_cu);
     run_kind<MAX3>(out, d_cyc, d_rt, n_cu);
-    run_kind<CNDMASK>(out, d_cyc, d_rt, n_cu);
     run_kind<PK_FMA>(out, d_cyc, d_rt, n_cu);
     run_kind<PK_MUL>(out, d_cyc, d_rt, n_cu);
     run_kind<RCP>(out, d_cyc, d_rt, n_cu);
     run_kind<FMA_DEP>(out, d_cyc, d_rt, n_cu);
     run_kind<FMA_16LANES>(out, d_cyc, d_rt, n_cu);
-    run_kind<MIX_SALU>(out, d_cyc, d_rt, n_cu);
+    run_kind<SUB>(out, d_cyc, d_rt, n_cu);
+    run_kind<FMAC>(out, d_cyc, d_rt, n_cu);
+    run_kind<CNDMASK>(out, d_cyc, d_rt, n_cu);
+    run_kind<CMP_F32>(out, d_cyc, d_rt, n_cu);
+    run_kind<CMP_U32>(out, d_cyc, d_rt, n_cu);
+    run_kind<AND>(out, d_cyc, d_rt, n_cu);
+    run_kind<OR>(out, d_cyc, d_rt, n_cu);
+    run_kind<LSHL>(out, d_cyc, d_rt, n_cu);
+    run_kind<ADD_U32>(out, d_cyc, d_rt, n_cu);
+    run_kind<MOV>(out, d_cyc, d_rt, n_cu);
+    run_kind<MIN_U32>(out, d_cyc, d_rt, n_cu);
+    run_kind<MED3>(out, d_cyc, d_rt, n_cu);
+    run_kind<MIN3>(out, d_cyc, d_rt, n_cu);
+    run_kind<AND_OR>(out, d_cyc, d_rt, n_cu);
+    run_kind<BFE>(out, d_cyc, d_rt, n_cu);
+    run_kind<CVT_F32_U32>(out, d_cyc, d_rt, n_cu);
+    run_kind<MUL_LO_U32>(out, d_cyc, d_rt, n_cu);
+    run_kind<MAD_U32_U24>(out, d_cyc, d_rt, n_cu);
+    run_kind<MOV_DPP>(out, d_cyc, d_rt, n_cu);
+    run_kind<SQRT>(out, d_cyc, d_rt, n_cu);
     return 0;
 }
