@@ -13,6 +13,14 @@ resident in HBM before the timed region starts.
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 Rank 0 prints ONE JSON line.  `value` = ray segments actually traced by all ranks / max-over-ranks time.
+At N = 1 the line also carries
+  parity        the image of the timed region's last step against the CPU oracle's render of the same workload (the
+                oracle walks the REFERENCE tree, the GPU the native one): relative L2 on the accumulation buffer, number of
+                differing pixels, tolerance 1e-4 -- the process exits with status 3 when the tolerance is exceeded;
+  cpu_baseline  that oracle render's rate on the host cores;
+  roofline      the dominant kernel (wf2_trace) alone: algorithmic bytes of the work it did / its launch duration, both
+                from serial launches, beside the HBM traffic of the committed rocprofv3 counter passes;
+  value_closeup the same scene with the camera at the box opening (every pixel sees geometry).
 """
 import argparse
 import json
@@ -22,33 +30,32 @@ import time
 
 import numpy as np
 
-# The HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4), dealt in the
-# order the streams are first used; streams that share a queue run in submission order.  The library keeps four
-# renders in flight on four streams plus the context's stream, so it wants more than four queues, and it wants to
-# stay off the LAST queue of the pool (a render stream that lands there costs 23 %: 1.58 instead of 1.28 ms on C3,
-# whatever the pool size -- DESIGN.md section 4).  Sixteen leaves room for the streams RCCL and torch use first.
-# Read at runtime start-up: set before torch is imported.
-if os.environ.get("JPT_BENCH_BACKEND", "nccl") == "nccl":   # (the gloo rehearsal puts several ranks on ONE GPU: their queues add up)
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+# (The library asks for its pool of hardware queues itself when it is loaded -- csrc/jpt_capi.hip, HwQueueRequest.  The
+# gloo rehearsal puts several ranks on ONE GPU, where the ranks' queues add up: it keeps the runtime's default of four.)
+if os.environ.get("JPT_BENCH_BACKEND", "nccl") != "nccl":
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "4")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+PARITY_TOLERANCE = 1e-4  # BASELINE.json north_star: relative L2 on the accumulated buffer
 
-# bytes one event touches in the flattened layout (DESIGN.md "Algorithmic bytes")
-WIDE_BYTES = dict(blas_expand=64, tri_tests=48, tlas_expand=64, inst_visits=64, rays=32 + 20)
-# native builder: four-child 128-byte records
-WIDE4_BYTES = dict(blas_expand=128, tri_tests=48, tlas_expand=128, inst_visits=64, rays=32 + 20)
+# bytes one event of the traversal kernels touches in the flattened layout
+WIDE_BYTES = dict(blas_expand=64, tri_tests=48, tlas_expand=64, inst_visits=64)    # two-child 64-byte records (reference-exact trees)
+WIDE4_BYTES = dict(blas_expand=128, tri_tests=48, tlas_expand=128, inst_visits=64)  # native builder: four-child 128-byte records
+RAY_IN, HIT_OUT = 32, 20   # a queued ray read, a hit record written
 # the same events priced in the reference layout
 REF_BYTES = dict(blas_expand=96, tri_tests=48, tlas_expand=64, inst_visits=224, shaded_hits=320)
 
+COUNTER_KEYS = ("rays", "blas_expand", "tri_tests", "tlas_expand", "inst_visits", "shaded_hits", "sky_culled")
 
-def algorithmic_bytes(stats, table):
-    """Bytes the traversal kernel asks for, from exact event counts: one 64-B record per BLAS/TLAS expansion,
-    48 B per triangle test, 64 B per instance visit, a 32-B ray in and a 20-B hit out per ray."""
-    return sum(stats[k] * v for k, v in table.items())
+
+def rel_l2(a, b):
+    a = a[..., :3].astype(np.float64)
+    b = b[..., :3].astype(np.float64)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
 
 
 def main():
@@ -61,14 +68,15 @@ def main():
     ap.add_argument("--spp", type=int, default=8)
     ap.add_argument("--bounces", type=int, default=4)
     ap.add_argument("--tris", type=int, default=51200)
-    ap.add_argument("--scene", default="demo", choices=["demo", "cornell", "inst"])
+    ap.add_argument("--scene", default="demo", choices=["demo", "cornell", "inst", "unique"])
     ap.add_argument("--builder", default="sah", choices=["sah", "exact", "watertight"])
     ap.add_argument("--accum", default="ldr8", choices=["ldr8", "hdr"])
     ap.add_argument("--kernel", default="wavefront", choices=["wavefront", "ref"])
     ap.add_argument("--camera", default="demo", choices=["demo", "closeup"],
                     help="demo = demo.tscn's camera (the box covers ~1/6 of the frame); closeup = camera at the box opening "
-                         "(every pixel sees geometry; not the headline config)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
+                         "(every pixel sees geometry; reported as value_closeup by the default run)")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the oracle legs (cpu_baseline and parity)")
+    ap.add_argument("--no-closeup", action="store_true", help="skip the second timed region (value_closeup)")
     ap.add_argument("--verify", action="store_true",
                     help="after the timed region, rank 0 re-renders the whole image alone and checks the assembled one bit for bit")
     ap.add_argument("--gather", choices=["ldr", "accum"], default="accum",
@@ -78,6 +86,8 @@ def main():
     ap.add_argument("--cpu-sample", default="auto")
     ap.add_argument("--pmc-json", default=os.path.join(ROOT, "profiles", "current_pmc.json"),
                     help="per-launch HBM bytes of each kernel from the committed rocprofv3 --pmc passes (tools/pmc.sh)")
+    ap.add_argument("--sq-json", default=os.path.join(ROOT, "profiles", "current_sq.json"),
+                    help="per-launch SQ counters of each kernel from the committed rocprofv3 --pmc passes (tools/diag.sh)")
     args = ap.parse_args()
 
     import torch
@@ -110,17 +120,21 @@ def main():
         sc = scenes.demo_scene(args.tris)
     elif args.scene == "cornell":
         sc = scenes.cornell_scene()
+    elif args.scene == "unique":
+        sc = scenes.unique_scene()
     else:
         sc = scenes.instanced_scene()
+    closeup_camera = scenes.CameraDesc(scenes.transform12(None, (0.0, 0.0, 4.2)), fov_deg=75.0)
     if args.camera == "closeup":
-        sc.camera = scenes.CameraDesc(scenes.transform12(None, (0.0, 0.0, 4.2)), fov_deg=75.0)
+        sc.camera = closeup_camera
     W, H, spp, bounces = args.width, args.height, args.spp, args.bounces
     cam = scenes.camera_block(sc.camera, W, H)
     accum_mode = capi.ACCUM_REF_LDR8 if args.accum == "ldr8" else capi.ACCUM_HDR_F32
+    builder = {"sah": capi.BUILD_SAH, "exact": capi.BUILD_REFERENCE_EXACT, "watertight": capi.BUILD_SAH_WATERTIGHT}[args.builder]
 
     ctx = host.Context(local_rank)
     t0 = time.time()
-    ctx.build_scene(sc, {"sah": capi.BUILD_SAH, "exact": capi.BUILD_REFERENCE_EXACT, "watertight": capi.BUILD_SAH_WATERTIGHT}[args.builder])
+    ctx.build_scene(sc, builder)
     build_s = time.time() - t0
     ctx.set_partition(rank, world)
     ctx.set_params(W, H, bounces, accum_mode)
@@ -132,7 +146,7 @@ def main():
     # created next, would land on the very queue the pool stream sits on -- one frame per render 0.40 instead of 0.31 ms.)
     stream = torch.cuda.ExternalStream(ctx.get_stream(), device=torch.device("cuda", local_rank))
     torch.cuda.set_stream(stream)
-    ctx.set_kernel_timing(False)   # per-launch HIP events serialise the frame groups: they are collected after the timed region
+    ctx.set_kernel_timing(False)   # per-launch HIP events serialise the launches: they are collected after the timed region
 
     # gather plumbing (N > 1): the local piece (rgba8 display rows, or float4 sums) viewed as a torch tensor, no copy
     piece = gathered = None
@@ -169,23 +183,37 @@ def main():
         if world > 1:
             exchange()
 
-    # exact event counts of one step (deterministic), outside the timed region
-    ctx.accum_reset()
-    ctx.render(spp, 1, counted=True)
-    st = ctx.stats()
-    counts = torch.tensor([st[k] for k in ("rays", "blas_expand", "tri_tests", "tlas_expand", "inst_visits", "shaded_hits")],
-                          dtype=torch.int64, device="cuda" if backend == "nccl" else "cpu")
-    if world > 1:
-        dist.all_reduce(counts)
-    rays, blas_expand, tri_tests, tlas_expand, inst_visits, shaded_hits = [int(x) for x in counts.tolist()]
-    total = dict(rays=rays, blas_expand=blas_expand, tri_tests=tri_tests, tlas_expand=tlas_expand,
-                 inst_visits=inst_visits, shaded_hits=shaded_hits)
+    def counted(n_bounces):
+        """exact event counts of one step (deterministic), outside the timed region; summed over the ranks"""
+        ctx.set_params(W, H, n_bounces, accum_mode)
+        ctx.accum_reset()
+        ctx.render(spp, 1, counted=True)
+        st = ctx.stats()
+        t = torch.tensor([st[k] for k in COUNTER_KEYS], dtype=torch.int64, device="cuda" if backend == "nccl" else "cpu")
+        if world > 1:
+            dist.all_reduce(t)
+        return dict(zip(COUNTER_KEYS, (int(x) for x in t.tolist())))
+
+    primary = counted(0) if args.kernel == "wavefront" else None   # the bounce-0 launch alone
+    total = counted(bounces)                                        # (leaves the context at the workload's bounce count)
+    rays = total["rays"]
 
     def barrier():
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+
+    def timed(n_steps):
+        t0 = time.perf_counter()
+        for _ in range(n_steps):
+            step()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
 
     # Set-up, like the allocations above: the library creates its pipeline slots (a stream and a workspace each) at
     # the first queued render -- ~25 ms once per context, which is not a property of a step (--warmup 0 is honoured
@@ -200,68 +228,90 @@ def main():
     # render's launch tails overlap the next renders' kernels; the accumulation kernels run in call order, chained
     # through the context's stream.  (A queue of K renders takes K x rate + the latency of the last one, ~3 ms: small
     # K reads lower.)
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        ctx.accum_reset()
-        ctx.render(spp, 1, asynchronous=True)
-        if world > 1:
-            exchange()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+    elapsed = timed(args.steps)
+    gpu_image = ctx.read_accum() if (world == 1 and rank == 0) else None   # the image the timed region left behind (parity)
     verified = None
     if args.verify and rank == 0:
         got = ctx.read_ldr() if (world > 1 and args.gather == "ldr") else ctx.read_accum()
         solo = host.Context(local_rank)
-        solo.build_scene(sc, {"sah": capi.BUILD_SAH, "exact": capi.BUILD_REFERENCE_EXACT, "watertight": capi.BUILD_SAH_WATERTIGHT}[args.builder])
+        solo.build_scene(sc, builder)
         solo.set_params(W, H, bounces, accum_mode)
         solo.set_camera(cam)
         solo.render(spp, 1)
         verified = bool(np.array_equal(got, solo.read_ldr() if (world > 1 and args.gather == "ldr") else solo.read_accum()))
         solo.close()
 
-    # Duration of the dominant kernel, measured live with HIP events on the stream it is launched on: the library
-    # brackets every traversal launch when kernel timing is on, which also makes it run the launches one after
-    # another (in the timed region above, the frame groups' launches overlap, so a per-launch duration is not
-    # defined there).  Three untimed renders, after the timed region.
+    # Launch durations of the traversal kernels, measured live with HIP events on the stream they are launched on: the
+    # library brackets every traversal launch when kernel timing is on, which also makes it run the launches one after
+    # another (in the timed region above launches of different renders overlap, so a per-launch duration is not defined
+    # there).  Three untimed renders, after the timed region.
     ctx.set_kernel_timing(True)
-    trace_ms, render_ms = [], []
+    trace_ms, primary_ms, render_ms = [], [], []
     for _ in range(3):
         ctx.accum_reset()
         ctx.render(spp, 1)
         st = ctx.stats()
         trace_ms.append(st["last_trace_ms"])
+        primary_ms.append(st["last_primary_ms"])
         render_ms.append(st["last_render_ms"])   # device time of ONE render on its own (no overlap with a neighbour)
     ctx.set_kernel_timing(False)
-    n_trace_launches = (bounces + 1) if args.kernel != "ref" else spp
-    kernel_ms = float(np.mean(trace_ms)) / n_trace_launches   # average duration of ONE launch of the dominant kernel
+    if args.kernel == "wavefront":
+        dom, n_dom = "wf2_trace", max(bounces, 1)
+        dom_ms = (float(np.mean(trace_ms)) - float(np.mean(primary_ms))) / n_dom    # average duration of ONE wf2_trace launch
+    else:
+        dom, n_dom = "ref_frame_kernel", spp
+        dom_ms = float(np.mean(trace_ms)) / n_dom
 
+    # the close-up camera on the same context: every pixel sees geometry, so rays/s here is the traversal rate proper
+    closeup = None
+    if world == 1 and args.camera == "demo" and args.scene == "demo" and not args.no_closeup:
+        ctx.set_camera(scenes.camera_block(closeup_camera, W, H))
+        ctx.accum_reset()
+        ctx.render(spp, 1)
+        c_rays = ctx.stats()["rays"]
+        c_steps = max(10, args.steps // 2)
+        for _ in range(2):
+            step()
+        barrier()
+        c_elapsed = timed(c_steps)
+        closeup = dict(value=round(c_rays * c_steps / c_elapsed / 1e6, 3), ms_per_step=round(c_elapsed / c_steps * 1e3, 4),
+                       rays_per_step=c_rays, steps=c_steps)
+        ctx.set_camera(cam)
+
+    status = 0
     if rank == 0:
         n_pixels = W * H
         ms_per_step = elapsed / args.steps * 1e3
         mrays = rays * args.steps / elapsed / 1e6
-        # roofline of the dominant kernel (this rank's share of the events ~ total / world)
+        # ---- roofline of the dominant kernel alone, from the work it DID: the events of the bounce launches are the
+        # counted render's totals minus those of a bounce-0-only render; sky-culled primaries fetch nothing and are in
+        # neither (they belong to the bounce-0 launch anyway)
         table = WIDE4_BYTES if (args.builder != "exact" and args.kernel == "wavefront") else WIDE_BYTES
-        alg = algorithmic_bytes(total, table) / world / n_trace_launches               # per launch
-        alg_ref = (algorithmic_bytes(total, REF_BYTES) + n_pixels * spp * 48) / world / n_trace_launches
-        achieved = alg / (kernel_ms * 1e-3) / 1e9
-        # HBM traffic of the dominant kernel: PMC counters cannot be read from inside the process, so the
-        # per-launch figure comes from the committed rocprofv3 passes of this same command (profiles/)
-        traffic, traffic_src = None, None
-        dom = "wf2_trace" if args.kernel == "wavefront" else "ref_frame_kernel"
-        default_run = (W, H, spp, bounces, args.tris, args.scene, args.builder, world, args.camera) == (1920, 1080, 8, 4, 51200, "demo", "sah", 1, "demo")
+        if args.kernel == "wavefront":
+            ev = {k: total[k] - primary[k] for k in table}
+            dom_rays = total["rays"] - primary["rays"]
+        else:
+            ev, dom_rays = {k: total[k] for k in table}, total["rays"]
+        alg = (sum(ev[k] * v for k, v in table.items()) + dom_rays * (RAY_IN + HIT_OUT)) / world / n_dom     # per launch, this rank
+        achieved = alg / (dom_ms * 1e-3) / 1e9
+        alg_ref = sum(total[k] * v for k, v in REF_BYTES.items()) + n_pixels * spp * 48
+        # HBM traffic of that kernel: PMC counters cannot be read from inside the process, so the per-launch figure comes
+        # from the committed rocprofv3 passes of this same command (profiles/)
+        traffic = traffic_src = valu = None
+        default_run = (W, H, spp, bounces, args.tris, args.scene, args.builder, world, args.camera, args.kernel) == \
+                      (1920, 1080, 8, 4, 51200, "demo", "sah", 1, "demo", "wavefront")
         if default_run and os.path.exists(args.pmc_json):
             try:
                 pj = json.load(open(args.pmc_json))
-                doms = ["wf2_primary", "wf2_trace"] if args.kernel == "wavefront" else [dom]
-                traffic = int(sum(pj[k]["hbm_bytes_per_launch"] * pj[k]["launches"] for k in doms) /
-                              sum(pj[k]["launches"] for k in doms))
-                traffic_src = os.path.relpath(args.pmc_json, ROOT) + ": (2*FETCH_SIZE + WRITE_SIZE) KiB per launch, separate --pmc passes"
+                traffic = int(pj[dom]["hbm_bytes_per_launch"])
+                traffic_src = os.path.relpath(args.pmc_json, ROOT) + ": (2*FETCH_SIZE + WRITE_SIZE) KiB per launch of %s, separate --pmc passes" % dom
             except Exception:
                 traffic = None
+        if default_run and os.path.exists(args.sq_json):
+            try:
+                valu = json.load(open(args.sq_json)).get(dom)
+            except Exception:
+                valu = None
         out = {
             "metric": "Mrays/sec at 1920x1080, 8 spp, 4 bounces",
             "value": round(mrays, 3),
@@ -285,26 +335,30 @@ def main():
                 "scene_build_s": round(build_s, 4),
             },
             "roofline": {
-                "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
-                "kernel": "wf2_primary + wf2_trace (one launch per bounce, %d per render)" % n_trace_launches if args.kernel != "ref"
-                else "ref_frame_kernel (one launch per frame)",
-                "kernel_ms": round(kernel_ms, 4),
+                "bound": "hbm", "kernel": "%s (%d launches per render, serial launches)" % (dom, n_dom),
+                "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+                "algorithmic_bytes": int(alg), "kernel_ms": round(dom_ms, 4),
+                "traffic": traffic, "traffic_source": traffic_src,
+                "hbm_frac": round(traffic / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if traffic else None,
+                "binding": "valu_issue",
+                "valu": valu,
+                "note": "achieved = bytes the kernel ASKS for (records, triangles, instances, rays in, hits out: exact event counts "
+                        "of the bounce launches x record sizes) / launch duration; the scene (6 MB) is L2 / Infinity-Cache resident, "
+                        "so these are cache-served requests and hbm_frac (counter traffic / duration / peak) is what reaches HBM. "
+                        "What binds the kernel is VALU issue at about a third of the lanes (valu: committed SQ counters; DESIGN.md section 4).",
+                "primary_kernel_ms": round(float(np.mean(primary_ms)), 4),
                 "render_ms": round(float(np.mean(render_ms)), 4),
                 "render_ms_note": "one render alone, launches serialised (kernel timing on); ms_per_step is the pipelined rate",
-                "algorithmic_bytes": int(alg),
                 # what a render must move through HBM whatever the caches do -- the framebuffers it leaves
                 # behind (float4 sums, rgba8 screen, r32f depth), per render, not per launch
                 "compulsory_framebuffer_bytes_per_render": int(n_pixels * (16 + 4 + 4)),
-                "ref_layout_algorithmic_bytes": int(alg_ref),
-                "ref_layout_achieved": round(alg_ref / (kernel_ms * 1e-3) / 1e9, 2),
-                "note": "scene is L2/Infinity-Cache resident; bytes are cache-served requests, not HBM traffic. The kernels are "
-                        "VALU-issue-bound: 7.6e8 wave-level VALU instructions per C3 render x 4 cycles / (1024 SIMDs x 2.4 GHz) = "
-                        "1.24 ms, against which ms_per_step (renders queued, four in flight) is to be read; lane utilisation of "
-                        "wf2_trace is 30 % (rocprofv3 SQ counters, profiles/r01/r01h_sq_counters.txt, DESIGN.md section 4)",
+                "ref_layout_algorithmic_bytes_per_render": int(alg_ref),
             },
             "counters": total,
         }
+        if closeup is not None:
+            out["value_closeup"] = closeup["value"]
+            out["closeup"] = closeup
         if verified is not None:
             out["verified_bit_identical_to_one_context"] = verified
         if world == 1 and not args.no_cpu_baseline:
@@ -327,7 +381,7 @@ def main():
                     sw, sh = W, H
             scam = scenes.camera_block(sc.camera, sw, sh)
             t0 = time.perf_counter()
-            _, _, _, cnt, used = ob.render(ref, scam, sw, sh, bounces, spp, 1, accum_mode)
+            want, _, _, cnt, used = ob.render(ref, scam, sw, sh, bounces, spp, 1, accum_mode)
             dt = time.perf_counter() - t0
             out["cpu_baseline"] = {
                 "value": round(cnt["rays"] / dt / 1e6, 3), "unit": "Mrays/s", "cores": used, "kind": "port",
@@ -335,10 +389,35 @@ def main():
                 "sample": "same scene/camera/seeds at %dx%d, %d spp, %d bounces (%.1f s, %d rays); oracle = C restatement "
                           "of main.glsl over the reference-layout BVH, pthreads" % (sw, sh, spp, bounces, dt, cnt["rays"]),
             }
+            # parity: the oracle's image of that sample against the GPU's -- the timed region's own last image when the
+            # sample is the whole workload, else one more render of the sample size on the same context
+            if (sw, sh) == (W, H):
+                got, what = gpu_image, "the image the timed region left behind"
+            else:
+                ctx.set_params(sw, sh, bounces, accum_mode)
+                ctx.set_camera(scam)
+                ctx.accum_reset()
+                ctx.render(spp, 1)
+                got, what = ctx.read_accum(), "a render of the CPU sample's size after the timed region"
+                rays_gpu = ctx.stats()["rays"]
+                if rays_gpu != cnt["rays"]:
+                    what += " (ray segments: GPU %d, oracle %d)" % (rays_gpu, cnt["rays"])
+            err = rel_l2(got, want)
+            out["parity"] = {
+                "rel_l2": err, "differing_pixels": int((got != want).any(axis=-1).sum()), "pixels": int(sw * sh),
+                "tolerance": PARITY_TOLERANCE, "ok": bool(err <= PARITY_TOLERANCE),
+                "against": "oracle/ (CPU restatement walking the reference-exact tree; parity unpinned: DESIGN.md section 2), %dx%d, %d spp, "
+                           "%d bounces; GPU side: %s" % (sw, sh, spp, bounces, what),
+            }
+            if not err <= PARITY_TOLERANCE:
+                status = 3
         print(json.dumps(out))
     ctx.close()
     if world > 1:
         dist.destroy_process_group()
+    if status:
+        sys.stderr.write("bench.py: parity above tolerance\n")
+    sys.exit(status)
 
 
 if __name__ == "__main__":

@@ -46,7 +46,7 @@ class Stats(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("frames", C.c_uint64), ("blas_expand", C.c_uint64), ("tri_tests", C.c_uint64),
                 ("tlas_expand", C.c_uint64), ("inst_visits", C.c_uint64), ("shaded_hits", C.c_uint64),
                 ("last_render_ms", C.c_double), ("last_trace_ms", C.c_double), ("last_build_ms", C.c_double),
-                ("phase", C.c_uint64 * 8)]
+                ("phase", C.c_uint64 * 8), ("sky_culled", C.c_uint64), ("last_primary_ms", C.c_double)]
 
     def as_dict(self):
         d = {n: getattr(self, n) for n, _ in self._fields_}

@@ -744,7 +744,10 @@ int do_render_batch(jpt_ctx* c, int32_t n_frames, uint32_t first_frame_index, bo
             double tms = 0.0;
             for (int32_t k = 0; k + 1 < c->trace_events_used; k += 2) {
                 float t = 0.0f;
-                if (hipEventElapsedTime(&t, c->trace_events[(size_t)k], c->trace_events[(size_t)k + 1]) == hipSuccess) tms += t;
+                if (hipEventElapsedTime(&t, c->trace_events[(size_t)k], c->trace_events[(size_t)k + 1]) == hipSuccess) {
+                    tms += t;
+                    if (k == 0) c->stats.last_primary_ms = t;
+                }
             }
             c->stats.last_trace_ms = tms;
         }
@@ -769,6 +772,7 @@ int do_render_batch(jpt_ctx* c, int32_t n_frames, uint32_t first_frame_index, bo
             c->stats.inst_visits = h.inst_visits;
             c->stats.shaded_hits = h.shaded_hits;
             for (int k = 0; k < 8; k++) c->stats.phase[k] = h.phase[k];
+            c->stats.sky_culled = h.phase[7];
         }
     }
     return JPT_OK;

@@ -15,7 +15,7 @@ struct DevCounters {  // SURVEY.md 8(d) event counters
     unsigned long long rays, blas_expand, tri_tests, tlas_expand, inst_visits, shaded_hits;
     // wave-level phase statistics of the tracing kernels (counting builds only): how many times a phase ran
     // in a wave and how many lanes took part -- [0] rounds, [1] node iterations, [2] lanes in them, [3] leaf
-    // phases, [4] lanes in them, [5] instance phases, [6] lanes in them, [7] refills
+    // phases, [4] lanes in them, [5] instance phases, [6] lanes in them, [7] primary rays finished by the sky cull
     unsigned long long phase[8];
 };
 

@@ -187,7 +187,10 @@ __global__ __launch_bounds__(kBlock, JPT_PRIMARY_WAVES) void wf2_primary(WideSce
                         for (int k = 0; k < 4; k++)
                             if (k < cull.n && px >= cull.x0[k] && px <= cull.x1[k] && py >= cull.y0[k] && py <= cull.y1[k]) outside = false;
                         if (outside) {
-                            if (COUNT) cnt.tlas_expand++;
+                            if (COUNT) {
+                                cnt.tlas_expand++;
+                                cnt.phase[7]++;
+                            }
                             const f3 sky = mk3(0.0f, 0.0f, 0.0f) + mk3(1.0f, 1.0f, 1.0f) * sample_sky(ray.d);
                             wb.rad[path] = make_float4(sky.x, sky.y, sky.z, 0.0f);
                             if ((int)f == fp.depth_frame) wb.first_depth[slot] = cam.far_;

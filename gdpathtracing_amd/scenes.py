@@ -267,6 +267,22 @@ def instanced_scene(n_side=32, n_unique=8, tris_per_mesh=1024, seed=7) -> Scene:
     return Scene("inst%d" % (n_side * n_side), meshes, inst, _demo_materials(), cam)
 
 
+def unique_scene(n_tris=1_000_000, seed=3) -> Scene:
+    """S-unique (the stress variant of C4): ONE BLAS of n_tris unique triangles -- a finely displaced
+    blob that fills the open cube -- plus the cube and the light, seen from the box opening so that every pixel traces.
+    At the default size the reference layout is ~160 MB (48 + 80 B per triangle + nodes) and the flattened records
+    ~110 MB: past the 32 MB of L2, inside the 256 MB Infinity Cache; n_tris = 4_000_000 leaves that too.  The only
+    configuration where the record layout meets the memory system rather than the caches."""
+    meshes = [plane_mesh(), cornell_cube_mesh(), blob_mesh(n_tris, seed, major=0.62, minor=0.30)]
+    inst = [
+        Instance(0, _LIGHT_T, [1]),
+        Instance(1, _BOX_T, [2, 3, 4]),
+        Instance(2, transform12(rot_y(25.0) * 3.1, (0.0, -0.9, -0.4)), [5]),
+    ]
+    cam = CameraDesc(transform12(None, (0.0, 0.0, 4.2)), fov_deg=75.0)
+    return Scene("unique%d" % n_tris, meshes, inst, _demo_materials(), cam)
+
+
 def random_scene(seed: int, n_meshes: int = 4, n_instances: int = 9, tris_per_surface: int = 40, textured: bool = True,
                  coincident: bool = True) -> Scene:
     """Fuzz input: triangle soups (slivers, a few degenerate triangles, non-unit and inconsistent vertex normals,

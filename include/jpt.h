@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define JPT_ABI_VERSION 1
+#define JPT_ABI_VERSION 2
 
 typedef struct jpt_ctx jpt_ctx;
 
@@ -109,6 +109,10 @@ typedef struct {
     double   last_trace_ms;    /* of which: the path-tracing kernel(s) */
     double   last_build_ms;    /* host time of the last scene commit (builder + flatten + upload) */
     uint64_t phase[8];         /* counting renders: wave-level phase statistics of the tracing kernels (diagnostic) */
+    uint64_t sky_culled;       /* counting renders: primary rays finished without a walk (their pixel lies outside the screen
+                                  rectangles of the TLAS root's boxes); they ARE counted in `rays` and `tlas_expand`, as the
+                                  reference expands the root for them, but no record is fetched */
+    double   last_primary_ms;  /* kernel timing on: the bounce-0 launch alone (last_trace_ms = all traversal launches) */
 } jpt_stats;
 
 /* ---- lifetime --------------------------------------------------------------------------------- */

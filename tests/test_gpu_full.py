@@ -411,6 +411,100 @@ def test_c5_like_config_reduced(oracle, hiplib):
     ctx.close()
 
 
+def test_c5_full_size_on_one_gpu(oracle, hiplib):
+    """BASELINE config C5 at its full size -- 3840x2160, 16 spp, 6 bounces: 132.7 M paths in flight, a 15 GB wavefront
+    workspace -- on ONE context, through size-independent properties: every rank of an 8-way screen partition renders
+    its strips to exactly the rows the whole-image render has (checked for two of the eight ranks, one of them with the
+    ragged last strip); rows that see only sky equal the oracle's rows bit for bit; a band through the middle of the
+    cube equals the oracle walking the REFERENCE tree bit for bit (16 frames x 6 bounces of the full-resolution
+    camera); the frames can be split over two calls; the ray count lies between its bounds."""
+    sc = scenes.demo_scene(51200)
+    w, h, spp, b = 3840, 2160, 16, 6
+    ctx = make_ctx(sc, w, h, b, wire.ACCUM_REF_LDR8)
+    ctx.render(spp, 1)
+    full, full_ldr, rays = ctx.read_accum(), ctx.read_ldr(), ctx.stats()["rays"]
+    assert w * h * spp <= rays <= w * h * spp * (b + 1)
+    assert (full[..., 3] == 1).all() and (full[..., :3] >= 0).all() and (full[..., :3] <= spp + 1e-4).all()
+    ctx.accum_reset()
+    ctx.render(5, 1)
+    ctx.render(11, 6)
+    assert np.array_equal(ctx.read_accum(), full) and np.array_equal(ctx.read_ldr(), full_ldr)
+    ctx.close()
+    for r in (3, 7):
+        part = make_ctx(sc, w, h, b, wire.ACCUM_REF_LDR8, rank=r, world=8)
+        part.render(spp, 1)
+        rows = partition.rows_of_rank(h, r, 8)
+        assert part.local_rows() == len(rows)
+        assert np.array_equal(part.read_accum()[rows], full[rows]) and np.array_equal(part.read_ldr()[rows], full_ldr[rows])
+        part.close()
+    ref = oracle.build_scene(sc)
+    cam = scenes.camera_block(sc.camera, w, h)
+    for band in ((0, 8), (1076, 1084)):   # sky rows; rows through the cube, both characters and the light
+        acc = None
+        for f in range(spp):
+            c = cam.copy()
+            c["frame_index"] = 1 + f
+            rad, _, _ = oracle.trace_frame(ref, c, w, h, b, rows=band)
+            q = oracle.screen_rgba8(rad[band[0]:band[1]])[..., :3].astype(np.float32) / np.float32(255)
+            acc = q if acc is None else q + acc
+        assert np.array_equal(full[band[0]:band[1], :, :3], acc), band
+
+
+def test_unique_triangle_scene_reduced(oracle, hiplib):
+    """S-unique (one BLAS of unique triangles filling the cube, seen from the box opening) at 20 000 triangles, 256x144,
+    2 spp, 4 bounces: both builders and both kernels against the oracle."""
+    sc = scenes.unique_scene(20000)
+    w, h = 256, 144
+    ref = oracle.build_scene(sc)
+    want, want_ldr, want_depth, cnt, _ = oracle.render(ref, scenes.camera_block(sc.camera, w, h), w, h, 4, 2, 1, wire.ACCUM_REF_LDR8)
+    for builder in (capi.BUILD_SAH, capi.BUILD_REFERENCE_EXACT):
+        for kernel in KERNELS:
+            ctx = make_ctx(sc, w, h, 4, wire.ACCUM_REF_LDR8, builder, kernel)
+            ctx.render(2, 1)
+            assert np.array_equal(ctx.read_accum(), want), (builder, kernel)
+            assert np.array_equal(ctx.read_depth(), want_depth) and ctx.stats()["rays"] == cnt["rays"]
+            ctx.close()
+
+
+def test_unique_triangle_scene_full_size(oracle, hiplib):
+    """S-unique at 1 000 012 unique triangles (~110 MB of flattened records: past L2, inside the Infinity Cache),
+    1920x1080, 2 spp, 4 bounces.  Properties: a 2-way partition reproduces the whole image; the audit kernel agrees bit
+    for bit; a band of rows equals the oracle walking the reference tree of the same million triangles; every pixel's
+    first ray hits (the camera sits in the box opening), so the depth image holds no `far`."""
+    sc = scenes.unique_scene()
+    assert sc.n_unique_tris > 1_000_000
+    w, h, spp, b = 1920, 1080, 2, 4
+    ctx = make_ctx(sc, w, h, b, wire.ACCUM_REF_LDR8)
+    ctx.render(spp, 1)
+    full, depth, rays = ctx.read_accum(), ctx.read_depth(), ctx.stats()["rays"]
+    ctx.set_kernel(capi.KERNEL_REFERENCE_LAYOUT)
+    ctx.accum_reset()
+    ctx.render(spp, 1)
+    assert np.array_equal(ctx.read_accum(), full) and ctx.stats()["rays"] == rays
+    ctx.close()
+    assert rays > 2.2 * w * h * spp                     # paths go on bouncing inside the box
+    cam = scenes.camera_block(sc.camera, w, h)
+    assert (depth < 0.9999).all()                       # a miss stores far / (far - near) * (1 - near / far) = 1 (main.glsl:432)
+    for r in range(2):
+        part = make_ctx(sc, w, h, b, wire.ACCUM_REF_LDR8, rank=r, world=2)
+        part.render(spp, 1)
+        rows = partition.rows_of_rank(h, r, 2)
+        assert np.array_equal(part.read_accum()[rows], full[rows])
+        part.close()
+    ref = oracle.build_scene(sc)
+    band = (536, 544)
+    acc = None
+    for f in range(spp):
+        c = cam.copy()
+        c["frame_index"] = 1 + f
+        rad, _, _ = oracle.trace_frame(ref, c, w, h, b, rows=band)
+        q = oracle.screen_rgba8(rad[band[0]:band[1]])[..., :3].astype(np.float32) / np.float32(255)
+        acc = q if acc is None else q + acc
+    got = full[band[0]:band[1], :, :3]
+    print("unique scene, rows 536..543: differing pixels", int((got != acc).any(axis=-1).sum()), "rel_l2", rel_l2(got, acc))
+    assert rel_l2(got, acc) <= 1e-4
+
+
 def test_frame_batching_under_a_workspace_budget(hiplib, monkeypatch):
     """With a small workspace budget a many-frame render is split into batches in frame order: same image, same
     ray count as the unbatched render."""

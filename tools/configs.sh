@@ -11,3 +11,4 @@ run "C3 scene, close-up camera (every pixel hits)" --camera closeup
 run "1 frame per render (interactive use)" --spp 1
 run "C3 reference-exact tree" --builder exact
 run "C3 audit kernel" --kernel ref
+run "S-unique: 1 M unique triangles in one BLAS, close-up camera, 1920x1080 8spp 4b" --scene unique
