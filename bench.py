@@ -30,10 +30,12 @@ import time
 
 import numpy as np
 
-# (The library asks for its pool of hardware queues itself when it is loaded -- csrc/jpt_capi.hip, HwQueueRequest.  The
-# gloo rehearsal puts several ranks on ONE GPU, where the ranks' queues add up: it keeps the runtime's default of four.)
-if os.environ.get("JPT_BENCH_BACKEND", "nccl") != "nccl":
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "4")
+# Hardware queues.  The library asks for a pool of 16 itself when it is LOADED (csrc/jpt_capi.hip, HwQueueRequest), which is
+# in time when nothing has started the HIP runtime before -- but this process imports torch first, and the variable is read
+# when the runtime starts: set it here, before that.  (With the default of four, the library's four slot streams and the
+# context's stream share queues and the queued rate drops from 1.3 to 1.65 ms per C3 render.)  The gloo rehearsal puts
+# several ranks on ONE GPU, where the ranks' queues add up: it keeps the runtime's default.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16" if os.environ.get("JPT_BENCH_BACKEND", "nccl") == "nccl" else "4")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:

@@ -30,6 +30,9 @@ SYMBOLS = [
     "jpt_set_params", "jpt_set_kernel", "jpt_set_kernel_timing", "jpt_set_partition", "jpt_set_camera", "jpt_render", "jpt_render_counted", "jpt_render_async",
     "jpt_sync", "jpt_accum_reset", "jpt_set_denoising_mode", "jpt_set_temporal_params", "jpt_read_ldr_rgba8", "jpt_readback_ldr_begin", "jpt_readback_ldr_end", "jpt_read_accum_f32", "jpt_read_depth_f32",
     "jpt_device_accum", "jpt_assemble_from_ranks", "jpt_device_ldr", "jpt_assemble_ldr_from_ranks", "jpt_local_rows", "jpt_get_stats",
+    "jpt_scene_share", "jpt_multi_create", "jpt_multi_destroy", "jpt_multi_last_error", "jpt_multi_world", "jpt_multi_ctx",
+    "jpt_multi_share_scene", "jpt_multi_set_params", "jpt_multi_set_camera", "jpt_multi_accum_reset", "jpt_multi_set_gather",
+    "jpt_multi_render", "jpt_multi_sync", "jpt_multi_read_ldr_rgba8", "jpt_multi_read_accum_f32",
 ]
 
 
@@ -131,6 +134,24 @@ def lib():
     L.jpt_local_rows.argtypes = [vp]
     L.jpt_local_rows.restype = i32
     L.jpt_get_stats.argtypes = [vp, C.POINTER(Stats)]
+    L.jpt_scene_share.argtypes = [vp, vp]
+    L.jpt_multi_create.argtypes = [C.POINTER(C.c_int), C.c_int, C.POINTER(vp)]
+    L.jpt_multi_destroy.argtypes = [vp]
+    L.jpt_multi_destroy.restype = None
+    L.jpt_multi_last_error.argtypes = [vp]
+    L.jpt_multi_last_error.restype = C.c_char_p
+    L.jpt_multi_world.argtypes = [vp]
+    L.jpt_multi_ctx.argtypes = [vp, C.c_int]
+    L.jpt_multi_ctx.restype = vp
+    L.jpt_multi_share_scene.argtypes = [vp]
+    L.jpt_multi_set_params.argtypes = [vp, i32, i32, i32, i32, i32]
+    L.jpt_multi_set_camera.argtypes = [vp, vp]
+    L.jpt_multi_accum_reset.argtypes = [vp]
+    L.jpt_multi_set_gather.argtypes = [vp, i32]
+    L.jpt_multi_render.argtypes = [vp, i32, u32]
+    L.jpt_multi_sync.argtypes = [vp]
+    L.jpt_multi_read_ldr_rgba8.argtypes = [vp, vp]
+    L.jpt_multi_read_accum_f32.argtypes = [vp, vp]
     _lib = L
     return L
 

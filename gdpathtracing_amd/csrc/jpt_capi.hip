@@ -1041,6 +1041,28 @@ int jpt_scene_commit(jpt_ctx* c, int32_t builder)
     return rc;
 }
 
+int jpt_scene_share(jpt_ctx* dst, jpt_ctx* src)
+{
+    if (!dst || !src) return JPT_E_INVALID;
+    if (dst == src) return JPT_OK;
+    if (!src->host_scene_ready || src->building) return fail(dst, JPT_E_STATE, "the source context holds no committed scene");
+    if (src->tlas_dirty || src->refit_active) {  // bring the source's host arrays up to date with its last transforms
+        const int rc = jpt_scene_update_tlas(src);
+        if (rc != JPT_OK) return fail(dst, rc, std::string("source context: ") + src->error);
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    dst->scene_ready = dst->host_scene_ready = false;
+    dst->builder = src->builder;   // so that jpt_scene_set_instance_transform / update_tlas keep working on the copy
+    dst->ref = src->ref;
+    dst->ref_is_exact = src->ref_is_exact;
+    dst->native_tree = src->native_tree;
+    dst->build_mode = src->build_mode;
+    dst->building = false;
+    const int rc = upload_scene(dst);   // flatten + upload to dst's device; no builder runs
+    dst->stats.last_build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return rc;
+}
+
 namespace {
 
 // instances / TLAS of c->ref changed (BLASes did not): re-flatten that part and upload it

@@ -1,0 +1,264 @@
+// jpt_multi.hip -- one image tiled across several GPUs of a node from ONE process (include/jpt.h, jpt_multi_*).
+//
+// The screen partition itself is in the single-context API (jpt_set_partition: 8-row strips dealt round-robin, every rank
+// renders all frames of its strips, per-pixel RNG streams make the assembled image bit-identical to one GPU's).  What a
+// C++ host -- the addon's PathTracingCamera is one (path_tracing_camera.cpp:193-232) -- needs on top is the exchange:
+// this file owns one context per device, fans a render out to all of them and gathers every rank's float4 accumulation
+// rows on device 0 with peer-to-peer copies (hipMemcpyPeerAsync: one xGMI link per peer, the point-to-point pattern the
+// multi-process path gets from RCCL send/recv in bench.py), then lets rank 0 assemble them (jpt_assemble_from_ranks).
+// Written entirely on the public C ABI plus the HIP runtime; no collective library is needed inside one process.
+#include "../../include/jpt.h"
+
+#include <hip/hip_runtime.h>
+
+#include <new>
+#include <string>
+#include <vector>
+
+struct jpt_multi {
+    std::vector<int> devices;
+    std::vector<jpt_ctx*> ctx;
+    std::vector<hipEvent_t> rendered;   // per rank: recorded on the rank's stream behind its render
+    hipEvent_t assembled = nullptr;     // recorded on rank 0's stream behind the assembly: the ranks' buffers are free again
+    bool assembled_valid = false;
+    void* gathered = nullptr;           // device 0: world x piece bytes, rank-major
+    size_t gathered_bytes = 0;
+    bool ldr_only = false;
+    std::string error;
+};
+
+namespace {
+
+thread_local std::string g_multi_create_error;
+
+int mfail(jpt_multi* m, int code, const std::string& msg)
+{
+    if (m) m->error = msg;
+    return code;
+}
+int mfail_ctx(jpt_multi* m, int rank, int code)
+{
+    if (m) m->error = "rank " + std::to_string(rank) + ": " + jpt_last_error(m->ctx[(size_t)rank]);
+    return code;
+}
+int mfail_hip(jpt_multi* m, hipError_t e, const char* what) { return mfail(m, JPT_E_DEVICE, std::string(what) + ": " + hipGetErrorString(e)); }
+
+#define M_HIP(m, expr)                                          \
+    do {                                                        \
+        hipError_t e_ = (expr);                                 \
+        if (e_ != hipSuccess) return mfail_hip((m), e_, #expr); \
+    } while (0)
+
+}  // namespace
+
+extern "C" {
+
+int jpt_multi_create(const int* device_ids, int n_devices, jpt_multi** out)
+{
+    if (!out) return JPT_E_INVALID;
+    *out = nullptr;
+    if (!device_ids || n_devices < 1 || n_devices > 64) {
+        g_multi_create_error = "need 1..64 device ids";
+        return JPT_E_INVALID;
+    }
+    jpt_multi* m = new (std::nothrow) jpt_multi();
+    if (!m) return JPT_E_DEVICE;
+    m->devices.assign(device_ids, device_ids + n_devices);
+    for (int r = 0; r < n_devices; r++) {
+        jpt_ctx* c = nullptr;
+        const int rc = jpt_create(device_ids[r], &c);
+        if (rc != JPT_OK) {
+            g_multi_create_error = std::string("device ") + std::to_string(device_ids[r]) + ": " + jpt_last_error(nullptr);
+            jpt_multi_destroy(m);
+            return rc;
+        }
+        m->ctx.push_back(c);
+        (void)jpt_set_partition(c, r, n_devices);
+    }
+    // rank 0 pulls the peers' rows: it needs access to their memory (a device may appear more than once -- rehearsal on
+    // a box with fewer GPUs -- and is then its own peer)
+    (void)hipSetDevice(device_ids[0]);
+    for (int r = 1; r < n_devices; r++)
+        if (device_ids[r] != device_ids[0]) {
+            int can = 0;
+            (void)hipDeviceCanAccessPeer(&can, device_ids[0], device_ids[r]);
+            if (can) {
+                const hipError_t e = hipDeviceEnablePeerAccess(device_ids[r], 0);
+                if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) {
+                    g_multi_create_error = std::string("hipDeviceEnablePeerAccess: ") + hipGetErrorString(e);
+                    jpt_multi_destroy(m);
+                    return JPT_E_DEVICE;
+                }
+                (void)hipGetLastError();
+            }   // (without peer access hipMemcpyPeerAsync stages through the host: slower, still correct)
+        }
+    for (int r = 0; r < n_devices; r++) {
+        (void)hipSetDevice(device_ids[r]);
+        hipEvent_t e = nullptr;
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) {
+            g_multi_create_error = "hipEventCreate failed";
+            jpt_multi_destroy(m);
+            return JPT_E_DEVICE;
+        }
+        m->rendered.push_back(e);
+    }
+    (void)hipSetDevice(device_ids[0]);
+    if (hipEventCreateWithFlags(&m->assembled, hipEventDisableTiming) != hipSuccess) {
+        g_multi_create_error = "hipEventCreate failed";
+        jpt_multi_destroy(m);
+        return JPT_E_DEVICE;
+    }
+    *out = m;
+    return JPT_OK;
+}
+
+void jpt_multi_destroy(jpt_multi* m)
+{
+    if (!m) return;
+    for (size_t r = 0; r < m->ctx.size(); r++) {
+        (void)hipSetDevice(m->devices[r]);
+        (void)jpt_sync(m->ctx[r]);
+    }
+    if (m->gathered) {
+        (void)hipSetDevice(m->devices[0]);
+        (void)hipFree(m->gathered);
+    }
+    for (size_t r = 0; r < m->rendered.size(); r++) {
+        (void)hipSetDevice(m->devices[r]);
+        (void)hipEventDestroy(m->rendered[r]);
+    }
+    if (m->assembled) {
+        (void)hipSetDevice(m->devices[0]);
+        (void)hipEventDestroy(m->assembled);
+    }
+    for (jpt_ctx* c : m->ctx) jpt_destroy(c);
+    delete m;
+}
+
+const char* jpt_multi_last_error(const jpt_multi* m) { return m ? m->error.c_str() : g_multi_create_error.c_str(); }
+int jpt_multi_world(const jpt_multi* m) { return m ? (int)m->ctx.size() : 0; }
+jpt_ctx* jpt_multi_ctx(jpt_multi* m, int rank) { return (m && rank >= 0 && rank < (int)m->ctx.size()) ? m->ctx[(size_t)rank] : nullptr; }
+
+int jpt_multi_share_scene(jpt_multi* m)
+{
+    if (!m) return JPT_E_INVALID;
+    for (size_t r = 1; r < m->ctx.size(); r++) {
+        const int rc = jpt_scene_share(m->ctx[r], m->ctx[0]);
+        if (rc != JPT_OK) return mfail_ctx(m, (int)r, rc);
+    }
+    return JPT_OK;
+}
+
+int jpt_multi_set_params(jpt_multi* m, int32_t width, int32_t height, int32_t max_bounces, int32_t accum_mode, int32_t sampler_mode)
+{
+    if (!m) return JPT_E_INVALID;
+    for (size_t r = 0; r < m->ctx.size(); r++) {
+        const int rc = jpt_set_params(m->ctx[r], width, height, max_bounces, accum_mode, sampler_mode);
+        if (rc != JPT_OK) return mfail_ctx(m, (int)r, rc);
+    }
+    m->assembled_valid = false;
+    return JPT_OK;
+}
+
+int jpt_multi_set_camera(jpt_multi* m, const void* camera160)
+{
+    if (!m) return JPT_E_INVALID;
+    for (size_t r = 0; r < m->ctx.size(); r++) {
+        const int rc = jpt_set_camera(m->ctx[r], camera160);
+        if (rc != JPT_OK) return mfail_ctx(m, (int)r, rc);
+    }
+    return JPT_OK;
+}
+
+int jpt_multi_accum_reset(jpt_multi* m)
+{
+    if (!m) return JPT_E_INVALID;
+    for (size_t r = 0; r < m->ctx.size(); r++) {
+        const int rc = jpt_accum_reset(m->ctx[r]);
+        if (rc != JPT_OK) return mfail_ctx(m, (int)r, rc);
+    }
+    return JPT_OK;
+}
+
+int jpt_multi_set_gather(jpt_multi* m, int32_t ldr_only)
+{
+    if (!m) return JPT_E_INVALID;
+    m->ldr_only = ldr_only != 0;
+    return JPT_OK;
+}
+
+int jpt_multi_render(jpt_multi* m, int32_t n_frames, uint32_t first_frame_index)
+{
+    if (!m) return JPT_E_INVALID;
+    const int world = (int)m->ctx.size();
+    // every rank: queue the render on its own device and mark its end; the piece of a rank may not be overwritten by its
+    // next render before rank 0 has pulled it, so the ranks' streams wait for the previous assembly
+    for (int r = 0; r < world; r++) {
+        M_HIP(m, hipSetDevice(m->devices[(size_t)r]));
+        void* s = nullptr;
+        if (jpt_get_stream(m->ctx[(size_t)r], &s) != JPT_OK) return mfail_ctx(m, r, JPT_E_DEVICE);
+        if (m->assembled_valid && r > 0) M_HIP(m, hipStreamWaitEvent((hipStream_t)s, m->assembled, 0));
+        const int rc = jpt_render_async(m->ctx[(size_t)r], n_frames, first_frame_index);
+        if (rc != JPT_OK) return mfail_ctx(m, r, rc);
+        M_HIP(m, hipEventRecord(m->rendered[(size_t)r], (hipStream_t)s));
+    }
+    if (world == 1) return JPT_OK;
+    // rank 0: pull every piece over its own link, then assemble
+    M_HIP(m, hipSetDevice(m->devices[0]));
+    void* s0v = nullptr;
+    if (jpt_get_stream(m->ctx[0], &s0v) != JPT_OK) return mfail_ctx(m, 0, JPT_E_DEVICE);
+    hipStream_t s0 = (hipStream_t)s0v;
+    size_t piece = 0;
+    (void)(m->ldr_only ? jpt_device_ldr(m->ctx[0], &piece) : jpt_device_accum(m->ctx[0], &piece));
+    if (m->gathered_bytes < piece * (size_t)world) {
+        M_HIP(m, hipStreamSynchronize(s0));
+        if (m->gathered) (void)hipFree(m->gathered);
+        m->gathered = nullptr;
+        m->gathered_bytes = 0;
+        M_HIP(m, hipMalloc(&m->gathered, piece * (size_t)world));
+        m->gathered_bytes = piece * (size_t)world;
+    }
+    for (int r = 0; r < world; r++) {
+        size_t bytes = 0;
+        void* src = m->ldr_only ? jpt_device_ldr(m->ctx[(size_t)r], &bytes) : jpt_device_accum(m->ctx[(size_t)r], &bytes);
+        if (bytes != piece) return mfail(m, JPT_E_STATE, "ranks disagree about the size of a piece (were all contexts given the same jpt_multi_set_params?)");
+        if (r > 0) M_HIP(m, hipStreamWaitEvent(s0, m->rendered[(size_t)r], 0));
+        char* dst = static_cast<char*>(m->gathered) + (size_t)r * piece;
+        if (piece) M_HIP(m, hipMemcpyPeerAsync(dst, m->devices[0], src, m->devices[(size_t)r], piece, s0));
+    }
+    const int rc = m->ldr_only ? jpt_assemble_ldr_from_ranks(m->ctx[0], m->gathered, world) : jpt_assemble_from_ranks(m->ctx[0], m->gathered, world);
+    if (rc != JPT_OK) return mfail_ctx(m, 0, rc);
+    M_HIP(m, hipEventRecord(m->assembled, s0));
+    m->assembled_valid = true;
+    return JPT_OK;
+}
+
+int jpt_multi_sync(jpt_multi* m)
+{
+    if (!m) return JPT_E_INVALID;
+    for (size_t r = 0; r < m->ctx.size(); r++) {
+        M_HIP(m, hipSetDevice(m->devices[r]));
+        const int rc = jpt_sync(m->ctx[r]);
+        if (rc != JPT_OK) return mfail_ctx(m, (int)r, rc);
+    }
+    return JPT_OK;
+}
+
+int jpt_multi_read_ldr_rgba8(jpt_multi* m, uint8_t* out)
+{
+    if (!m) return JPT_E_INVALID;
+    M_HIP(m, hipSetDevice(m->devices[0]));
+    const int rc = jpt_read_ldr_rgba8(m->ctx[0], out);
+    return rc == JPT_OK ? rc : mfail_ctx(m, 0, rc);
+}
+
+int jpt_multi_read_accum_f32(jpt_multi* m, float* out)
+{
+    if (!m) return JPT_E_INVALID;
+    if (m->ldr_only && m->ctx.size() > 1) return mfail(m, JPT_E_STATE, "only the display rows are gathered (jpt_multi_set_gather): the sums stay on their ranks");
+    M_HIP(m, hipSetDevice(m->devices[0]));
+    const int rc = jpt_read_accum_f32(m->ctx[0], out);
+    return rc == JPT_OK ? rc : mfail_ctx(m, 0, rc);
+}
+
+}  // extern "C"

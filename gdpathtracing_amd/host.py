@@ -42,22 +42,36 @@ def _close_live_contexts():
 class Context:
     """One jpt_ctx (one GPU).  Thin, explicit wrapper: every method is one C-ABI call."""
 
-    def __init__(self, device: int = 0):
+    def __init__(self, device: int = 0, _borrowed=None):
         self._lib = capi.lib()
-        h = C.c_void_p()
-        rc = self._lib.jpt_create(device, C.byref(h))
-        if rc != capi.OK:
-            msg = self._lib.jpt_last_error(None)
-            raise capi.JptError("jpt_create failed (%d): %s" % (rc, msg.decode() if msg else "?"))
-        self.h = h
+        self._owned = _borrowed is None
+        if _borrowed is not None:       # a rank's context inside a MultiContext: the jpt_multi owns it
+            self.h = _borrowed
+        else:
+            h = C.c_void_p()
+            rc = self._lib.jpt_create(device, C.byref(h))
+            if rc != capi.OK:
+                msg = self._lib.jpt_last_error(None)
+                raise capi.JptError("jpt_create failed (%d): %s" % (rc, msg.decode() if msg else "?"))
+            self.h = h
         self.width = self.height = 0
         self._keep = []
-        _live_contexts.add(self)
+        if self._owned:
+            _live_contexts.add(self)
 
     def close(self):
         if getattr(self, "h", None):
-            self._lib.jpt_destroy(self.h)
+            if self._owned:
+                self._lib.jpt_destroy(self.h)
             self.h = None
+
+    def last_error(self) -> str:
+        msg = self._lib.jpt_last_error(self.h)
+        return msg.decode() if msg else ""
+
+    def share_scene_from(self, other: "Context"):
+        """jpt_scene_share: the committed scene of `other` becomes this context's scene too (no builder runs)."""
+        self._ck(self._lib.jpt_scene_share(self.h, other.h), "jpt_scene_share")
 
     def __del__(self):
         try:
@@ -344,3 +358,74 @@ class PathTracingCamera:
         self.ctx.render(n_frames, first)
         self.frame_index += n_frames
         return self.ctx.read_ldr()                                  # get_image_uniform_buffer (:228-229)
+
+
+class MultiContext:
+    """One jpt_multi: one image tiled across several GPUs from this process (jpt.h, jpt_multi_*).  `devices` may name a
+    device more than once (rehearsal on a box with fewer GPUs)."""
+
+    def __init__(self, devices):
+        self._lib = capi.lib()
+        ids = (C.c_int * len(devices))(*devices)
+        h = C.c_void_p()
+        rc = self._lib.jpt_multi_create(ids, len(devices), C.byref(h))
+        if rc != capi.OK:
+            msg = self._lib.jpt_multi_last_error(None)
+            raise capi.JptError("jpt_multi_create failed (%d): %s" % (rc, msg.decode() if msg else "?"))
+        self.h = h
+        self.world = len(devices)
+        self.width = self.height = 0
+        _live_contexts.add(self)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self._lib.jpt_multi_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc, what):
+        if rc != capi.OK:
+            msg = self._lib.jpt_multi_last_error(self.h)
+            raise capi.JptError("%s failed (%d): %s" % (what, rc, msg.decode() if msg else "?"))
+
+    def ctx(self, rank: int) -> Context:
+        return Context(_borrowed=C.c_void_p(self._lib.jpt_multi_ctx(self.h, rank)))
+
+    def build_scene(self, scene, builder=capi.BUILD_SAH):
+        self.ctx(0).build_scene(scene, builder)
+        self._ck(self._lib.jpt_multi_share_scene(self.h), "jpt_multi_share_scene")
+
+    def set_params(self, width, height, max_bounces=4, accum_mode=capi.ACCUM_REF_LDR8, sampler_mode=0):
+        self._ck(self._lib.jpt_multi_set_params(self.h, width, height, max_bounces, accum_mode, sampler_mode), "jpt_multi_set_params")
+        self.width, self.height = width, height
+
+    def set_camera(self, camera_block):
+        cam = np.ascontiguousarray(camera_block, dtype=wire.CAMERA).reshape(1)
+        self._ck(self._lib.jpt_multi_set_camera(self.h, _ptr(cam)), "jpt_multi_set_camera")
+
+    def set_gather(self, ldr_only: bool):
+        self._ck(self._lib.jpt_multi_set_gather(self.h, 1 if ldr_only else 0), "jpt_multi_set_gather")
+
+    def accum_reset(self):
+        self._ck(self._lib.jpt_multi_accum_reset(self.h), "jpt_multi_accum_reset")
+
+    def render(self, n_frames, first_frame_index):
+        self._ck(self._lib.jpt_multi_render(self.h, n_frames, first_frame_index), "jpt_multi_render")
+
+    def sync(self):
+        self._ck(self._lib.jpt_multi_sync(self.h), "jpt_multi_sync")
+
+    def read_accum(self):
+        out = np.zeros((self.height, self.width, 4), dtype=np.float32)
+        self._ck(self._lib.jpt_multi_read_accum_f32(self.h, _ptr(out)), "jpt_multi_read_accum_f32")
+        return out
+
+    def read_ldr(self):
+        out = np.zeros((self.height, self.width, 4), dtype=np.uint8)
+        self._ck(self._lib.jpt_multi_read_ldr_rgba8(self.h, _ptr(out)), "jpt_multi_read_ldr_rgba8")
+        return out

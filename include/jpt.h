@@ -170,6 +170,10 @@ int jpt_scene_commit(jpt_ctx *ctx, int32_t builder);
  * out may be NULL to query the size. */
 int jpt_scene_get_reference_buffer(jpt_ctx *ctx, int32_t which, void *out, size_t capacity, size_t *size_out);
 
+/* The committed scene of `src` (either route) made the scene of `dst` as well -- another context, normally on another
+ * GPU: host arrays are copied and uploaded to dst's device, no builder runs again.  For one scene on several GPUs. */
+int jpt_scene_share(jpt_ctx *dst, jpt_ctx *src);
+
 /* ---- moving instances ---------------------------------------------------------
  * The reference has no incremental path: a moved MeshInstance3D means GeometryGroup3D::build() again
  * (geometry_group3d.cpp:78-366) and new ComputeShader buffers; its README lists a runtime TLAS update as wanted
@@ -293,6 +297,34 @@ int jpt_assemble_ldr_from_ranks(jpt_ctx *ctx, const void *device_gathered_rgba8,
 int32_t jpt_local_rows(jpt_ctx *ctx);
 
 int jpt_get_stats(jpt_ctx *ctx, jpt_stats *out);
+
+/* ---- one image on several GPUs from ONE process ------------------------------------------------------
+ * The addon's host is a single C++ process (path_tracing_camera.cpp:193-232).  A jpt_multi owns one context per listed
+ * device, each rendering its strips of the screen partition (jpt_set_partition); jpt_multi_render fans the render out,
+ * pulls every rank's float4 accumulation rows to device 0 with peer-to-peer copies over xGMI (one link per peer, behind
+ * an event on the rank's stream; the next renders' path kernels overlap with it) and assembles them there, so the
+ * jpt_multi_read_* calls return the whole image -- bit-identical to one GPU's.  Scene set-up: build it once on
+ * jpt_multi_ctx(m, 0) with the jpt_scene_* calls, then jpt_multi_share_scene.  (Processes that hold one GPU each --
+ * bench.py under torch.distributed -- use jpt_set_partition / jpt_device_accum / jpt_assemble_from_ranks with RCCL
+ * send/recv in between instead.)  A device id may be listed more than once (rehearsal on a box with fewer GPUs). */
+typedef struct jpt_multi jpt_multi;
+int jpt_multi_create(const int *device_ids, int n_devices, jpt_multi **out);
+void jpt_multi_destroy(jpt_multi *m);
+const char *jpt_multi_last_error(const jpt_multi *m);     /* m may be NULL: error of the last failed jpt_multi_create */
+int jpt_multi_world(const jpt_multi *m);
+jpt_ctx *jpt_multi_ctx(jpt_multi *m, int rank);            /* the context of one rank (scene calls, statistics) */
+int jpt_multi_share_scene(jpt_multi *m);                   /* jpt_scene_share(rank r, rank 0) for every other rank */
+int jpt_multi_set_params(jpt_multi *m, int32_t width, int32_t height, int32_t max_bounces, int32_t accum_mode, int32_t sampler_mode);
+int jpt_multi_set_camera(jpt_multi *m, const void *camera160);
+int jpt_multi_accum_reset(jpt_multi *m);
+/* what crosses the links each render: 0 (default) the float4 accumulation rows (16 B per pixel; BASELINE.json's exchange),
+ * 1 only the finished rgba8 display rows (4 B per pixel, what the reference reads back) */
+int jpt_multi_set_gather(jpt_multi *m, int32_t ldr_only);
+/* asynchronous: queues the render on every rank, the gather and the assembly; jpt_multi_sync or a read waits */
+int jpt_multi_render(jpt_multi *m, int32_t n_frames, uint32_t first_frame_index);
+int jpt_multi_sync(jpt_multi *m);
+int jpt_multi_read_ldr_rgba8(jpt_multi *m, uint8_t *out);
+int jpt_multi_read_accum_f32(jpt_multi *m, float *out);
 
 #ifdef __cplusplus
 }

@@ -531,4 +531,69 @@ class PathTracingCamera {
     bool ready = false, temporal_ready = false, readback_queued = false;
 };
 
+// PathTracingCamera over several GPUs of one node, from this one process (jpt.h, jpt_multi_*): the scene is built once
+// and shared with every device, each device renders its strips of the screen partition, rank 0 pulls the rows over
+// xGMI and assembles them.  Progressive rendering (the default mode) and NONE; the temporal pass needs the whole image
+// on one device (path_tracing_camera.cpp:215-221 reads neighbouring pixels' history).  The image is bit-identical to
+// one GPU's.
+class PathTracingCameraMulti {
+  public:
+    explicit PathTracingCameraMulti(const std::vector<int>& devices)
+    {
+        if (jpt_multi_create(devices.data(), (int)devices.size(), &multi) != JPT_OK)
+            throw std::runtime_error(std::string("jpt_multi_create: ") + jpt_multi_last_error(nullptr));
+    }
+    ~PathTracingCameraMulti() { jpt_multi_destroy(multi); }
+    PathTracingCameraMulti(const PathTracingCameraMulti&) = delete;
+    PathTracingCameraMulti& operator=(const PathTracingCameraMulti&) = delete;
+
+    void set_fov(float v) { fov = v; }
+    void set_geometry_group(GeometryGroup3D* g) { geometry_group = g; }
+    void set_global_transform(const Transform3D& t) { global_transform = t; }
+    jpt_multi* handle() const { return multi; }
+    int max_bounces = 4;
+    int accum_mode = JPT_ACCUM_REF_LDR8;
+    bool gather_display_rows_only = false;   // 4 B per pixel over the links instead of 16 (the sums stay on their ranks)
+
+    void init(int w, int h)   // path_tracing_camera.cpp:111-187
+    {
+        if (!geometry_group) throw std::runtime_error("No geometry group set.");
+        width = w;
+        height = h;
+        geometry_group->build(jpt_multi_ctx(multi, 0));     // one build ...
+        mcheck(jpt_multi_share_scene(multi), "jpt_multi_share_scene");   // ... every device gets the arrays
+        projection_matrix = Projection::create_perspective(fov, float(width) / float(height), 0.01f, 1000.0f, false);
+        mcheck(jpt_multi_set_params(multi, width, height, max_bounces, accum_mode, JPT_SAMPLER_NEAREST_CLAMP), "jpt_multi_set_params");
+        mcheck(jpt_multi_set_gather(multi, gather_display_rows_only ? 1 : 0), "jpt_multi_set_gather");
+        ready = true;
+    }
+    PackedByteArray render()  // path_tracing_camera.cpp:193-232, progressive mode
+    {
+        if (!ready) return {};
+        camera.set_camera_transform(global_transform, projection_matrix);
+        camera.frame_index++;
+        mcheck(jpt_multi_set_camera(multi, &camera), "jpt_multi_set_camera");
+        if (progressive_renderer.render(global_transform)) mcheck(jpt_multi_accum_reset(multi), "jpt_multi_accum_reset");
+        mcheck(jpt_multi_render(multi, 1, camera.frame_index), "jpt_multi_render");
+        PackedByteArray out((size_t)width * height * 4);
+        mcheck(jpt_multi_read_ldr_rgba8(multi, out.data()), "jpt_multi_read_ldr_rgba8");
+        return out;
+    }
+    Camera camera;
+    ProgressiveRendering progressive_renderer;
+
+  private:
+    void mcheck(int rc, const char* what) const
+    {
+        if (rc != JPT_OK) throw std::runtime_error(std::string(what) + ": " + jpt_multi_last_error(multi));
+    }
+    jpt_multi* multi = nullptr;
+    GeometryGroup3D* geometry_group = nullptr;
+    Transform3D global_transform;
+    Projection projection_matrix;
+    float fov = 90.0f;
+    int width = 0, height = 0;
+    bool ready = false;
+};
+
 }  // namespace jpt_host

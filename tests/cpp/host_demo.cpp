@@ -164,6 +164,29 @@ int main(int argc, char** argv)
                         cam.progressive_renderer.frame_count);
             return 0;
         }
+        if (mode == "multi" && argc >= 10) {
+            // PathTracingCameraMulti: the same frame loop with the image tiled over argv[9] devices (device 0 listed that
+            // many times on a one-GPU box), one process
+            const int w = std::atoi(argv[4]), h = std::atoi(argv[5]), frames = std::atoi(argv[6]);
+            PathTracingCameraMulti cam(std::vector<int>((size_t)std::atoi(argv[9]), 0));
+            group.builder = std::atoi(argv[7]);
+            cam.accum_mode = std::atoi(argv[8]);
+            cam.set_fov(fov);
+            cam.set_geometry_group(&group);
+            cam.set_global_transform(cam_t);
+            cam.camera.frame_index = 0;
+            cam.init(w, h);
+            PackedByteArray screen;
+            for (int f = 0; f < frames; f++) screen = cam.render();
+            std::vector<float> accum((size_t)w * h * 4);
+            if (jpt_multi_read_accum_f32(cam.handle(), accum.data()) != JPT_OK) throw std::runtime_error(jpt_multi_last_error(cam.handle()));
+            dump(prefix + "_accum.bin", accum.data(), accum.size() * 4);
+            dump(prefix + "_ldr.bin", screen.data(), screen.size());
+            dump(prefix + "_camera.bin", &cam.camera, sizeof(Camera));
+            std::printf("rendered %d frames on %d devices, frame_index %u, frame_count %u\n", frames, jpt_multi_world(cam.handle()),
+                        cam.camera.frame_index, cam.progressive_renderer.frame_count);
+            return 0;
+        }
         if (mode == "animate" && argc >= 8) {
             // moving nodes on the GPU: every step shifts child i by (0.25 i, 0, -0.125 i), update_transforms(refit),
             // one frame in the NONE mode (the screen is that frame alone); the last screen is dumped

@@ -247,3 +247,23 @@ def test_cpp_moving_nodes_on_the_gpu(host_demo, refit):
     want = ctx.read_ldr()
     ctx.close()
     assert np.array_equal(got, want)
+
+
+@pytest.mark.gpu
+def test_cpp_multi_device_camera_renders_like_the_oracle(oracle, host_demo):
+    """PathTracingCameraMulti (include/jpt_host.hpp over jpt_multi_*): three devices' worth of contexts in one process, the
+    scene built once and shared, rows gathered to rank 0 peer-to-peer -- the image equals the oracle's bit for bit."""
+    exe, d = host_demo
+    sc = scenes.cornell_scene()
+    path = os.path.join(d, "c.jpts")
+    scenes.write_scene_file(sc, path)
+    w, h, frames = 96, 70, 3
+    out = subprocess.run([exe, "multi", path, os.path.join(d, "mu"), str(w), str(h), str(frames), str(capi.BUILD_SAH),
+                          str(wire.ACCUM_REF_LDR8), "3"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    assert "on 3 devices, frame_index %d, frame_count %d" % (frames, frames) in out.stdout
+    cam = np.frombuffer(open(os.path.join(d, "mu_camera.bin"), "rb").read(), dtype=wire.CAMERA)[0]
+    got = np.frombuffer(open(os.path.join(d, "mu_accum.bin"), "rb").read(), dtype=np.float32).reshape(h, w, 4)
+    got_ldr = np.frombuffer(open(os.path.join(d, "mu_ldr.bin"), "rb").read(), dtype=np.uint8).reshape(h, w, 4)
+    want, want_ldr, _, _, _ = oracle.render(oracle.build_scene(sc), cam, w, h, 4, frames, 1, wire.ACCUM_REF_LDR8)
+    assert np.array_equal(got, want) and np.array_equal(got_ldr, want_ldr)

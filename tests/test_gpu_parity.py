@@ -2,7 +2,7 @@
 import numpy as np
 import pytest
 
-from gdpathtracing_amd import capi, host, scenes, wire
+from gdpathtracing_amd import capi, host, partition, scenes, wire
 
 pytestmark = pytest.mark.gpu
 
@@ -428,3 +428,39 @@ def test_tie_between_instances_with_different_transforms(oracle, hiplib, kernel)
             ctx.close()
         assert np.array_equal(got, want), route
         assert np.array_equal(got_depth, want_depth)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 3])
+def test_one_process_multi_device_gather_is_bit_identical(hiplib, world):
+    """jpt_multi_* (one process, one context per listed device, peer-to-peer gather of the float4 rows to rank 0,
+    assembly there): the assembled accumulation buffer and display image equal a single context's, over three renders that
+    continue one accumulation and then a restarted one; the display-rows-only gather gives the same screen.  The box has
+    one GPU, so the device is listed `world` times: the copies are device-local, the protocol is the real one."""
+    sc = scenes.demo_scene(3000)
+    w, h, b = 200, 117, 3          # 117 rows: a ragged last strip
+    cam = scenes.camera_block(sc.camera, w, h)
+    one = host.Context(0)
+    one.build_scene(sc, capi.BUILD_SAH)
+    one.set_params(w, h, b, wire.ACCUM_REF_LDR8)
+    one.set_camera(cam)
+    m = host.MultiContext([0] * world)
+    m.build_scene(sc, capi.BUILD_SAH)
+    m.set_params(w, h, b, wire.ACCUM_REF_LDR8)
+    m.set_camera(cam)
+    for first, n in ((1, 2), (3, 1), (4, 3)):
+        one.render(n, first)
+        m.render(n, first)
+        assert np.array_equal(m.read_accum(), one.read_accum()) and np.array_equal(m.read_ldr(), one.read_ldr())
+    one.accum_reset()
+    m.accum_reset()
+    m.set_gather(True)
+    for _ in range(3):              # queued back to back: a rank's next render waits for rank 0 to have pulled its rows
+        one.render(2, 7)
+        m.render(2, 7)
+    assert np.array_equal(m.read_ldr(), one.read_ldr())
+    with pytest.raises(capi.JptError, match="display rows"):
+        m.read_accum()
+    assert m.ctx(1).stats()["frames"] == 6 and m.ctx(1).local_rows() == len(partition.rows_of_rank(h, 1, world))
+    m.close()
+    one.close()
