@@ -103,3 +103,44 @@ def pack_texture_array(images, resolution: int) -> np.ndarray:
             a = np.clip(np.floor(top * (1.0 - fy) + bot * fy + 0.5), 0, 255).astype(np.uint8)
         layers.append(a)
     return np.stack(layers)
+
+
+def load_mtl(text: str):
+    """Wavefront MTL -> (dict name -> GpuMaterial record (wire.MATERIAL), list of albedo map file names), with the
+    conventions of include/jpt_host.hpp::load_mtl (the C++ product code; this is its test mirror): Kd -> albedo; Ke ->
+    emission colour, energy multiplier 1 or the largest component when that exceeds 1; Pr -> roughness, else
+    sqrt(2 / (Ns + 2)) from the Phong exponent; Pm -> metallic; map_Kd -> albedo texture index in order of first use."""
+    from .scenes import material
+    out, maps = {}, []
+    cur = None
+    for line in text.splitlines():
+        p = line.split()
+        if not p or p[0].startswith("#"):
+            continue
+        if p[0] == "newmtl":
+            cur = dict(albedo=(1.0, 1.0, 1.0), emission=(0.0, 0.0, 0.0), energy=1.0, metallic=0.0, roughness=1.0, texture=-1, has_pr=False)
+            out[p[1] if len(p) > 1 else ""] = cur
+        elif cur is None:
+            continue
+        elif p[0] == "Kd":
+            cur["albedo"] = tuple(np.float32(x) for x in p[1:4])
+        elif p[0] == "Ke":
+            r, g, b = (np.float32(x) for x in p[1:4])
+            m = max(r, g, b)
+            if m > 1.0:
+                cur["emission"], cur["energy"] = (r / m, g / m, b / m), m
+            else:
+                cur["emission"], cur["energy"] = (r, g, b), np.float32(1.0)
+        elif p[0] == "Pr":
+            cur["roughness"], cur["has_pr"] = np.float32(p[1]), True
+        elif p[0] == "Ns" and not cur["has_pr"]:
+            cur["roughness"] = np.sqrt(np.float32(2.0) / (max(np.float32(p[1]), np.float32(0.0)) + np.float32(2.0)))
+        elif p[0] == "Pm":
+            cur["metallic"] = np.float32(p[1])
+        elif p[0] == "map_Kd":
+            if p[1] not in maps:
+                maps.append(p[1])
+            cur["texture"] = maps.index(p[1])
+    recs = {k: material(albedo=v["albedo"], emission=v["emission"], energy=float(v["energy"]), metallic=float(v["metallic"]),
+                        roughness=float(v["roughness"]), texture=v["texture"]) for k, v in out.items()}
+    return recs, maps

@@ -19,9 +19,13 @@
 #include <array>
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
+#include <map>
+#include <sstream>
 #include <stdexcept>
 #include <string>
+#include <tuple>
 #include <vector>
 
 namespace jpt_host {
@@ -215,6 +219,202 @@ struct GpuMaterial {  // render_parameters.h:49-57
     float padding[5];
 };
 static_assert(sizeof(GpuMaterial) == 64, "GpuMaterial");
+
+// ---- scene ingest without Godot ---------------------------------------------------------------
+// In the addon, Godot's importers turn .obj / .mtl / images into ArrayMesh, StandardMaterial3D and Image objects
+// before GeometryGroup3D::build ever runs (geometry_group3d.cpp:119-304 only reads them).  These three functions
+// stand in for that step so a host can feed the path from files.  They are NOT a claim about Godot's importers:
+// the conventions are written down here.
+
+// Wavefront OBJ -> ArrayMesh: one surface per `usemtl` group in order of first use (`surface_materials` gets the
+// names), corners de-indexed to unique (position, uv, normal) triples in order of appearance, polygons fan-
+// triangulated and emitted with Godot's clockwise front faces (main.glsl:254-255 derives `front` from the winding),
+// a missing normal replaced by the face normal of the polygon's first three corners, a missing uv by (0, 0).
+inline void load_obj(const std::string& text, ArrayMesh& mesh, std::vector<std::string>& surface_materials)
+{
+    struct Group {
+        std::map<std::tuple<long, long, long, long>, int32_t> lut;
+        Surface s;
+    };
+    std::vector<std::array<double, 3>> pos, nrm;   // kept in double, rounded to float once when a corner is emitted
+    std::vector<std::array<double, 2>> uvs;
+    std::vector<std::string> order;
+    std::map<std::string, Group> groups;
+    Group* cur = nullptr;
+    auto use = [&](const std::string& name) {
+        if (!groups.count(name)) order.push_back(name);
+        cur = &groups[name];
+    };
+    use("");
+    std::istringstream in(text);
+    std::string line;
+    long face_counter = 0;
+    while (std::getline(in, line)) {
+        std::istringstream ls(line);
+        std::string tag;
+        if (!(ls >> tag) || tag[0] == '#') continue;
+        if (tag == "v" || tag == "vn") {
+            std::array<double, 3> v{0, 0, 0};
+            ls >> v[0] >> v[1] >> v[2];
+            (tag == "v" ? pos : nrm).push_back(v);
+        } else if (tag == "vt") {
+            std::array<double, 2> t{0, 0};
+            ls >> t[0] >> t[1];
+            uvs.push_back(t);
+        } else if (tag == "usemtl") {
+            std::string name;
+            ls >> name;
+            use(name);
+        } else if (tag == "f") {
+            struct Corner { long v, t, n; };
+            std::vector<Corner> corners;
+            std::string tok;
+            while (ls >> tok) {
+                long idx[3] = {0, 0, 0};
+                bool has[3] = {false, false, false};
+                size_t start = 0;
+                for (int k = 0; k < 3 && start <= tok.size(); k++) {
+                    const size_t slash = tok.find('/', start);
+                    const std::string part = tok.substr(start, slash == std::string::npos ? std::string::npos : slash - start);
+                    if (!part.empty()) {
+                        idx[k] = std::strtol(part.c_str(), nullptr, 10);
+                        has[k] = true;
+                    }
+                    if (slash == std::string::npos) break;
+                    start = slash + 1;
+                }
+                if (!has[0]) throw std::runtime_error("OBJ: face corner without a vertex index");
+                auto resolve = [](long i, size_t n) { return i > 0 ? i - 1 : (long)n + i; };
+                Corner c{resolve(idx[0], pos.size()), has[1] ? resolve(idx[1], uvs.size()) : -1, has[2] ? resolve(idx[2], nrm.size()) : -1};
+                if (c.v < 0 || c.v >= (long)pos.size() || c.t >= (long)uvs.size() || c.n >= (long)nrm.size()) throw std::runtime_error("OBJ: index out of range");
+                corners.push_back(c);
+            }
+            if (corners.size() < 3) continue;
+            std::array<double, 3> fn{0, 0, 0};
+            bool need_fn = false;
+            for (const Corner& c : corners) need_fn = need_fn || c.n < 0;
+            if (need_fn) {
+                const auto &a = pos[(size_t)corners[0].v], &b = pos[(size_t)corners[1].v], &c = pos[(size_t)corners[2].v];
+                const double e1[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]};
+                const double e2[3] = {c[0] - a[0], c[1] - a[1], c[2] - a[2]};
+                double n[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
+                const double len = std::max(std::sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]), 1e-30);
+                fn = {n[0] / len, n[1] / len, n[2] / len};
+            }
+            std::vector<int32_t> ids;
+            for (size_t k = 0; k < corners.size(); k++) {
+                const Corner& c = corners[k];
+                // a corner without a normal is unique to its face (it carries that face's normal)
+                const auto key = c.n >= 0 ? std::make_tuple(c.v, c.t, c.n, -1L) : std::make_tuple(c.v, c.t, -2L - face_counter, (long)k);
+                auto it = cur->lut.find(key);
+                if (it == cur->lut.end()) {
+                    const int32_t id = (int32_t)(cur->s.vertices.size() / 3);
+                    it = cur->lut.emplace(key, id).first;
+                    const auto& p = pos[(size_t)c.v];
+                    const auto n = c.n >= 0 ? nrm[(size_t)c.n] : fn;
+                    cur->s.vertices.insert(cur->s.vertices.end(), {(float)p[0], (float)p[1], (float)p[2]});
+                    cur->s.normals.insert(cur->s.normals.end(), {(float)n[0], (float)n[1], (float)n[2]});
+                    if (c.t >= 0) cur->s.uvs.insert(cur->s.uvs.end(), {(float)uvs[(size_t)c.t][0], (float)uvs[(size_t)c.t][1]});
+                    else cur->s.uvs.insert(cur->s.uvs.end(), {0.0f, 0.0f});
+                }
+                ids.push_back(it->second);
+            }
+            for (size_t k = 1; k + 1 < ids.size(); k++) cur->s.indices.insert(cur->s.indices.end(), {ids[0], ids[k + 1], ids[k]});
+            face_counter++;
+        }
+    }
+    mesh.surfaces.clear();
+    surface_materials.clear();
+    for (const std::string& name : order)
+        if (!groups[name].s.indices.empty()) {
+            mesh.surfaces.push_back(std::move(groups[name].s));
+            surface_materials.push_back(name);
+        }
+}
+
+// Wavefront MTL -> StandardMaterial3D (the fields GeometryGroup3D converts to GpuMaterial, geometry_group3d.cpp:271-292):
+// Kd -> albedo; Ke -> emission colour (energy multiplier 1, or the largest component when it exceeds 1, the colour
+// scaled back into [0,1]); Pr -> roughness, else from the Phong exponent Ns as sqrt(2 / (Ns + 2)); Pm -> metallic (else 0);
+// map_Kd -> albedo_texture = index of that file name in `albedo_maps` (appended on first use).
+inline std::map<std::string, StandardMaterial3D> load_mtl(const std::string& text, std::vector<std::string>& albedo_maps)
+{
+    std::map<std::string, StandardMaterial3D> out;
+    StandardMaterial3D* cur = nullptr;
+    bool has_pr = false;
+    std::istringstream in(text);
+    std::string line;
+    while (std::getline(in, line)) {
+        std::istringstream ls(line);
+        std::string tag;
+        if (!(ls >> tag) || tag[0] == '#') continue;
+        if (tag == "newmtl") {
+            std::string name;
+            ls >> name;
+            cur = &out[name];
+            *cur = StandardMaterial3D();
+            has_pr = false;
+        } else if (!cur) {
+            continue;
+        } else if (tag == "Kd") {
+            ls >> cur->albedo.r >> cur->albedo.g >> cur->albedo.b;
+        } else if (tag == "Ke") {
+            float r = 0, g = 0, b = 0;
+            ls >> r >> g >> b;
+            const float m = std::max(r, std::max(g, b));
+            if (m > 1.0f) {
+                cur->emission = Color{r / m, g / m, b / m, 1};
+                cur->emission_energy_multiplier = m;
+            } else {
+                cur->emission = Color{r, g, b, 1};
+                cur->emission_energy_multiplier = 1.0f;
+            }
+        } else if (tag == "Pr") {
+            ls >> cur->roughness;
+            has_pr = true;
+        } else if (tag == "Ns" && !has_pr) {
+            float ns = 0;
+            ls >> ns;
+            cur->roughness = std::sqrt(2.0f / (std::max(ns, 0.0f) + 2.0f));
+        } else if (tag == "Pm") {
+            ls >> cur->metallic;
+        } else if (tag == "map_Kd") {
+            std::string file;
+            ls >> file;
+            size_t k = std::find(albedo_maps.begin(), albedo_maps.end(), file) - albedo_maps.begin();
+            if (k == albedo_maps.size()) albedo_maps.push_back(file);
+            cur->albedo_texture = (int)k;
+        }
+    }
+    return out;
+}
+
+// One layer of the texture array (geometry_group3d.cpp:294-300: decompress + Image::resize to texture_array_resolution):
+// an RGBA8 image of any size -> res x res RGBA8, bilinear over pixel centres (an image that already has the array's size
+// passes through unchanged).  Godot's Image::resize is engine code: no texel-for-texel claim for other sizes.
+inline PackedByteArray resize_rgba8(const uint8_t* rgba, int w, int h, int res)
+{
+    PackedByteArray out((size_t)res * res * 4);
+    if (w == res && h == res) {
+        std::memcpy(out.data(), rgba, out.size());
+        return out;
+    }
+    for (int y = 0; y < res; y++) {
+        const double ys = (y + 0.5) * h / res - 0.5;
+        const int y0 = std::min(std::max((int)std::floor(ys), 0), h - 1), y1 = std::min(y0 + 1, h - 1);
+        const double fy = std::min(std::max(ys - std::floor(ys), 0.0), 1.0);
+        for (int x = 0; x < res; x++) {
+            const double xs = (x + 0.5) * w / res - 0.5;
+            const int x0 = std::min(std::max((int)std::floor(xs), 0), w - 1), x1 = std::min(x0 + 1, w - 1);
+            const double fx = std::min(std::max(xs - std::floor(xs), 0.0), 1.0);
+            for (int c = 0; c < 4; c++) {
+                auto px = [&](int xx, int yy) { return (double)rgba[((size_t)yy * w + xx) * 4 + c]; };
+                const double top = px(x0, y0) * (1.0 - fx) + px(x1, y0) * fx, bot = px(x0, y1) * (1.0 - fx) + px(x1, y1) * fx;
+                out[((size_t)y * res + x) * 4 + c] = (uint8_t)std::min(std::max(std::floor(top * (1.0 - fy) + bot * fy + 0.5), 0.0), 255.0);
+            }
+        }
+    }
+    return out;
+}
 
 inline void check(jpt_ctx* ctx, int rc, const char* what)
 {

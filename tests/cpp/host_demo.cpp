@@ -7,13 +7,19 @@
 //   host_demo render  <scene.bin> <prefix> <w> <h> <frames> <builder> <accum_mode> [denoising_mode] [overlapped]   GPU 0
 //   host_demo moved   <scene.bin> <prefix>                      host-only context, update_transforms()
 //   host_demo animate <scene.bin> <prefix> <w> <h> <steps> <refit>   GPU 0: move, update_transforms(refit), render, repeat
+//   host_demo multi   <scene.bin> <prefix> <w> <h> <frames> <builder> <accum_mode> <n>   PathTracingCameraMulti over n x device 0
+//   host_demo obj     <file.obj>  <prefix> <w> <h> <frames> <file.mtl | -> [host]   no scene file, no Python: load_obj + load_mtl
+//                     (map_Kd names binary PPM files beside the .mtl), one MeshInstance3D at the origin seen by demo.tscn's
+//                     camera; `host` = host-only context: dumps the get_*_buffer() arrays instead of rendering
 #include <jpt_host.hpp>
 
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
 #include <iostream>
+#include <iterator>
 #include <memory>
+#include <sstream>
 
 using namespace jpt_host;
 
@@ -44,6 +50,71 @@ int main(int argc, char** argv)
     try {
         if (argc < 4) { std::fprintf(stderr, "usage\n"); return 2; }
         const std::string mode = argv[1], prefix = argv[3];
+        if (mode == "obj" && argc >= 8) {
+            auto slurp = [](const std::string& p) {
+                std::ifstream f(p, std::ios::binary);
+                if (!f) throw std::runtime_error("cannot open " + p);
+                return std::string((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+            };
+            const int w = std::atoi(argv[4]), h = std::atoi(argv[5]), frames = std::atoi(argv[6]);
+            const std::string mtl_path = argv[7];
+            const bool host_only = argc >= 9 && std::string(argv[8]) == "host";
+            ArrayMesh mesh;
+            std::vector<std::string> names;
+            load_obj(slurp(argv[2]), mesh, names);
+            std::vector<std::string> maps;
+            std::map<std::string, StandardMaterial3D> lib;
+            if (mtl_path != "-") lib = load_mtl(slurp(mtl_path), maps);
+            GeometryGroup3D group;
+            group.texture_array_resolution = 64;
+            const std::string dir = mtl_path.find('/') == std::string::npos ? std::string(".") : mtl_path.substr(0, mtl_path.rfind('/'));
+            for (const std::string& file : maps) {   // binary PPM (P6, maxval 255) -> one RGBA8 layer of the array
+                const std::string ppm = slurp(dir + "/" + file);
+                std::istringstream hs(ppm);
+                std::string magic;
+                int pw = 0, ph = 0, maxv = 0;
+                hs >> magic >> pw >> ph >> maxv;
+                if (magic != "P6" || maxv != 255 || pw <= 0 || ph <= 0) throw std::runtime_error("map_Kd: binary PPM (P6, 255) expected: " + file);
+                const size_t at = (size_t)hs.tellg() + 1;
+                std::vector<uint8_t> rgba((size_t)pw * ph * 4, 255);
+                for (size_t i = 0; i < (size_t)pw * ph; i++)
+                    for (int c = 0; c < 3; c++) rgba[i * 4 + c] = (uint8_t)ppm.at(at + i * 3 + c);
+                group.textures.push_back(resize_rgba8(rgba.data(), pw, ph, group.texture_array_resolution));
+            }
+            MeshInstance3D node;
+            node.mesh = &mesh;
+            for (const std::string& n : names) node.surface_override_materials.push_back(lib.count(n) ? &lib[n] : nullptr);
+            group.add_child(node);
+            std::printf("obj: %d surfaces, %zu materials in the library, %zu texture layers\n", mesh.get_surface_count(), lib.size(), group.textures.size());
+            if (host_only) {
+                jpt_ctx* ctx = nullptr;
+                check(nullptr, jpt_create(JPT_DEVICE_HOST_ONLY, &ctx), "jpt_create");
+                group.builder = JPT_BUILD_REFERENCE_EXACT;
+                group.build(ctx);
+                const PackedByteArray bufs[3] = {group.get_triangles_geometry_buffer(), group.get_triangles_data_buffer(), group.get_materials_buffer()};
+                for (int k = 0; k < 3; k++) dump(prefix + "_buf" + std::to_string(k) + ".bin", bufs[k].data(), bufs[k].size());
+                for (size_t k = 0; k < group.textures.size(); k++) dump(prefix + "_tex" + std::to_string(k) + ".bin", group.textures[k].data(), group.textures[k].size());
+                jpt_destroy(ctx);
+                return 0;
+            }
+            PathTracingCamera cam(0);
+            group.builder = JPT_BUILD_SAH;
+            cam.set_fov(79.5f);                                   // demo.tscn:50-53
+            cam.set_geometry_group(&group);
+            Transform3D t;
+            t.origin.z = 9.7694f;
+            cam.set_global_transform(t);
+            cam.camera.frame_index = 0;
+            cam.init(w, h);
+            PackedByteArray screen;
+            for (int f = 0; f < frames; f++) screen = cam.render();
+            std::vector<float> accum((size_t)w * h * 4);
+            check(cam.context(), jpt_read_accum_f32(cam.context(), accum.data()), "jpt_read_accum_f32");
+            dump(prefix + "_accum.bin", accum.data(), accum.size() * 4);
+            dump(prefix + "_ldr.bin", screen.data(), screen.size());
+            dump(prefix + "_camera.bin", &cam.camera, sizeof(Camera));
+            return 0;
+        }
         Reader r(argv[2]);
         if (r.get<uint32_t>() != 0x5354504au) throw std::runtime_error("bad magic");
         std::vector<std::unique_ptr<ArrayMesh>> meshes;

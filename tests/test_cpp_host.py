@@ -267,3 +267,120 @@ def test_cpp_multi_device_camera_renders_like_the_oracle(oracle, host_demo):
     got_ldr = np.frombuffer(open(os.path.join(d, "mu_ldr.bin"), "rb").read(), dtype=np.uint8).reshape(h, w, 4)
     want, want_ldr, _, _, _ = oracle.render(oracle.build_scene(sc), cam, w, h, 4, frames, 1, wire.ACCUM_REF_LDR8)
     assert np.array_equal(got, want) and np.array_equal(got_ldr, want_ldr)
+
+
+# ---- scene ingest without Godot: include/jpt_host.hpp load_obj / load_mtl / resize_rgba8 -----------------------------
+
+_OBJ = """# an open cube of three surfaces plus a quad without normals or uvs (public Cornell-box numbers)
+mtllib box.mtl
+v 5 5 -5
+v 5 -5 -5
+v 5 5 5
+v 5 -5 5
+v -5 5 -5
+v -5 -5 -5
+v -5 5 5
+v -5 -5 5
+v -2 -4.99 -2
+v 2 -4.99 -2
+v 2 -4.99 2
+v -2 -4.99 2
+vn 0 -1 0
+vn 0 0 -1
+vn 1 0 0
+vn 0 1 0
+vn 0 0 1
+vt 0.625 0.5
+vt 0.375 0.5
+vt 0.125 0.25
+vt 0.875 0.75
+usemtl white
+f 1/1/1 3/2/1 7/3/1 5/4/1
+f 8/2/3 6/3/3 5/4/3 7/1/3
+f 6/1/4 8/2/4 4/3/4 2/4/4
+usemtl green
+f 6/1/5 2/2/5 1/3/5 5/4/5
+usemtl red
+f 4/1/2 8/2/2 7/3/2 3/4/2
+usemtl lamp
+f 9 12 11 10
+f -4 -1 -2
+"""
+_MTL = """newmtl white
+Ns 250.0
+Kd 0.8 0.8 0.8
+map_Kd checker.ppm
+newmtl green
+Pr 0.35
+Ns 10
+Kd 0.03 0.77 0.06
+Pm 0.25
+newmtl red
+Ns 2
+Kd 0.8 0.064 0.019
+newmtl lamp
+Kd 1 1 1
+Ke 6.0 4.5 3.0
+"""
+
+
+def _write_obj_inputs(d):
+    open(os.path.join(d, "box.obj"), "w").write(_OBJ)
+    open(os.path.join(d, "box.mtl"), "w").write(_MTL)
+    tex = scenes.checker_texture(32, 4)[0]                       # 32 x 32, resized to the array's 64 x 64 by the loader
+    with open(os.path.join(d, "checker.ppm"), "wb") as f:
+        f.write(b"P6\n32 32\n255\n" + tex[..., :3].tobytes())
+    return tex
+
+
+def _python_side_of_the_obj_scene(tex):
+    from gdpathtracing_amd import objio
+    mesh = objio.load_obj(_OBJ)
+    recs, maps = objio.load_mtl(_MTL)
+    assert maps == ["checker.ppm"] and len(mesh.surfaces) == 4
+    mats = np.stack([scenes.material(albedo=(0.5, 0.5, 0.5), roughness=0.5)] + [recs[k] for k in ("white", "green", "red", "lamp")])
+    layers = objio.pack_texture_array([tex], 64)
+    sc = scenes.Scene("obj", [mesh], [scenes.Instance(0, scenes.transform12(None, (0, 0, 0)), [1, 2, 3, 4])], mats,
+                      scenes.CameraDesc(scenes.transform12(None, (0, 0, 9.7694)), fov_deg=79.5), textures=layers)
+    return sc, mats, layers
+
+
+def test_cpp_obj_and_mtl_ingest_equals_the_python_mirror(oracle, host_demo):
+    """load_obj + load_mtl + resize_rgba8 of include/jpt_host.hpp (product code) fed through GeometryGroup3D::build on a
+    host-only context: the triangle buffers, the GpuMaterial table and the texture layer equal what the Python mirror
+    (objio.py) and the oracle's builder make of the same text -- surfaces per usemtl, face normals where the file has
+    none, negative indices, Ke above 1 split into colour and energy, roughness from Pr or Ns, map_Kd resized."""
+    exe, d = host_demo
+    tex = _write_obj_inputs(d)
+    out = subprocess.run([exe, "obj", os.path.join(d, "box.obj"), os.path.join(d, "o"), "64", "36", "1", os.path.join(d, "box.mtl"), "host"],
+                         capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    assert "obj: 4 surfaces, 4 materials in the library, 1 texture layers" in out.stdout
+    sc, mats, layers = _python_side_of_the_obj_scene(tex)
+    ref = oracle.build_scene(sc)
+    # a mesh of four surfaces: the fourth surface's material slot does not exist in the 176-byte record (SURVEY A-6 / A-24)
+    assert open(os.path.join(d, "o_buf0.bin"), "rb").read() == ref.tri_geom.tobytes()
+    assert open(os.path.join(d, "o_buf1.bin"), "rb").read() == ref.tri_data.tobytes()
+    got_mats = np.frombuffer(open(os.path.join(d, "o_buf2.bin"), "rb").read(), dtype=wire.MATERIAL)
+    assert got_mats.tobytes() == mats.tobytes()
+    assert float(got_mats[4]["emission"][3]) == 6.0 and np.allclose(got_mats[4]["emission"][:3], [1.0, 0.75, 0.5])
+    assert np.isclose(got_mats[1]["roughness"], np.sqrt(2.0 / 252.0)) and got_mats[2]["roughness"] == np.float32(0.35)
+    assert open(os.path.join(d, "o_tex0.bin"), "rb").read() == layers[0].tobytes()
+
+
+@pytest.mark.gpu
+def test_cpp_obj_scene_renders_like_the_oracle(oracle, host_demo):
+    """The same files rendered by host_demo without Python in the loop (OBJ + MTL + PPM -> GeometryGroup3D ->
+    PathTracingCamera::render x 3): accumulation buffer and screen equal the oracle's render of the Python-side scene."""
+    exe, d = host_demo
+    tex = _write_obj_inputs(d)
+    w, h, frames = 96, 54, 3
+    out = subprocess.run([exe, "obj", os.path.join(d, "box.obj"), os.path.join(d, "og"), str(w), str(h), str(frames), os.path.join(d, "box.mtl")],
+                         capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    sc, _, _ = _python_side_of_the_obj_scene(tex)
+    cam = np.frombuffer(open(os.path.join(d, "og_camera.bin"), "rb").read(), dtype=wire.CAMERA)[0]
+    got = np.frombuffer(open(os.path.join(d, "og_accum.bin"), "rb").read(), dtype=np.float32).reshape(h, w, 4)
+    got_ldr = np.frombuffer(open(os.path.join(d, "og_ldr.bin"), "rb").read(), dtype=np.uint8).reshape(h, w, 4)
+    want, want_ldr, _, _, _ = oracle.render(oracle.build_scene(sc), cam, w, h, 4, frames, 1, wire.ACCUM_REF_LDR8)
+    assert np.array_equal(got, want) and np.array_equal(got_ldr, want_ldr)
