@@ -249,3 +249,27 @@ def test_sampler_modes_match_the_numpy_restatement(oracle, mode):
             assert np.array_equal(sample(u, v, 0), sample(u + 2.0, v - 1.0, 0))
     else:          # clamp-to-edge: everything beyond the edge texel centre is the edge texel
         assert np.array_equal(sample(-3.0, 0.5, 0), sample(0.01, 0.5, 0)) and np.array_equal(sample(7.0, 0.5, 0), sample(0.99, 0.5, 0))
+
+
+@pytest.mark.parametrize("frame", [1, 7])
+def test_whole_path_numpy_float32_restatement_equals_the_oracle(oracle, frame):
+    """tests/np_path.py: the whole path (jittered primary ray, closest hit, shading fetch, BRDF sample / pdf / value, 5
+    segments) restated in vectorised float32 numpy WITHOUT any tree -- every triangle of every instance against every
+    ray -- on the 36-triangle, 4-instance Cornell scene at 32x32.  The oracle's tree-independent mode
+    (JPTO_FLAG_NO_CULL) must give the same float radiance and depth bit for bit; the oracle's normal walk of the
+    reference tree must give that image too (no crack at this size)."""
+    import np_path
+    sc = scenes.cornell_scene()
+    sc.camera = scenes.CameraDesc(scenes.transform12(None, (0.0, 0.0, 4.2)), fov_deg=75.0)   # at the box opening: every pixel traces
+    w = h = 32
+    cam = scenes.camera_block(sc.camera, w, h).copy()
+    cam["frame_index"] = frame
+    ref = oracle.build_scene(sc)
+    rad, depth = np_path.trace_frame(ref, cam, w, h, 4)
+    want, want_depth, cnt = oracle.trace_frame(ref, cam, w, h, 4, flags=1)
+    walk, walk_depth, _ = oracle.trace_frame(ref, cam, w, h, 4)
+    assert cnt["rays"] > 2.5 * w * h                      # paths really bounce
+    bad = np.argwhere((rad != want[..., :3]).any(axis=-1))
+    assert len(bad) == 0, "pixels %s differ: numpy %s oracle %s" % (bad[:4].tolist(), rad[tuple(bad[0])], want[tuple(bad[0])][:3])
+    assert np.array_equal(depth, want_depth)
+    assert np.array_equal(walk, want) and np.array_equal(walk_depth, want_depth)
