@@ -91,6 +91,7 @@ struct jpt_ctx {
     DevBuf<WideTri> d_wtris;
     DevBuf<WideInstance> d_winst, d_winst4;
     DevBuf<WideNode4> d_nodes4;   // four-child records: BLAS part, then room for the TLAS part (one index space)
+    DevBuf<WideNodeQ> d_nodesq;   // their quantised form (jpt_nodeq.h), same indices: what the kernels walk
     DevBuf<ReachTri> d_reach_tri;   // reach records (JPT_BUILD_SAH): per triangle / per instance (one per copy of the instance level)
     DevBuf<ReachInst> d_reach_inst;
     BuildMode build_mode = BuildMode::ReferenceExact;
@@ -238,12 +239,24 @@ int upload_nodes4(jpt_ctx* c, bool tlas_only)
     hipStream_t s = c->stream;
     if (w.instances4.empty() && nb == 0) {
         c->ds.nodes4 = nullptr;
+        c->ds.nodesq = nullptr;
         c->ds.tlas_root4 = 0;
         return JPT_OK;
     }
+    auto quantised = [](const std::vector<WideNode4>& in) {
+        std::vector<WideNodeQ> out(in.size());
+        for (size_t i = 0; i < in.size(); i++) quantize_node4(in[i], out[i]);
+        return out;
+    };
     if (!tlas_only || c->d_nodes4.n < cap) {
         HIP_TRY(c, c->d_nodes4.resize(cap));
-        if (nb) HIP_TRY(c, hipMemcpyAsync(c->d_nodes4.p, w.blas_nodes4.data(), nb * sizeof(WideNode4), hipMemcpyHostToDevice, s));
+        HIP_TRY(c, c->d_nodesq.resize(cap));
+        if (nb) {
+            const std::vector<WideNodeQ> q = quantised(w.blas_nodes4);
+            HIP_TRY(c, hipMemcpyAsync(c->d_nodes4.p, w.blas_nodes4.data(), nb * sizeof(WideNode4), hipMemcpyHostToDevice, s));
+            HIP_TRY(c, hipMemcpyAsync(c->d_nodesq.p, q.data(), nb * sizeof(WideNodeQ), hipMemcpyHostToDevice, s));
+            HIP_TRY(c, hipStreamSynchronize(s));  // `q` is pageable host memory
+        }
     }
     for (int copy = 0; copy < jpt_ctx::kInstanceSets; copy++) {
         const size_t base = nb + (size_t)copy * cap_t;
@@ -251,14 +264,17 @@ int upload_nodes4(jpt_ctx* c, bool tlas_only)
         for (WideNode4& n : tail)
             for (int k = 0; k < 4; k++)
                 if (n.child[k] >= 0) n.child[k] += (int32_t)base;
+        const std::vector<WideNodeQ> qtail = quantised(tail);
         if (nt) HIP_TRY(c, hipMemcpyAsync(c->d_nodes4.p + base, tail.data(), nt * sizeof(WideNode4), hipMemcpyHostToDevice, s));
-        HIP_TRY(c, hipStreamSynchronize(s));  // `tail` is pageable host memory
+        if (nt) HIP_TRY(c, hipMemcpyAsync(c->d_nodesq.p + base, qtail.data(), nt * sizeof(WideNodeQ), hipMemcpyHostToDevice, s));
+        HIP_TRY(c, hipStreamSynchronize(s));  // `tail`, `qtail` are pageable host memory
     }
     c->tlas4_cap = cap_t;
     c->cur_set = 0;
     c->set_b_ready = false;  // the instance arrays of the other copies are made (again) by the next refit
     for (int k = 0; k < jpt_ctx::kInstanceSets; k++) c->set_retired_valid[k] = false;
     c->ds.nodes4 = c->d_nodes4.p;
+    c->ds.nodesq = c->d_nodesq.p;
     c->ds.tlas_root4 = w.tlas_root4 >= 0 ? w.tlas_root4 + (int32_t)nb : w.tlas_root4;
     {
         // bottom-up schedule of the TLAS records, for refits on the device
@@ -1205,7 +1221,7 @@ int jpt_scene_refit_tlas(jpt_ctx* c, const float* transforms12, uint32_t n_insta
     const uint32_t tail_base = (uint32_t)(c->wide.blas_nodes4.size() + (size_t)next * c->tlas4_cap);
     ReachInst* reach_next = c->ds.reach_tri ? (next ? c->d_reach_inst_more[next - 1].p : c->d_reach_inst.p) : nullptr;
     launch_tlas4_refit(rs, dev_view, n_instances, c->d_bvh.p, inst_next, nullptr, winst4_next, c->d_nodes4.p, tail_base,
-                       c->d_tlas4_order.p, c->d_tlas4_levels.p, c->n_tlas4_levels, reach_next);
+                       c->d_tlas4_order.p, c->d_tlas4_levels.p, c->n_tlas4_levels, reach_next, c->d_nodesq.p, (uint32_t)c->wide.tlas_nodes4.size());
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipEventRecord(c->ev_refit_copied[st], rs));
     HIP_TRY(c, hipEventRecord(c->ev_refit_done, rs));

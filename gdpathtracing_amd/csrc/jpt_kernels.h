@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "jpt_nodeq.h"
 #include "jpt_shade.h"
 #include "jpt_types.h"
 
@@ -55,7 +56,9 @@ struct DeviceScene {
     uint32_t n_blas_nodes = 0, n_tlas_nodes = 0;
     // four-child collapse of the same trees (native builder only; null otherwise)
     bool use4 = false;
-    const WideNode4* nodes4 = nullptr;       // BLAS records followed by the TLAS records, one index space
+    const WideNode4* nodes4 = nullptr;       // BLAS records followed by the TLAS records, one index space (float form: the
+                                             // device refit of the TLAS works on these) ...
+    const WideNodeQ* nodesq = nullptr;       // ... and their 64-byte quantised form, same indices: what the kernels walk
     const WideInstance* wide_instances4 = nullptr;
     int32_t tlas_root4 = 0;
     // reach records (jpt_types.h): null unless the scene was committed with JPT_BUILD_SAH
@@ -162,7 +165,7 @@ void launch_wf2_render(hipStream_t stream, const DeviceScene& ds, const FramePar
 void launch_tlas4_refit(hipStream_t stream, const float* transforms12, uint32_t n_instances, const RefBvhNode* bvh,
                         RefInstance* ref_instances, WideInstance* wide_instances, WideInstance* wide_instances4, WideNode4* nodes4,
                         uint32_t n_blas_records, const uint32_t* order, const uint32_t* level_start, uint32_t n_levels,
-                        ReachInst* reach_instances /* may be null */);
+                        ReachInst* reach_instances /* may be null */, WideNodeQ* nodesq, uint32_t n_tlas_records);
 
 // one dispatch of temporal_reprojection.glsl over a whole image (jpt_kernels_post.hip): screen rgba8 in/out, depth
 // read-only, hist1 / hist2 the two rgba32f history images

@@ -157,16 +157,32 @@ __global__ __launch_bounds__(1024) void tlas4_refit_kernel(WideNode4* __restrict
     }
 }
 
+// the refitted float records of one TLAS tail -> their quantised form (the same function the host uses at upload)
+__global__ __launch_bounds__(256) void quantize_tail_kernel(const WideNode4* __restrict__ nodes4, WideNodeQ* __restrict__ nodesq, uint32_t first,
+                                                            uint32_t n)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    WideNodeQ q;
+    quantize_node4(nodes4[first + i], q);
+    nodesq[first + i] = q;
+}
+
 void launch_tlas4_refit(hipStream_t stream, const float* transforms12, uint32_t n_instances, const RefBvhNode* bvh,
                         RefInstance* ref_instances, WideInstance* wide_instances, WideInstance* wide_instances4, WideNode4* nodes4,
-                        uint32_t n_blas_records, const uint32_t* order, const uint32_t* level_start, uint32_t n_levels, ReachInst* reach)
+                        uint32_t n_blas_records, const uint32_t* order, const uint32_t* level_start, uint32_t n_levels, ReachInst* reach,
+                        WideNodeQ* nodesq, uint32_t n_tlas_records)
 {
     if (n_instances == 0) return;
     hipLaunchKernelGGL(instance_refit_kernel, dim3((n_instances + 255) / 256), dim3(256), 0, stream, transforms12, n_instances, bvh,
                        ref_instances, wide_instances, wide_instances4, reach);
-    if (n_levels)
+    if (n_levels) {
         hipLaunchKernelGGL(tlas4_refit_kernel, dim3(1), dim3(1024), 0, stream, nodes4, n_blas_records, order, level_start, n_levels,
                            ref_instances);
+        if (nodesq && n_tlas_records)
+            hipLaunchKernelGGL(quantize_tail_kernel, dim3((n_tlas_records + 255) / 256), dim3(256), 0, stream, nodes4, nodesq, n_blas_records,
+                               n_tlas_records);
+    }
 }
 
 void launch_temporal(hipStream_t stream, const RefTemporalParams& tp, uint32_t* screen, const float* depth, float4* hist1,

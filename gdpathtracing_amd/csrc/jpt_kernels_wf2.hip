@@ -670,7 +670,7 @@ void launch_wf2_render(hipStream_t stream, const DeviceScene& ds, const FramePar
     WideSceneDev sc;
     sc.blas_nodes = ds.blas_nodes;
     sc.tlas_nodes = ds.tlas_nodes;
-    sc.nodes4 = ds.nodes4;
+    sc.nodesq = ds.nodesq;
     sc.tris = ds.wide_tris;
     sc.instances = w4 ? ds.wide_instances4 : ds.wide_instances;
     sc.tlas_root = w4 ? ds.tlas_root4 : ds.tlas_root;

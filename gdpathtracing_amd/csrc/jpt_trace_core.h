@@ -25,9 +25,9 @@ constexpr int32_t kSentinel = 0x7fffffff;  // "leave the instance" marker on the
 struct WideSceneDev {
     const WideNode* __restrict__ blas_nodes;   // two-child records (W4 = false)
     const WideNode* __restrict__ tlas_nodes;
-    const WideNode4* __restrict__ nodes4;      // four-child records (W4 = true): BLAS records, then the TLAS records, in
-                                               // ONE array (internal child references of both levels index it), so a
-                                               // step needs no per-lane choice of base pointer
+    const WideNodeQ* __restrict__ nodesq;      // four-child records (W4 = true), 64-byte quantised form (jpt_nodeq.h): BLAS
+                                               // records, then the TLAS records, in ONE array (internal child references
+                                               // of both levels index it), so a step needs no per-lane choice of base pointer
     const WideTri* __restrict__ tris;
     const WideInstance* __restrict__ instances;  // roots refer to the record kind in use
     int32_t tlas_root;
@@ -50,20 +50,6 @@ __device__ __forceinline__ float slab(const f3& o, const f3& rD, float mnx, floa
     return (tmax >= tmin && tmax > 0.0f) ? tmin : 1e30f;
 }
 
-// the same test with the entry distance and the verdict kept apart (no 1e30 select on the way to a sort key)
-__device__ __forceinline__ float slab_entry(const f3& o, const f3& rD, float mnx, float mny, float mnz, float mxx, float mxy,
-                                            float mxz, bool& hit)
-{
-    const float tx1 = (mnx - o.x) * rD.x, tx2 = (mxx - o.x) * rD.x;
-    float tmin = fmin_(tx1, tx2), tmax = fmax_(tx1, tx2);
-    const float ty1 = (mny - o.y) * rD.y, ty2 = (mxy - o.y) * rD.y;
-    tmin = fmax_(tmin, fmin_(ty1, ty2)), tmax = fmin_(tmax, fmax_(ty1, ty2));
-    const float tz1 = (mnz - o.z) * rD.z, tz2 = (mxz - o.z) * rD.z;
-    tmin = fmax_(tmin, fmin_(tz1, tz2)), tmax = fmin_(tmax, fmax_(tz1, tz2));
-    hit = (tmax >= tmin) & (tmax > 0.0f);
-    return tmin;
-}
-
 // TraceHit::inst holds two instance ids (a TLAS addresses at most 32 767 instances, bvh.h:59): bits 0..14 the
 // instance hitInfo.blas names -- it moves only on a strictly smaller distance -- and bits 15..29 the instance whose
 // local ray found the triangle kept, which is where hitInfo.position and hitInfo.out_dir come from (main.glsl:
@@ -83,8 +69,19 @@ struct TraceHit {
 // tests that decide reachability in main.glsl:270-350 (jpt_types.h, reach records).
 template <bool COUNT, bool W4 = false, bool REACH = false>
 struct Traversal {
-    f3 wo, wd, wrD;   // world ray and its reciprocal direction (kept so leaving an instance costs no divisions)
-    f3 o, d, rD;      // current-level ray (world at TLAS level, instance-local below)
+    // The native route's four-child records are 64-byte quantised records (jpt_nodeq.h: four 16-byte loads instead of
+    // seven -- the kernel is bound by the CU's load-instruction rate) walked with box tests that only have to be
+    // CONSERVATIVE: the native boxes are padded and rounded outwards, and what the reference's own boxes let through is
+    // decided by the reach records.  Entry / exit distances are one fused multiply-add per plane, t = q * (scale * rD) +
+    // (origin * rD + ood) with ood = -o * rD, on the near and far plane words picked by the sign of the direction, with a
+    // reciprocal from v_rcp_f32.  (The two-child records of reference trees use intersectAABB as written, with the exact
+    // quotient 1 / d, and so do the REACH tests.)  On gfx950 an fma costs 2.3 SIMD cycles, a min / max / compare / select
+    // 4.2 (tools/micro/valu_issue.hip).
+    static constexpr bool kLean = W4;
+    f3 wo, wd, wrD;   // world ray; wrD = its exact reciprocal direction (two-child records and REACH only)
+    f3 o, d, rD;      // current-level ray (world at TLAS level, instance-local below); kLean: rD from v_rcp_f32
+    f3 ood;           // kLean: -o * rD
+    f3 xrD;           // REACH on four-child records: the exact 1 / d of the current level (the reference's intersectAABB)
     TraceHit hit;
     int32_t cur;
     int sp;
@@ -128,8 +125,8 @@ struct Traversal {
         wd = rd;
         o = ro;
         d = rd;
-        rD = rcp3(rd);
-        wrD = rD;
+        set_level();
+        wrD = (kLean && REACH) ? xrD : rD;
         hit.t = 1e9f;  // main.glsl:354
         hit.u = hit.v = 0.0f;
         hit.tri = hit.inst = 0;
@@ -141,6 +138,18 @@ struct Traversal {
         have = sc.n_instances != 0;
     }
 
+    // slab constants of the current-level ray (o, d)
+    __device__ __forceinline__ void set_level()
+    {
+        if (kLean) {
+            rD = mk3(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
+            ood = mk3(-(o.x * rD.x), -(o.y * rD.y), -(o.z * rD.z));
+            if (REACH) xrD = rcp3(d);
+        } else {
+            rD = rcp3(d);
+        }
+    }
+
     // ---- the three kinds of records, as separate pieces so a kernel can run them in phases ----------------
 
     __device__ __forceinline__ bool wants_node() const { return have && cur >= 0; }
@@ -148,55 +157,43 @@ struct Traversal {
     __device__ __forceinline__ bool wants_instance() const { return have && cur < 0 && !in_blas; }
     __device__ __forceinline__ bool finished() const { return !have && sp == 0; }
 
-    // four-child record (128 B = one L1 line): four slab tests, children visited nearest first.  The order
-    // among children is a performance choice only (the closest hit does not depend on it).
-    struct NodeData {  // one record as fetched (7 float4 for the four-child form, 4 for the two-child form)
-        float4 q[7];
-    };
-    __device__ __forceinline__ NodeData node_fetch(const WideSceneDev& sc) const
-    {
-        NodeData nd;
-        if (W4) {
-            const WideNode4* n = sc.nodes4 + cur;
-            nd.q[0] = ld4(&n->lo_x[0]); nd.q[1] = ld4(&n->lo_y[0]); nd.q[2] = ld4(&n->lo_z[0]);
-            nd.q[3] = ld4(&n->hi_x[0]); nd.q[4] = ld4(&n->hi_y[0]); nd.q[5] = ld4(&n->hi_z[0]);
-            nd.q[6] = ld4(&n->child[0]);
-        } else {
-            const WideNode* n = (in_blas ? sc.blas_nodes : sc.tlas_nodes) + cur;
-            nd.q[0] = ld4(&n->lmin[0]); nd.q[1] = ld4(&n->lmax[1]); nd.q[2] = ld4(&n->rmin[2]); nd.q[3] = ld4(&n->left);
-        }
-        return nd;
-    }
+    // four-child record: four box tests on the quantised planes, children visited nearest first.  The order among
+    // children is a performance choice only (the closest hit does not depend on it).
     __device__ __forceinline__ void node_step4(const WideSceneDev& sc, const Stack& st, DevCounters& cnt)
     {
-        node_apply4(node_fetch(sc), st, cnt);
-    }
-    __device__ __forceinline__ void node_apply4(const NodeData& nd, const Stack& st, DevCounters& cnt)
-    {
-        const float4 lx = nd.q[0], ly = nd.q[1], lz = nd.q[2];
-        const float4 hx = nd.q[3], hy = nd.q[4], hz = nd.q[5];
-        const float4 cf = nd.q[6];
+        const char* __restrict__ base = reinterpret_cast<const char*>(sc.nodesq);
+        const uint32_t rec = (uint32_t)cur << 6;
+        const float4 h0 = ld4(base + rec);           // origin.xyz, scale.x
+        const float4 h1 = ld4(base + (rec + 16u));   // scale.y, scale.z, lo_x, lo_y
+        const float4 h2 = ld4(base + (rec + 32u));   // lo_z, hi_x, hi_y, hi_z
+        const float4 cf = ld4(base + (rec + 48u));   // child references
         if (COUNT) {
             if (in_blas) cnt.blas_expand++;
             else cnt.tlas_expand++;
         }
+        // t = (origin + q * scale - o) * rD = q * (scale * rD) + (origin * rD + ood)
+        const float ax = h0.w * rD.x, ay = h1.x * rD.y, az = h1.y * rD.z;
+        const float bx = __builtin_fmaf(h0.x, rD.x, ood.x), by = __builtin_fmaf(h0.y, rD.y, ood.y), bz = __builtin_fmaf(h0.z, rD.z, ood.z);
+        // the plane words a ray meets first / last on each axis: lo / hi, swapped where the direction is negative
+        const bool negx = __float_as_int(d.x) < 0, negy = __float_as_int(d.y) < 0, negz = __float_as_int(d.z) < 0;
+        const uint32_t lox = __float_as_uint(h1.z), loy = __float_as_uint(h1.w), loz = __float_as_uint(h2.x);
+        const uint32_t hix = __float_as_uint(h2.y), hiy = __float_as_uint(h2.z), hiz = __float_as_uint(h2.w);
+        const uint32_t nwx = negx ? hix : lox, fwx = negx ? lox : hix;
+        const uint32_t nwy = negy ? hiy : loy, fwy = negy ? loy : hiy;
+        const uint32_t nwz = negz ? hiz : loz, fwz = negz ? loz : hiz;
         int32_t r0 = __float_as_int(cf.x), r1 = __float_as_int(cf.y), r2 = __float_as_int(cf.z), r3 = __float_as_int(cf.w);
-        bool h0, h1, h2, h3;
-        const float d0 = slab_entry(o, rD, lx.x, ly.x, lz.x, hx.x, hy.x, hz.x, h0);
-        const float d1 = slab_entry(o, rD, lx.y, ly.y, lz.y, hx.y, hy.y, hz.y, h1);
-        const float d2 = slab_entry(o, rD, lx.z, ly.z, lz.z, hx.z, hy.z, hz.z, h2);
-        const float d3 = slab_entry(o, rD, lx.w, ly.w, lz.w, hx.w, hy.w, hz.w, h3);
-        // sort keys: distance clamped to >= 0 (so the bit pattern orders like the value), child slot in the two
-        // low mantissa bits (keys are distinct); unusable children (empty slot, box missed, or not closer than
-        // the current hit) sort last
         constexpr uint32_t kInvalid = 0x7f800000u;
         const float tcur = hit.t;
-        auto key = [&](float d, bool h, int32_t c, uint32_t slot) -> uint32_t {
-            const bool ok = h & (c != kEmptyChild) & (d < tcur);
-            const uint32_t bits = (__float_as_uint(fmax_(d, 0.0f)) & ~3u) | slot;
-            return ok ? bits : (kInvalid | slot);
+        // entry = max over the axes of the near-plane distances (and 0), exit = min of the far-plane distances (and the
+        // current hit); usable when entry <= exit and the slot is not empty
+        auto key = [&](int k, int32_t ch) -> uint32_t {
+            const float qnx = (float)((nwx >> (8 * k)) & 255u), qny = (float)((nwy >> (8 * k)) & 255u), qnz = (float)((nwz >> (8 * k)) & 255u);
+            const float qfx = (float)((fwx >> (8 * k)) & 255u), qfy = (float)((fwy >> (8 * k)) & 255u), qfz = (float)((fwz >> (8 * k)) & 255u);
+            const float t_in = fmax_(fmax_(fmax_(__builtin_fmaf(qnx, ax, bx), __builtin_fmaf(qny, ay, by)), __builtin_fmaf(qnz, az, bz)), 0.0f);
+            const float t_out = fmin_(fmin_(fmin_(__builtin_fmaf(qfx, ax, bx), __builtin_fmaf(qfy, ay, by)), __builtin_fmaf(qfz, az, bz)), tcur);
+            return ((t_in <= t_out) & (ch != kEmptyChild)) ? __float_as_uint(t_in) : kInvalid;
         };
-        uint32_t k0 = key(d0, h0, r0, 0u), k1 = key(d1, h1, r1, 1u), k2 = key(d2, h2, r2, 2u), k3 = key(d3, h3, r3, 3u);
+        uint32_t k0 = key(0, r0), k1 = key(1, r1), k2 = key(2, r2), k3 = key(3, r3);
         // 5-comparator network on (key, child reference) pairs: one compare, min, max and two selects per
         // exchange.  (Looking the references up by slot after a key-only sort compiled to nested branches.)
         auto cswap = [](uint32_t& ka, uint32_t& kb, int32_t& ra, int32_t& rb) {
@@ -229,14 +226,11 @@ struct Traversal {
             node_step4(sc, st, cnt);
             return;
         }
-        node_apply2(node_fetch(sc), st, cnt);
-    }
-    __device__ __forceinline__ void node_apply2(const NodeData& nd, const Stack& st, DevCounters& cnt)
-    {
-        const float4 a = nd.q[0];  // lmin.xyz lmax.x
-        const float4 b = nd.q[1];  // lmax.yz rmin.xy
-        const float4 c = nd.q[2];  // rmin.z rmax.xyz
-        const float4 e = nd.q[3];  // left right pad pad
+        const WideNode* n = (in_blas ? sc.blas_nodes : sc.tlas_nodes) + cur;
+        const float4 a = ld4(&n->lmin[0]);  // lmin.xyz lmax.x
+        const float4 b = ld4(&n->lmax[1]);  // lmax.yz rmin.xy
+        const float4 c = ld4(&n->rmin[2]);  // rmin.z rmax.xyz
+        const float4 e = ld4(&n->left);     // left right pad pad
         if (COUNT) {
             if (in_blas) cnt.blas_expand++;
             else cnt.tlas_expand++;
@@ -335,7 +329,7 @@ struct Traversal {
     {
         const float4 a = ld4(&sc.reach_tri[ti].lo[0]), b = ld4(&sc.reach_tri[ti].hi[0]);
         if (__float_as_uint(a.w) != 0u) return true;  // the reference's BLAS root is this leaf: no box test on the way
-        return slab(o, rD, a.x, a.y, a.z, b.x, b.y, b.z) < 1e30f;
+        return slab(o, kLean ? xrD : rD, a.x, a.y, a.z, b.x, b.y, b.z) < 1e30f;   // intersectAABB with the exact 1 / d
     }
 
     // TLAS leaf: enter the instance (main.glsl:316-322)
@@ -363,7 +357,7 @@ struct Traversal {
                 m0.z * wo.x + m1.y * wo.y + m2.x * wo.z + m2.w);
         d = mk3(m0.x * wd.x + m0.w * wd.y + m1.z * wd.z, m0.y * wd.x + m1.x * wd.y + m1.w * wd.z,
                 m0.z * wd.x + m1.y * wd.y + m2.x * wd.z);
-        rD = rcp3(d);
+        set_level();
         in_blas = true;
         push(st, kSentinel);
         cur = root;
@@ -378,7 +372,8 @@ struct Traversal {
         if (cur == kSentinel) {
             o = wo;
             d = wd;
-            rD = wrD;
+            if (kLean) set_level();   // (recomputed rather than kept: three v_rcp_f32 per instance left, registers saved)
+            else rD = wrD;
             in_blas = false;
             if (sp == 0) return;
             cur = pop(st);

@@ -2,6 +2,7 @@
 // and the flattened device layout the native kernels traverse.
 #pragma once
 
+#include <stddef.h>
 #include <stdint.h>
 
 namespace jpt {
@@ -118,12 +119,16 @@ static_assert(sizeof(WideNode) == 64, "WideNode");
 // the four slab tests read whole float4s, plus four child references (same encoding as WideNode;
 // kEmptyChild marks an unused slot).  Built by collapsing the binary tree (flatten4): a ray makes about half
 // as many dependent fetches as on the two-child records.
+// Byte layout: the three lo planes in the first 64 bytes (with the child references), the three hi planes 64 bytes
+// further on, so "the plane of axis a a ray meets first / last" is at a * 16 + (direction negative ? 64 : 0) and that
+// offset XOR 64: the walk fetches near and far planes directly and never compares the two planes of an axis.
 struct alignas(128) WideNode4 {
     float lo_x[4], lo_y[4], lo_z[4];
-    float hi_x[4], hi_y[4], hi_z[4];
     int32_t child[4];
+    float hi_x[4], hi_y[4], hi_z[4];
     uint32_t _pad[4];
 };
+static_assert(offsetof(WideNode4, child) == 48 && offsetof(WideNode4, hi_x) == 64, "WideNode4 plane offsets");
 static_assert(sizeof(WideNode4) == 128, "WideNode4");
 constexpr int32_t kEmptyChild = (int32_t)0x80000000;  // ~0x7fffffff: never a valid leaf reference
 

@@ -1,12 +1,16 @@
-// node_fetch.hip -- how fast can a CU of gfx950 serve DIVERGENT 128-byte record fetches (every lane its own record, the
-// next record's index read from the one just fetched: the access pattern of a BVH walk)?
+// node_fetch.hip -- what does the vector-memory path of a gfx950 CU charge for DIVERGENT record fetches (every lane its
+// own record, the next record's index read from the one just fetched: the access pattern of a BVH walk)?
 //
-// A table of `n` 128-byte records (7 x float4 of payload + 4 "child" indices, like WideNode4); every lane walks its own
-// pseudo-random chain through it: fetch the record as 8 x 16-byte loads, do `valu` dependent FMAs per step on the
-// payload (stand-in for the slab tests), continue at child[k].  Reported per configuration: record fetches per
-// microsecond per CU, bytes per cycle per CU, and the time one dependent step takes a wave.  Sweeps: table size
-// (6 MB = L2-resident like the C3 scene, 96 MB = Infinity Cache, 768 MB = HBM), waves per SIMD, enabled lanes per wave,
-// VALU work per step.
+// A table of 128-byte-aligned records; every lane walks its own pseudo-random chain through it.  Per step a lane loads
+// the first NLOADS x 16 bytes of its record (NLOADS = 1, 2, 4, 7, 8: how much of the cost is per load instruction and how
+// much per byte), with 64-bit per-lane addresses or with a scalar base + 32-bit per-lane offset, does `valu` dependent
+// FMAs on the payload, and continues at the index stored in the record.  Reported per configuration: record fetches
+// per microsecond per CU, the CU's time per wave-level load instruction, and the time one dependent step takes a wave.
+// Sweeps: table size (6 MB = L2-resident like the C3 scene, 96 MB = Infinity Cache), waves per SIMD, enabled lanes.
+//
+// Findings on MI355X (profiles/r02/node_fetch.txt): the rate is set per CU by the vector-memory path, not by L2 or HBM
+// bandwidth: a load instruction costs the CU about (fixed + per-enabled-lane) cycles, so what a record costs is its
+// number of 16-byte load instructions, whatever the table size up to the Infinity Cache's.
 //
 //   hipcc --offload-arch=gfx950 -O2 -o node_fetch node_fetch.hip && ./node_fetch
 #include <hip/hip_runtime.h>
@@ -17,10 +21,10 @@
 #include <vector>
 
 struct alignas(128) Rec {
-    float4 q[7];
-    int32_t child[4];
+    float4 q[8];   // q[0].w holds the next record's index (bits)
 };
 
+template <int NLOADS, bool SADDR>
 __global__ __launch_bounds__(256) void walk(const Rec* __restrict__ table, uint32_t n, int steps, int lanes_on, int valu, float* __restrict__ out)
 {
     const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -28,17 +32,24 @@ __global__ __launch_bounds__(256) void walk(const Rec* __restrict__ table, uint3
     if (lane >= lanes_on) return;
     uint32_t cur = (tid * 2654435761u) % n;
     float acc = 0.0f;
+    const char* base = reinterpret_cast<const char*>(table);
     for (int s = 0; s < steps; s++) {
-        const Rec* r = table + cur;
-        const float4 a = r->q[0], b = r->q[1], c = r->q[2], d = r->q[3], e = r->q[4], f = r->q[5], g = r->q[6];
-        const int4 ch = *reinterpret_cast<const int4*>(r->child);
-        // every component is used, so the compiler keeps the eight 16-byte loads (27 adds: the floor of VALU work per step)
-        float v = ((a.x + a.y) + (a.z + a.w)) + ((b.x + b.y) + (b.z + b.w)) + ((c.x + c.y) + (c.z + c.w)) + ((d.x + d.y) + (d.z + d.w)) +
-                  ((e.x + e.y) + (e.z + e.w)) + ((f.x + f.y) + (f.z + f.w)) + ((g.x + g.y) + (g.z + g.w));
-        for (int k = 0; k < valu; k++) v = v * 1.0001f + 0.5f;   // dependent chain: `valu` VALU instructions
-        acc += v;
-        const int k = (int)(s & 3);
-        cur = (uint32_t)(k == 0 ? ch.x : k == 1 ? ch.y : k == 2 ? ch.z : ch.w);
+        float4 v[NLOADS];
+        if (SADDR) {
+            const uint32_t off = cur << 7;   // scalar base + 32-bit offset (tables up to 4 GB)
+#pragma unroll
+            for (int k = 0; k < NLOADS; k++) v[k] = *reinterpret_cast<const float4*>(base + (off + 16u * k));
+        } else {
+            const Rec* r = table + cur;
+#pragma unroll
+            for (int k = 0; k < NLOADS; k++) v[k] = r->q[k];
+        }
+        float x = 0.0f;
+#pragma unroll
+        for (int k = 0; k < NLOADS; k++) x += (v[k].x + v[k].y) + (v[k].z + (k == 0 ? 0.0f : v[k].w));   // every component is used: the loads stay whole
+        for (int k = 0; k < valu; k++) x = x * 1.0001f + 0.5f;   // dependent chain: `valu` VALU instructions
+        acc += x;
+        cur = __float_as_uint(v[0].w);
     }
     out[tid] = acc;
 }
@@ -52,6 +63,32 @@ __global__ __launch_bounds__(256) void walk(const Rec* __restrict__ table, uint3
         }                                                                   \
     } while (0)
 
+template <int NLOADS, bool SADDR>
+static void run(const Rec* d, uint32_t n, int n_cu, int waves, int lanes_on, int valu, float* out)
+{
+    const int steps = 300;
+    const int blocks = n_cu * waves;
+    hipLaunchKernelGGL((walk<NLOADS, SADDR>), dim3(blocks), dim3(256), 0, 0, d, n, 20, lanes_on, valu, out);
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    CK(hipEventRecord(e0));
+    hipLaunchKernelGGL((walk<NLOADS, SADDR>), dim3(blocks), dim3(256), 0, 0, d, n, steps, lanes_on, valu, out);
+    CK(hipEventRecord(e1));
+    CK(hipEventSynchronize(e1));
+    float ms = 0;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    const double fetches = (double)blocks * 4.0 * lanes_on * steps;
+    const double per_us_cu = fetches / (ms * 1e3) / n_cu;
+    const double instr_per_cu = (double)waves * 4.0 * steps * NLOADS;   // wave-level load instructions one CU issued
+    std::printf("table %4.0f MB  %s  loads/record %d  waves/SIMD %d  lanes %2d  valu/step %3d: %7.1f records/us/CU, %5.1f ns of CU time per load "
+                "instruction, step time per wave %.0f ns\n",
+                (double)n * 128.0 / 1048576.0, SADDR ? "sbase+off32" : "addr64     ", NLOADS, waves, lanes_on, valu, per_us_cu,
+                ms * 1e6 / instr_per_cu, ms * 1e6 / steps);
+    CK(hipEventDestroy(e0));
+    CK(hipEventDestroy(e1));
+}
+
 int main()
 {
     hipDeviceProp_t prop;
@@ -60,44 +97,32 @@ int main()
     std::printf("%s, %d CUs\n", prop.gcnArchName, n_cu);
     float* out;
     CK(hipMalloc(&out, (size_t)n_cu * 8 * 256 * sizeof(float)));
-    for (uint32_t n : {49152u, 786432u, 6291456u}) {   // 6 MB, 96 MB, 768 MB
+    for (uint32_t n : {49152u, 786432u}) {   // 6 MB, 96 MB
         std::vector<Rec> h(n);
         uint32_t s = 12345u;
         for (uint32_t i = 0; i < n; i++) {
-            for (int k = 0; k < 7; k++) h[i].q[k] = make_float4(1e-3f * (float)(i & 255), 0.5f, 0.25f, 0.125f);
-            for (int k = 0; k < 4; k++) {
-                s = s * 1664525u + 1013904223u;
-                h[i].child[k] = (int32_t)((s >> 4) % n);
-            }
+            for (int k = 0; k < 8; k++) h[i].q[k] = make_float4(1e-3f * (float)(i & 255), 0.5f, 0.25f, 0.125f);
+            s = s * 1664525u + 1013904223u;
+            const uint32_t next = (s >> 4) % n;
+            h[i].q[0].w = *reinterpret_cast<const float*>(&next);
         }
         Rec* d;
         CK(hipMalloc(&d, (size_t)n * sizeof(Rec)));
         CK(hipMemcpy(d, h.data(), (size_t)n * sizeof(Rec), hipMemcpyHostToDevice));
-        for (int waves : {1, 2, 4, 7, 8})
-            for (int lanes_on : {64, 32, 16})
-                for (int valu : {0, 64, 192}) {
-                    if ((lanes_on != 64 || valu != 64) && waves != 7) continue;   // full sweep only at 7 waves/SIMD
-                    const int steps = 400;
-                    const int blocks = n_cu * waves;
-                    hipLaunchKernelGGL(walk, dim3(blocks), dim3(256), 0, 0, d, n, 20, lanes_on, valu, out);
-                    hipEvent_t e0, e1;
-                    CK(hipEventCreate(&e0));
-                    CK(hipEventCreate(&e1));
-                    CK(hipEventRecord(e0));
-                    hipLaunchKernelGGL(walk, dim3(blocks), dim3(256), 0, 0, d, n, steps, lanes_on, valu, out);
-                    CK(hipEventRecord(e1));
-                    CK(hipEventSynchronize(e1));
-                    float ms = 0;
-                    CK(hipEventElapsedTime(&ms, e0, e1));
-                    const double fetches = (double)blocks * 4.0 * lanes_on * steps;
-                    const double per_us_cu = fetches / (ms * 1e3) / n_cu;
-                    std::printf("table %4.0f MB  waves/SIMD %d  lanes %2d  valu/step %3d: %7.1f record fetches/us/CU = %5.1f B/cycle/CU at 2.4 GHz, "
-                                "%6.1f Grec/s chip, step time per wave %.0f ns\n",
-                                (double)n * 128.0 / 1048576.0, waves, lanes_on, valu, per_us_cu, per_us_cu * 128.0 / 2400.0, fetches / (ms * 1e6),
-                                ms * 1e6 / steps);
-                    CK(hipEventDestroy(e0));
-                    CK(hipEventDestroy(e1));
-                }
+        for (int lanes_on : {64, 24, 16}) {
+            run<1, false>(d, n, n_cu, 7, lanes_on, 64, out);
+            run<2, false>(d, n, n_cu, 7, lanes_on, 64, out);
+            run<4, false>(d, n, n_cu, 7, lanes_on, 64, out);
+            run<7, false>(d, n, n_cu, 7, lanes_on, 64, out);
+            run<8, false>(d, n, n_cu, 7, lanes_on, 64, out);
+            run<4, true>(d, n, n_cu, 7, lanes_on, 64, out);
+            run<7, true>(d, n, n_cu, 7, lanes_on, 64, out);
+        }
+        if (n == 49152u) {
+            for (int waves : {2, 4, 8}) run<7, true>(d, n, n_cu, waves, 24, 64, out);
+            for (int valu : {0, 192, 384}) run<7, true>(d, n, n_cu, 7, 24, valu, out);
+            for (int valu : {0, 192, 384}) run<4, true>(d, n, n_cu, 7, 24, valu, out);
+        }
         CK(hipFree(d));
     }
     return 0;
