@@ -86,7 +86,8 @@ struct Wf2Buffers {
     float4* hit_a;      // t, u, v, tri bits          (same index as the ray)
     uint32_t* hit_b;    // inst | front << 31
     float4* thr;        // per path: throughput.xyz, w = seed.x bits
-    float4* rad;        // per path: radiance.xyz,   w = seed.y bits  ([frame][slot]: also the per-frame output)
+    float4* rad;        // per path: radiance.xyz,   w = seed.y bits  ([frame][slot]; HDR_F32 mode: also the finished paths' output)
+    uint32_t* fin8;     // REF_LDR8 mode: [frame][slot] the finished path's radiance as the rgba8 main.glsl:434 stores (4 bytes, not 16)
     float* first_depth; // per slot of the LAST frame: distance of the first hit (or far)
     uint32_t* qcount;   // [max_bounces + 2][kSegments] queue sizes; row b = rays traced in bounce b (b >= 1)
     uint32_t* redo_count;  // [0]: paths set aside because the reference cannot reach their hit (wf2_finish) ...
@@ -122,6 +123,25 @@ __device__ __forceinline__ void slot_to_pixel(uint32_t slot, const Wf2Dims& dm, 
     const uint32_t ty = fdiv(tile, dm.by_tiles_x), tx = tile - ty * (uint32_t)dm.tiles_x;
     px = (int)(tx * 8u + (lane & 7u));
     ly = (int)(ty * 8u + (lane >> 3));
+}
+
+// a path is over: its radiance goes where wf2_accumulate reads it -- in REF_LDR8 mode already as the rgba8 value of
+// main.glsl:434 (the accumulation sums exactly those quantised values, progressive_rendering.glsl:33), 4 bytes per path
+__device__ __forceinline__ void store_final(const Wf2Buffers& wb, int accum_mode, uint32_t p, f3 r)
+{
+    if (accum_mode == 0) wb.fin8[p] = unorm8(r.x) | (unorm8(r.y) << 8) | (unorm8(r.z) << 16);
+    else wb.rad[p] = make_float4(r.x, r.y, r.z, 0.0f);
+}
+
+// Is pixel (px, py) outside the screen rectangles of all the boxes the TLAS root offers (SkyCull, jpt_kernels.h)?  Its
+// primary ray then fails every box test of the root: sky.  Such (pixel, frame) paths are not stored anywhere: the primary
+// launch skips them and wf2_accumulate recomputes their sky colour from (x, y, frame).
+__device__ __forceinline__ bool sky_culled(const SkyCull& cull, int px, int py)
+{
+    bool outside = cull.n >= 0;
+    for (int k = 0; k < 4; k++)
+        if (k < cull.n && px >= cull.x0[k] && px <= cull.x1[k] && py >= cull.y0[k] && py <= cull.y1[k]) outside = false;
+    return outside;
 }
 
 __device__ __forceinline__ uint32_t lanes_below(unsigned long long mask, int lane)
@@ -177,24 +197,19 @@ __global__ __launch_bounds__(kBlock, JPT_PRIMARY_WAVES) void wf2_primary(WideSce
                     slot_to_pixel(slot, dm, px, ly);
                     if (chunk < dm.n_chunks && px < fp.width && ly < fp.local_rows) {
                         const int py = local_to_global_row(ly, fp);
-                        uint32_t sx, sy;
-                        const Ray ray = primary_ray(cam, fp.width, fp.height, px, py, fp.frame_index + f, sx, sy);
                         path = f * dm.slots_per_frame + slot;
                         if (COUNT) cnt.rays++;
                         // a pixel outside the screen rectangles of all the boxes the TLAS root offers: the walk would
-                        // expand the root, fail every box test and end -- the result is written here instead
-                        bool outside = cull.n >= 0;
-                        for (int k = 0; k < 4; k++)
-                            if (k < cull.n && px >= cull.x0[k] && px <= cull.x1[k] && py >= cull.y0[k] && py <= cull.y1[k]) outside = false;
-                        if (outside) {
+                        // expand the root, fail every box test and end in the sky -- nothing is generated, traced or
+                        // stored for it here; wf2_accumulate makes up its colour from (x, y, frame)
+                        if (sky_culled(cull, px, py)) {
                             if (COUNT) {
                                 cnt.tlas_expand++;
                                 cnt.phase[7]++;
                             }
-                            const f3 sky = mk3(0.0f, 0.0f, 0.0f) + mk3(1.0f, 1.0f, 1.0f) * sample_sky(ray.d);
-                            wb.rad[path] = make_float4(sky.x, sky.y, sky.z, 0.0f);
-                            if ((int)f == fp.depth_frame) wb.first_depth[slot] = cam.far_;
                         } else {
+                            uint32_t sx, sy;
+                            const Ray ray = primary_ray(cam, fp.width, fp.height, px, py, fp.frame_index + f, sx, sy);
                             tr.begin(sc, ray.o, ray.d);
                             active = true;
                         }
@@ -219,7 +234,7 @@ __global__ __launch_bounds__(kBlock, JPT_PRIMARY_WAVES) void wf2_primary(WideSce
                     wb.hit_b[seg_base + j] = tr.hit.inst | (tr.hit.front ? 0x80000000u : 0u);
                 } else {                // sky: radiance += 1 * sampleSky(d), path over (main.glsl:380,395-397)
                     const f3 sky = mk3(0.0f, 0.0f, 0.0f) + mk3(1.0f, 1.0f, 1.0f) * sample_sky(tr.wd);
-                    wb.rad[path] = make_float4(sky.x, sky.y, sky.z, 0.0f);  // path over: its seed is never used again
+                    store_final(wb, fp.accum_mode, path, sky);
                     if (last_frame) wb.first_depth[path - f * dm.slots_per_frame] = cam.far_;
                 }
             }
@@ -386,11 +401,13 @@ __device__ __forceinline__ bool shade_entry(const SceneShading& sh, const Wf2Buf
         if (bounce == 0 && (int)f == fp.depth_frame) wb.first_depth[slot] = length3(s.position - ray.o);
         if (bounce < fp.max_bounces) alive = bounce_step(s, sx, sy, ray, throughput);
     }
-    wb.rad[p] = make_float4(radiance.x, radiance.y, radiance.z, __uint_as_float(sy));
     if (alive) {
+        wb.rad[p] = make_float4(radiance.x, radiance.y, radiance.z, __uint_as_float(sy));
         wb.thr[p] = make_float4(throughput.x, throughput.y, throughput.z, __uint_as_float(sx));
         no = make_float4(ray.o.x, ray.o.y, ray.o.z, 0.0f);
         nd = make_float4(ray.d.x, ray.d.y, ray.d.z, __uint_as_float(p));
+    } else {
+        store_final(wb, fp.accum_mode, p, radiance);
     }
     return alive;
 }
@@ -480,7 +497,7 @@ __global__ __launch_bounds__(64) void wf2_finish(WideSceneDev sc, SceneShading s
 
 // ---- per pixel: frames in order -> accumulation buffer, display image, depth ----------------------------------
 
-__global__ __launch_bounds__(kBlock) void wf2_accumulate(Wf2Buffers wb, Wf2Dims dm, FrameParams fp, RefCamera cam,
+__global__ __launch_bounds__(kBlock) void wf2_accumulate(Wf2Buffers wb, Wf2Dims dm, FrameParams fp, RefCamera cam, SkyCull cull,
                                                          float4* __restrict__ accum, uint32_t* __restrict__ ldr,
                                                          float* __restrict__ depth_out)
 {
@@ -498,12 +515,31 @@ __global__ __launch_bounds__(kBlock) void wf2_accumulate(Wf2Buffers wb, Wf2Dims 
         sum = mk3(prev.x, prev.y, prev.z);
     }
     f3 last = mk3(0.0f, 0.0f, 0.0f);
+    // the primary launch neither traced nor stored the paths of a sky-culled pixel: their radiance is the sky along the
+    // primary ray of (x, y, frame) (main.glsl:380,395-397 with throughput 1), made up here
+    const int py = local_to_global_row(ly, fp);
+    const bool culled = sky_culled(cull, px, py);
     for (int f = 0; f < fp.n_frames; f++) {
-        const float4 r = wb.rad[(size_t)f * dm.slots_per_frame + slot];
-        f3 cur = mk3(r.x, r.y, r.z);
-        last = cur;
-        if (fp.accum_mode == 0)  // rgba8 store of main.glsl:434, load of progressive_rendering.glsl:33
-            cur = mk3(from_unorm8(unorm8(cur.x)), from_unorm8(unorm8(cur.y)), from_unorm8(unorm8(cur.z)));
+        f3 cur;
+        if (culled) {
+            uint32_t sx, sy;
+            const Ray ray = primary_ray(cam, fp.width, fp.height, px, py, fp.frame_index + (uint32_t)f, sx, sy);
+            cur = mk3(0.0f, 0.0f, 0.0f) + mk3(1.0f, 1.0f, 1.0f) * sample_sky(ray.d);
+            if (fp.accum_mode == 0) {  // rgba8 store of main.glsl:434, load of progressive_rendering.glsl:33
+                last = mk3(from_unorm8(unorm8(cur.x)), from_unorm8(unorm8(cur.y)), from_unorm8(unorm8(cur.z)));
+                cur = last;
+            } else {
+                last = cur;
+            }
+        } else if (fp.accum_mode == 0) {
+            const uint32_t q = wb.fin8[(size_t)f * dm.slots_per_frame + slot];
+            cur = mk3(from_unorm8(q & 255u), from_unorm8((q >> 8) & 255u), from_unorm8((q >> 16) & 255u));
+            last = cur;   // (display_mode 1 shows the last frame's rgba8 image itself: quantising it again gives the same bytes)
+        } else {
+            const float4 r = wb.rad[(size_t)f * dm.slots_per_frame + slot];
+            cur = mk3(r.x, r.y, r.z);
+            last = cur;
+        }
         sum = have_prev ? cur + sum : cur;  // progressive_rendering.glsl:34-36
         have_prev = true;
     }
@@ -513,7 +549,7 @@ __global__ __launch_bounds__(kBlock) void wf2_accumulate(Wf2Buffers wb, Wf2Dims 
         const f3 col = fp.display_mode == 1 ? last : aces_film(mk3(sum.x / fc, sum.y / fc, sum.z / fc) * 1.0f);
         ldr[idx] = unorm8(col.x) | (unorm8(col.y) << 8) | (unorm8(col.z) << 16) | 0xFF000000u;
         if (depth_out) {
-            const float dist = wb.first_depth[slot];
+            const float dist = culled ? cam.far_ : wb.first_depth[slot];
             depth_out[idx] = cam.far_ / (cam.far_ - cam.near_) * (1.0f - cam.near_ / dist);  // main.glsl:432
         }
     }
@@ -604,6 +640,7 @@ size_t wf2_workspace_bytes(int width, int local_rows, int n_frames, int max_boun
         }
         const Wf2Dims all = make_dims(width, local_rows, n_frames);
         b += (size_t)all.slots_per_frame * (size_t)n_frames * sizeof(float4) + 256;  // rad: [frame][slot], shared by the groups
+        b += (size_t)all.slots_per_frame * (size_t)n_frames * sizeof(uint32_t) + 256;  // fin8
         b += (size_t)all.slots_per_frame * sizeof(float) + 256;
         worst = b > worst ? b : worst;
     }
@@ -642,6 +679,7 @@ void launch_wf2_render(hipStream_t stream, const DeviceScene& ds, const FramePar
         gb[g].redo_count = gb[g].qcount + (size_t)nq * kSegments;
     }
     float4* rad_all = (float4*)carve((size_t)dm_all.slots_per_frame * (size_t)fp.n_frames * sizeof(float4));
+    uint32_t* fin8_all = (uint32_t*)carve((size_t)dm_all.slots_per_frame * (size_t)fp.n_frames * sizeof(uint32_t));
     float* first_depth = (float*)carve((size_t)dm_all.slots_per_frame * sizeof(float));
     for (int g = 0; g < groups; g++) {
         int f0, nf;
@@ -659,6 +697,7 @@ void launch_wf2_render(hipStream_t stream, const DeviceScene& ds, const FramePar
         wb.redo_rec = (float4*)carve(paths * 2 * sizeof(float4));
         wb.thr = (float4*)carve(paths * sizeof(float4));
         wb.rad = rad_all + (size_t)f0 * dm_all.slots_per_frame;  // this group's frames of the [frame][slot] array
+        wb.fin8 = fin8_all + (size_t)f0 * dm_all.slots_per_frame;
         wb.first_depth = first_depth;
         gfp[g] = fp;
         gfp[g].frame_index = fp.frame_index + (uint32_t)f0;
@@ -752,6 +791,7 @@ void launch_wf2_render(hipStream_t stream, const DeviceScene& ds, const FramePar
     }
     Wf2Buffers wb_all = gb[0];
     wb_all.rad = rad_all;
+    wb_all.fin8 = fin8_all;
     wb_all.first_depth = first_depth;
     // the accumulation touches the framebuffers, so it runs where the context's renders are ordered: on acc_stream,
     // which may differ from the stream the path kernels of this render ran on (render pipelining, jpt_capi.hip)
@@ -763,7 +803,7 @@ void launch_wf2_render(hipStream_t stream, const DeviceScene& ds, const FramePar
     }
     if (async.before_acc) (void)hipStreamWaitEvent(acc_stream, async.before_acc, 0);
     const uint32_t ablocks = (dm_all.slots_per_frame + kBlock - 1) / kBlock;
-    hipLaunchKernelGGL(wf2_accumulate, dim3(ablocks), block, 0, acc_stream, wb_all, dm_all, fp, cam, accum, ldr, depth);
+    hipLaunchKernelGGL(wf2_accumulate, dim3(ablocks), block, 0, acc_stream, wb_all, dm_all, fp, cam, async.cull, accum, ldr, depth);
 }
 
 // the number of frame groups a blocking render of this size wants (helper streams permitting)

@@ -21,7 +21,7 @@ import sys
 
 
 def kname(s):
-    m = re.search(r"(wf2?_\w+|ref_frame_kernel|assemble_kernel)", s)
+    m = re.search(r"(wf2?_\w+|ref_frame_kernel|assemble_kernel|instance_refit_kernel|tlas4_refit_kernel)", s)
     if not m:
         return s.split("(")[0][:40]
     return m.group(1) + ("_counted" if "<true" in s else "")
