@@ -8,12 +8,17 @@
 //
 //   bytes  0..15   origin.xyz (the lo corner of the union of the children's boxes), scale.x
 //         16..31   scale.y, scale.z, lo_x, lo_y        each plane word holds the four children's planes, one byte each
-//         32..47   lo_z, hi_x, hi_y, hi_z              (child k in byte k): plane = origin + q * scale, scale a power of 2
+//         32..47   lo_z, hi_x, hi_y, hi_z              (child k in byte k)
 //         48..63   child[0..3]                         same references as WideNode4
 //
-// The planes are rounded outwards (lo down, hi up), so a quantised box contains the float box; with a power-of-two
-// scale and q <= 255 the products q * scale are exact.  Boxes grow by at most scale = extent / 255 .. extent / 127 per
-// side, i.e. a child of half the node's size is inflated by 1-2 %.
+// A child's box is [origin + (lo - kPlaneSlack) * scale, origin + (hi + kPlaneSlack) * scale] per axis, scale = extent /
+// 254 (the grid's ends lie on the node's own faces), kPlaneSlack = 1/256 of a step.  lo is the largest and hi the
+// smallest step for which that interval contains the float box, so a quantised box contains the float box and grows by
+// less than a step = extent / 254 per side.  The slack is what keeps FLAT children flat: a wall that lies in a face of
+// its parent has lo = hi (the float box is only as thick as the builder's padding, a fraction of the slack), and a
+// bounce ray that starts 0.001 above the wall does not enter its box again -- with planes rounded outwards to whole
+// steps the wall became a slab a step thick, and every ray leaving a wall re-tested the wall's triangles (+30 %
+// triangle tests on the Cornell scenes).  The kernel applies the slack as two biases per axis (jpt_trace_core.h).
 #pragma once
 
 #include "jpt_instance_math.h"   // JPT_HD, imin_, imax_
@@ -29,6 +34,8 @@ struct alignas(64) WideNodeQ {
     int32_t child[4];
 };
 static_assert(sizeof(WideNodeQ) == 64, "WideNodeQ");
+
+constexpr float kPlaneSlack = 1.0f / 256.0f;
 
 // smallest power of two >= x (x > 0, finite); tiny or zero extents get the smallest normal number
 JPT_HD float pow2_at_least(float x)
@@ -46,8 +53,8 @@ JPT_HD float pow2_at_least(float x)
     return v.f;
 }
 
-JPT_HD float qfloor_(float x) { const float t = (float)(int)x; return t > x ? t - 1.0f : t; }   // |x| < 2^23 here
-JPT_HD float qceil_(float x) { const float t = (float)(int)x; return t < x ? t + 1.0f : t; }
+JPT_HD double qfloor_(double x) { const double t = (double)(long long)x; return t > x ? t - 1.0 : t; }   // |x| < 2^52 here
+JPT_HD double qceil_(double x) { const double t = (double)(long long)x; return t < x ? t + 1.0 : t; }
 
 JPT_HD void quantize_node4(const WideNode4& n, WideNodeQ& q)
 {
@@ -65,8 +72,8 @@ JPT_HD void quantize_node4(const WideNode4& n, WideNodeQ& q)
     float s[3];
     for (int a = 0; a < 3; a++) {
         const float ext = hi[a] - lo[a];
-        // 254 steps for the extent leave the last step for the rounding of (plane - origin)
-        s[a] = (ext > 0.0f && ext < 3.0e38f) ? pow2_at_least(ext / 254.0f) : pow2_at_least(0.0f);
+        s[a] = (ext > 0.0f && ext < 3.0e38f) ? ext / 254.0f : 0.0f;
+        if (!(s[a] >= 1.17549435e-38f)) s[a] = 1.17549435e-38f;   // flat or degenerate node: the smallest normal number
     }
     q.ox = lo[0]; q.oy = lo[1]; q.oz = lo[2];
     q.sx = s[0]; q.sy = s[1]; q.sz = s[2];
@@ -76,12 +83,13 @@ JPT_HD void quantize_node4(const WideNode4& n, WideNodeQ& q)
         const bool empty = n.child[k] == kEmptyChild;
         const float cl[3] = {n.lo_x[k], n.lo_y[k], n.lo_z[k]}, ch[3] = {n.hi_x[k], n.hi_y[k], n.hi_z[k]};
         for (int a = 0; a < 3; a++) {
-            float ql = 255.0f, qh = 0.0f;   // an empty slot: lo beyond hi
+            double ql = 255.0, qh = 0.0;   // an empty slot: lo beyond hi
             if (!empty) {
-                ql = qfloor_((cl[a] - lo[a]) / s[a]);
-                qh = qceil_((ch[a] - lo[a]) / s[a]);
-                ql = ql < 0.0f ? 0.0f : (ql > 255.0f ? 255.0f : ql);
-                qh = qh < 0.0f ? 0.0f : (qh > 255.0f ? 255.0f : qh);
+                // exact differences and quotients of floats in double, up to 1e-16 relative: far inside the builder's padding
+                ql = qfloor_(((double)cl[a] - (double)lo[a]) / (double)s[a] + (double)kPlaneSlack);
+                qh = qceil_(((double)ch[a] - (double)lo[a]) / (double)s[a] - (double)kPlaneSlack);
+                ql = ql >= 0.0 ? (ql > 255.0 ? 255.0 : ql) : 0.0;   // (NaN boxes of degenerate scenes: whole range)
+                qh = qh <= 255.0 ? (qh < 0.0 ? 0.0 : qh) : 255.0;
             }
             wlo[a] |= (uint32_t)ql << (8 * k);
             whi[a] |= (uint32_t)qh << (8 * k);

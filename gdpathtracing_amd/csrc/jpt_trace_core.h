@@ -174,6 +174,10 @@ struct Traversal {
         // t = (origin + q * scale - o) * rD = q * (scale * rD) + (origin * rD + ood)
         const float ax = h0.w * rD.x, ay = h1.x * rD.y, az = h1.y * rD.z;
         const float bx = __builtin_fmaf(h0.x, rD.x, ood.x), by = __builtin_fmaf(h0.y, rD.y, ood.y), bz = __builtin_fmaf(h0.z, rD.z, ood.z);
+        // the planes' slack of 1/256 step (jpt_nodeq.h), outwards: entry planes earlier, exit planes later
+        const float nbx = __builtin_fmaf(-kPlaneSlack, __builtin_fabsf(ax), bx), fbx = __builtin_fmaf(kPlaneSlack, __builtin_fabsf(ax), bx);
+        const float nby = __builtin_fmaf(-kPlaneSlack, __builtin_fabsf(ay), by), fby = __builtin_fmaf(kPlaneSlack, __builtin_fabsf(ay), by);
+        const float nbz = __builtin_fmaf(-kPlaneSlack, __builtin_fabsf(az), bz), fbz = __builtin_fmaf(kPlaneSlack, __builtin_fabsf(az), bz);
         // the plane words a ray meets first / last on each axis: lo / hi, swapped where the direction is negative
         const bool negx = __float_as_int(d.x) < 0, negy = __float_as_int(d.y) < 0, negz = __float_as_int(d.z) < 0;
         const uint32_t lox = __float_as_uint(h1.z), loy = __float_as_uint(h1.w), loz = __float_as_uint(h2.x);
@@ -189,8 +193,8 @@ struct Traversal {
         auto key = [&](int k, int32_t ch) -> uint32_t {
             const float qnx = (float)((nwx >> (8 * k)) & 255u), qny = (float)((nwy >> (8 * k)) & 255u), qnz = (float)((nwz >> (8 * k)) & 255u);
             const float qfx = (float)((fwx >> (8 * k)) & 255u), qfy = (float)((fwy >> (8 * k)) & 255u), qfz = (float)((fwz >> (8 * k)) & 255u);
-            const float t_in = fmax_(fmax_(fmax_(__builtin_fmaf(qnx, ax, bx), __builtin_fmaf(qny, ay, by)), __builtin_fmaf(qnz, az, bz)), 0.0f);
-            const float t_out = fmin_(fmin_(fmin_(__builtin_fmaf(qfx, ax, bx), __builtin_fmaf(qfy, ay, by)), __builtin_fmaf(qfz, az, bz)), tcur);
+            const float t_in = fmax_(fmax_(fmax_(__builtin_fmaf(qnx, ax, nbx), __builtin_fmaf(qny, ay, nby)), __builtin_fmaf(qnz, az, nbz)), 0.0f);
+            const float t_out = fmin_(fmin_(fmin_(__builtin_fmaf(qfx, ax, fbx), __builtin_fmaf(qfy, ay, fby)), __builtin_fmaf(qfz, az, fbz)), tcur);
             return ((t_in <= t_out) & (ch != kEmptyChild)) ? __float_as_uint(t_in) : kInvalid;
         };
         uint32_t k0 = key(0, r0), k1 = key(1, r1), k2 = key(2, r2), k3 = key(3, r3);
