@@ -506,8 +506,16 @@ int do_render(jpt_ctx* c, int32_t n_frames, uint32_t first_frame_index, bool cou
         return do_render_batch(c, n_frames, first_frame_index, counted, blocking);  // reports the error / no-op
     const int32_t per = frames_per_batch(c, n_frames);
     if (per >= n_frames) return do_render_batch(c, n_frames, first_frame_index, counted, blocking);
-    // more frames than the workspace budget holds at once: batches in frame order (the accumulation continues),
-    // statistics summed over the batches
+    // more frames than the workspace budget holds at once: batches in frame order (the accumulation continues).  A
+    // queued render queues its batches (each takes the next pipeline slot; the statistics are those of the last one) ...
+    if (!blocking && !counted) {
+        for (int32_t done = 0; done < n_frames; done += per) {
+            const int rc = do_render_batch(c, std::min(per, n_frames - done), first_frame_index + (uint32_t)done, false, false);
+            if (rc != JPT_OK) return rc;
+        }
+        return JPT_OK;
+    }
+    // ... a blocking one runs them one after another, statistics summed over the batches
     jpt_stats sum;
     std::memset(&sum, 0, sizeof sum);
     for (int32_t done = 0; done < n_frames; done += per) {

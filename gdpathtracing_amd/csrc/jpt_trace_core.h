@@ -292,16 +292,22 @@ struct Traversal {
                 if (REACH) {
                     if (!out && !reaches_triangle(sc, ti)) out = true;
                 }
-                const bool front = dot3(mk3(q0.w, q1.w, q2.w), d) > 0.0f;  // the record carries cross(edge1, edge2)
+                float facing = dot3(mk3(q0.w, q1.w, q2.w), d);  // the record carries cross(edge1, edge2)
+                asm volatile("" : "+v"(facing));                // (keeps this, and with it the whole 16-byte loads, ahead of the branch below)
+                const bool front = facing > 0.0f;
                 // hitInfo.blas follows `if (hitInfo.t < minT)` after the instance's walk (main.glsl:324-327): a hit that
                 // only TIES the distance found in an earlier instance replaces the triangle but not the instance
-                const bool closer = t < hit.t;
-                hit.inst = out ? hit.inst : (((closer ? cur_inst : hit.inst) & kInstMask) | (cur_inst << kInstBits));
-                hit.t = out ? hit.t : t;
-                hit.u = out ? hit.u : u;
-                hit.v = out ? hit.v : v;
-                hit.tri = out ? hit.tri : ti;
-                hit.front = out ? hit.front : front;
+                // (under exec: moves instead of selects, skipped when no lane of the wave has a hit.  `front` is computed
+                // before the branch so that the record stays three 16-byte loads: inside it the compiler splits them.)
+                if (!out) {
+                    const bool closer = t < hit.t;
+                    hit.inst = ((closer ? cur_inst : hit.inst) & kInstMask) | (cur_inst << kInstBits);
+                    hit.t = t;
+                    hit.u = u;
+                    hit.v = v;
+                    hit.tri = ti;
+                    hit.front = front;
+                }
             } else {
                 const f3 pvec = cross3(d, edge2);
                 const float det = dot3(edge1, pvec);

@@ -9,7 +9,7 @@ namespace jpt {
 
 struct Tuning {
     bool sky_cull = true;          // JPT_SKY_CULL=0: trace every primary ray
-    long workspace_budget_mb = 16384;  // JPT_WORKSPACE_BUDGET_MB: frames in flight per launch set
+    long workspace_budget_mb = 24576;  // JPT_WORKSPACE_BUDGET_MB: frames in flight per launch set
     bool pipelining = true;        // JPT_PIPELINE=0: asynchronous renders run one after another
     int pipe_slots = 0;            // JPT_PIPE_SLOTS=2..4: renders in flight (0: the library's rule)
     bool acc_on_slot = true;       // JPT_ACC_ON_SLOT=0: accumulation kernels on the context's stream

@@ -508,7 +508,8 @@ def test_unique_triangle_scene_full_size(oracle, hiplib):
 
 def test_frame_batching_under_a_workspace_budget(hiplib, monkeypatch):
     """With a small workspace budget a many-frame render is split into batches in frame order: same image, same
-    ray count as the unbatched render."""
+    ray count as the unbatched render; queued (asynchronous) renders queue their batches and give the image of one
+    blocking render of all the frames."""
     import subprocess, sys, json
     code = r'''
 import sys, json, numpy as np
@@ -517,7 +518,12 @@ from gdpathtracing_amd import capi, host, scenes
 sc = scenes.cornell_scene(); w, h = 160, 96
 ctx = host.Context(0); ctx.build_scene(sc, capi.BUILD_SAH); ctx.set_params(w, h, 3, 0); ctx.set_camera(scenes.camera_block(sc.camera, w, h))
 ctx.render(7, 1)
-a = ctx.read_accum(); print(json.dumps(dict(sum=float(a.sum()), rays=ctx.stats()["rays"], crc=int(np.frombuffer(a.tobytes(), dtype=np.uint32).sum() %% (1 << 32)))))
+a = ctx.read_accum(); rays = ctx.stats()["rays"]
+ctx.accum_reset(); ctx.render(7, 1, asynchronous=True); ctx.render(3, 8, asynchronous=True); ctx.sync()   # queued renders queue their batches
+ctx2 = host.Context(0); ctx2.build_scene(sc, capi.BUILD_SAH); ctx2.set_params(w, h, 3, 0); ctx2.set_camera(scenes.camera_block(sc.camera, w, h))
+ctx2.render(10, 1)
+assert np.array_equal(ctx.read_accum(), ctx2.read_accum()) and np.array_equal(ctx.read_ldr(), ctx2.read_ldr())
+print(json.dumps(dict(sum=float(a.sum()), rays=rays, crc=int(np.frombuffer(a.tobytes(), dtype=np.uint32).sum() %% (1 << 32)))))
 ''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs = []
     for budget in ("16384", "1"):   # 1 MiB: two frames per batch at this size
