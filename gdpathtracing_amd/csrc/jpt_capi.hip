@@ -789,10 +789,23 @@ int do_render_batch(jpt_ctx* c, int32_t n_frames, uint32_t first_frame_index, bo
         if (counted) {
             DevCounters h;
             HIP_TRY(c, hipMemcpy(&h, cnt, sizeof h, hipMemcpyDeviceToHost));
-            c->stats.rays = h.rays;
+            // (pixel, frame) pairs outside the render's window were never enumerated on the device: each is one primary
+            // segment that ends at the TLAS root, like the culled ones inside the window
+            uint64_t outside = 0;
+            if (wf2) {
+                FrameParams wfp;
+                wfp.width = c->width;
+                wfp.height = c->height;
+                wfp.local_rows = c->local_rows;
+                wfp.rank = c->rank;
+                wfp.world = c->world;
+                outside = wf2_pixels_outside_window(c->async.cull, wfp) * (uint64_t)n_frames;
+            }
+            h.phase[7] += outside;
+            c->stats.rays = h.rays + outside;
             c->stats.blas_expand = h.blas_expand;
             c->stats.tri_tests = h.tri_tests;
-            c->stats.tlas_expand = h.tlas_expand;
+            c->stats.tlas_expand = h.tlas_expand + outside;
             c->stats.inst_visits = h.inst_visits;
             c->stats.shaded_hits = h.shaded_hits;
             for (int k = 0; k < 8; k++) c->stats.phase[k] = h.phase[k];

@@ -173,6 +173,10 @@ void launch_temporal(hipStream_t stream, const RefTemporalParams& tp, uint32_t* 
                      float4* hist2);
 
 int wf2_wanted_groups(int n_frames, size_t paths);
+// pixels of this context's share of the image that lie outside the render's window (the tile-aligned bounding rectangle
+// of the sky cull's screen rectangles): the primary launch does not even enumerate them (their rays are sky by the
+// cull's argument; the event counters are completed with their number on the host)
+uint64_t wf2_pixels_outside_window(const SkyCull& cull, const FrameParams& fp);
 
 // rank-major gathered strips -> full framebuffer (multi-GPU assemble)
 void launch_assemble(hipStream_t stream, const float4* gathered, int world, int width, int height, int max_local_rows,

@@ -108,21 +108,25 @@ __device__ __forceinline__ uint32_t fdiv(uint32_t n, const FastDiv& f)
 }
 
 struct Wf2Dims {
-    int32_t tiles_x, tiles_y;
+    // The paths of a render are those of the WINDOW: the tile-aligned rectangle of the image outside which every pixel is
+    // sky-culled (the whole image when the cull is off).  Tiles, slots, chunks and path ids count inside it.
+    int32_t tile_x0, tile_y0;  // the window's first tile (local tile rows)
+    int32_t tiles_x, tiles_y;  // the window's size in tiles
+    int32_t full_tiles_x, full_tiles_y;  // the context's whole share of the image in tiles (wf2_accumulate walks it)
     uint32_t tiles_per_frame;
     uint32_t slots_per_frame;  // tiles_per_frame * 64
     uint32_t n_chunks;         // tiles_per_frame * n_frames
     uint32_t seg_cap;          // entries per segment
     uint32_t run_shift;        // a segment is dealt runs of 2^run_shift consecutive chunks (neighbouring tiles of one frame)
-    FastDiv by_tiles_x, by_tiles_per_frame, by_slots_per_frame;
+    FastDiv by_tiles_x, by_tiles_per_frame, by_slots_per_frame, by_full_tiles_x;
 };
 
 __device__ __forceinline__ void slot_to_pixel(uint32_t slot, const Wf2Dims& dm, int& px, int& ly)
 {
     const uint32_t tile = slot >> 6, lane = slot & 63u;
     const uint32_t ty = fdiv(tile, dm.by_tiles_x), tx = tile - ty * (uint32_t)dm.tiles_x;
-    px = (int)(tx * 8u + (lane & 7u));
-    ly = (int)(ty * 8u + (lane >> 3));
+    px = (int)((tx + (uint32_t)dm.tile_x0) * 8u + (lane & 7u));
+    ly = (int)((ty + (uint32_t)dm.tile_y0) * 8u + (lane >> 3));
 }
 
 // a path is over: its radiance goes where wf2_accumulate reads it -- in REF_LDR8 mode already as the rgba8 value of
@@ -501,11 +505,16 @@ __global__ __launch_bounds__(kBlock) void wf2_accumulate(Wf2Buffers wb, Wf2Dims 
                                                          float4* __restrict__ accum, uint32_t* __restrict__ ldr,
                                                          float* __restrict__ depth_out)
 {
-    const uint32_t slot = blockIdx.x * kBlock + threadIdx.x;
-    if (slot >= dm.slots_per_frame) return;
-    int px, ly;
-    slot_to_pixel(slot, dm, px, ly);
+    // one thread per pixel of the context's share of the image, tile by tile; `slot` is the pixel's place in the window
+    const uint32_t full_slot = blockIdx.x * kBlock + threadIdx.x;
+    const uint32_t ftile = full_slot >> 6, flane = full_slot & 63u;
+    const uint32_t fty = fdiv(ftile, dm.by_full_tiles_x), ftx = ftile - fty * (uint32_t)dm.full_tiles_x;
+    if ((int)fty >= dm.full_tiles_y) return;
+    const int px = (int)(ftx * 8u + (flane & 7u)), ly = (int)(fty * 8u + (flane >> 3));
     if (px >= fp.width || ly >= fp.local_rows) return;
+    const int wtx = (int)ftx - dm.tile_x0, wty = (int)fty - dm.tile_y0;
+    const bool in_window = wtx >= 0 && wtx < dm.tiles_x && wty >= 0 && wty < dm.tiles_y;
+    const uint32_t slot = in_window ? ((uint32_t)wty * (uint32_t)dm.tiles_x + (uint32_t)wtx) * 64u + flane : 0u;
     const size_t idx = (size_t)ly * fp.width + px;
     // fp.frame_count = ProgressiveRendering frame_count of the FIRST frame of this render
     f3 sum = mk3(0.0f, 0.0f, 0.0f);
@@ -518,7 +527,7 @@ __global__ __launch_bounds__(kBlock) void wf2_accumulate(Wf2Buffers wb, Wf2Dims 
     // the primary launch neither traced nor stored the paths of a sky-culled pixel: their radiance is the sky along the
     // primary ray of (x, y, frame) (main.glsl:380,395-397 with throughput 1), made up here
     const int py = local_to_global_row(ly, fp);
-    const bool culled = sky_culled(cull, px, py);
+    const bool culled = !in_window || sky_culled(cull, px, py);
     for (int f = 0; f < fp.n_frames; f++) {
         f3 cur;
         if (culled) {
@@ -555,11 +564,51 @@ __global__ __launch_bounds__(kBlock) void wf2_accumulate(Wf2Buffers wb, Wf2Dims 
     }
 }
 
-Wf2Dims make_dims(int width, int local_rows, int n_frames)
+// the window of a render (local tiles): x0, y0, nx, ny
+struct TileWindow {
+    int x0, y0, nx, ny;
+};
+TileWindow full_window(int width, int local_rows) { return TileWindow{0, 0, (width + 7) / 8, (local_rows + 7) / 8}; }
+
+// The tile-aligned bounding rectangle of the cull's screen rectangles, in this context's local tile rows (8-row strips
+// s with s % world == rank: local tile row t is image tile row t * world + rank).  Outside it every pixel is
+// sky-culled, so no path starts there.  Nothing visible at all: one tile (its pixels are culled one by one).
+TileWindow cull_window(const SkyCull& cull, const FrameParams& fp)
+{
+    const TileWindow full = full_window(fp.width, fp.local_rows);
+    if (cull.n < 0) return full;
+    const TileWindow none{0, 0, 1, 1};
+    int gx0 = INT32_MAX, gy0 = INT32_MAX, gx1 = INT32_MIN, gy1 = INT32_MIN;
+    for (int k = 0; k < 4 && k < cull.n; k++) {
+        if (cull.x0[k] > cull.x1[k] || cull.y0[k] > cull.y1[k]) continue;
+        gx0 = std::min(gx0, cull.x0[k]);
+        gy0 = std::min(gy0, cull.y0[k]);
+        gx1 = std::max(gx1, cull.x1[k]);
+        gy1 = std::max(gy1, cull.y1[k]);
+    }
+    gx0 = std::max(gx0, 0);
+    gy0 = std::max(gy0, 0);
+    gx1 = std::min(gx1, fp.width - 1);
+    gy1 = std::min(gy1, fp.height - 1);
+    if (gx0 > gx1 || gy0 > gy1) return none;
+    const int world = fp.world > 0 ? fp.world : 1;
+    const int ty0 = gy0 / 8 - fp.rank, ty1 = gy1 / 8 - fp.rank;   // image tile rows, shifted so that this rank's are the multiples of world
+    if (ty1 < 0) return none;
+    const int lt0 = ty0 <= 0 ? 0 : (ty0 + world - 1) / world, lt1 = std::min(ty1 / world, full.ny - 1);
+    if (lt0 > lt1) return none;
+    return TileWindow{gx0 / 8, lt0, gx1 / 8 - gx0 / 8 + 1, lt1 - lt0 + 1};
+}
+
+Wf2Dims make_dims(int width, int local_rows, int n_frames, const TileWindow& win)
 {
     Wf2Dims dm;
-    dm.tiles_x = (width + 7) / 8;
-    dm.tiles_y = (local_rows + 7) / 8;
+    dm.tile_x0 = win.x0;
+    dm.tile_y0 = win.y0;
+    dm.tiles_x = win.nx;
+    dm.tiles_y = win.ny;
+    dm.full_tiles_x = (width + 7) / 8;
+    dm.full_tiles_y = (local_rows + 7) / 8;
+    dm.by_full_tiles_x = make_fastdiv((uint32_t)dm.full_tiles_x);
     dm.tiles_per_frame = (uint32_t)dm.tiles_x * (uint32_t)dm.tiles_y;
     dm.slots_per_frame = dm.tiles_per_frame * 64u;
     dm.n_chunks = dm.tiles_per_frame * (uint32_t)n_frames;
@@ -568,10 +617,13 @@ Wf2Dims make_dims(int width, int local_rows, int n_frames)
     // primary launch at 49 of 64 lanes instead of 37).  Longer runs start to unbalance the segments, and so do runs
     // at all when a segment has few chunks (ms per queued render with runs of 1 / 2 / 4 / 8: C3 1.261 / 1.242 / 1.240 /
     // 1.300, 1920x1080x16 2.417 / 2.374 / 2.358 / 2.369, 3840x2160x16 9.34 / 9.04 / 8.94 / 9.02, 1280x720x4 0.440 / 0.421 /
-    // 0.424 / 0.495; 1920x1080x2 0.431 / 0.444 / 0.452, one frame 0.331 / 0.367 / 0.376).  JPT_RUN_SHIFT overrides.
+    // 0.424 / 0.495; 1920x1080x2 0.431 / 0.444 / 0.452, one frame 0.331 / 0.367 / 0.376).  Those figures are from before
+    // the window: the chunks counted here are now the window's, i.e. nearly all of them are walked, and the thresholds
+    // are lower (C3's window: 24 chunks per segment, runs of 1 / 2 / 4 / 8: 1.125 / 1.120 / 1.114 / 1.116 ms; C2's: 5 per
+    // segment, 0.363 / 0.362 / 0.373).  JPT_RUN_SHIFT overrides.
     const int forced_shift = tuning().run_shift;
     const uint32_t per_segment = dm.n_chunks / kSegments;
-    const uint32_t run_shift = forced_shift >= 0 ? (uint32_t)forced_shift : (n_frames < 4 || per_segment < 32u ? 0u : (per_segment < 64u ? 1u : 2u));
+    const uint32_t run_shift = forced_shift >= 0 ? (uint32_t)forced_shift : (n_frames < 4 || per_segment < 8u ? 0u : (per_segment < 16u ? 1u : 2u));
     dm.run_shift = run_shift;
     const uint32_t n_runs = (dm.n_chunks + (1u << run_shift) - 1u) >> run_shift;
     dm.seg_cap = (((n_runs + kSegments - 1u) / kSegments) << run_shift) * 64u;
@@ -628,7 +680,7 @@ size_t wf2_workspace_bytes(int width, int local_rows, int n_frames, int max_boun
         for (int g = 0; g < groups; g++) {
             int f0, nf;
             group_frames(n_frames, groups, g, f0, nf);
-            const Wf2Dims dm = make_dims(width, local_rows, nf);
+            const Wf2Dims dm = make_dims(width, local_rows, nf, full_window(width, local_rows));
             const size_t q = (size_t)dm.seg_cap * kSegments;                  // queue entries
             const size_t paths = (size_t)dm.slots_per_frame * (size_t)nf;
             b += q * sizeof(float4) * 4 + 4 * 256;    // two ray queues (o, d)
@@ -638,7 +690,7 @@ size_t wf2_workspace_bytes(int width, int local_rows, int n_frames, int max_boun
             b += ((size_t)(max_bounces + 2) * kSegments + 64) * sizeof(uint32_t) + 256;   // queue sizes + the set-aside count
             b += paths * 2 * sizeof(float4) + 256;    // set-aside records (a path is set aside at most once)
         }
-        const Wf2Dims all = make_dims(width, local_rows, n_frames);
+        const Wf2Dims all = make_dims(width, local_rows, n_frames, full_window(width, local_rows));
         b += (size_t)all.slots_per_frame * (size_t)n_frames * sizeof(float4) + 256;  // rad: [frame][slot], shared by the groups
         b += (size_t)all.slots_per_frame * (size_t)n_frames * sizeof(uint32_t) + 256;  // fin8
         b += (size_t)all.slots_per_frame * sizeof(float) + 256;
@@ -659,7 +711,8 @@ void launch_wf2_render(hipStream_t stream, const DeviceScene& ds, const FramePar
                        float4* accum, uint32_t* ldr, float* depth, DevCounters* counters, hipEvent_t* trace_events,
                        const Wf2Async& async, hipStream_t acc_stream, hipEvent_t paths_done)
 {
-    const Wf2Dims dm_all = make_dims(fp.width, fp.local_rows, fp.n_frames);
+    const TileWindow window = cull_window(async.cull, fp);
+    const Wf2Dims dm_all = make_dims(fp.width, fp.local_rows, fp.n_frames, window);
     if (dm_all.n_chunks == 0) return;
     char* w = reinterpret_cast<char*>(workspace);
     auto carve = [&](size_t bytes) {
@@ -684,7 +737,7 @@ void launch_wf2_render(hipStream_t stream, const DeviceScene& ds, const FramePar
     for (int g = 0; g < groups; g++) {
         int f0, nf;
         group_frames(fp.n_frames, groups, g, f0, nf);
-        gdm[g] = make_dims(fp.width, fp.local_rows, nf);
+        gdm[g] = make_dims(fp.width, fp.local_rows, nf, window);
         const size_t q = (size_t)gdm[g].seg_cap * kSegments;
         const size_t paths = (size_t)gdm[g].slots_per_frame * (size_t)nf;
         Wf2Buffers& wb = gb[g];
@@ -802,8 +855,17 @@ void launch_wf2_render(hipStream_t stream, const DeviceScene& ds, const FramePar
         acc_stream = stream;
     }
     if (async.before_acc) (void)hipStreamWaitEvent(acc_stream, async.before_acc, 0);
-    const uint32_t ablocks = (dm_all.slots_per_frame + kBlock - 1) / kBlock;
+    const uint32_t ablocks = ((uint32_t)dm_all.full_tiles_x * (uint32_t)dm_all.full_tiles_y * 64u + kBlock - 1) / kBlock;
     hipLaunchKernelGGL(wf2_accumulate, dim3(ablocks), block, 0, acc_stream, wb_all, dm_all, fp, cam, async.cull, accum, ldr, depth);
+}
+
+uint64_t wf2_pixels_outside_window(const SkyCull& cull, const FrameParams& fp)
+{
+    const TileWindow w = cull_window(cull, fp);
+    const int64_t x0 = (int64_t)w.x0 * 8, x1 = std::min<int64_t>((int64_t)(w.x0 + w.nx) * 8, fp.width);
+    const int64_t y0 = (int64_t)w.y0 * 8, y1 = std::min<int64_t>((int64_t)(w.y0 + w.ny) * 8, fp.local_rows);
+    const int64_t inside = std::max<int64_t>(x1 - x0, 0) * std::max<int64_t>(y1 - y0, 0);
+    return (uint64_t)((int64_t)fp.width * (int64_t)fp.local_rows - inside);
 }
 
 // the number of frame groups a blocking render of this size wants (helper streams permitting)
