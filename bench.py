@@ -46,7 +46,7 @@ PARITY_TOLERANCE = 1e-4  # BASELINE.json north_star: relative L2 on the accumula
 
 # bytes one event of the traversal kernels touches in the flattened layout
 WIDE_BYTES = dict(blas_expand=64, tri_tests=48, tlas_expand=64, inst_visits=64)    # two-child 64-byte records (reference-exact trees)
-WIDE4_BYTES = dict(blas_expand=128, tri_tests=48, tlas_expand=128, inst_visits=64)  # native builder: four-child 128-byte records
+WIDE4_BYTES = dict(blas_expand=64, tri_tests=48, tlas_expand=64, inst_visits=64)   # native builder: four-child records, 64-byte quantised form
 RAY_IN, HIT_OUT = 32, 20   # a queued ray read, a hit record written
 # the same events priced in the reference layout
 REF_BYTES = dict(blas_expand=96, tri_tests=48, tlas_expand=64, inst_visits=224, shaded_hits=320)

@@ -397,6 +397,34 @@ def test_ragged_partition_matches_single_context(hiplib, world):
     assert rows_seen == h and np.array_equal(got, want)
 
 
+@pytest.mark.parametrize("view", ["far", "narrow", "behind"])
+def test_render_window_under_a_partition(hiplib, view):
+    """The render window (tile-aligned bounding rectangle of the sky cull's screen rectangles) under a 5-way strip
+    partition: with the scene far away, in a narrow lens or behind the camera the window holds a few tile rows, so some
+    ranks own none of them (their window is one culled tile) -- rows, depth and ray counts still add up to the whole
+    image's."""
+    from tests.test_gpu_parity import _look_at
+    sc = scenes.demo_scene(1500)
+    sc.camera = {"far": scenes.CameraDesc(scenes.transform12(None, (0.3, 0.2, 70.0)), fov_deg=30.0),
+                 "narrow": scenes.CameraDesc(_look_at((8.0, 1.0, 8.0), (2.9, 2.0, 0.0)), fov_deg=8.0),
+                 "behind": scenes.CameraDesc(_look_at((0.0, 0.0, 9.0), (0.0, 0.0, 20.0)), fov_deg=79.5)}[view]
+    w, h, world = 200, 117, 5
+    full = make_ctx(sc, w, h, 3, wire.ACCUM_REF_LDR8)
+    full.render(3, 1)
+    want, want_depth, want_rays = full.read_accum(), full.read_depth(), full.stats()["rays"]
+    full.close()
+    got, got_depth, rays = np.zeros_like(want), np.zeros_like(want_depth), 0
+    for r in range(world):
+        ctx = make_ctx(sc, w, h, 3, wire.ACCUM_REF_LDR8, rank=r, world=world)
+        ctx.render(3, 1)
+        rows = partition.rows_of_rank(h, r, world)
+        got[rows] = ctx.read_accum()[rows]
+        got_depth[rows] = ctx.read_depth()[rows]
+        rays += ctx.stats()["rays"]
+        ctx.close()
+    assert np.array_equal(got, want) and np.array_equal(got_depth, want_depth) and rays == want_rays
+
+
 def test_c5_like_config_reduced(oracle, hiplib):
     """Config C5's depth (6 bounces, 16 spp) at 160x90 on one GPU."""
     sc = scenes.demo_scene(51200)
