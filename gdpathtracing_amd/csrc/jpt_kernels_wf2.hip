@@ -80,13 +80,18 @@ __device__ __forceinline__ bool walk_round(Traversal<COUNT, W4>& tr, bool active
     return active && tr.finished();
 }
 
+constexpr uint32_t kHasRadiance = 0x80000000u;   // queue entry, direction.w: rad[path] holds the path's radiance (else it is 0)
+constexpr uint32_t kPathMask = 0x7fffffffu;
+
 struct Wf2Buffers {
-    float4* ray_o[2];   // queue entry: origin.xyz
-    float4* ray_d[2];   // direction.xyz, w = path id bits
+    float4* ray_o[2];   // queue entry: origin.xyz, w = seed.y bits of the path (bounces >= 1)
+    float4* ray_d[2];   // direction.xyz, w = path id bits | kHasRadiance
     float4* hit_a;      // t, u, v, tri bits          (same index as the ray)
     uint32_t* hit_b;    // inst | front << 31
     float4* thr;        // per path: throughput.xyz, w = seed.x bits
-    float4* rad;        // per path: radiance.xyz,   w = seed.y bits  ([frame][slot]; HDR_F32 mode: also the finished paths' output)
+    float4* rad;        // per path: radiance.xyz -- touched only by vertices that ADD radiance (emitters) and by paths that
+                        // carry some (kHasRadiance in the queue entry): most vertices neither read nor write it
+                        // ([frame][slot]; HDR_F32 mode: also the finished paths' output; w = seed.y of a set-aside path)
     uint32_t* fin8;     // REF_LDR8 mode: [frame][slot] the finished path's radiance as the rgba8 main.glsl:434 stores (4 bytes, not 16)
     float* first_depth; // per slot of the LAST frame: distance of the first hit (or far)
     uint32_t* qcount;   // [max_bounces + 2][kSegments] queue sizes; row b = rays traced in bounce b (b >= 1)
@@ -343,7 +348,8 @@ __device__ __forceinline__ bool shade_entry(const SceneShading& sh, const Wf2Buf
                                             bool& unreachable, float4& no, float4& nd, DevCounters& cnt)
 {
     unreachable = false;
-    const uint32_t p = __float_as_uint(rd.w);
+    const uint32_t p = __float_as_uint(rd.w) & kPathMask;
+    const bool had_radiance = (__float_as_uint(rd.w) & kHasRadiance) != 0u;
     f3 throughput, radiance;
     uint32_t sx, sy;
     const uint32_t f = fdiv(p, dm.by_slots_per_frame), slot = p - f * dm.slots_per_frame;
@@ -387,12 +393,17 @@ __device__ __forceinline__ bool shade_entry(const SceneShading& sh, const Wf2Buf
         throughput = mk3(1.0f, 1.0f, 1.0f);
         radiance = mk3(0.0f, 0.0f, 0.0f);
     } else {
-        const float4 t4 = wb.thr[p], r4 = wb.rad[p];
+        const float4 t4 = wb.thr[p];
         throughput = mk3(t4.x, t4.y, t4.z);
-        radiance = mk3(r4.x, r4.y, r4.z);
+        radiance = mk3(0.0f, 0.0f, 0.0f);
+        if (had_radiance) {
+            const float4 r4 = wb.rad[p];
+            radiance = mk3(r4.x, r4.y, r4.z);
+        }
         sx = __float_as_uint(t4.w);
-        sy = __float_as_uint(r4.w);
+        sy = __float_as_uint(ro.w);
     }
+    const f3 radiance_in = radiance;
     if (COUNT && bounce > 0) cnt.rays++;
     bool alive = false;
     if (!is_hit) {
@@ -406,10 +417,12 @@ __device__ __forceinline__ bool shade_entry(const SceneShading& sh, const Wf2Buf
         if (bounce < fp.max_bounces) alive = bounce_step(s, sx, sy, ray, throughput);
     }
     if (alive) {
-        wb.rad[p] = make_float4(radiance.x, radiance.y, radiance.z, __uint_as_float(sy));
+        // (radiance starts as +0 and +0 + x is x or +0, never -0: "unchanged and never written" means exactly +0)
+        const bool changed = radiance.x != radiance_in.x || radiance.y != radiance_in.y || radiance.z != radiance_in.z;
+        if (changed) wb.rad[p] = make_float4(radiance.x, radiance.y, radiance.z, 0.0f);
         wb.thr[p] = make_float4(throughput.x, throughput.y, throughput.z, __uint_as_float(sx));
-        no = make_float4(ray.o.x, ray.o.y, ray.o.z, 0.0f);
-        nd = make_float4(ray.d.x, ray.d.y, ray.d.z, __uint_as_float(p));
+        no = make_float4(ray.o.x, ray.o.y, ray.o.z, __uint_as_float(sy));
+        nd = make_float4(ray.d.x, ray.d.y, ray.d.z, __uint_as_float(p | ((had_radiance || changed) ? kHasRadiance : 0u)));
     } else {
         store_final(wb, fp.accum_mode, p, radiance);
     }
@@ -441,8 +454,16 @@ __global__ __launch_bounds__(kBlock, JPT_SHADE_WAVES) void wf2_shade(SceneShadin
         alive = shade_entry<COUNT>(sh, wb, dm, fp, cam_far, bounce, ro, rd, ha, hb, true, unreachable, no, nd, cnt);
         if (unreachable) {  // a few paths in 10^7: they leave the wavefront here and are finished, exactly, by wf2_finish
             const size_t k = atomicAdd(&wb.redo_count[0], 1u);
+            float4 rd2 = rd;
+            if (bounce > 0) {   // its seed.y (the entry's origin.w) waits in rad[path].w, beside the radiance so far
+                const uint32_t pw = __float_as_uint(rd.w), p = pw & kPathMask;
+                float4 r4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                if (pw & kHasRadiance) r4 = wb.rad[p];
+                wb.rad[p] = make_float4(r4.x, r4.y, r4.z, ro.w);
+                rd2.w = __uint_as_float(p | kHasRadiance);
+            }
             wb.redo_rec[2 * k] = make_float4(ro.x, ro.y, ro.z, __uint_as_float((uint32_t)bounce));
-            wb.redo_rec[2 * k + 1] = rd;
+            wb.redo_rec[2 * k + 1] = rd2;
         }
     }
     // active-ray packing: wave ballot + prefix popcount, one atomic per wave on the SEGMENT's counter (1792
@@ -480,6 +501,7 @@ __global__ __launch_bounds__(64) void wf2_finish(WideSceneDev sc, SceneShading s
     for (uint32_t k = blockIdx.x * 64u + threadIdx.x; k < n; k += gridDim.x * 64u) {
         float4 ro = wb.redo_rec[2 * (size_t)k], rd = wb.redo_rec[2 * (size_t)k + 1];
         const int first = (int)__float_as_uint(ro.w);
+        if (first > 0) ro.w = wb.rad[__float_as_uint(rd.w) & kPathMask].w;   // the seed.y parked there when the path was set aside
         for (int bounce = first;; bounce++) {
             Traversal<COUNT, W4, true> tr;
             tr.begin(sc, mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z));
