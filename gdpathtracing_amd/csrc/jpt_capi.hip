@@ -81,7 +81,7 @@ struct jpt_ctx {
 
     // device scene
     DevBuf<RefTriGeometry> d_tri_geom;
-    DevBuf<RefTriData> d_tri_data;
+    DevBuf<ShadeTri> d_shade_tris;
     DevBuf<RefMaterial> d_materials;
     DevBuf<RefBvhNode> d_bvh;
     DevBuf<RefInstance> d_instances;
@@ -319,7 +319,20 @@ int upload_scene(jpt_ctx* c)
     HIP_TRY(c, hipSetDevice(c->device));
     hipStream_t s = c->stream;
     HIP_TRY(c, c->d_tri_geom.upload(c->ref.tri_geom, s));
-    HIP_TRY(c, c->d_tri_data.upload(c->ref.tri_data, s));
+    {
+        std::vector<ShadeTri> st(c->ref.tri_data.size());
+        for (size_t i = 0; i < st.size(); i++) {
+            const RefTriData& t = c->ref.tri_data[i];
+            ShadeTri& o = st[i];
+            for (int k = 0; k < 3; k++) o.n0[k] = t.n0[k];
+            o.n1[0] = t.n1.x; o.n1[1] = t.n1.y; o.n1[2] = t.n1.z;
+            o.n2[0] = t.n2.x; o.n2[1] = t.n2.y; o.n2[2] = t.n2.z;
+            for (int k = 0; k < 3; k++) o.uvs[k][0] = t.uvs[k][0], o.uvs[k][1] = t.uvs[k][1];
+            o.material_index = t.material_index;
+        }
+        HIP_TRY(c, c->d_shade_tris.upload(st, s));
+        HIP_TRY(c, hipStreamSynchronize(s));   // (the staging vector goes out of scope)
+    }
     HIP_TRY(c, c->d_materials.upload(c->ref.materials, s));
     HIP_TRY(c, c->d_bvh.upload(c->ref.bvh_nodes, s));
     HIP_TRY(c, c->d_instances.upload(c->ref.instances, s));
@@ -343,7 +356,7 @@ int upload_scene(jpt_ctx* c)
     d.reach_tri = reach ? c->d_reach_tri.p : nullptr;
     d.reach_inst = reach ? c->d_reach_inst.p : nullptr;
     d.ref_tri_geom = c->d_tri_geom.p;
-    d.ref_tri_data = c->d_tri_data.p;
+    d.shade_tris = c->d_shade_tris.p;
     d.ref_materials = c->d_materials.p;
     d.ref_bvh = c->d_bvh.p;
     d.ref_instances = c->d_instances.p;

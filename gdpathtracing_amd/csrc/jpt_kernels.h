@@ -38,7 +38,7 @@ struct FrameParams {
 struct DeviceScene {
     // reference layout (drop-in route + cold shading data)
     const RefTriGeometry* ref_tri_geom = nullptr;
-    const RefTriData* ref_tri_data = nullptr;
+    const ShadeTri* shade_tris = nullptr;   // (the 80-byte GpuTriangleData array itself stays on the host: jpt_scene_get_reference_buffer)
     const RefMaterial* ref_materials = nullptr;
     const RefBvhNode* ref_bvh = nullptr;
     const RefInstance* ref_instances = nullptr;
@@ -68,7 +68,7 @@ struct DeviceScene {
     SceneShading shading() const
     {
         SceneShading s;
-        s.tri_data = ref_tri_data;
+        s.tri_data = shade_tris;
         s.instances = ref_instances;
         s.materials = ref_materials;
         s.tex = tex;

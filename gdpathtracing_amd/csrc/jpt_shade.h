@@ -31,7 +31,7 @@ struct Shading {  // main.glsl:73-82
 };
 
 struct SceneShading {  // cold, once-per-hit data: kept in the reference layout
-    const RefTriData* __restrict__ tri_data;
+    const ShadeTri* __restrict__ tri_data;
     const RefInstance* __restrict__ instances;
     const RefMaterial* __restrict__ materials;
     const uint8_t* __restrict__ tex;
@@ -153,9 +153,11 @@ __device__ __forceinline__ f3 sample_texture(const SceneShading& sc, float u, fl
 __device__ __forceinline__ Shading get_shading_data(const SceneShading& sc, const Hit& h, bool front)
 {
     Shading s;
-    const RefTriData& tri = sc.tri_data[h.tri];
+    // the record as four aligned 16-byte loads: n0.xyz n1.x | n1.yz n2.xy | n2.z uv0 uv1.x | uv1.y uv2 slot
+    const float4* tq = reinterpret_cast<const float4*>(sc.tri_data + h.tri);
+    const float4 q0 = tq[0], q1 = tq[1], q2 = tq[2], q3 = tq[3];
     const RefInstance& b = sc.instances[h.inst];
-    const uint32_t slot = tri.material_index;
+    const uint32_t slot = __float_as_uint(q3.w);
     // b.materials[tri.materialIndex] is unchecked in the reference (main.glsl:198): slots past 2 read on into the next
     // instance's record; a read past the END of the instance buffer returns 0 (Vulkan robust buffer access; the same
     // pin as the oracle's), so no uploaded material_index can make the kernel read outside the array
@@ -169,10 +171,9 @@ __device__ __forceinline__ Shading get_shading_data(const SceneShading& sc, cons
     s.out_dir = normalize3(xform_dir(b.transform, -h.ld));
     const float u = h.u, v = h.v;
     const float w0 = 1.0f - u - v;
-    const float uvx = tri.uvs[0][0] * w0 + tri.uvs[1][0] * u + tri.uvs[2][0] * v;
-    const float uvy = tri.uvs[0][1] * w0 + tri.uvs[1][1] * u + tri.uvs[2][1] * v;
-    f3 n = mk3(tri.n0[0], tri.n0[1], tri.n0[2]) * w0 + mk3(tri.n1.x, tri.n1.y, tri.n1.z) * u +
-           mk3(tri.n2.x, tri.n2.y, tri.n2.z) * v;
+    const float uvx = q2.y * w0 + q2.w * u + q3.y * v;
+    const float uvy = q2.z * w0 + q3.x * u + q3.z * v;
+    f3 n = mk3(q0.x, q0.y, q0.z) * w0 + mk3(q0.w, q1.x, q1.y) * u + mk3(q1.z, q1.w, q2.x) * v;
     n = normalize3(xform_dir(b.transform, n));
     s.normal = front ? n : -n;
 

@@ -147,6 +147,18 @@ struct alignas(16) WideTri {
 };
 static_assert(sizeof(WideTri) == 48, "WideTri");
 
+// 64-byte shading record of a triangle: the 72 bytes get_shading_data needs of the 80-byte GpuTriangleData (vertex normals,
+// uvs, material slot) without its padding -- ONE aligned cache line per shaded hit, where the 80-byte stride always
+// straddles two.  Same values, same order of use; made on upload from the reference-layout array, index for index.
+struct alignas(64) ShadeTri {
+    float n0[3];
+    float n1[3];
+    float n2[3];
+    float uvs[3][2];
+    uint32_t material_index;
+};
+static_assert(sizeof(ShadeTri) == 64, "ShadeTri");
+
 // 64-byte hot instance record (traversal): rows of the 3x4 inverse transform + BLAS root reference.
 struct alignas(64) WideInstance {
     float inv[12];   // column-major 3x4: c0.xyz, c1.xyz, c2.xyz, c3.xyz
