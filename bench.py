@@ -343,6 +343,10 @@ def main():
                 "traffic": traffic, "traffic_source": traffic_src,
                 "hbm_frac": round(traffic / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if traffic else None,
                 "binding": "valu_issue",
+                # what binds the kernel, from the committed SQ-counter passes of this command (profiles/current_sq.json):
+                # share of the SIMDs' cycles that issue VALU instructions, and share of the 64 lanes those have enabled
+                "valu_issue_frac": (valu or {}).get("valu_busy_frac"),
+                "lane_utilisation": (valu or {}).get("lane_utilisation"),
                 "valu": valu,
                 "note": "achieved = bytes the kernel ASKS for (records, triangles, instances, rays in, hits out: exact event counts "
                         "of the bounce launches x record sizes) / launch duration; the scene (6 MB) is L2 / Infinity-Cache resident, "
