@@ -228,7 +228,10 @@ struct SahBlasBuilder {
     std::vector<uint32_t> order;     // permutation being built
     float pad = 0.0f;
 
-    static constexpr int kBins = 16;
+#ifndef JPT_SAH_BINS
+#define JPT_SAH_BINS 16
+#endif
+    static constexpr int kBins = JPT_SAH_BINS;
     // largest leaf the builder keeps without a split that pays (JPT_MAX_LEAF overrides, for tuning runs)
     static int max_leaf() { return tuning().max_leaf; }
 
