@@ -25,10 +25,15 @@ for seed in range(8,72):
             if not ok: bad+=1; print("MISMATCH seed",seed,route,kernel)
             ctx.close()
     if seed%3==0:
-        wantn,_,_,_,_ = ob.render(ref,cam,w,h,b,f,1+seed,1,flags=1)
-        ctx = host.Context(0); ctx.build_scene(sc, capi.BUILD_SAH); ctx.set_params(w,h,b,1); ctx.set_camera(cam); ctx.render(f,1+seed)
-        got=ctx.read_accum(); ctx.close()
-        m = ~(np.isnan(got).any(-1)|np.isnan(wantn).any(-1))
-        if not (np.array_equal(np.isnan(got).any(-1),np.isnan(wantn).any(-1)) and np.array_equal(got[m],wantn[m])):
-            bad+=1; print("SAH MISMATCH seed",seed, int((got[m]!=wantn[m]).any(-1).sum()))
+        # native tree with reach records against the oracle's reach-only mode (every triangle tested + the two reach tests),
+        # native tree alone against the tree-independent mode; in both accumulation modes, blocking and queued
+        for builder, flags in ((capi.BUILD_SAH, 2), (capi.BUILD_SAH_WATERTIGHT, 1)):
+            amode = (seed // 3) % 2
+            wantn,wln,wdn,_,_ = ob.render(ref,cam,w,h,b,f,1+seed,amode,flags=flags)
+            ctx = host.Context(0); ctx.build_scene(sc, builder); ctx.set_params(w,h,b,amode); ctx.set_camera(cam)
+            ctx.render(f,1+seed,asynchronous=(seed%2==1)); ctx.sync()
+            got=ctx.read_accum(); gd=ctx.read_depth(); ctx.close()
+            m = ~(np.isnan(got).any(-1)|np.isnan(wantn).any(-1))
+            if not (np.array_equal(np.isnan(got).any(-1),np.isnan(wantn).any(-1)) and np.array_equal(got[m],wantn[m]) and np.array_equal(gd,wdn,equal_nan=True)):
+                bad+=1; print("SAH MISMATCH seed",seed,"builder",builder, int((got[m]!=wantn[m]).any(-1).sum()))
 print("extended fuzz done, mismatches:",bad)
