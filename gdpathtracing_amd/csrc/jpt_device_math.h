@@ -84,7 +84,17 @@ __device__ __forceinline__ uint32_t unorm8(float x)
 {
     return (uint32_t)__builtin_floorf(clamp_(x, 0.0f, 1.0f) * 255.0f + 0.5f);
 }
-__device__ __forceinline__ float from_unorm8(uint32_t q) { return (float)q / 255.0f; }
+// q / 255.0f, correctly rounded, for q in 0..255 (rgba8 imageLoad, texel decode) without the ~11-instruction division
+// sequence: y = q * c with c = RN(1 / 255), one residual and one correction step, three 2-cycle instructions.  Equal to
+// the IEEE quotient for ALL 256 inputs -- checked exhaustively in exact rational arithmetic
+// (tests/test_oracle_kats.py::test_unorm8_decode_without_division_is_exact); other inputs do not occur.
+__device__ __forceinline__ float from_unorm8(uint32_t q)
+{
+    const float x = (float)q, c = 1.0f / 255.0f;
+    const float y = x * c;
+    const float r = __builtin_fmaf(-255.0f, y, x);
+    return __builtin_fmaf(r, c, y);
+}
 // ivec2(vec2): truncation; out of range saturates, NaN gives 0 (pinned; GLSL leaves both undefined)
 __device__ __forceinline__ int32_t f2i_sat(float f)
 {

@@ -251,6 +251,26 @@ def test_sampler_modes_match_the_numpy_restatement(oracle, mode):
         assert np.array_equal(sample(-3.0, 0.5, 0), sample(0.01, 0.5, 0)) and np.array_equal(sample(7.0, 0.5, 0), sample(0.99, 0.5, 0))
 
 
+def test_unorm8_decode_without_division_is_exact():
+    """csrc/jpt_device_math.h::from_unorm8 computes q / 255.0f as y = q * c, r = fma(-255, y, q), fma(r, c, y) with
+    c = RN(1 / 255).  Emulated here in exact rational arithmetic with a correct round-to-nearest-even to binary32: equal to
+    the IEEE quotient (the pinned semantics, oracle_pins.h) for every q in 0..255 -- the only inputs there are."""
+    from fractions import Fraction
+
+    def rn32(x):
+        f = np.float32(float(x))
+        cands = [np.nextafter(f, np.float32(-np.inf)), f, np.nextafter(f, np.float32(np.inf))]
+        return np.float32(min(cands, key=lambda c: (abs(Fraction(float(c)) - x), int(np.float32(c).view(np.uint32)) & 1)))
+
+    c = np.float32(1.0) / np.float32(255.0)
+    for q in range(256):
+        want = np.float32(q) / np.float32(255.0)
+        assert want == rn32(Fraction(q, 255))
+        y = rn32(Fraction(q) * Fraction(float(c)))
+        r = rn32(Fraction(q) - 255 * Fraction(float(y)))
+        assert rn32(Fraction(float(r)) * Fraction(float(c)) + Fraction(float(y))) == want, q
+
+
 @pytest.mark.parametrize("frame", [1, 7])
 def test_whole_path_numpy_float32_restatement_equals_the_oracle(oracle, frame):
     """tests/np_path.py: the whole path (jittered primary ray, closest hit, shading fetch, BRDF sample / pdf / value, 5
