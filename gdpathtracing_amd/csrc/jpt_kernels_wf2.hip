@@ -25,10 +25,11 @@
 #include "jpt_trace_core.h"
 #include "jpt_tuning.h"
 
-// the primary kernel carries the ray set-up and the sky-cull test besides the walk: at 72 VGPRs it spills 48 bytes,
-// at 80 (6 waves/SIMD) it does not, and the queued render rate is 2 % better (1.48 vs 1.51 ms on C3)
+// the primary kernel carries the ray set-up and the sky-cull test besides the walk: 74 VGPRs on its own.  Round 1 (float
+// records) ran it at 6 waves/SIMD because 72 registers spilled; with the quantised records two registers are all the
+// cap takes away and 7 waves/SIMD are 0.3-0.5 % ahead of 6 (four A/B repetitions, tools/ab_rates.sh); 5 are 1 % behind
 #ifndef JPT_PRIMARY_WAVES
-#define JPT_PRIMARY_WAVES 6
+#define JPT_PRIMARY_WAVES 7
 #endif
 
 namespace jpt {
@@ -335,7 +336,7 @@ __global__ __launch_bounds__(kBlock, JPT_WAVES_PER_SIMD) void wf2_trace(WideScen
 // ---- shading: one path vertex per queue entry (main.glsl:378-397) -------------------------------------------
 
 #ifndef JPT_SHADE_WAVES
-#define JPT_SHADE_WAVES 1
+#define JPT_SHADE_WAVES 5   // 96 VGPRs: two fewer than the body wants, five waves per SIMD instead of four for a kernel that waits on gathers (C3 +4 %); 6 spills
 #endif
 // One path vertex (main.glsl:378-397): the queue entry's ray and closest hit in, radiance / throughput / seeds of the path
 // updated, returns true when the path goes on (no / nd = its next ray).  With reach records (JPT_BUILD_SAH) and
