@@ -201,7 +201,7 @@ __global__ __launch_bounds__(256) void ref_frame_kernel(RefSceneDev sc, SceneSha
             if (COUNT) cnt.shaded_hits++;
             Hit h;
             h.t = hit.t; h.u = hit.u; h.v = hit.v; h.tri = hit.tri; h.inst = hit.inst; h.lo = hit.lo; h.ld = hit.ld;
-            const Shading s = get_shading_data(sh, h, hit.front);
+            const Shading s = get_shading_data(sh, h, hit.front, load_shade_tri(sh, h.tri));
             radiance = radiance + throughput * s.emission;
             if (i == 0) depth = length3(s.position - ray.o);
             if (!bounce_step(s, sx, sy, ray, throughput)) break;

@@ -358,7 +358,15 @@ __device__ __forceinline__ bool shade_entry(const SceneShading& sh, const Wf2Buf
     ray.o = mk3(ro.x, ro.y, ro.z);
     ray.d = mk3(rd.x, rd.y, rd.z);
     const bool is_hit = ha.x < 1e9f;  // main.glsl:349
+    // The kernel waits on gathers, so everything whose address is known once the queue entry is here is asked for at
+    // once, ahead of the branches that use it: the path's state now, the instance and the reach boxes below.
+    float4 t4 = make_float4(1.0f, 1.0f, 1.0f, 0.0f), r4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (bounce > 0) {
+        t4 = wb.thr[p];
+        if (had_radiance) r4 = wb.rad[p];
+    }
     Hit h;
+    ShadeTriRegs stri;
     uint32_t found_in = 0;
     if (is_hit) {
         h.t = ha.x;
@@ -367,17 +375,24 @@ __device__ __forceinline__ bool shade_entry(const SceneShading& sh, const Wf2Buf
         h.tri = __float_as_uint(ha.w);
         h.inst = hb & kInstMask;                   // hitInfo.blas
         found_in = (hb >> kInstBits) & kInstMask;  // the instance whose local ray found the triangle
+        const bool check = check_reach && sh.reach_tri != nullptr;
+        stri = load_shade_tri(sh, h.tri);
+        float4 ta, tb, ia, ib;
+        if (check) {   // (whole records, unconditionally: a flag test first would put two round trips in a row)
+            ta = ld4(&sh.reach_tri[h.tri].lo[0]);
+            tb = ld4(&sh.reach_tri[h.tri].hi[0]);
+            if (sh.n_instances > 1u) {
+                ia = ld4(&sh.reach_inst[found_in].lo[0]);
+                ib = ld4(&sh.reach_inst[found_in].hi[0]);
+            }
+        }
         // the hit instance's local ray: the expression ray_trace_tlas evaluates (main.glsl:319-320)
         const RefInstance& b = sh.instances[found_in];
         h.lo = xform_point(b.inverse_transform, ray.o);
         h.ld = xform_dir(b.inverse_transform, ray.d);
-        if (check_reach && sh.reach_tri) {
-            const float4 ta = ld4(&sh.reach_tri[h.tri].lo[0]), tb = ld4(&sh.reach_tri[h.tri].hi[0]);
+        if (check) {
             bool reached = __float_as_uint(ta.w) != 0u || slab(h.lo, rcp3(h.ld), ta.x, ta.y, ta.z, tb.x, tb.y, tb.z) < 1e30f;
-            if (reached && sh.n_instances > 1u) {
-                const float4 ia = ld4(&sh.reach_inst[found_in].lo[0]), ib = ld4(&sh.reach_inst[found_in].hi[0]);
-                reached = slab(ray.o, rcp3(ray.d), ia.x, ia.y, ia.z, ib.x, ib.y, ib.z) < 1e30f;
-            }
+            if (reached && sh.n_instances > 1u) reached = slab(ray.o, rcp3(ray.d), ia.x, ia.y, ia.z, ib.x, ib.y, ib.z) < 1e30f;
             if (!reached) {
                 unreachable = true;
                 return false;
@@ -394,13 +409,8 @@ __device__ __forceinline__ bool shade_entry(const SceneShading& sh, const Wf2Buf
         throughput = mk3(1.0f, 1.0f, 1.0f);
         radiance = mk3(0.0f, 0.0f, 0.0f);
     } else {
-        const float4 t4 = wb.thr[p];
         throughput = mk3(t4.x, t4.y, t4.z);
-        radiance = mk3(0.0f, 0.0f, 0.0f);
-        if (had_radiance) {
-            const float4 r4 = wb.rad[p];
-            radiance = mk3(r4.x, r4.y, r4.z);
-        }
+        radiance = mk3(r4.x, r4.y, r4.z);
         sx = __float_as_uint(t4.w);
         sy = __float_as_uint(ro.w);
     }
@@ -412,7 +422,7 @@ __device__ __forceinline__ bool shade_entry(const SceneShading& sh, const Wf2Buf
         if (bounce == 0 && (int)f == fp.depth_frame) wb.first_depth[slot] = cam_far;  // (only a redone primary hit can turn into a miss here)
     } else {
         if (COUNT) cnt.shaded_hits++;
-        const Shading s = get_shading_data(sh, h, (hb >> 31) != 0u);
+        const Shading s = get_shading_data(sh, h, (hb >> 31) != 0u, stri);
         radiance = radiance + throughput * s.emission;
         if (bounce == 0 && (int)f == fp.depth_frame) wb.first_depth[slot] = length3(s.position - ray.o);
         if (bounce < fp.max_bounces) alive = bounce_step(s, sx, sy, ray, throughput);

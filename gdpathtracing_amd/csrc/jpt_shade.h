@@ -150,12 +150,21 @@ __device__ __forceinline__ f3 sample_texture(const SceneShading& sc, float u, fl
 
 // ---- shading record (main.glsl:194-222) -------------------------------------------------------
 
-__device__ __forceinline__ Shading get_shading_data(const SceneShading& sc, const Hit& h, bool front)
+// the triangle's shading record as four aligned 16-byte loads: n0.xyz n1.x | n1.yz n2.xy | n2.z uv0 uv1.x | uv1.y uv2 slot
+struct ShadeTriRegs {
+    float4 q0, q1, q2, q3;
+};
+__device__ __forceinline__ ShadeTriRegs load_shade_tri(const SceneShading& sc, uint32_t tri)
+{
+    const float4* tq = reinterpret_cast<const float4*>(sc.tri_data + tri);
+    return ShadeTriRegs{tq[0], tq[1], tq[2], tq[3]};
+}
+
+// (the record is passed in so that a caller can ask for it early, together with its other gathers)
+__device__ __forceinline__ Shading get_shading_data(const SceneShading& sc, const Hit& h, bool front, const ShadeTriRegs& tr)
 {
     Shading s;
-    // the record as four aligned 16-byte loads: n0.xyz n1.x | n1.yz n2.xy | n2.z uv0 uv1.x | uv1.y uv2 slot
-    const float4* tq = reinterpret_cast<const float4*>(sc.tri_data + h.tri);
-    const float4 q0 = tq[0], q1 = tq[1], q2 = tq[2], q3 = tq[3];
+    const float4 q0 = tr.q0, q1 = tr.q1, q2 = tr.q2, q3 = tr.q3;
     const RefInstance& b = sc.instances[h.inst];
     const uint32_t slot = __float_as_uint(q3.w);
     // b.materials[tri.materialIndex] is unchecked in the reference (main.glsl:198): slots past 2 read on into the next
