@@ -590,7 +590,25 @@ bool ensure_pipe_slot(jpt_ctx* c, int slot)
 {
     if (c->pipe_stream[slot] && c->ev_paths_done[slot] && c->ev_acc_done[slot]) return true;
     bool ok = true;
-    if (!c->pipe_stream[slot]) ok = hipStreamCreateWithFlags(&c->pipe_stream[slot], hipStreamNonBlocking) == hipSuccess;
+    if (!c->pipe_stream[slot]) {
+        // Streams of different PRIORITY levels take their hardware queues from different pools (three levels on this
+        // device, GPU_MAX_HW_QUEUES queues each).  The slots' four streams are created at the HIGHEST level: they have that
+        // level's pool to themselves -- the host's streams, torch's, RCCL's and this library's own helper streams are all
+        // at the normal level -- so they never share a queue, even when the pool is the runtime's default of four, which
+        // the library cannot always change (the variable is read at the process's first HIP call; HwQueueRequest above).
+        // C3 queued rate in bench.py (torch loaded, counted and blocking renders before the timed region), pool of 4 / 16:
+        // all slots normal 1.339 / 1.036 ms, all high 1.052 / 1.051, dealt over the three levels 1.230 / 1.212 (the normal-level
+        // slot shares a queue with host streams), all low 1.137 / 1.135 (tools/prio_probe.sh, profiles/r02/prio_probe.txt).
+        int least = 0, greatest = 0;
+        const int mode = tuning().slot_prio;
+        if (mode && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least > greatest) {
+            const int levels = least - greatest + 1;
+            const int prio = mode == 1 ? greatest + (slot % levels) : (mode == 2 ? (slot < 2 ? greatest : least) : (mode == 4 ? least : greatest));
+            ok = hipStreamCreateWithPriority(&c->pipe_stream[slot], hipStreamNonBlocking, prio) == hipSuccess;
+        } else {
+            ok = hipStreamCreateWithFlags(&c->pipe_stream[slot], hipStreamNonBlocking) == hipSuccess;
+        }
+    }
     if (ok && !c->ev_paths_done[slot]) ok = hipEventCreateWithFlags(&c->ev_paths_done[slot], hipEventDisableTiming) == hipSuccess;
     if (ok && !c->ev_acc_done[slot]) ok = hipEventCreateWithFlags(&c->ev_acc_done[slot], hipEventDisableTiming) == hipSuccess;
     if (!ok) (void)hipGetLastError();
@@ -886,10 +904,8 @@ int jpt_create(int device_id, jpt_ctx** out)
     }
     c->stream = c->own_stream;
     (void)tuning();  // environment switches are read here, once per process
-    if (const char* q = getenv("GPU_MAX_HW_QUEUES"))
-        if (atoi(q) < 6)
-            c->error = std::string("note: GPU_MAX_HW_QUEUES=") + q + " -- queued renders (jpt_render_async) use five streams; with fewer "
-                       "hardware queues they share queues and the queued rate drops by up to 2x (DESIGN.md section 4)";
+    // (a small GPU_MAX_HW_QUEUES pool is no longer a problem worth a note: the pipeline slots' streams are dealt over the
+    // stream priority levels, each of which has a pool of its own -- ensure_pipe_slot)
     *out = c;
     return JPT_OK;
 }

@@ -13,6 +13,8 @@ struct Tuning {
     bool pipelining = true;        // JPT_PIPELINE=0: asynchronous renders run one after another
     int pipe_slots = 0;            // JPT_PIPE_SLOTS=2..4: renders in flight (0: the library's rule)
     bool acc_on_slot = true;       // JPT_ACC_ON_SLOT=0: accumulation kernels on the context's stream
+    int slot_prio = 3;             // JPT_SLOT_PRIO: priority of the pipeline slots' streams -- 0 all normal, 1 dealt over the device's
+                                   // priority levels, 2 two high + two low, 3 (default) all high, 4 all low (jpt_capi.hip, ensure_pipe_slot)
     int bvh_width = 4;             // JPT_BVH_WIDTH=2: two-child records on the native tree
     int run_shift = -1;            // JPT_RUN_SHIFT: tiles dealt to a segment in runs of 2^n (-1: the library's rule)
     int groups = 0;                // JPT_GROUPS=1..4: frame groups of a blocking render (0: the library's rule)
@@ -36,6 +38,7 @@ inline const Tuning& tuning()
         v.pipelining = geti("JPT_PIPELINE", 1) != 0;
         v.pipe_slots = geti("JPT_PIPE_SLOTS", 0);
         v.acc_on_slot = geti("JPT_ACC_ON_SLOT", 1) != 0;
+        v.slot_prio = geti("JPT_SLOT_PRIO", 3);
         v.bvh_width = geti("JPT_BVH_WIDTH", 4) == 2 ? 2 : 4;
         v.run_shift = geti("JPT_RUN_SHIFT", -1);
         if (v.run_shift > 8) v.run_shift = 8;
