@@ -18,8 +18,8 @@ struct Tuning {
     int bvh_width = 4;             // JPT_BVH_WIDTH=2: two-child records on the native tree
     int run_shift = -1;            // JPT_RUN_SHIFT: tiles dealt to a segment in runs of 2^n (-1: the library's rule)
     int groups = 0;                // JPT_GROUPS=1..4: frame groups of a blocking render (0: the library's rule)
-    int refill_idle = 32;          // JPT_REFILL_IDLE: a wave refills when this many lanes are idle
-    int node_min_lanes = 16;       // JPT_NODE_MIN_LANES: leave the record loop below this many descending lanes
+    int refill_idle = 24;          // JPT_REFILL_IDLE: a wave refills when this many lanes are idle (20..32 x 20..32 swept: a 1 % plateau)
+    int node_min_lanes = 24;       // JPT_NODE_MIN_LANES: leave the record loop below this many descending lanes
     int trace_chain = 0;           // JPT_TRACE_CHAIN=1..4: segments per block of the tracing launches (0: the library's rule)
     int max_leaf = 2;              // JPT_MAX_LEAF: native builder leaf size
     int reach = 2;                 // JPT_REACH=0: ignore the reach records; 1: check but never redo (timing experiments only)
@@ -43,8 +43,8 @@ inline const Tuning& tuning()
         v.run_shift = geti("JPT_RUN_SHIFT", -1);
         if (v.run_shift > 8) v.run_shift = 8;
         v.groups = geti("JPT_GROUPS", 0);
-        v.refill_idle = geti("JPT_REFILL_IDLE", 32);
-        v.node_min_lanes = geti("JPT_NODE_MIN_LANES", 16);
+        v.refill_idle = geti("JPT_REFILL_IDLE", 24);
+        v.node_min_lanes = geti("JPT_NODE_MIN_LANES", 24);
         v.trace_chain = geti("JPT_TRACE_CHAIN", 0);
         v.max_leaf = geti("JPT_MAX_LEAF", 2);
         v.reach = geti("JPT_REACH", 2);
