@@ -41,6 +41,9 @@ constexpr uint32_t kSegments = 256u * JPT_WAVES_PER_SIMD;  // persistent grid: o
 struct WfTune {
     int refill_idle;     // refill when at least this many lanes of a wave are idle
     int node_min_lanes;  // leave the node loop when fewer lanes than this still descend
+    int leaf_min_lanes;  // a leaf / instance phase with fewer takers than this is put off to the next round, as long as
+    int inst_min_lanes;  // other lanes of the wave can make progress meanwhile
+    int phase_frac16;    // ... and never more than this many sixteenths of the wave's active rays
 };
 
 // One round of the walk for every active lane of the wave, "while-while" style so that lanes in different
@@ -48,10 +51,21 @@ struct WfTune {
 // leaf wait), (2) triangle leaves, (3) instance entries.  Returns true for lanes whose walk is complete.
 template <bool COUNT, bool W4>
 __device__ __forceinline__ bool walk_round(Traversal<COUNT, W4>& tr, bool active, const WideSceneDev& sc,
-                                           const typename Traversal<COUNT, W4>::Stack& st, DevCounters& cnt, int kNodeMinLanes)
+                                           const typename Traversal<COUNT, W4>::Stack& st, DevCounters& cnt, const WfTune& tune)
 {
+    const int kNodeMinLanes = tune.node_min_lanes;
     const bool lane0 = (threadIdx.x & 63) == 0;
     if (COUNT && lane0) cnt.phase[0]++;
+    // A thinly attended leaf or instance phase waits for more takers while the wave has other work -- lanes that still
+    // descend (the next round's record loop) or the other phase: a phase costs the wave the same whether 4 or 40 lanes take
+    // part.  The thresholds shrink with the wave's rays (never more than phase_frac16 sixteenths of them): a wave that is
+    // draining must not make its last rays wait.  C3 -3.5 %, close-up -5.5 %, C2 -3 % (tools/sweep_sched.sh: a plateau
+    // from 8 to 32 lanes for leaves and 4 to 16 for instance entries at a quarter of the rays; without the cap small
+    // renders lose 10 %).  Skipping a thinly attended record loop in the same way changes nothing.
+    const int na = __popcll(__ballot(active));
+    const int cap = (na * tune.phase_frac16) >> 4;
+    const int lmin = tune.leaf_min_lanes < cap ? tune.leaf_min_lanes : cap;
+    const int imin = tune.inst_min_lanes < cap ? tune.inst_min_lanes : cap;
     for (int it = 0; it < 64; it++) {
         if (active && !tr.have && tr.sp > 0) tr.pop_next(st);
         const bool want = active && tr.wants_node();
@@ -63,8 +77,16 @@ __device__ __forceinline__ bool walk_round(Traversal<COUNT, W4>& tr, bool active
         }
         if (want) tr.node_step(sc, st, cnt);
     }
-    const bool wl = active && tr.wants_leaf();
-    const bool wi = active && tr.wants_instance();
+    bool wl = active && tr.wants_leaf();
+    bool wi = active && tr.wants_instance();
+    if (tune.leaf_min_lanes > 1 || tune.inst_min_lanes > 1) {
+        const int nl = __popcll(__ballot(wl)), ni = __popcll(__ballot(wi));
+        const bool nodes_left = __any(active && tr.wants_node()) || __any(active && !tr.have && tr.sp > 0);
+        const bool run_l = nl >= lmin || !(nodes_left || ni >= imin);
+        const bool run_i = ni >= imin || !(nodes_left || (run_l && nl > 0));
+        wl = wl && run_l;
+        wi = wi && run_i;
+    }
     if (COUNT) {
         const int nl = __popcll(__ballot(wl)), ni = __popcll(__ballot(wi));
         if (lane0 && nl) {
@@ -232,7 +254,7 @@ __global__ __launch_bounds__(kBlock, JPT_PRIMARY_WAVES) void wf2_primary(WideSce
             continue;
         }
         {
-            if (walk_round<COUNT, W4>(tr, active, sc, my_stack, cnt, tune.node_min_lanes)) {
+            if (walk_round<COUNT, W4>(tr, active, sc, my_stack, cnt, tune)) {
                 active = false;
                 const uint32_t f = fdiv(path, dm.by_slots_per_frame);
                 const bool last_frame = (int)f == fp.depth_frame;
@@ -323,7 +345,7 @@ __global__ __launch_bounds__(kBlock, JPT_WAVES_PER_SIMD) void wf2_trace(WideScen
             continue;
         }
         {
-            if (walk_round<COUNT, W4>(tr, active, sc, my_stack, cnt, tune.node_min_lanes)) {
+            if (walk_round<COUNT, W4>(tr, active, sc, my_stack, cnt, tune)) {
                 active = false;
                 wb.hit_a[my_loc] = make_float4(tr.hit.t, tr.hit.u, tr.hit.v, __uint_as_float(tr.hit.tri));
                 wb.hit_b[my_loc] = tr.hit.inst | (tr.hit.front ? 0x80000000u : 0u);
@@ -805,7 +827,7 @@ void launch_wf2_render(hipStream_t stream, const DeviceScene& ds, const FramePar
     SceneShading sh = ds.shading();
     if (tuning().reach == 0) sh.reach_tri = nullptr;
     const dim3 block(kBlock);
-    const WfTune tune{tuning().refill_idle, tuning().node_min_lanes};
+    const WfTune tune{tuning().refill_idle, tuning().node_min_lanes, tuning().leaf_min_lanes, tuning().inst_min_lanes, tuning().phase_frac16};
 
     const int chain = [&] {  // JPT_TRACE_CHAIN overrides (tuning runs); two frame groups share the chip: half-width launches
         const int c = tuning().trace_chain > 0 ? tuning().trace_chain : (groups == 2 ? 2 : async.trace_chain);

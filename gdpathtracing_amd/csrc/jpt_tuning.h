@@ -20,6 +20,9 @@ struct Tuning {
     int groups = 0;                // JPT_GROUPS=1..4: frame groups of a blocking render (0: the library's rule)
     int refill_idle = 24;          // JPT_REFILL_IDLE: a wave refills when this many lanes are idle (20..32 x 20..32 swept: a 1 % plateau)
     int node_min_lanes = 24;       // JPT_NODE_MIN_LANES: leave the record loop below this many descending lanes
+    int leaf_min_lanes = 16;       // JPT_LEAF_MIN_LANES / JPT_INST_MIN_LANES: a leaf / instance phase with fewer takers waits a round
+    int inst_min_lanes = 12;       // (while the wave has other work); 1 = every round, as before
+    int phase_frac16 = 4;          // JPT_PHASE_FRAC16: ... capped at this many sixteenths of the wave's active rays
     int trace_chain = 0;           // JPT_TRACE_CHAIN=1..4: segments per block of the tracing launches (0: the library's rule)
     int max_leaf = 2;              // JPT_MAX_LEAF: native builder leaf size
     int reach = 2;                 // JPT_REACH=0: ignore the reach records; 1: check but never redo (timing experiments only)
@@ -45,6 +48,9 @@ inline const Tuning& tuning()
         v.groups = geti("JPT_GROUPS", 0);
         v.refill_idle = geti("JPT_REFILL_IDLE", 24);
         v.node_min_lanes = geti("JPT_NODE_MIN_LANES", 24);
+        v.leaf_min_lanes = geti("JPT_LEAF_MIN_LANES", 16);
+        v.inst_min_lanes = geti("JPT_INST_MIN_LANES", 12);
+        v.phase_frac16 = geti("JPT_PHASE_FRAC16", 4);
         v.trace_chain = geti("JPT_TRACE_CHAIN", 0);
         v.max_leaf = geti("JPT_MAX_LEAF", 2);
         v.reach = geti("JPT_REACH", 2);
