@@ -256,23 +256,24 @@ __device__ __forceinline__ f3 sample_brdf(const Shading& sh, float xi0, float xi
     const f3 c2 = nrm;
 
     const float diffuse_prob = diffuse_probability(sh);
+    // The two strategies share their azimuth: sin / cos of 2 pi xi0' with xi0' rescaled per strategy.  The lanes of a wave
+    // choose at random, so a wave runs both sides of the branch; the 60-instruction sincos_ is kept out of it.
+    const bool diffuse = xi0 < diffuse_prob;
+    if (diffuse) xi0 = xi0 / diffuse_prob;
+    else xi0 = (xi0 - diffuse_prob) / (1.0f - diffuse_prob);
+    float sp, cp;
+    sincos_((2.0f * JPT_PI) * xi0, sp, cp);
     f3 local;
-    if (xi0 < diffuse_prob) {
-        xi0 = xi0 / diffuse_prob;
+    if (diffuse) {
         // sample_hemisphere_psa (brdfs.glsl:95-101)
-        float sp, cp;
-        sincos_((2.0f * JPT_PI) * xi0, sp, cp);
         const float radius = __builtin_sqrtf(xi1);
         const float z = __builtin_sqrtf(1.0f - radius * radius);
         local = mk3(radius * cp, radius * sp, z);
     } else {
-        xi0 = (xi0 - diffuse_prob) / (1.0f - diffuse_prob);
         const f3 view = mk3(dot3(c0, sh.out_dir), dot3(c1, sh.out_dir), dot3(c2, sh.out_dir));
         // sample_ggx_vndf (brdfs.glsl:40-54), roughness = vec2(r)
         const float rg = sh.roughness;
         const f3 tv = normalize3(mk3(view.x * rg, view.y * rg, view.z));
-        float sp, cp;
-        sincos_((2.0f * JPT_PI) * xi0, sp, cp);
         const float z = 1.0f - xi1 * (1.0f + tv.z);
         const float sin_theta = __builtin_sqrtf(fmax_(0.0f, 1.0f - z * z));
         const f3 hs = mk3(sin_theta * cp, sin_theta * sp, z);
