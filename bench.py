@@ -30,12 +30,8 @@ import time
 
 import numpy as np
 
-# Hardware queues.  The library asks for a pool of 16 itself when it is LOADED (csrc/jpt_capi.hip, HwQueueRequest), which is
-# in time when nothing has started the HIP runtime before -- but this process imports torch first, and the variable is read
-# when the runtime starts: set it here, before that.  (With the default of four, the library's four slot streams and the
-# context's stream share queues and the queued rate drops from 1.3 to 1.65 ms per C3 render.)  The gloo rehearsal puts
-# several ranks on ONE GPU, where the ranks' queues add up: it keeps the runtime's default.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16" if os.environ.get("JPT_BENCH_BACKEND", "nccl") == "nccl" else "4")
+# (No environment is prepared for the library: its pipeline streams take their hardware queues from the highest stream
+# priority level's own pool; round 1 needed GPU_MAX_HW_QUEUES=16 exported before torch started HIP.)
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:

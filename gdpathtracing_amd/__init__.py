@@ -6,12 +6,3 @@ reference's GeometryGroup3D / PathTracingCamera / ProgressiveRendering interface
 (synthetic inputs and wire formats).  The CPU oracle is NOT part of this package (see oracle/).
 """
 __version__ = "0.1.0"
-
-import os as _os
-
-# Hardware queues.  The HIP runtime reads GPU_MAX_HW_QUEUES when it STARTS -- at the first HIP call of the process, not when
-# it is loaded (measured: tools/hwq_probe.py) -- and the library's queued renders want more than its default pool of four
-# (csrc/jpt_capi.hip, HwQueueRequest: the library asks for 16 itself when it is loaded, which is in time for a C++ host).
-# A Python process usually imports torch first; importing this package before the first torch.cuda call still gets the
-# request in.  A value the host has set is kept.
-_os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")

@@ -22,16 +22,6 @@ namespace {
 
 thread_local std::string g_create_error;
 
-// Hardware queues.  The HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4),
-// dealt in the order the streams are first used; streams that share a queue run in submission order.  Queued renders
-// use four pipeline-slot streams plus the context's stream, so the library asks for a pool of 16 itself: the variable is
-// read when the HIP runtime initialises (first HIP call of the process), and this runs when the library is loaded --
-// before main() of a program that links it, at dlopen()/ctypes time otherwise.  A value the host has set is kept;
-// jpt_create reports one that is too small (and cannot know about a runtime that was initialised before the load).
-struct HwQueueRequest {
-    HwQueueRequest() { (void)setenv("GPU_MAX_HW_QUEUES", "16", /*overwrite*/ 0); }
-} g_hw_queue_request;
-
 template <typename T>
 struct DevBuf {
     T* p = nullptr;
@@ -556,13 +546,13 @@ int do_render(jpt_ctx* c, int32_t n_frames, uint32_t first_frame_index, bool cou
 }
 
 // Helper streams and events are made on first use: most contexts (tests, tools, one-off renders) never queue renders
-// or render enough paths to split them.  NOTE on hardware queues: the HIP runtime multiplexes all streams of a
-// process onto GPU_MAX_HW_QUEUES hardware queues (default 4) in the order of their first use, and two streams that
-// share a queue execute in submission order.  Four pipeline slots + the context's stream need five queues to be
-// independent; with the default of four the rate of queued renders depends on which streams happen to share (C3: 1.32
-// ms per render with the most fortunate order, 1.60 and 2.39 with others), with GPU_MAX_HW_QUEUES >= 8 it does not
-// (1.27-1.29) -- unless a slot's stream lands on the LAST queue of the pool (1.58).  The variable
-// is read when the runtime starts, i.e. it has to be in the environment of the process (bench.py sets it to 16).
+// or render enough paths to split them.  NOTE on hardware queues: the HIP runtime multiplexes the streams of a process
+// onto GPU_MAX_HW_QUEUES hardware queues (default 4) per stream priority level, in the order of their first use, and two
+// streams that share a queue execute in submission order.  With all of this library's streams at the normal level the
+// rate of queued renders depended on which streams happened to share a queue (round 1, C3: 1.32 ms per render with the
+// most fortunate order, 1.60 and 2.39 with others); the pipeline slots now take their queues from the highest priority
+// level's pool (ensure_pipe_slot below), and the helper streams of frame groups stay at the normal level with the
+// context's stream.
 // frame groups: `groups - 1` helper streams (launch_wf2_render); false = not available, renders run serially
 bool ensure_group_streams(jpt_ctx* c, int groups)
 {
@@ -595,7 +585,7 @@ bool ensure_pipe_slot(jpt_ctx* c, int slot)
         // device, GPU_MAX_HW_QUEUES queues each).  The slots' four streams are created at the HIGHEST level: they have that
         // level's pool to themselves -- the host's streams, torch's, RCCL's and this library's own helper streams are all
         // at the normal level -- so they never share a queue, even when the pool is the runtime's default of four, which
-        // the library cannot always change (the variable is read at the process's first HIP call; HwQueueRequest above).
+        // a library cannot change (the variable is read at the process's first HIP call: tools/hwq_probe.py) and should not.
         // C3 queued rate in bench.py (torch loaded, counted and blocking renders before the timed region), pool of 4 / 16:
         // all slots normal 1.339 / 1.036 ms, all high 1.052 / 1.051, dealt over the three levels 1.230 / 1.212 (the normal-level
         // slot shares a queue with host streams), all low 1.137 / 1.135 (tools/prio_probe.sh, profiles/r02/prio_probe.txt).
@@ -904,8 +894,6 @@ int jpt_create(int device_id, jpt_ctx** out)
     }
     c->stream = c->own_stream;
     (void)tuning();  // environment switches are read here, once per process
-    // (a small GPU_MAX_HW_QUEUES pool is no longer a problem worth a note: the pipeline slots' streams are dealt over the
-    // stream priority levels, each of which has a pool of its own -- ensure_pipe_slot)
     *out = c;
     return JPT_OK;
 }

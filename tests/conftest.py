@@ -8,9 +8,6 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
-# (hardware queues: see gdpathtracing_amd/__init__.py -- the variable has to be in place before the first HIP call below)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
-
 # torch's bundled HIP runtime must be the first one loaded in a process that also uses torch.cuda
 # (see gdpathtracing_amd/capi.py); harmless on the CPU-only box.
 try:

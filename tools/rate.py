@@ -1,6 +1,5 @@
 # queued-render rate of one context at a given size: python tools/rate.py W H SPP [steps]   (env switches apply)
 import os, sys, time; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 import torch
 from gdpathtracing_amd import capi, host, scenes
 w, h, spp = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
