@@ -111,7 +111,8 @@ struct Wf2Buffers {
     float4* ray_d[2];   // direction.xyz, w = path id bits | kHasRadiance
     float4* hit_a;      // t, u, v, tri bits          (same index as the ray)
     uint32_t* hit_b;    // inst | front << 31
-    float4* thr;        // per path: throughput.xyz, w = seed.x bits
+    float4* thr_q[2];   // queue entry: the path's throughput.xyz, w = seed.x bits (dense, beside the ray: read with it)
+    float4* thr;        // per path: where a set-aside path parks that float4 until wf2_finish (otherwise untouched)
     float4* rad;        // per path: radiance.xyz -- touched only by vertices that ADD radiance (emitters) and by paths that
                         // carry some (kHasRadiance in the queue entry): most vertices neither read nor write it
                         // ([frame][slot]; HDR_F32 mode: also the finished paths' output; w = seed.y of a set-aside path)
@@ -367,8 +368,8 @@ __global__ __launch_bounds__(kBlock, JPT_WAVES_PER_SIMD) void wf2_trace(WideScen
 // not shaded: `unreachable` comes back true and nothing has been written; the path leaves the wavefront and is finished by wf2_finish.
 template <bool COUNT>
 __device__ __forceinline__ bool shade_entry(const SceneShading& sh, const Wf2Buffers& wb, const Wf2Dims& dm, const FrameParams& fp, float cam_far,
-                                            int bounce, const float4 ro, const float4 rd, const float4 ha, const uint32_t hb, bool check_reach,
-                                            bool& unreachable, float4& no, float4& nd, DevCounters& cnt)
+                                            int bounce, const float4 ro, const float4 rd, const float4 tin, const float4 ha, const uint32_t hb,
+                                            bool check_reach, bool& unreachable, float4& no, float4& nd, float4& nt, DevCounters& cnt)
 {
     unreachable = false;
     const uint32_t p = __float_as_uint(rd.w) & kPathMask;
@@ -382,11 +383,9 @@ __device__ __forceinline__ bool shade_entry(const SceneShading& sh, const Wf2Buf
     const bool is_hit = ha.x < 1e9f;  // main.glsl:349
     // The kernel waits on gathers, so everything whose address is known once the queue entry is here is asked for at
     // once, ahead of the branches that use it: the path's state now, the instance and the reach boxes below.
-    float4 t4 = make_float4(1.0f, 1.0f, 1.0f, 0.0f), r4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    if (bounce > 0) {
-        t4 = wb.thr[p];
-        if (had_radiance) r4 = wb.rad[p];
-    }
+    const float4 t4 = tin;   // (the entry's throughput and seed.x: came with the ray)
+    float4 r4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (bounce > 0 && had_radiance) r4 = wb.rad[p];
     Hit h;
     ShadeTriRegs stri;
     uint32_t found_in = 0;
@@ -453,7 +452,7 @@ __device__ __forceinline__ bool shade_entry(const SceneShading& sh, const Wf2Buf
         // (radiance starts as +0 and +0 + x is x or +0, never -0: "unchanged and never written" means exactly +0)
         const bool changed = radiance.x != radiance_in.x || radiance.y != radiance_in.y || radiance.z != radiance_in.z;
         if (changed) wb.rad[p] = make_float4(radiance.x, radiance.y, radiance.z, 0.0f);
-        wb.thr[p] = make_float4(throughput.x, throughput.y, throughput.z, __uint_as_float(sx));
+        nt = make_float4(throughput.x, throughput.y, throughput.z, __uint_as_float(sx));
         no = make_float4(ray.o.x, ray.o.y, ray.o.z, __uint_as_float(sy));
         nd = make_float4(ray.d.x, ray.d.y, ray.d.z, __uint_as_float(p | ((had_radiance || changed) ? kHasRadiance : 0u)));
     } else {
@@ -478,13 +477,14 @@ __global__ __launch_bounds__(kBlock, JPT_SHADE_WAVES) void wf2_shade(SceneShadin
     DevCounters cnt = {};
     const uint32_t i = base + threadIdx.x;
     bool alive = false;
-    float4 no, nd;
+    float4 no, nd, nt;
     if (i < n) {
         const float4 ro = wb.ray_o[in][seg_base + i], rd = wb.ray_d[in][seg_base + i];
+        const float4 tin = bounce > 0 ? wb.thr_q[in][seg_base + i] : make_float4(1.0f, 1.0f, 1.0f, 0.0f);
         const float4 ha = wb.hit_a[seg_base + i];
         const uint32_t hb = wb.hit_b[seg_base + i];
         bool unreachable;
-        alive = shade_entry<COUNT>(sh, wb, dm, fp, cam_far, bounce, ro, rd, ha, hb, true, unreachable, no, nd, cnt);
+        alive = shade_entry<COUNT>(sh, wb, dm, fp, cam_far, bounce, ro, rd, tin, ha, hb, true, unreachable, no, nd, nt, cnt);
         if (unreachable) {  // a few paths in 10^7: they leave the wavefront here and are finished, exactly, by wf2_finish
             const size_t k = atomicAdd(&wb.redo_count[0], 1u);
             float4 rd2 = rd;
@@ -493,6 +493,7 @@ __global__ __launch_bounds__(kBlock, JPT_SHADE_WAVES) void wf2_shade(SceneShadin
                 float4 r4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                 if (pw & kHasRadiance) r4 = wb.rad[p];
                 wb.rad[p] = make_float4(r4.x, r4.y, r4.z, ro.w);
+                wb.thr[p] = tin;
                 rd2.w = __uint_as_float(p | kHasRadiance);
             }
             wb.redo_rec[2 * k] = make_float4(ro.x, ro.y, ro.z, __uint_as_float((uint32_t)bounce));
@@ -510,6 +511,7 @@ __global__ __launch_bounds__(kBlock, JPT_SHADE_WAVES) void wf2_shade(SceneShadin
             const size_t j = seg_base + wbase + lanes_below(m, lane);
             wb.ray_o[out][j] = no;
             wb.ray_d[out][j] = nd;
+            wb.thr_q[out][j] = nt;
         }
     }
     if (COUNT) flush_counters(cnt, counters);
@@ -534,7 +536,11 @@ __global__ __launch_bounds__(64) void wf2_finish(WideSceneDev sc, SceneShading s
     for (uint32_t k = blockIdx.x * 64u + threadIdx.x; k < n; k += gridDim.x * 64u) {
         float4 ro = wb.redo_rec[2 * (size_t)k], rd = wb.redo_rec[2 * (size_t)k + 1];
         const int first = (int)__float_as_uint(ro.w);
-        if (first > 0) ro.w = wb.rad[__float_as_uint(rd.w) & kPathMask].w;   // the seed.y parked there when the path was set aside
+        float4 tin = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
+        if (first > 0) {   // the seed.y and the throughput parked when the path was set aside
+            ro.w = wb.rad[__float_as_uint(rd.w) & kPathMask].w;
+            tin = wb.thr[__float_as_uint(rd.w) & kPathMask];
+        }
         for (int bounce = first;; bounce++) {
             Traversal<COUNT, W4, true> tr;
             tr.begin(sc, mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z));
@@ -545,10 +551,11 @@ __global__ __launch_bounds__(64) void wf2_finish(WideSceneDev sc, SceneShading s
             const float4 ha = make_float4(tr.hit.t, tr.hit.u, tr.hit.v, __uint_as_float(tr.hit.tri));
             const uint32_t hb = tr.hit.inst | (tr.hit.front ? 0x80000000u : 0u);
             bool unreachable;
-            float4 no, nd;
-            if (!shade_entry<COUNT>(sh, wb, dm, fp, cam_far, bounce, ro, rd, ha, hb, false, unreachable, no, nd, cnt)) break;
+            float4 no, nd, nt;
+            if (!shade_entry<COUNT>(sh, wb, dm, fp, cam_far, bounce, ro, rd, tin, ha, hb, false, unreachable, no, nd, nt, cnt)) break;
             ro = no;
             rd = nd;
+            tin = nt;
         }
     }
     if (COUNT) flush_counters(cnt, counters);
@@ -738,7 +745,7 @@ size_t wf2_workspace_bytes(int width, int local_rows, int n_frames, int max_boun
             const Wf2Dims dm = make_dims(width, local_rows, nf, full_window(width, local_rows));
             const size_t q = (size_t)dm.seg_cap * kSegments;                  // queue entries
             const size_t paths = (size_t)dm.slots_per_frame * (size_t)nf;
-            b += q * sizeof(float4) * 4 + 4 * 256;    // two ray queues (o, d)
+            b += q * sizeof(float4) * 6 + 6 * 256;    // two ray queues (o, d, throughput)
             b += q * sizeof(float4) + 256;            // hit_a
             b += q * sizeof(uint32_t) + 256;          // hit_b
             b += paths * sizeof(float4) + 256;        // thr
@@ -800,6 +807,8 @@ void launch_wf2_render(hipStream_t stream, const DeviceScene& ds, const FramePar
         wb.ray_o[1] = (float4*)carve(q * sizeof(float4));
         wb.ray_d[0] = (float4*)carve(q * sizeof(float4));
         wb.ray_d[1] = (float4*)carve(q * sizeof(float4));
+        wb.thr_q[0] = (float4*)carve(q * sizeof(float4));
+        wb.thr_q[1] = (float4*)carve(q * sizeof(float4));
         wb.hit_a = (float4*)carve(q * sizeof(float4));
         wb.hit_b = (uint32_t*)carve(q * sizeof(uint32_t));
         wb.redo_rec = (float4*)carve(paths * 2 * sizeof(float4));
