@@ -7,7 +7,8 @@ from gdpathtracing_amd import capi, host, scenes, wire
 from oracle import binding as ob
 bad=0
 import faulthandler; faulthandler.enable()
-for seed in range(8,72):
+import os
+for seed in range(int(os.environ.get('FUZZ_FROM', '8')), int(os.environ.get('FUZZ_TO', '72'))):
     print("seed", seed, flush=True)
     sc = scenes.random_scene(seed, n_meshes=2+seed%4, n_instances=3+seed%11, tris_per_surface=9+7*(seed%9), coincident=(seed%3!=0))
     w,h,b,f = 96+8*(seed%5), 64+8*(seed%3), seed%5, 1+seed%3
