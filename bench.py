@@ -119,7 +119,7 @@ def main():
     elif args.scene == "cornell":
         sc = scenes.cornell_scene()
     elif args.scene == "unique":
-        sc = scenes.unique_scene()
+        sc = scenes.unique_scene(args.tris if args.tris != 51200 else 1_000_000)   # --tris 4000000 leaves the Infinity Cache too
     else:
         sc = scenes.instanced_scene()
     closeup_camera = scenes.CameraDesc(scenes.transform12(None, (0.0, 0.0, 4.2)), fov_deg=75.0)
