@@ -1,5 +1,6 @@
-"""Does the quantised-record walk stay conservative when the ray origin is far from the geometry (t = q * a + b cancels two
-terms of size |origin| * rD)?  Demo scene seen from 50 .. 500 000 units through a lens narrow enough to fill the frame;
+"""How far from the geometry may the ray origin be before the native route differs from the reference tree's image?  (Far
+away hit distances are coarse, different triangles tie exactly, and the order of the tests decides: DESIGN.md section 8.)
+Demo scene seen from 50 .. 500 000 units through a lens narrow enough to fill the frame;
 native route (reach records) against the oracle's walk of the reference tree, and against the watertight / NO_CULL pair.
 gpurun -- python tools/far_probe.py"""
 import os, sys; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
