@@ -380,12 +380,12 @@ struct Traversal {
     {
         cur = pop(st);
         if (cur == kSentinel) {
+            in_blas = false;
+            if (sp == 0) return;   // the instance was the last record of the walk: nobody needs the world ray's constants any more
             o = wo;
             d = wd;
             if (kLean) set_level();   // (recomputed rather than kept: three v_rcp_f32 per instance left, registers saved)
             else rD = wrD;
-            in_blas = false;
-            if (sp == 0) return;
             cur = pop(st);
         }
         have = true;
