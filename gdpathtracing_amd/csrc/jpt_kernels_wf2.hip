@@ -79,7 +79,7 @@ __device__ __forceinline__ bool walk_round(Traversal<COUNT, W4>& tr, bool active
     }
     bool wl = active && tr.wants_leaf();
     bool wi = active && tr.wants_instance();
-    if (tune.leaf_min_lanes > 1 || tune.inst_min_lanes > 1) {
+    if (W4 && (tune.leaf_min_lanes > 1 || tune.inst_min_lanes > 1)) {   // (reference trees, with leaves of up to 64 triangles, lose 5 % by waiting)
         const int nl = __popcll(__ballot(wl)), ni = __popcll(__ballot(wi));
         const bool nodes_left = __any(active && tr.wants_node()) || __any(active && !tr.have && tr.sp > 0);
         const bool run_l = nl >= lmin || !(nodes_left || ni >= imin);
