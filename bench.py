@@ -68,6 +68,12 @@ def main():
     ap.add_argument("--tris", type=int, default=51200)
     ap.add_argument("--scene", default="demo", choices=["demo", "cornell", "inst", "unique"])
     ap.add_argument("--builder", default="sah", choices=["sah", "exact", "watertight"])
+    ap.add_argument("--route", default="commit", choices=["commit", "upload", "upload-given"],
+                    help="scene ingest: commit = jpt_scene_begin/.../commit with --builder (route ii); upload = the reference-layout "
+                         "arrays GeometryGroup3D::build emits, handed to jpt_scene_upload_reference_layout (route i, the addon's "
+                         "drop-in route: walked on the native tree, reported as `dropin` by the default run); upload-given = the "
+                         "same arrays walked node for node (audit)")
+    ap.add_argument("--no-dropin", action="store_true", help="skip the third timed region (route i on the same workload)")
     ap.add_argument("--accum", default="ldr8", choices=["ldr8", "hdr"])
     ap.add_argument("--kernel", default="wavefront", choices=["wavefront", "ref"])
     ap.add_argument("--camera", default="demo", choices=["demo", "closeup"],
@@ -130,10 +136,28 @@ def main():
     accum_mode = capi.ACCUM_REF_LDR8 if args.accum == "ldr8" else capi.ACCUM_HDR_F32
     builder = {"sah": capi.BUILD_SAH, "exact": capi.BUILD_REFERENCE_EXACT, "watertight": capi.BUILD_SAH_WATERTIGHT}[args.builder]
 
+    def reference_layout_arrays():
+        """what GeometryGroup3D::build leaves in its vectors (geometry_group3d.cpp:305-365, get_*_buffer :40-68): made by
+        the library's reference-exact builder on a host-only context (byte-identical to the reference's; tests)"""
+        from gdpathtracing_amd import wire
+        hc = host.Context(-1)
+        hc.build_scene(sc, capi.BUILD_REFERENCE_EXACT)
+        arrs = [hc.reference_buffer(w, d) for w, d in (
+            (capi.BUF_TRI_GEOMETRY, wire.TRI_GEOMETRY), (capi.BUF_TRI_DATA, wire.TRI_DATA), (capi.BUF_MATERIALS, wire.MATERIAL),
+            (capi.BUF_BVH_NODES, wire.BVH_NODE), (capi.BUF_INSTANCES, wire.BLAS_INSTANCE), (capi.BUF_TLAS_NODES, wire.TLAS_NODE))]
+        hc.close()
+        return arrs
+
     ctx = host.Context(local_rank)
-    t0 = time.time()
-    ctx.build_scene(sc, builder)
-    build_s = time.time() - t0
+    if args.route == "commit":
+        t0 = time.time()
+        ctx.build_scene(sc, builder)
+        build_s = time.time() - t0
+    else:
+        arrs = reference_layout_arrays()
+        t0 = time.time()
+        ctx.upload_reference_layout(*arrs, textures=sc.textures, as_given=args.route == "upload-given")
+        build_s = time.time() - t0
     ctx.set_partition(rank, world)
     ctx.set_params(W, H, bounces, accum_mode)
     ctx.set_camera(cam)
@@ -276,6 +300,42 @@ def main():
                        rays_per_step=c_rays, steps=c_steps)
         ctx.set_camera(cam)
 
+    # the drop-in route on the same workload: the reference-layout arrays of the same scene handed to
+    # jpt_scene_upload_reference_layout (what the addon does when GeometryGroup3D::build() stays), on a second context
+    dropin = None
+    if world == 1 and args.route == "commit" and args.kernel == "wavefront" and not args.no_dropin and gpu_image is not None:
+        arrs = reference_layout_arrays()
+        dctx = host.Context(local_rank)
+        t0 = time.perf_counter()
+        dctx.upload_reference_layout(*arrs, textures=sc.textures)
+        upload_s = time.perf_counter() - t0
+        kind = dctx.tree_kind()
+        dctx.set_params(W, H, bounces, accum_mode)
+        dctx.set_camera(cam)
+        main_ctx, ctx = ctx, dctx      # step() / timed() drive `ctx`
+        try:
+            torch.cuda.set_stream(torch.cuda.ExternalStream(dctx.get_stream(), device=torch.device("cuda", local_rank)))
+            dctx.accum_reset()
+            dctx.render(spp, 1)
+            d_rays = dctx.stats()["rays"]
+            step()
+            barrier()
+            for _ in range(2):
+                step()
+            barrier()
+            d_steps = max(10, args.steps // 2)
+            d_elapsed = timed(d_steps)
+            d_image = dctx.read_accum()
+        finally:
+            ctx = main_ctx
+            torch.cuda.set_stream(stream)
+        dropin = dict(value=round(d_rays * d_steps / d_elapsed / 1e6, 3), ms_per_step=round(d_elapsed / d_steps * 1e3, 4), steps=d_steps,
+                      tree={capi.TREE_AS_GIVEN: "as given", capi.TREE_NATIVE_REACH: "native + reach records"}.get(kind, str(kind)),
+                      upload_s=round(upload_s, 4), note=dctx.upload_note() or None,
+                      differing_pixels_vs_commit_route=int((d_image != gpu_image).any(axis=-1).sum()),
+                      what="jpt_scene_upload_reference_layout of the reference-layout arrays (route i), same workload, queued renders")
+        dctx.close()
+
     status = 0
     if rank == 0:
         n_pixels = W * H
@@ -284,7 +344,7 @@ def main():
         # ---- roofline of the dominant kernel alone, from the work it DID: the events of the bounce launches are the
         # counted render's totals minus those of a bounce-0-only render; sky-culled primaries fetch nothing and are in
         # neither (they belong to the bounce-0 launch anyway)
-        table = WIDE4_BYTES if (args.builder != "exact" and args.kernel == "wavefront") else WIDE_BYTES
+        table = WIDE4_BYTES if (args.builder != "exact" and args.kernel == "wavefront" and args.route != "upload-given") else WIDE_BYTES
         if args.kernel == "wavefront":
             ev = {k: total[k] - primary[k] for k in table}
             dom_rays = total["rays"] - primary["rays"]
@@ -296,8 +356,8 @@ def main():
         # HBM traffic of that kernel: PMC counters cannot be read from inside the process, so the per-launch figure comes
         # from the committed rocprofv3 passes of this same command (profiles/)
         traffic = traffic_src = valu = None
-        default_run = (W, H, spp, bounces, args.tris, args.scene, args.builder, world, args.camera, args.kernel) == \
-                      (1920, 1080, 8, 4, 51200, "demo", "sah", 1, "demo", "wavefront")
+        default_run = (W, H, spp, bounces, args.tris, args.scene, args.builder, world, args.camera, args.kernel, args.route) == \
+                      (1920, 1080, 8, 4, 51200, "demo", "sah", 1, "demo", "wavefront", "commit")
         if default_run and os.path.exists(args.pmc_json):
             try:
                 pj = json.load(open(args.pmc_json))
@@ -325,7 +385,7 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": "C3: S-demo (open Cornell cube + light + 2 instances of a %d-tri procedural mesh), %dx%d, %d spp, "
-                            "%d bounces, accum=%s, builder=%s, kernel=%s" % (args.tris, W, H, spp, bounces, args.accum, args.builder, args.kernel)
+                            "%d bounces, accum=%s, builder=%s, kernel=%s" % (args.tris, W, H, spp, bounces, args.accum, args.builder if args.route == "commit" else args.route, args.kernel)
                 if (args.scene == "demo" and args.camera == "demo") else "%s (camera %s) %dx%d %d spp %d bounces" % (sc.name, args.camera, W, H, spp, bounces),
                 "unique_tris": sc.n_unique_tris, "instances": len(sc.instances),
                 "rays_per_step": rays, "nominal_rays_per_step": n_pixels * spp * (bounces + 1),
@@ -361,6 +421,9 @@ def main():
         if closeup is not None:
             out["value_closeup"] = closeup["value"]
             out["closeup"] = closeup
+        if dropin is not None:
+            out["value_dropin"] = dropin["value"]
+            out["dropin"] = dropin
         if verified is not None:
             out["verified_bit_identical_to_one_context"] = verified
         if world == 1 and not args.no_cpu_baseline:

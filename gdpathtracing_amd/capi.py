@@ -19,16 +19,18 @@ BUILD_REFERENCE_EXACT, BUILD_SAH, BUILD_SAH_WATERTIGHT = 0, 1, 2
 KERNEL_WAVEFRONT, KERNEL_REFERENCE_LAYOUT = 0, 1
 SAMPLER_NEAREST_CLAMP, SAMPLER_NEAREST_REPEAT, SAMPLER_LINEAR_CLAMP, SAMPLER_LINEAR_REPEAT = 0, 1, 2, 3
 DENOISE_PROGRESSIVE, DENOISE_TEMPORAL, DENOISE_NONE = 0, 1, 2
-BUF_TRI_GEOMETRY, BUF_TRI_DATA, BUF_MATERIALS, BUF_BVH_NODES, BUF_INSTANCES, BUF_TLAS_NODES, BUF_TRIANGLES = range(7)
+UPLOAD_NATIVE_TREE, UPLOAD_WALK_AS_GIVEN = 0, 1
+TREE_NONE, TREE_AS_GIVEN, TREE_REFERENCE_EXACT, TREE_NATIVE_REACH, TREE_NATIVE_WATERTIGHT = range(5)
+BUF_TRI_GEOMETRY, BUF_TRI_DATA, BUF_MATERIALS, BUF_BVH_NODES, BUF_INSTANCES, BUF_TLAS_NODES, BUF_TRIANGLES, BUF_REACH_TRIANGLES, BUF_REACH_INSTANCES = range(9)
 
 # every symbol include/jpt.h declares
 SYMBOLS = [
     "jpt_abi_version", "jpt_create", "jpt_destroy", "jpt_last_error", "jpt_set_stream", "jpt_get_stream",
-    "jpt_scene_upload_reference_layout", "jpt_scene_begin", "jpt_scene_add_mesh", "jpt_scene_add_instance",
+    "jpt_scene_upload_reference_layout", "jpt_set_upload_mode", "jpt_scene_tree_kind", "jpt_scene_upload_note", "jpt_scene_begin", "jpt_scene_add_mesh", "jpt_scene_add_instance",
     "jpt_scene_set_materials", "jpt_scene_set_textures", "jpt_scene_commit", "jpt_scene_get_reference_buffer",
     "jpt_scene_set_instance_transform", "jpt_scene_update_tlas", "jpt_scene_refit_tlas", "jpt_scene_update_reference_tlas",
     "jpt_set_params", "jpt_set_kernel", "jpt_set_kernel_timing", "jpt_set_partition", "jpt_set_camera", "jpt_render", "jpt_render_counted", "jpt_render_async",
-    "jpt_sync", "jpt_accum_reset", "jpt_set_denoising_mode", "jpt_set_temporal_params", "jpt_read_ldr_rgba8", "jpt_readback_ldr_begin", "jpt_readback_ldr_end", "jpt_read_accum_f32", "jpt_read_depth_f32",
+    "jpt_sync", "jpt_accum_reset", "jpt_set_progressive_frame_count", "jpt_set_denoising_mode", "jpt_set_temporal_params", "jpt_read_ldr_rgba8", "jpt_readback_ldr_begin", "jpt_readback_ldr_end", "jpt_read_accum_f32", "jpt_read_depth_f32",
     "jpt_device_accum", "jpt_assemble_from_ranks", "jpt_device_ldr", "jpt_assemble_ldr_from_ranks", "jpt_local_rows", "jpt_get_stats",
     "jpt_scene_share", "jpt_multi_create", "jpt_multi_destroy", "jpt_multi_last_error", "jpt_multi_world", "jpt_multi_ctx",
     "jpt_multi_share_scene", "jpt_multi_set_params", "jpt_multi_set_camera", "jpt_multi_accum_reset", "jpt_multi_set_gather",
@@ -98,6 +100,10 @@ def lib():
     L.jpt_set_stream.argtypes = [vp, vp]
     L.jpt_get_stream.argtypes = [vp, C.POINTER(vp)]
     L.jpt_scene_upload_reference_layout.argtypes = [vp, vp, u32, vp, vp, u32, vp, u32, vp, u32, vp, u32, vp, i32, i32]
+    L.jpt_set_upload_mode.argtypes = [vp, i32]
+    L.jpt_scene_tree_kind.argtypes = [vp]
+    L.jpt_scene_upload_note.argtypes = [vp]
+    L.jpt_scene_upload_note.restype = C.c_char_p
     L.jpt_scene_begin.argtypes = [vp]
     L.jpt_scene_add_mesh.argtypes = [vp, C.POINTER(Surface), i32, C.POINTER(u32)]
     L.jpt_scene_add_instance.argtypes = [vp, u32, vp, vp, i32]
@@ -118,6 +124,7 @@ def lib():
         getattr(L, n).argtypes = [vp, i32, u32]
     L.jpt_sync.argtypes = [vp]
     L.jpt_accum_reset.argtypes = [vp]
+    L.jpt_set_progressive_frame_count.argtypes = [vp, u32]
     L.jpt_set_denoising_mode.argtypes = [vp, i32]
     L.jpt_set_temporal_params.argtypes = [vp, vp]
     L.jpt_read_ldr_rgba8.argtypes = [vp, vp]

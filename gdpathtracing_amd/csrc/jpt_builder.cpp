@@ -25,6 +25,8 @@ void RefScene::clear()
     reach_tri.clear();
     reach_inst.clear();
     mesh_ref_root.clear();
+    up_mesh_root.clear();
+    up_blas_index.clear();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -597,6 +599,27 @@ bool build_tlas_sah(const std::vector<RefInstance>& inst, std::vector<RefTlasNod
 
 }  // namespace
 
+// Triangle -> GpuTriangleGeometry / GpuTriangleData (geometry_group3d.cpp:356-365)
+static void split_triangles(RefScene& out)
+{
+    out.tri_geom.resize(out.triangles.size());
+    out.tri_data.resize(out.triangles.size());
+    for (size_t i = 0; i < out.triangles.size(); i++) {
+        const RefTriangle& t = out.triangles[i];
+        for (int k = 0; k < 3; k++) out.tri_geom[i].vertices[k] = t.vertices[k];
+        RefTriData& d = out.tri_data[i];
+        std::memset(&d, 0, sizeof d);
+        d.n0[0] = t.normals[0].x; d.n0[1] = t.normals[0].y; d.n0[2] = t.normals[0].z;
+        d.material_index = t.materialIndex;
+        d.n1 = t.normals[1];
+        d.n2 = t.normals[2];
+        for (int k = 0; k < 3; k++) {
+            d.uvs[k][0] = t.uvs[k][0];
+            d.uvs[k][1] = t.uvs[k][1];
+        }
+    }
+}
+
 void SceneBuilder::begin()
 {
     meshes_.clear();
@@ -737,23 +760,266 @@ bool SceneBuilder::commit(BuildMode mode, RefScene& out, std::string& err)
         out.mesh_roots.push_back(root);
     }
     if (!rebuild_instances(mode, out, err)) return false;
-    // Triangle -> GpuTriangleGeometry / GpuTriangleData (geometry_group3d.cpp:356-365)
-    out.tri_geom.resize(out.triangles.size());
-    out.tri_data.resize(out.triangles.size());
-    for (size_t i = 0; i < out.triangles.size(); i++) {
-        const RefTriangle& t = out.triangles[i];
-        for (int k = 0; k < 3; k++) out.tri_geom[i].vertices[k] = t.vertices[k];
-        RefTriData& d = out.tri_data[i];
-        std::memset(&d, 0, sizeof d);
-        d.n0[0] = t.normals[0].x; d.n0[1] = t.normals[0].y; d.n0[2] = t.normals[0].z;
-        d.material_index = t.materialIndex;
-        d.n1 = t.normals[1];
-        d.n2 = t.normals[2];
-        for (int k = 0; k < 3; k++) {
-            d.uvs[k][0] = t.uvs[k][0];
-            d.uvs[k][1] = t.uvs[k][1];
+    split_triangles(out);
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------------
+// route (i) on the native tree: native SAH trees + reach records from uploaded reference-layout arrays
+
+namespace {
+
+inline bool box_inside(const float* lo, const float* hi, const float* plo, const float* phi)
+{
+    // (written so that a NaN anywhere answers "no")
+    return lo[0] >= plo[0] && lo[1] >= plo[1] && lo[2] >= plo[2] && hi[0] <= phi[0] && hi[1] <= phi[1] && hi[2] <= phi[2];
+}
+
+// transform * inverse_transform == identity, to float accuracy?  (column-major 4x4, as utils.h:15-37 writes them)
+bool transforms_belong_together(const RefInstance& in)
+{
+    const float *a = in.transform, *b = in.inverse_transform;
+    for (int r = 0; r < 4; r++)
+        for (int c = 0; c < 4; c++) {
+            double p = 0.0, mag = 0.0;
+            for (int k = 0; k < 4; k++) {
+                const double t = (double)a[k * 4 + r] * (double)b[c * 4 + k];
+                p += t;
+                mag += std::fabs(t);
+            }
+            const double want = r == c ? 1.0 : 0.0;
+            if (!(std::fabs(p - want) <= 1e-4 * (1.0 + mag))) return false;
+        }
+    return true;
+}
+
+}  // namespace
+
+bool native_instances_from_uploaded(const std::vector<RefInstance>& up_inst, const std::vector<RefTlasNode>& up_tlas, RefScene& out,
+                                    std::string& why)
+{
+    const size_t ni = up_inst.size();
+    std::vector<RefInstance> instances;
+    std::vector<ReachInst> reach;
+    std::vector<uint32_t> up_index(ni);
+    if (ni > 0) {
+        if (up_tlas.empty()) {
+            why = "instances without a TLAS";
+            return false;
+        }
+        // the TLAS leaf of every instance (ray_trace_tlas starts at slot 0 and tests the boxes of the children it pushes,
+        // main.glsl:307-350): each instance in exactly one leaf, no node reachable twice, child boxes inside their parent's
+        // (the root's own box is never tested)
+        constexpr uint32_t kNone = 0xffffffffu;
+        std::vector<uint32_t> leaf_of(ni, kNone);
+        std::vector<uint8_t> seen(up_tlas.size(), 0);
+        std::vector<std::pair<uint32_t, uint32_t>> todo;  // (node, parent)
+        todo.emplace_back(0u, kNone);
+        while (!todo.empty()) {
+            const uint32_t n = todo.back().first, parent = todo.back().second;
+            todo.pop_back();
+            if (seen[n]) {
+                why = "a TLAS node is reachable twice";
+                return false;
+            }
+            seen[n] = 1;
+            const RefTlasNode& node = up_tlas[n];
+            if (parent != kNone && parent != 0u && !box_inside(node.aabbMin, node.aabbMax, up_tlas[parent].aabbMin, up_tlas[parent].aabbMax)) {
+                why = "TLAS boxes are not nested";
+                return false;
+            }
+            if (node.leftRight == 0u) {
+                if (node.blas >= ni) {
+                    why = "a TLAS leaf names an instance that does not exist";
+                    return false;
+                }
+                if (leaf_of[node.blas] != kNone) {
+                    why = "an instance is in two TLAS leaves";
+                    return false;
+                }
+                leaf_of[node.blas] = n;
+                continue;
+            }
+            const uint32_t l = node.leftRight & 0xffffu, r = node.leftRight >> 16;
+            if (l >= up_tlas.size() || r >= up_tlas.size()) {
+                why = "TLAS child index out of range";
+                return false;
+            }
+            todo.emplace_back(r, n);
+            todo.emplace_back(l, n);
+        }
+        instances.resize(ni);
+        reach.resize(ni);
+        for (size_t i = 0; i < ni; i++) {
+            if (leaf_of[i] == kNone) {
+                why = "an instance is in no TLAS leaf";
+                return false;
+            }
+            const RefInstance& in = up_inst[i];
+            size_t mesh = out.up_mesh_root.size();
+            for (size_t m = 0; m < out.up_mesh_root.size(); m++)
+                if (out.up_mesh_root[m] == in.blas_index) {
+                    mesh = m;
+                    break;
+                }
+            if (mesh == out.up_mesh_root.size()) {
+                why = "an instance names a BLAS root the uploaded scene did not have";
+                return false;
+            }
+            if (!transforms_belong_together(in)) {
+                why = "an instance's inverse_transform is not the inverse of its transform";
+                return false;
+            }
+            up_index[i] = in.blas_index;
+            RefInstance n = in;  // matrices and material slots as uploaded (the device reads exactly these)
+            n.blas_index = out.mesh_roots[mesh];
+            const RefBvhNode& root = out.bvh_nodes[n.blas_index];
+            instance_world_box(n.transform, root.aabbMin, root.aabbMax, /*pad_box*/ true, n.aabbMin, n.aabbMax);
+            instances[i] = n;
+            // the reach record: the box ray_trace_tlas tests before it enters the instance is its TLAS leaf's
+            ReachInst r = out.mesh_ref_root[mesh];
+            const RefTlasNode& leaf = up_tlas[leaf_of[i]];
+            for (int k = 0; k < 3; k++) {
+                r.lo[k] = leaf.aabbMin[k];
+                r.hi[k] = leaf.aabbMax[k];
+            }
+            reach[i] = r;
         }
     }
+    std::vector<RefTlasNode> tlas;
+    std::string err;
+    if (!build_tlas_sah(instances, tlas, err)) {
+        why = err;
+        return false;
+    }
+    out.instances = std::move(instances);
+    out.reach_inst = std::move(reach);
+    out.tlas_nodes = std::move(tlas);
+    out.up_blas_index = std::move(up_index);
+    return true;
+}
+
+bool native_from_uploaded(const RefScene& up, RefScene& out, std::string& why)
+{
+    out.clear();
+    constexpr uint32_t kNone = 0xffffffffu;
+    const size_t nn = up.bvh_nodes.size(), nt = up.tri_geom.size();
+    if (up.tri_data.size() != nt) {
+        why = "triangle geometry/data counts differ";
+        return false;
+    }
+    std::vector<uint8_t> node_seen(nn, 0);
+    std::vector<uint32_t> tri_leaf(nt, kNone);  // the uploaded leaf that holds each triangle
+    for (const RefInstance& in : up.instances) {
+        const uint32_t up_root = in.blas_index;
+        if (std::find(out.up_mesh_root.begin(), out.up_mesh_root.end(), up_root) != out.up_mesh_root.end()) continue;
+        if (up_root >= nn) {
+            why = "instance root index out of range";
+            return false;
+        }
+        // the triangles under this root, in the order ray_trace_blas would meet the leaves going left first
+        std::vector<uint32_t> mesh_tris;
+        std::vector<std::pair<uint32_t, uint32_t>> todo;  // (node, parent)
+        todo.emplace_back(up_root, kNone);
+        while (!todo.empty()) {
+            const uint32_t n = todo.back().first, parent = todo.back().second;
+            todo.pop_back();
+            if (node_seen[n]) {
+                why = "a BVH node is reachable twice (shared subtree or cycle)";
+                return false;
+            }
+            node_seen[n] = 1;
+            const RefBvhNode& node = up.bvh_nodes[n];
+            // a leaf's box must lie inside the box of every ancestor that is tested on the way down (all but the root)
+            if (parent != kNone && parent != up_root &&
+                !box_inside(&node.aabbMin.x, &node.aabbMax.x, &up.bvh_nodes[parent].aabbMin.x, &up.bvh_nodes[parent].aabbMax.x)) {
+                why = "BVH boxes are not nested";
+                return false;
+            }
+            if (node.tri_count > 0) {
+                if ((size_t)node.first_tri_index + node.tri_count > nt) {
+                    why = "BVH leaf triangle range out of bounds";
+                    return false;
+                }
+                for (uint32_t k = 0; k < node.tri_count; k++) {
+                    const uint32_t t = node.first_tri_index + k;
+                    if (tri_leaf[t] != kNone) {
+                        why = "a triangle is in two leaves";
+                        return false;
+                    }
+                    tri_leaf[t] = n;
+                    mesh_tris.push_back(t);
+                }
+                continue;
+            }
+            if (node.left_child == 0 && node.right_child == 0) continue;  // a leaf without triangles
+            if (node.left_child >= nn || node.right_child >= nn) {
+                why = "BVH child index out of range";
+                return false;
+            }
+            todo.emplace_back(node.right_child, n);
+            todo.emplace_back(node.left_child, n);
+        }
+        const int start = (int)out.triangles.size();
+        for (uint32_t t : mesh_tris) {
+            const RefTriGeometry& g = up.tri_geom[t];
+            const RefTriData& d = up.tri_data[t];
+            RefTriangle tri;
+            std::memset(&tri, 0, sizeof tri);
+            for (int j = 0; j < 3; j++) tri.vertices[j] = g.vertices[j];
+            tri.normals[0] = Vec4{d.n0[0], d.n0[1], d.n0[2], 1.0f};
+            tri.normals[1] = d.n1;
+            tri.normals[2] = d.n2;
+            for (int j = 0; j < 3; j++) {
+                tri.uvs[j][0] = d.uvs[j][0];
+                tri.uvs[j][1] = d.uvs[j][1];
+            }
+            tri.materialIndex = d.material_index;
+            const Vec4 &a = tri.vertices[0], &b = tri.vertices[1], &c = tri.vertices[2];
+            tri.centroid = Vec4{((a.x + b.x) + c.x) * 0.33333333f, ((a.y + b.y) + c.y) * 0.33333333f,
+                                ((a.z + b.z) + c.z) * 0.33333333f, ((a.w + b.w) + c.w) * 0.33333333f};
+            out.triangles.push_back(tri);
+        }
+        const int end = (int)out.triangles.size();
+        uint32_t root = 0;
+        if (end > start) {
+            SahBlasBuilder b{out.bvh_nodes, out.triangles};
+            b.prepare(start, end);
+            root = b.build(0, end - start);
+            b.apply_order(start, end);
+            out.reach_tri.resize((size_t)end);
+            for (int i = 0; i < end - start; i++) {
+                const uint32_t leaf = tri_leaf[mesh_tris[b.order[(size_t)i]]];
+                const RefBvhNode& ln = up.bvh_nodes[leaf];
+                ReachTri r;
+                r.lo[0] = ln.aabbMin.x; r.lo[1] = ln.aabbMin.y; r.lo[2] = ln.aabbMin.z;
+                r.hi[0] = ln.aabbMax.x; r.hi[1] = ln.aabbMax.y; r.hi[2] = ln.aabbMax.z;
+                r.always = leaf == up_root ? 1u : 0u;  // the root is popped without a box test (main.glsl:272-283)
+                r._pad = 0;
+                out.reach_tri[(size_t)(start + i)] = r;
+            }
+        } else {
+            root = (uint32_t)out.bvh_nodes.size();  // nothing under this root: a valid empty leaf (as SceneBuilder::commit)
+            RefBvhNode n;
+            std::memset(&n, 0, sizeof n);
+            out.bvh_nodes.push_back(n);
+        }
+        ReachInst rr;
+        std::memset(&rr, 0, sizeof rr);
+        const RefBvhNode& ur = up.bvh_nodes[up_root];
+        rr.root_lo[0] = ur.aabbMin.x; rr.root_lo[1] = ur.aabbMin.y; rr.root_lo[2] = ur.aabbMin.z;
+        rr.root_hi[0] = ur.aabbMax.x; rr.root_hi[1] = ur.aabbMax.y; rr.root_hi[2] = ur.aabbMax.z;
+        out.mesh_ref_root.push_back(rr);
+        out.mesh_roots.push_back(root);
+        out.up_mesh_root.push_back(up_root);
+    }
+    out.reach_tri.resize(out.triangles.size());
+    if (!native_instances_from_uploaded(up.instances, up.tlas_nodes, out, why)) return false;
+    split_triangles(out);
+    out.materials = up.materials;
+    out.textures = up.textures;
+    out.tex_res = up.tex_res;
+    out.n_layers = up.n_layers;
     return true;
 }
 

@@ -43,6 +43,11 @@ struct RefScene {
     std::vector<ReachTri> reach_tri;
     std::vector<ReachInst> reach_inst;
     std::vector<ReachInst> mesh_ref_root;     // root_lo / root_hi filled; one per unique mesh
+    // route (i) on the native tree (native_from_uploaded): per unique BLAS the node index the CALLER's arrays gave its
+    // root, and per instance the blas_index the caller uploaded -- what jpt_scene_update_reference_tlas matches new
+    // BLASInstance records against
+    std::vector<uint32_t> up_mesh_root;
+    std::vector<uint32_t> up_blas_index;
     void clear();
 };
 
@@ -97,6 +102,22 @@ class SceneBuilder {
 
 // reach record of one instance: mesh_root (root_lo / root_hi) + the world box the reference computes for this transform
 ReachInst reach_instance(const float* transform12, const ReachInst& mesh_root);
+
+// ---- route (i) on the native tree ------------------------------------------------------------------------------------
+// The arrays GeometryGroup3D emits (get_*_buffer, geometry_group3d.cpp:40-68) hold everything the fast route needs: the
+// triangles (GpuTriangleGeometry / GpuTriangleData), the instance matrices, and -- directly readable -- the two boxes that
+// decide what the reference's traversal can reach: the box of the reference leaf that holds each triangle (BVHNode with
+// tri_count > 0) and the box of each instance's TLAS leaf.  native_from_uploaded builds the native SAH trees over the
+// uploaded triangles of every BLAS an instance names and takes the reach records from those boxes; no builder of the
+// reference runs.  `out` is a scene in reference layout whose trees are the native ones (like a JPT_BUILD_SAH commit).
+// Returns false, with the reason in `why`, when the uploaded arrays are not a tree the reach rule applies to (a node or
+// a triangle reachable twice, boxes that are not nested, an instance in no or several TLAS leaves, transform and
+// inverse_transform that do not belong together): the caller then walks the arrays as given.
+bool native_from_uploaded(const RefScene& up, RefScene& out, std::string& why);
+// The same for the instance level alone (jpt_scene_update_reference_tlas): new BLASInstance / TLASNode arrays over the
+// BLASes `out` already holds; each instance must name the BLAS it named at upload time.
+bool native_instances_from_uploaded(const std::vector<RefInstance>& up_instances, const std::vector<RefTlasNode>& up_tlas,
+                                    RefScene& out, std::string& why);
 
 // Bottom-up schedule of the four-child TLAS records for a refit on the device (jpt_kernels_post.hip): `order` lists the
 // records of w.tlas_nodes4 deepest level first, level l is order[level_start[l] .. level_start[l + 1]).

@@ -65,6 +65,9 @@ struct jpt_ctx {
     WideScene wide;
     bool building = false, scene_ready = false, ref_is_exact = false, native_tree = false, tlas_dirty = false;
     bool host_scene_ready = false;  // c->ref / c->wide hold a complete scene (also true on host-only contexts)
+    bool from_commit = false;       // the scene came from jpt_scene_commit: c->builder holds its meshes and transforms
+    int32_t upload_mode = JPT_UPLOAD_NATIVE_TREE;  // jpt_set_upload_mode
+    std::string upload_note;        // why the last reference-layout upload is walked as given (empty: it is not)
     std::vector<RefMaterial> pending_materials;
     std::vector<uint8_t> pending_tex;
     int32_t pending_tex_res = 0, pending_layers = 0;
@@ -372,9 +375,8 @@ int upload_scene(jpt_ctx* c)
     return JPT_OK;
 }
 
-int validate_ref_scene(jpt_ctx* c)
+int validate_ref_scene(jpt_ctx* c, const RefScene& r)
 {
-    const RefScene& r = c->ref;
     if (r.tri_geom.size() != r.tri_data.size()) return fail(c, JPT_E_INVALID, "triangle geometry/data counts differ");
     if (r.materials.empty()) return fail(c, JPT_E_INVALID, "material table is empty (entry 0 is the default material)");
     for (const RefInstance& i : r.instances)
@@ -977,38 +979,77 @@ int jpt_scene_upload_reference_layout(jpt_ctx* c, const void* tri_geometry, uint
     if (n_instances > 32767) return fail(c, JPT_E_LIMIT, "more instances than a TLAS with 16-bit child indices can hold (bvh.h:59; 32 767)");
     const auto t0 = std::chrono::steady_clock::now();
     c->scene_ready = c->host_scene_ready = false;
-    RefScene& r = c->ref;
-    r.clear();
+    c->from_commit = false;
+    c->upload_note.clear();
+    RefScene up;
     auto put = [](auto& vec, const void* src, uint32_t n) {
         using T = typename std::remove_reference<decltype(vec)>::type::value_type;
         vec.resize(n);
         if (n) std::memcpy(vec.data(), src, (size_t)n * sizeof(T));
     };
-    put(r.tri_geom, tri_geometry, n_triangles);
-    put(r.tri_data, tri_data, n_triangles);
-    put(r.materials, materials, n_materials);
-    put(r.bvh_nodes, bvh_nodes, n_bvh_nodes);
-    put(r.instances, blas_instances, n_instances);
-    put(r.tlas_nodes, tlas_nodes, n_tlas_nodes);
-    r.textures.clear();
-    r.tex_res = r.n_layers = 0;
+    put(up.tri_geom, tri_geometry, n_triangles);
+    put(up.tri_data, tri_data, n_triangles);
+    put(up.materials, materials, n_materials);
+    put(up.bvh_nodes, bvh_nodes, n_bvh_nodes);
+    put(up.instances, blas_instances, n_instances);
+    put(up.tlas_nodes, tlas_nodes, n_tlas_nodes);
     if (tex_rgba8 && tex_res > 0 && n_layers > 0) {
-        r.textures.assign(tex_rgba8, tex_rgba8 + (size_t)tex_res * tex_res * 4 * n_layers);
-        r.tex_res = tex_res;
-        r.n_layers = n_layers;
+        up.textures.assign(tex_rgba8, tex_rgba8 + (size_t)tex_res * tex_res * 4 * n_layers);
+        up.tex_res = tex_res;
+        up.n_layers = n_layers;
+    }
+    int rc = validate_ref_scene(c, up);
+    if (rc != JPT_OK) return rc;
+    // Default: the kernels walk the NATIVE tree (four-child quantised records over the uploaded triangles) and the boxes of
+    // the uploaded leaves / TLAS leaves become the reach records that keep the image the reference's (jpt_builder.h,
+    // native_from_uploaded) -- the addon keeps GeometryGroup3D::build() and gets the fast route's rate.  Arrays the reach
+    // rule does not apply to, JPT_UPLOAD_WALK_AS_GIVEN and JPT_UPLOAD_WALK=given are walked node for node as uploaded.
+    bool native = c->upload_mode == JPT_UPLOAD_NATIVE_TREE && !tuning().upload_as_given;
+    if (native) {
+        std::string why;
+        native = native_from_uploaded(up, c->ref, why);
+        if (!native) c->upload_note = "reference-layout upload is walked as given: " + why;
+    } else {
+        c->upload_note = "reference-layout upload is walked as given: requested";
+    }
+    if (!native) {
+        c->ref.clear();
+        c->ref.tri_geom = std::move(up.tri_geom);
+        c->ref.tri_data = std::move(up.tri_data);
+        c->ref.materials = std::move(up.materials);
+        c->ref.bvh_nodes = std::move(up.bvh_nodes);
+        c->ref.instances = std::move(up.instances);
+        c->ref.tlas_nodes = std::move(up.tlas_nodes);
+        c->ref.textures = std::move(up.textures);
+        c->ref.tex_res = up.tex_res;
+        c->ref.n_layers = up.n_layers;
     }
     c->ref_is_exact = false;
-    c->native_tree = false;  // uploaded trees are walked as given
-    c->build_mode = BuildMode::ReferenceExact;
-    r.reach_tri.clear();
-    r.reach_inst.clear();
-    r.mesh_ref_root.clear();
-    int rc = validate_ref_scene(c);
-    if (rc != JPT_OK) return rc;
+    c->native_tree = native;
+    c->build_mode = native ? BuildMode::Sah : BuildMode::ReferenceExact;
     rc = upload_scene(c);
     c->stats.last_build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return rc;
 }
+
+int jpt_set_upload_mode(jpt_ctx* c, int32_t mode)
+{
+    if (!c) return JPT_E_INVALID;
+    if (mode != JPT_UPLOAD_NATIVE_TREE && mode != JPT_UPLOAD_WALK_AS_GIVEN) return fail(c, JPT_E_INVALID, "unknown upload mode");
+    c->upload_mode = mode;
+    return JPT_OK;
+}
+
+int jpt_scene_tree_kind(jpt_ctx* c)
+{
+    if (!c) return JPT_E_INVALID;
+    if (!c->host_scene_ready) return JPT_TREE_NONE;
+    if (c->ref_is_exact) return JPT_TREE_REFERENCE_EXACT;
+    if (!c->native_tree) return JPT_TREE_AS_GIVEN;
+    return c->build_mode == BuildMode::Sah ? JPT_TREE_NATIVE_REACH : JPT_TREE_NATIVE_WATERTIGHT;
+}
+
+const char* jpt_scene_upload_note(const jpt_ctx* c) { return c ? c->upload_note.c_str() : ""; }
 
 int jpt_scene_begin(jpt_ctx* c)
 {
@@ -1087,8 +1128,10 @@ int jpt_scene_commit(jpt_ctx* c, int32_t builder)
     c->ref.n_layers = c->pending_layers;
     c->ref_is_exact = (builder == JPT_BUILD_REFERENCE_EXACT);
     c->native_tree = is_native(c->build_mode);
-    int rc = validate_ref_scene(c);
+    int rc = validate_ref_scene(c, c->ref);
     if (rc != JPT_OK) return rc;
+    c->from_commit = true;
+    c->upload_note.clear();
     rc = upload_scene(c);
     c->building = false;
     c->stats.last_build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -1100,7 +1143,7 @@ int jpt_scene_share(jpt_ctx* dst, jpt_ctx* src)
     if (!dst || !src) return JPT_E_INVALID;
     if (dst == src) return JPT_OK;
     if (!src->host_scene_ready || src->building) return fail(dst, JPT_E_STATE, "the source context holds no committed scene");
-    if (src->tlas_dirty || src->refit_active) {  // bring the source's host arrays up to date with its last transforms
+    if (src->from_commit && (src->tlas_dirty || src->refit_active)) {  // bring the source's host arrays up to date with its last transforms
         const int rc = jpt_scene_update_tlas(src);
         if (rc != JPT_OK) return fail(dst, rc, std::string("source context: ") + src->error);
     }
@@ -1111,6 +1154,8 @@ int jpt_scene_share(jpt_ctx* dst, jpt_ctx* src)
     dst->ref_is_exact = src->ref_is_exact;
     dst->native_tree = src->native_tree;
     dst->build_mode = src->build_mode;
+    dst->from_commit = src->from_commit;
+    dst->upload_note = src->upload_note;
     dst->building = false;
     const int rc = upload_scene(dst);   // flatten + upload to dst's device; no builder runs
     dst->stats.last_build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -1166,7 +1211,7 @@ int upload_tlas_update(jpt_ctx* c)
 int jpt_scene_set_instance_transform(jpt_ctx* c, uint32_t instance, const float* transform12)
 {
     if (!c) return JPT_E_INVALID;
-    if (!c->host_scene_ready || c->building || !(c->ref_is_exact || c->native_tree))
+    if (!c->host_scene_ready || c->building || !c->from_commit)
         return fail(c, JPT_E_STATE, "jpt_scene_set_instance_transform needs a scene made by jpt_scene_commit");
     if (!transform12) return fail(c, JPT_E_INVALID, "null transform");
     if (!c->builder.set_instance_transform(instance, transform12)) return fail(c, JPT_E_INVALID, "no such instance");
@@ -1177,7 +1222,7 @@ int jpt_scene_set_instance_transform(jpt_ctx* c, uint32_t instance, const float*
 int jpt_scene_update_tlas(jpt_ctx* c)
 {
     if (!c) return JPT_E_INVALID;
-    if (!c->host_scene_ready || c->building || !(c->ref_is_exact || c->native_tree))
+    if (!c->host_scene_ready || c->building || !c->from_commit)
         return fail(c, JPT_E_STATE, "jpt_scene_update_tlas needs a scene made by jpt_scene_commit");
     if (!c->tlas_dirty) return JPT_OK;
     const auto t0 = std::chrono::steady_clock::now();
@@ -1195,7 +1240,7 @@ int jpt_scene_update_tlas(jpt_ctx* c)
 int jpt_scene_refit_tlas(jpt_ctx* c, const float* transforms12, uint32_t n_instances)
 {
     if (!c) return JPT_E_INVALID;
-    if (!c->host_scene_ready || c->building || !c->native_tree)
+    if (!c->host_scene_ready || c->building || !c->native_tree || !c->from_commit)
         return fail(c, JPT_E_STATE, "jpt_scene_refit_tlas needs a scene made by jpt_scene_commit with the native builder");
     if (!transforms12 && n_instances) return fail(c, JPT_E_INVALID, "null transforms");
     if (n_instances != c->ref.instances.size()) return fail(c, JPT_E_INVALID, "one transform per instance of the committed scene");
@@ -1328,27 +1373,42 @@ int jpt_scene_update_reference_tlas(jpt_ctx* c, const void* blas_instances, uint
     if (!c->host_scene_ready || c->building) return fail(c, JPT_E_STATE, "no scene to update");
     if ((n_instances && !blas_instances) || (n_tlas_nodes && !tlas_nodes)) return fail(c, JPT_E_INVALID, "null buffer with non-zero count");
     if (n_tlas_nodes > 65536) return fail(c, JPT_E_LIMIT, "TLAS has more nodes than 16-bit child indices address (bvh.h:59)");
+    if (c->from_commit) return fail(c, JPT_E_STATE, "the scene was made by jpt_scene_commit: use jpt_scene_set_instance_transform / jpt_scene_update_tlas");
     if (n_instances != c->ref.instances.size())
         return fail(c, JPT_E_INVALID, "instance count changed: upload the whole scene again");
+    const bool native = c->native_tree;  // the upload built the native tree: instances are matched by the roots the caller named then
     const RefInstance* in = static_cast<const RefInstance*>(blas_instances);
     for (uint32_t i = 0; i < n_instances; i++) {
         RefInstance one;
         std::memcpy(&one, reinterpret_cast<const char*>(in) + (size_t)i * sizeof(RefInstance), sizeof one);
-        if (one.blas_index != c->ref.instances[i].blas_index)
+        if (one.blas_index != (native ? c->ref.up_blas_index[i] : c->ref.instances[i].blas_index))
             return fail(c, JPT_E_INVALID, "an instance now names another BLAS: upload the whole scene again");
     }
     const auto t0 = std::chrono::steady_clock::now();
     // keep the old arrays until the new ones are known to flatten
     std::vector<RefInstance> old_inst = c->ref.instances;
     std::vector<RefTlasNode> old_tlas = c->ref.tlas_nodes;
-    if (n_instances) std::memcpy(c->ref.instances.data(), blas_instances, (size_t)n_instances * sizeof(RefInstance));
-    c->ref.tlas_nodes.resize(n_tlas_nodes);
-    if (n_tlas_nodes) std::memcpy(c->ref.tlas_nodes.data(), tlas_nodes, (size_t)n_tlas_nodes * sizeof(RefTlasNode));
+    std::vector<ReachInst> old_reach = c->ref.reach_inst;
+    if (native) {
+        std::vector<RefInstance> ni(n_instances);
+        std::vector<RefTlasNode> nt(n_tlas_nodes);
+        if (n_instances) std::memcpy(ni.data(), blas_instances, (size_t)n_instances * sizeof(RefInstance));
+        if (n_tlas_nodes) std::memcpy(nt.data(), tlas_nodes, (size_t)n_tlas_nodes * sizeof(RefTlasNode));
+        std::string why;
+        if (!native_instances_from_uploaded(ni, nt, c->ref, why))  // (c->ref is untouched when this fails)
+            return fail(c, JPT_E_INVALID, "the new instance level does not fit the native tree of the last upload (" + why +
+                                              "): upload the whole scene again, or with JPT_UPLOAD_WALK_AS_GIVEN");
+    } else {
+        if (n_instances) std::memcpy(c->ref.instances.data(), blas_instances, (size_t)n_instances * sizeof(RefInstance));
+        c->ref.tlas_nodes.resize(n_tlas_nodes);
+        if (n_tlas_nodes) std::memcpy(c->ref.tlas_nodes.data(), tlas_nodes, (size_t)n_tlas_nodes * sizeof(RefTlasNode));
+    }
     int rc = upload_tlas_update(c);
     if (rc != JPT_OK && rc != JPT_E_DEVICE) {
         const std::string msg = c->error;
         c->ref.instances = old_inst;
         c->ref.tlas_nodes = old_tlas;
+        c->ref.reach_inst = old_reach;
         const int back = upload_tlas_update(c);
         c->host_scene_ready = (back == JPT_OK);
         c->scene_ready = c->host_scene_ready && c->device >= 0;
@@ -1361,7 +1421,7 @@ int jpt_scene_update_reference_tlas(jpt_ctx* c, const void* blas_instances, uint
 int jpt_scene_get_reference_buffer(jpt_ctx* c, int32_t which, void* out, size_t capacity, size_t* size_out)
 {
     if (!c) return JPT_E_INVALID;
-    if (c->refit_active && (which == JPT_BUF_INSTANCES || which == JPT_BUF_TLAS_NODES)) {
+    if (c->refit_active && (which == JPT_BUF_INSTANCES || which == JPT_BUF_TLAS_NODES || which == JPT_BUF_REACH_INSTANCES)) {
         // the instance level was last refitted on the device: bring the host mirrors (and the device) to a fresh build
         const int rc = jpt_scene_update_tlas(c);
         if (rc != JPT_OK) return rc;
@@ -1377,6 +1437,8 @@ int jpt_scene_get_reference_buffer(jpt_ctx* c, int32_t which, void* out, size_t 
         case JPT_BUF_INSTANCES: src = r.instances.data(); bytes = r.instances.size() * sizeof(RefInstance); break;
         case JPT_BUF_TLAS_NODES: src = r.tlas_nodes.data(); bytes = r.tlas_nodes.size() * sizeof(RefTlasNode); break;
         case JPT_BUF_TRIANGLES: src = r.triangles.data(); bytes = r.triangles.size() * sizeof(RefTriangle); break;
+        case JPT_BUF_REACH_TRIANGLES: src = r.reach_tri.data(); bytes = r.reach_tri.size() * sizeof(ReachTri); break;
+        case JPT_BUF_REACH_INSTANCES: src = r.reach_inst.data(); bytes = r.reach_inst.size() * sizeof(ReachInst); break;
         default: return fail(c, JPT_E_INVALID, "unknown buffer id");
     }
     if (size_out) *size_out = bytes;
@@ -1472,6 +1534,16 @@ int jpt_accum_reset(jpt_ctx* c)
     c->stats.frames = 0;
     c->assembled = c->assembled_ldr = false;
     c->hist_valid = false;  // temporal mode: history images start from zero again (a new TemporalReprojection object)
+    return JPT_OK;
+}
+
+int jpt_set_progressive_frame_count(jpt_ctx* c, uint32_t next_frame_count)
+{
+    if (!c) return JPT_E_INVALID;
+    if (next_frame_count == 0) return fail(c, JPT_E_INVALID, "frame_count starts at 1 (progressive_rendering.cpp:20)");
+    c->frame_count = next_frame_count - 1u;
+    c->stats.frames = c->frame_count;
+    c->assembled = c->assembled_ldr = false;
     return JPT_OK;
 }
 

@@ -56,14 +56,10 @@ JPT_HD void affine_inverse12(const float* t, float* o)
     o[11] = m[6] * nx + m[7] * ny + m[8] * nz;
 }
 
-// transform, inverse_transform, aabbMin, aabbMax of `inst` from the instance's Transform3D and the box of its BLAS
-// root (BLASInstance::update_aabb, bvh.h:90-115); `pad` = the native builder's outward padding of the world box
-JPT_HD void instance_record(const float* t12, const Vec4& root_min, const Vec4& root_max, bool pad_box, RefInstance& inst)
+// aabbMin / aabbMax of an instance from its column-major transform and the box of its BLAS root
+// (BLASInstance::update_aabb, bvh.h:90-115); `pad_box` = the native builder's outward padding of the world box
+JPT_HD void instance_world_box(const float* transform16, const Vec4& root_min, const Vec4& root_max, bool pad_box, Vec4& lo_out, Vec4& hi_out)
 {
-    float inv12[12];
-    affine_inverse12(t12, inv12);
-    transform12_to_mat16(t12, inst.transform);
-    transform12_to_mat16(inv12, inst.inverse_transform);
     Vec4 lo = Vec4{1e34f, 1e34f, 1e34f, 1.0f};
     Vec4 hi = Vec4{-1e34f, -1e34f, -1e34f, 1.0f};
     for (int i = 0; i < 8; i++) {
@@ -71,7 +67,7 @@ JPT_HD void instance_record(const float* t12, const Vec4& root_min, const Vec4& 
                                  (i & 4) ? root_max.z : root_min.z, 1.0f};
         float tc[4] = {0.0f, 0.0f, 0.0f, 1.0f};
         for (int j = 0; j < 4; j++)
-            for (int k = 0; k < 4; k++) tc[j] += inst.transform[k * 4 + j] * corner[k];
+            for (int k = 0; k < 4; k++) tc[j] += transform16[k * 4 + j] * corner[k];
         const float s = 2.0f / tc[3];
         const Vec4 c{tc[0] * s, tc[1] * s, tc[2] * s, tc[3] * s};
         lo = Vec4{imin_(lo.x, c.x), imin_(lo.y, c.y), imin_(lo.z, c.z), imin_(lo.w, c.w)};
@@ -87,8 +83,19 @@ JPT_HD void instance_record(const float* t12, const Vec4& root_min, const Vec4& 
         lo = Vec4{lo.x - pad, lo.y - pad, lo.z - pad, 1.0f};
         hi = Vec4{hi.x + pad, hi.y + pad, hi.z + pad, 1.0f};
     }
-    inst.aabbMin = lo;
-    inst.aabbMax = hi;
+    lo_out = lo;
+    hi_out = hi;
+}
+
+// transform, inverse_transform, aabbMin, aabbMax of `inst` from the instance's Transform3D and the box of its BLAS
+// root (BLASInstance::set_transform, bvh.h:81-88)
+JPT_HD void instance_record(const float* t12, const Vec4& root_min, const Vec4& root_max, bool pad_box, RefInstance& inst)
+{
+    float inv12[12];
+    affine_inverse12(t12, inv12);
+    transform12_to_mat16(t12, inst.transform);
+    transform12_to_mat16(inv12, inst.inverse_transform);
+    instance_world_box(inst.transform, root_min, root_max, pad_box, inst.aabbMin, inst.aabbMax);
 }
 
 }  // namespace jpt

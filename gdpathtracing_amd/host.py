@@ -83,13 +83,29 @@ class Context:
         capi.check(self.h, rc, what)
 
     # ---- scene
-    def upload_reference_layout(self, tri_geom, tri_data, materials, bvh_nodes, instances, tlas_nodes, textures=None):
+    def upload_reference_layout(self, tri_geom, tri_data, materials, bvh_nodes, instances, tlas_nodes, textures=None,
+                                as_given: bool = False):
+        """Route (i).  Default: the kernels walk the native tree built over the uploaded triangles, with reach records
+        from the uploaded leaf / TLAS-leaf boxes.  as_given=True: the uploaded trees are walked node for node (audits)."""
+        self._ck(self._lib.jpt_set_upload_mode(self.h, capi.UPLOAD_WALK_AS_GIVEN if as_given else capi.UPLOAD_NATIVE_TREE),
+                 "jpt_set_upload_mode")
         arrs = [np.ascontiguousarray(a) for a in (tri_geom, tri_data, materials, bvh_nodes, instances, tlas_nodes)]
         tex = None if textures is None else np.ascontiguousarray(textures, dtype=np.uint8)
         self._ck(self._lib.jpt_scene_upload_reference_layout(
             self.h, _ptr(arrs[0]), len(arrs[0]), _ptr(arrs[1]), _ptr(arrs[2]), len(arrs[2]), _ptr(arrs[3]), len(arrs[3]),
             _ptr(arrs[4]), len(arrs[4]), _ptr(arrs[5]), len(arrs[5]), _ptr(tex),
             0 if tex is None else tex.shape[1], 0 if tex is None else tex.shape[0]), "jpt_scene_upload_reference_layout")
+
+    def tree_kind(self) -> int:
+        """capi.TREE_*: which tree the kernels walk for the current scene."""
+        k = self._lib.jpt_scene_tree_kind(self.h)
+        if k < 0:
+            self._ck(k, "jpt_scene_tree_kind")
+        return k
+
+    def upload_note(self) -> str:
+        msg = self._lib.jpt_scene_upload_note(self.h)
+        return msg.decode() if msg else ""
 
     def build_scene(self, scene: scenes.Scene, builder: int = capi.BUILD_SAH):
         L = self._lib

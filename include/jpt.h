@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define JPT_ABI_VERSION 2
+#define JPT_ABI_VERSION 3
 
 typedef struct jpt_ctx jpt_ctx;
 
@@ -84,7 +84,10 @@ enum {
     JPT_BUF_BVH_NODES = 3,    /* BVH::BVHNode[]         48 B */
     JPT_BUF_INSTANCES = 4,    /* BVH::BLASInstance[]   176 B */
     JPT_BUF_TLAS_NODES = 5,   /* BVH::TLASNode[]        32 B */
-    JPT_BUF_TRIANGLES = 6     /* BVH::Triangle[]       144 B (builder-internal, bvh.h:22-29) */
+    JPT_BUF_TRIANGLES = 6,    /* BVH::Triangle[]       144 B (builder-internal, bvh.h:22-29) */
+    /* not reference buffers -- the reach records of a native-tree scene (csrc/jpt_types.h), for tests and audits: */
+    JPT_BUF_REACH_TRIANGLES = 7, /* 32 B per triangle (JPT_BUF_TRI_GEOMETRY order): lo.xyz, always, hi.xyz, pad */
+    JPT_BUF_REACH_INSTANCES = 8  /* 64 B per instance: world box lo.xyz _ hi.xyz _, reference root box lo.xyz _ hi.xyz _ */
 };
 
 /* One ArrayMesh surface as BVHBuilder::BuildBVH reads it (bvh.cpp:192-198). */
@@ -141,7 +144,16 @@ int jpt_get_stream(jpt_ctx *ctx, void **hip_stream);
 
 /* replaces: the six cs->create_storage_buffer_uniform(geometry_group->get_*_buffer(), b, 1) calls and
  * cs->create_layered_image_uniform(textures, ...) (path_tracing_camera.cpp:170-175,178-184).  Buffers are
- * byte-for-byte what GeometryGroup3D emits; they are re-flattened on upload.  tex_rgba8 may be NULL. */
+ * byte-for-byte what GeometryGroup3D emits (geometry_group3d.cpp:40-68).  tex_rgba8 may be NULL.
+ * What the kernels then walk is the library's NATIVE tree (four-child quantised records built over the uploaded
+ * triangles of every BLAS an instance names), and the uploaded boxes that decide what the reference's traversal can reach
+ * -- each triangle's BVHNode leaf (tri_count > 0), each instance's TLAS leaf -- become the reach records that keep the
+ * image the reference's (see JPT_BUILD_SAH): the addon keeps GeometryGroup3D::build() and renders at the native route's
+ * rate.  No builder of the reference is re-run.  Arrays that are not such a tree (a node or triangle reachable twice,
+ * boxes that are not nested, an instance in no / several TLAS leaves, transform and inverse_transform that do not belong
+ * together) are walked node for node as uploaded, like JPT_UPLOAD_WALK_AS_GIVEN; jpt_scene_upload_note says why.
+ * After a native upload jpt_scene_get_reference_buffer returns the native trees in reference layout (triangles in the
+ * native order), not the caller's arrays. */
 int jpt_scene_upload_reference_layout(jpt_ctx *ctx,
                                       const void *tri_geometry, uint32_t n_triangles,
                                       const void *tri_data,
@@ -150,6 +162,26 @@ int jpt_scene_upload_reference_layout(jpt_ctx *ctx,
                                       const void *blas_instances, uint32_t n_instances,
                                       const void *tlas_nodes, uint32_t n_tlas_nodes,
                                       const uint8_t *tex_rgba8, int32_t tex_res, int32_t n_layers);
+
+/* How the next jpt_scene_upload_reference_layout treats the trees it is given (no reference counterpart). */
+enum {
+    JPT_UPLOAD_NATIVE_TREE = 0,   /* default: native tree + reach records from the uploaded leaf / instance boxes */
+    JPT_UPLOAD_WALK_AS_GIVEN = 1  /* audit route: the uploaded BVHNode / TLASNode arrays are walked node for node, in the
+                                     reference's visit order (event counters and exact-tie winners equal the reference's);
+                                     ~20x slower on the demo scene, whose reference boxes are inflated to the origin */
+};
+int jpt_set_upload_mode(jpt_ctx *ctx, int32_t mode);
+/* Which tree the kernels walk for the scene this context holds (>= 0), or a negative JPT_E_* code. */
+enum {
+    JPT_TREE_NONE = 0,              /* no scene */
+    JPT_TREE_AS_GIVEN = 1,          /* uploaded reference-layout arrays, node for node */
+    JPT_TREE_REFERENCE_EXACT = 2,   /* JPT_BUILD_REFERENCE_EXACT commit */
+    JPT_TREE_NATIVE_REACH = 3,      /* native tree + reach records (JPT_BUILD_SAH commit, or a native upload) */
+    JPT_TREE_NATIVE_WATERTIGHT = 4  /* JPT_BUILD_SAH_WATERTIGHT commit */
+};
+int jpt_scene_tree_kind(jpt_ctx *ctx);
+/* Empty unless the last jpt_scene_upload_reference_layout is walked as given: then the reason. */
+const char *jpt_scene_upload_note(const jpt_ctx *ctx);
 
 /* ---- scene ingest, route (ii): native build --------------------------------------------------- */
 
@@ -247,6 +279,14 @@ int jpt_sync(jpt_ctx *ctx);
 /* replaces: camera_moved -> frame_count = 1 (progressive_rendering.cpp:53-57).  In temporal mode: the history
  * images start from zero again, as for a newly created TemporalReprojection (temporal_reprojection.cpp:42-43). */
 int jpt_accum_reset(jpt_ctx *ctx);
+/* replaces: the frame_count word of ProgressiveRendering's Params (progressive_rendering.cpp:53-61, read at
+ * progressive_rendering.glsl:34,39), for hosts that keep that counter themselves (the gdcs-shaped adapter hands over
+ * what the reference's own ProgressiveRendering::render computed).  The next frame rendered is accumulated as frame
+ * number `next_frame_count`: 1 overwrites the float sum (what jpt_accum_reset arranges), n > 1 adds to whatever the
+ * buffer holds -- zeros after jpt_set_params, like the reference's freshly created frameBuffer image -- and the screen
+ * is ACES(sum / n).  (The reference's very first frame has n = 2 when the camera's transform is the identity:
+ * previous_transform starts as the identity, so camera_moved is false.) */
+int jpt_set_progressive_frame_count(jpt_ctx *ctx, uint32_t next_frame_count);
 
 /* replaces: the denoising_mode switch of PathTracingCamera::render (path_tracing_camera.cpp:207-225).
  *   JPT_DENOISE_PROGRESSIVE (default)  as described above.

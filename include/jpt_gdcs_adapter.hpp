@@ -45,6 +45,7 @@
 #include <cstring>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -53,22 +54,46 @@ namespace jpt_gdcs {
 // One jpt context shared by the main pass and the post-processing passes that add_existing_buffer() its images.
 struct SharedDevice {
     jpt_ctx* ctx = nullptr;
+    const void* key = nullptr;   // the RenderingDevice this context stands for
     int width = 0, height = 0;
     bool scene_ready = false, params_ready = false;
     uint32_t camera_frame_index = 0;
-    bool restart = true;
+    uint32_t progressive_frame_count = 1;  // Params.frame_count as ProgressiveRendering::render last uploaded it
     bool frame_pending = false;  // main.glsl was dispatched, the frame has not been rendered yet
-    ~SharedDevice() { jpt_destroy(ctx); }
+    ~SharedDevice();
 };
 
-// device pointer -> context; weak, so the context goes with the last ComputeShader on that device
+// device pointer -> context; weak, so the context goes with the last ComputeShader on that device.  Guarded by a mutex
+// (Godot creates local rendering devices from any thread); an entry is erased when its context is destroyed, so a
+// RenderingDevice allocated later at the same address starts with a context of its own.
+struct DeviceRegistry {
+    std::mutex lock;
+    std::map<const void*, std::weak_ptr<SharedDevice>> entries;
+    static DeviceRegistry& get()
+    {
+        static DeviceRegistry r;
+        return r;
+    }
+};
+inline SharedDevice::~SharedDevice()
+{
+    {
+        DeviceRegistry& r = DeviceRegistry::get();
+        std::lock_guard<std::mutex> g(r.lock);
+        auto it = r.entries.find(key);
+        if (it != r.entries.end() && it->second.expired()) r.entries.erase(it);
+    }
+    jpt_destroy(ctx);
+}
 inline std::shared_ptr<SharedDevice> shared_device_of(const void* rendering_device)
 {
-    static std::map<const void*, std::weak_ptr<SharedDevice>> registry;
-    std::shared_ptr<SharedDevice> d = registry[rendering_device].lock();
+    DeviceRegistry& r = DeviceRegistry::get();
+    std::lock_guard<std::mutex> g(r.lock);
+    std::shared_ptr<SharedDevice> d = r.entries[rendering_device].lock();
     if (!d) {
         d = std::make_shared<SharedDevice>();
-        registry[rendering_device] = d;
+        d->key = rendering_device;
+        r.entries[rendering_device] = d;
     }
     return d;
 }
@@ -184,7 +209,7 @@ class ComputeShader {
                 if (progressive_ && kv.second.set == 0 && kv.second.binding == 0 && kv.second.bytes.size() >= 12) {
                     uint32_t frame_count;  // Params{width, height, frame_count} (progressive_rendering.h:14-27)
                     std::memcpy(&frame_count, kv.second.bytes.data() + 8, 4);
-                    dev_->restart = frame_count == 1;  // camera moved (progressive_rendering.cpp:56-57)
+                    dev_->progressive_frame_count = frame_count;  // 1 after a camera move (progressive_rendering.cpp:56-60)
                 }
             }
     }
@@ -213,7 +238,9 @@ class ComputeShader {
             }
             rc = jpt_set_temporal_params(dev_->ctx, p->bytes.data());
         }
-        if (rc == JPT_OK && progressive_ && dev_->restart) rc = jpt_accum_reset(dev_->ctx);
+        // the frame is accumulated under the frame_count the caller's ProgressiveRendering::render computed, whatever it is
+        // (1 restarts; the reference's first frame has 2 when the camera transform is the identity)
+        if (rc == JPT_OK && progressive_) rc = jpt_set_progressive_frame_count(dev_->ctx, dev_->progressive_frame_count);
         if (rc == JPT_OK) rc = jpt_render(dev_->ctx, 1, dev_->camera_frame_index);
         if (rc != JPT_OK) error_ = jpt_last_error(dev_->ctx);
         dev_->frame_pending = false;

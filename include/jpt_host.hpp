@@ -608,6 +608,12 @@ class TemporalReprojection {
     // temporal_reprojection.cpp:56-72; view_matrix = get_global_transform().affine_inverse() (path_tracing_camera.cpp:220)
     void render(jpt_ctx* ctx, const Transform3D& view_matrix, const Projection& projection_matrix)
     {
+        advance(view_matrix, projection_matrix);
+        check(ctx, jpt_set_temporal_params(ctx, &render_parameters), "jpt_set_temporal_params");  // :67
+    }
+    // the host arithmetic of that call alone: the next frame's RenderParameters (no library call)
+    void advance(const Transform3D& view_matrix, const Projection& projection_matrix)
+    {
         const Projection vp = projection_matrix * Projection(view_matrix);
         // `Transform3D deltaMatrix = previous_vp * vp.inverse()`: the conversion drops the projective row, and
         // projection_to_float() of that Transform3D writes 0 0 0 1 back (:63,66)
@@ -616,7 +622,6 @@ class TemporalReprojection {
         render_parameters.frame_count++;
         for (int i = 0; i < 4; i++)
             for (int j = 0; j < 4; j++) render_parameters.deltaMatrix[i * 4 + j] = delta.columns[i][j];
-        check(ctx, jpt_set_temporal_params(ctx, &render_parameters), "jpt_set_temporal_params");  // :67
     }
 
   private:

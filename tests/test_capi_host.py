@@ -20,7 +20,7 @@ def test_every_declared_symbol_is_exported(hiplib):
     for name in declared:
         assert hasattr(hiplib, name), "libjpt_hip.so does not export %s" % name
     assert sorted(capi.SYMBOLS) == declared
-    assert hiplib.jpt_abi_version() == 2
+    assert hiplib.jpt_abi_version() == 3
 
 
 def test_no_gpu_means_loud_failure_not_fallback(hiplib):
@@ -132,11 +132,14 @@ def test_too_deep_tree_is_rejected_at_upload(hiplib, oracle):
     tlas["aabbMin"], tlas["aabbMax"] = -1, 1
     ctx = host.Context(-1)
     with pytest.raises(capi.JptError, match="too deep"):
-        ctx.upload_reference_layout(tri, dat, ref.materials, nodes, inst, tlas)
+        ctx.upload_reference_layout(tri, dat, ref.materials, nodes, inst, tlas, as_given=True)
     shallow = nodes.copy()
     shallow[2 * 40]["left_child"] = shallow[2 * 40]["right_child"] = 0   # cut the chain at depth 40
     shallow[2 * 40]["first_tri_index"], shallow[2 * 40]["tri_count"] = 40, 1
-    ctx.upload_reference_layout(tri, dat, ref.materials, shallow, inst, tlas)
+    ctx.upload_reference_layout(tri, dat, ref.materials, shallow, inst, tlas, as_given=True)
+    # the default upload walks its own tree over the same triangles: the depth of the uploaded one does not matter
+    ctx.upload_reference_layout(tri, dat, ref.materials, nodes, inst, tlas)
+    assert ctx.tree_kind() == capi.TREE_NATIVE_REACH
     ctx.close()
 
 

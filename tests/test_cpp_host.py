@@ -192,12 +192,53 @@ def test_gdcs_shaped_adapter_replays_the_reference_call_sequence(oracle, gdcs_te
     out = subprocess.run([exe, path, os.path.join(d, "g"), str(w), str(h), str(frames)], capture_output=True, text=True)
     assert out.returncode == 0, out.stderr
     assert "frame_count %d" % frames in out.stdout
+    assert "tree %d" % capi.TREE_NATIVE_REACH in out.stdout     # the adapter's upload is walked on the native tree
     cam = np.frombuffer(open(os.path.join(d, "g_camera.bin"), "rb").read(), dtype=wire.CAMERA)[0]
     got = np.frombuffer(open(os.path.join(d, "g_accum.bin"), "rb").read(), dtype=np.float32).reshape(h, w, 4)
     got_ldr = np.frombuffer(open(os.path.join(d, "g_ldr.bin"), "rb").read(), dtype=np.uint8).reshape(h, w, 4)
     ref = oracle.build_scene(sc)
     want, want_ldr, _, _, _ = oracle.render(ref, cam, w, h, 4, frames, 1, wire.ACCUM_REF_LDR8)
     assert np.array_equal(got, want) and np.array_equal(got_ldr, want_ldr)
+
+
+@pytest.mark.gpu
+def test_gdcs_adapter_when_the_first_camera_transform_is_the_identity(oracle, gdcs_test):
+    """ProgressiveRendering's previous_transform starts as the identity (progressive_rendering.h:44), so a camera node left
+    at the origin never "moves": the reference's first frame already has frame_count = 2 (progressive_rendering.cpp:53-60),
+    the shader adds the zero-filled frameBuffer and divides by 2 (progressive_rendering.glsl:33-39), and every later
+    frame divides by one more than the frames summed.  The adapter hands the library the frame_count the caller computed."""
+    exe, d = gdcs_test
+    sc = scenes.cornell_scene()
+    path = os.path.join(d, "c.jpts")
+    scenes.write_scene_file(sc, path)
+    w, h, frames = 80, 48, 3
+    out = subprocess.run([exe, path, os.path.join(d, "gi"), str(w), str(h), str(frames), "0", "1"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    assert "frame_count %d" % (frames + 1) in out.stdout
+    cam = np.frombuffer(open(os.path.join(d, "gi_camera.bin"), "rb").read(), dtype=wire.CAMERA)[0]
+    got = np.frombuffer(open(os.path.join(d, "gi_accum.bin"), "rb").read(), dtype=np.float32).reshape(h, w, 4)
+    got_ldr = np.frombuffer(open(os.path.join(d, "gi_ldr.bin"), "rb").read(), dtype=np.uint8).reshape(h, w, 4)
+    ref = oracle.build_scene(sc)
+    want, _, _, _, _ = oracle.render(ref, cam, w, h, 4, frames, 1, wire.ACCUM_REF_LDR8)
+    assert np.array_equal(got, want)          # the sums are those of `frames` frames (0 + f1 + f2 + f3) ...
+    # ... and the screen is ACES(sum / (frames + 1)), through the oracle's own ACES and rgba8 conversion
+    import ctypes as C
+    L = oracle.lib()
+    L.jpto_aces.argtypes = [C.c_void_p, C.c_void_p]
+    L.jpto_aces.restype = None
+    L.jpto_unorm8.argtypes = [C.c_float]
+    L.jpto_unorm8.restype = C.c_uint8
+    avg = (want[..., :3] / np.float32(frames + 1)).astype(np.float32)
+    want_ldr = np.zeros((h, w, 4), np.uint8)
+    want_ldr[..., 3] = 255
+    col = np.zeros(3, np.float32)
+    for y in range(h):
+        for x in range(w):
+            px = np.ascontiguousarray(avg[y, x])
+            L.jpto_aces(px.ctypes.data_as(C.c_void_p), col.ctypes.data_as(C.c_void_p))
+            for k in range(3):
+                want_ldr[y, x, k] = L.jpto_unorm8(float(col[k]))
+    assert np.array_equal(got_ldr, want_ldr)
 
 
 @pytest.mark.gpu

@@ -55,7 +55,7 @@ def test_reference_tree_routes_are_bit_exact(oracle, hiplib, seed, kernel):
             ctx.set_kernel(kernel)
             if route == "upload":
                 ctx.upload_reference_layout(ref.tri_geom, ref.tri_data, ref.materials, ref.bvh_nodes, ref.instances,
-                                            ref.tlas_nodes, ref.textures)
+                                            ref.tlas_nodes, ref.textures, as_given=True)   # node for node: the counters too
             else:
                 ctx.build_scene(sc, capi.BUILD_REFERENCE_EXACT)
             ctx.set_params(w, h, bounces, mode)
@@ -102,14 +102,17 @@ def test_native_tree_matches_the_tree_independent_answer(oracle, hiplib, seed):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("route", ["commit", "upload"])
 @pytest.mark.parametrize("kernel", [capi.KERNEL_WAVEFRONT, capi.KERNEL_REFERENCE_LAYOUT])
 @pytest.mark.parametrize("seed", SEEDS)
-def test_native_tree_with_reach_records_answers_like_the_reference(oracle, hiplib, seed, kernel):
+def test_native_tree_with_reach_records_answers_like_the_reference(oracle, hiplib, seed, kernel, route):
     """JPT_BUILD_SAH = native tree + reach records: a triangle counts only if the reference's traversal can reach it (the
     world ray passes the instance's reference world box, the local ray passes the box of the triangle's reference leaf).
     Checked against the oracle's statement of exactly that rule on the REFERENCE arrays (JPTO_FLAG_REACH_ONLY: no internal
     box, no distance cull, so no tree order is involved) bit for bit, and against the oracle's normal walk of the
-    reference tree within the north-star tolerance.  Soups without coincident triangles (exact ties depend on the order)."""
+    reference tree within the north-star tolerance.  Soups without coincident triangles (exact ties depend on the order).
+    route "upload": the same through jpt_scene_upload_reference_layout, whose reach records are the uploaded leaf /
+    TLAS-leaf boxes themselves (no builder of the reference runs in the library)."""
     sc = scenes.random_scene(seed, coincident=False)
     w, h, bounces, frames = 96, 64, 3, 2
     cam = scenes.camera_block(sc.camera, w, h)
@@ -119,7 +122,12 @@ def test_native_tree_with_reach_records_answers_like_the_reference(oracle, hipli
     ctx = host.Context(0)
     try:
         ctx.set_kernel(kernel)
-        ctx.build_scene(sc, capi.BUILD_SAH)
+        if route == "upload":
+            ctx.upload_reference_layout(ref.tri_geom, ref.tri_data, ref.materials, ref.bvh_nodes, ref.instances,
+                                        ref.tlas_nodes, ref.textures)
+            assert ctx.tree_kind() == capi.TREE_NATIVE_REACH, ctx.upload_note()
+        else:
+            ctx.build_scene(sc, capi.BUILD_SAH)
         ctx.set_params(w, h, bounces, wire.ACCUM_HDR_F32)
         ctx.set_camera(cam)
         ctx.render(frames, 1)

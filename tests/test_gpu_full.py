@@ -20,6 +20,17 @@ def rel_l2(a, b):
     return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
 
 
+def upload_ctx(ref, cam, w, h, bounces, mode, as_given=False):
+    """route (i): the reference-layout arrays (here: the oracle's builder's, i.e. what GeometryGroup3D::build emits)"""
+    ctx = host.Context(0)
+    ctx.upload_reference_layout(ref.tri_geom, ref.tri_data, ref.materials, ref.bvh_nodes, ref.instances, ref.tlas_nodes,
+                                ref.textures, as_given=as_given)
+    assert ctx.tree_kind() == (capi.TREE_AS_GIVEN if as_given else capi.TREE_NATIVE_REACH), ctx.upload_note()
+    ctx.set_params(w, h, bounces, mode)
+    ctx.set_camera(cam)
+    return ctx
+
+
 def make_ctx(sc, w, h, bounces, mode, builder=capi.BUILD_SAH, kernel=capi.KERNEL_WAVEFRONT, rank=0, world=1):
     ctx = host.Context(0)
     ctx.set_kernel(kernel)
@@ -185,6 +196,18 @@ def test_c3_full_size_equals_the_oracle(oracle, hiplib):
     assert np.array_equal(ctx.read_ldr(), want_ldr) and np.array_equal(ctx.read_depth(), want_depth)
     assert ctx.stats()["rays"] == cnt["rays"]
     ctx.close()
+    # The drop-in route at the same size: the reference-layout arrays uploaded as the addon would
+    # (path_tracing_camera.cpp:170-175), walked on the native tree the upload builds, reach records from the uploaded
+    # leaf / TLAS-leaf boxes: the same image, bit for bit.
+    up = upload_ctx(ref, cam, W, H, B, wire.ACCUM_REF_LDR8)
+    up.render(SPP, 1)
+    got = up.read_accum()
+    print("C3 via reference-layout upload: differing pixels", int((got != want).any(axis=-1).sum()), "rel_l2", rel_l2(got, want),
+          "render ms", up.stats()["last_render_ms"])
+    assert np.array_equal(got, want)
+    assert np.array_equal(up.read_ldr(), want_ldr) and np.array_equal(up.read_depth(), want_depth)
+    assert up.stats()["rays"] == cnt["rays"]
+    up.close()
 
 
 @pytest.mark.parametrize("config", ["C2", "C4"])
@@ -220,6 +243,15 @@ def test_other_baseline_configs_at_full_size(oracle, hiplib, config):
     assert len(ys) <= (0 if config == "C2" else 2), "pixels %s differ from the reference tree's image" % list(zip(xs.tolist(), ys.tolist()))[:8]
     assert fast.stats()["rays"] == cnt["rays"] or config != "C2"
     fast.close()
+    # The same through the drop-in route (reference-layout upload -> native tree + reach records from the uploaded boxes)
+    up = upload_ctx(ref, cam, w, h, b, wire.ACCUM_REF_LDR8)
+    up.render(spp, 1)
+    got = up.read_accum()
+    ys, xs = np.nonzero((got != want).any(axis=-1))
+    print(config, "reference-layout upload on the native tree: differing pixels", len(ys), "rel_l2", rel_l2(got, want))
+    assert rel_l2(got, want) <= 1e-4
+    assert len(ys) <= (0 if config == "C2" else 2), "pixels %s differ from the reference tree's image" % list(zip(xs.tolist(), ys.tolist()))[:8]
+    up.close()
     # The native builder ALONE (JPT_BUILD_SAH_WATERTIGHT) does not reproduce the cracks: it differs from the reference
     # in those pixels and only there, and its value is the tree-independent answer -- the oracle with every box
     # test passing (JPTO_FLAG_NO_CULL, all triangles tested), run on that pixel's row.  One such pixel weighs about 1e-4

@@ -13,13 +13,15 @@ def rel_l2(a, b):
     return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
 
 
-def _render_hip(sc, cam, w, h, bounces, frames, mode, builder=None, ref=None, first=1, kernel=capi.KERNEL_WAVEFRONT):
+def _render_hip(sc, cam, w, h, bounces, frames, mode, builder=None, ref=None, first=1, kernel=capi.KERNEL_WAVEFRONT,
+                as_given=False):
     ctx = host.Context(0)
     try:
         ctx.set_kernel(kernel)
         if ref is not None:
             ctx.upload_reference_layout(ref.tri_geom, ref.tri_data, ref.materials, ref.bvh_nodes, ref.instances,
-                                        ref.tlas_nodes, ref.textures)
+                                        ref.tlas_nodes, ref.textures, as_given=as_given)
+            assert ctx.tree_kind() == (capi.TREE_AS_GIVEN if as_given else capi.TREE_NATIVE_REACH), ctx.upload_note()
         else:
             ctx.build_scene(sc, builder)
         ctx.set_params(w, h, bounces, mode)
@@ -33,35 +35,43 @@ def _render_hip(sc, cam, w, h, bounces, frames, mode, builder=None, ref=None, fi
 KERNELS = [capi.KERNEL_WAVEFRONT, capi.KERNEL_REFERENCE_LAYOUT]
 
 
+@pytest.mark.parametrize("as_given", [False, True])
 @pytest.mark.parametrize("kernel", KERNELS)
 @pytest.mark.parametrize("mode", [wire.ACCUM_REF_LDR8, wire.ACCUM_HDR_F32])
-def test_c1_cornell_reference_layout_bit_exact(oracle, hiplib, mode, kernel):
-    """Config C1: Cornell box 256x256, 1 spp, 2 bounces; drop-in route (reference-layout upload)."""
+def test_c1_cornell_reference_layout_bit_exact(oracle, hiplib, mode, kernel, as_given):
+    """Config C1: Cornell box 256x256, 1 spp, 2 bounces; drop-in route (reference-layout upload), on the native tree the
+    upload builds by default and on the uploaded trees walked as given."""
     sc = scenes.cornell_scene()
     w = h = 256
     cam = scenes.camera_block(sc.camera, w, h)
     ref = oracle.build_scene(sc)
     want, want_ldr, want_depth, _, _ = oracle.render(ref, cam, w, h, 2, 1, 1, mode)
-    got, got_ldr, got_depth = _render_hip(sc, cam, w, h, 2, 1, mode, ref=ref, kernel=kernel)
+    got, got_ldr, got_depth = _render_hip(sc, cam, w, h, 2, 1, mode, ref=ref, kernel=kernel, as_given=as_given)
     assert rel_l2(got, want) <= 1e-4        # north-star tolerance
     assert np.array_equal(got, want)        # and in fact bit-identical
     assert np.array_equal(got_ldr, want_ldr)
     assert np.array_equal(got_depth, want_depth)
 
 
+UPLOAD_NATIVE, UPLOAD_AS_GIVEN = "upload", "upload as given"
+
+
 @pytest.mark.parametrize("kernel", KERNELS)
-@pytest.mark.parametrize("builder", [capi.BUILD_REFERENCE_EXACT, capi.BUILD_SAH])
+@pytest.mark.parametrize("builder", [capi.BUILD_REFERENCE_EXACT, capi.BUILD_SAH, UPLOAD_NATIVE, UPLOAD_AS_GIVEN])
 def test_demo_scene_multi_frame(oracle, hiplib, builder, kernel):
     sc = scenes.demo_scene(5000)
     w, h = 192, 108
     cam = scenes.camera_block(sc.camera, w, h)
     ref = oracle.build_scene(sc)
     want, want_ldr, _, _, _ = oracle.render(ref, cam, w, h, 4, 4, 1, wire.ACCUM_REF_LDR8)
-    got, got_ldr, _ = _render_hip(sc, cam, w, h, 4, 4, wire.ACCUM_REF_LDR8, builder=builder, kernel=kernel)
+    if builder in (UPLOAD_NATIVE, UPLOAD_AS_GIVEN):
+        got, got_ldr, _ = _render_hip(sc, cam, w, h, 4, 4, wire.ACCUM_REF_LDR8, ref=ref, kernel=kernel, as_given=builder == UPLOAD_AS_GIVEN)
+    else:
+        got, got_ldr, _ = _render_hip(sc, cam, w, h, 4, 4, wire.ACCUM_REF_LDR8, builder=builder, kernel=kernel)
     ndiff = int((got != want).any(axis=-1).sum())
     print("builder", builder, "kernel", kernel, "differing pixels", ndiff, "rel_l2", rel_l2(got, want))
     assert rel_l2(got, want) <= 1e-4
-    if builder == capi.BUILD_REFERENCE_EXACT:
+    if builder in (capi.BUILD_REFERENCE_EXACT, UPLOAD_AS_GIVEN):
         assert ndiff == 0  # same tree, same visit order: bit-identical
         assert np.array_equal(got_ldr, want_ldr)
 
@@ -284,8 +294,10 @@ def test_device_refit_records_equal_the_host_builders(hiplib):
         ctx.close()
 
 
-def test_reference_tlas_update_route(oracle, hiplib):
-    """Route (i): the addon keeps its own builder and hands over new BLASInstance[] + TLASNode[] only."""
+@pytest.mark.parametrize("as_given", [False, True])
+def test_reference_tlas_update_route(oracle, hiplib, as_given):
+    """Route (i): the addon keeps its own builder and hands over new BLASInstance[] + TLASNode[] only (on the native tree
+    of the upload: new native instance boxes, new reach boxes from the new TLAS leaves, a new native TLAS)."""
     sc = scenes.instanced_scene(n_side=5, n_unique=2, tris_per_mesh=96)
     w, h = 128, 80
     cam = scenes.camera_block(sc.camera, w, h)
@@ -293,7 +305,8 @@ def test_reference_tlas_update_route(oracle, hiplib):
     r0, r1 = oracle.build_scene(sc), oracle.build_scene(_moved(sc, moves))
     ctx = host.Context(0)
     try:
-        ctx.upload_reference_layout(r0.tri_geom, r0.tri_data, r0.materials, r0.bvh_nodes, r0.instances, r0.tlas_nodes)
+        ctx.upload_reference_layout(r0.tri_geom, r0.tri_data, r0.materials, r0.bvh_nodes, r0.instances, r0.tlas_nodes, as_given=as_given)
+        assert ctx.tree_kind() == (capi.TREE_AS_GIVEN if as_given else capi.TREE_NATIVE_REACH)
         ctx.set_params(w, h, 3, wire.ACCUM_REF_LDR8)
         ctx.set_camera(cam)
         ctx.render(1, 1)
@@ -407,7 +420,8 @@ def test_duplicated_instance_keeps_the_first_visited_one(oracle, hiplib, kernel)
         try:
             ctx.set_kernel(kernel)
             if route == "upload":
-                ctx.upload_reference_layout(ref.tri_geom, ref.tri_data, ref.materials, ref.bvh_nodes, ref.instances, ref.tlas_nodes)
+                # (which instance wins an exact tie depends on the visiting order: the uploaded trees, node for node)
+                ctx.upload_reference_layout(ref.tri_geom, ref.tri_data, ref.materials, ref.bvh_nodes, ref.instances, ref.tlas_nodes, as_given=True)
             else:
                 ctx.build_scene(sc, capi.BUILD_REFERENCE_EXACT)
             ctx.set_params(w, h, bounces, wire.ACCUM_HDR_F32)
@@ -444,7 +458,8 @@ def test_tie_between_instances_with_different_transforms(oracle, hiplib, kernel)
         try:
             ctx.set_kernel(kernel)
             if route == "upload":
-                ctx.upload_reference_layout(ref.tri_geom, ref.tri_data, ref.materials, ref.bvh_nodes, ref.instances, ref.tlas_nodes)
+                # (which instance wins an exact tie depends on the visiting order: the uploaded trees, node for node)
+                ctx.upload_reference_layout(ref.tri_geom, ref.tri_data, ref.materials, ref.bvh_nodes, ref.instances, ref.tlas_nodes, as_given=True)
             else:
                 ctx.build_scene(sc, capi.BUILD_REFERENCE_EXACT)
             ctx.set_params(w, h, bounces, wire.ACCUM_HDR_F32)

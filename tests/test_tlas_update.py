@@ -87,7 +87,7 @@ def test_reference_layout_route(hiplib, oracle):
     r0 = oracle.build_scene(sc)
     r1 = oracle.build_scene(moved(sc, moves))
     ctx = host.Context(-1)
-    ctx.upload_reference_layout(r0.tri_geom, r0.tri_data, r0.materials, r0.bvh_nodes, r0.instances, r0.tlas_nodes)
+    ctx.upload_reference_layout(r0.tri_geom, r0.tri_data, r0.materials, r0.bvh_nodes, r0.instances, r0.tlas_nodes, as_given=True)
     ctx.update_reference_tlas(r1.instances, r1.tlas_nodes)
     inst, tlas, _ = arrays(ctx)
     assert inst.tobytes() == r1.instances.tobytes() and tlas.tobytes() == r1.tlas_nodes.tobytes()

@@ -1,0 +1,192 @@
+"""Route (i) on the native tree, host side (no GPU): jpt_scene_upload_reference_layout builds the native SAH trees over
+the uploaded triangles and takes the reach records from the uploaded leaf / TLAS-leaf boxes.  The bar here: those records
+equal, triangle for triangle and instance for instance, what a JPT_BUILD_SAH commit of the same scene records by running
+the reference's builder; arrays the reach rule does not apply to fall back to "walk as given" with a stated reason."""
+import numpy as np
+import pytest
+
+from gdpathtracing_amd import capi, host, scenes, wire
+
+REACH_TRI = np.dtype([("lo", "<f4", (3,)), ("always", "<u4"), ("hi", "<f4", (3,)), ("_pad", "<u4")])
+REACH_INST = np.dtype([("lo", "<f4", (3,)), ("_p0", "<u4"), ("hi", "<f4", (3,)), ("_p1", "<u4"),
+                       ("root_lo", "<f4", (3,)), ("_p2", "<u4"), ("root_hi", "<f4", (3,)), ("_p3", "<u4")])
+
+
+def _upload(ref, **kw):
+    ctx = host.Context(-1)
+    ctx.upload_reference_layout(ref.tri_geom, ref.tri_data, ref.materials, ref.bvh_nodes, ref.instances, ref.tlas_nodes,
+                                ref.textures, **kw)
+    return ctx
+
+
+def _tri_keys(ctx):
+    """one bytes key per triangle: geometry + shading data (what identifies a triangle across the two orders)"""
+    g = ctx.reference_buffer(capi.BUF_TRI_GEOMETRY, wire.TRI_GEOMETRY)
+    d = ctx.reference_buffer(capi.BUF_TRI_DATA, wire.TRI_DATA)
+    return [g[i].tobytes() + d[i].tobytes() for i in range(len(g))]
+
+
+SCENES = [
+    ("cornell", lambda: scenes.cornell_scene()),
+    ("demo", lambda: scenes.demo_scene(3000)),
+    ("instanced", lambda: scenes.instanced_scene(n_side=4, n_unique=3, tris_per_mesh=128)),
+]
+
+
+@pytest.mark.parametrize("name,make", SCENES)
+def test_native_upload_reach_records_equal_the_sah_commits(hiplib, oracle, name, make):
+    sc = make()
+    ref = oracle.build_scene(sc)
+    up = _upload(ref)
+    assert up.tree_kind() == capi.TREE_NATIVE_REACH and up.upload_note() == ""
+    com = host.Context(-1)
+    com.build_scene(sc, capi.BUILD_SAH)
+    assert com.tree_kind() == capi.TREE_NATIVE_REACH
+    # instance level: same order on both routes
+    ri_up = up.reference_buffer(capi.BUF_REACH_INSTANCES, REACH_INST)
+    ri_co = com.reference_buffer(capi.BUF_REACH_INSTANCES, REACH_INST)
+    assert len(ri_up) == len(sc.instances)
+    assert ri_up.tobytes() == ri_co.tobytes()
+    in_up = up.reference_buffer(capi.BUF_INSTANCES, wire.BLAS_INSTANCE)
+    in_co = com.reference_buffer(capi.BUF_INSTANCES, wire.BLAS_INSTANCE)
+    for f in ("transform", "inverse_transform", "material"):      # the matrices the device reads are the uploaded ones
+        assert np.array_equal(in_up[f], ref.instances[f])
+    # the native world boxes are those the commit computes (same native root boxes, same arithmetic)
+    assert np.array_equal(in_up["aabbMin"], in_co["aabbMin"]) and np.array_equal(in_up["aabbMax"], in_co["aabbMax"])
+    # triangle level: the two routes order triangles differently only where the SAH partition saw them in another input
+    # order; match them by content
+    ku, kc = _tri_keys(up), _tri_keys(com)
+    assert sorted(ku) == sorted(kc) and len(ku) == len(ref.tri_geom)
+    rt_up = up.reference_buffer(capi.BUF_REACH_TRIANGLES, REACH_TRI)
+    rt_co = com.reference_buffer(capi.BUF_REACH_TRIANGLES, REACH_TRI)
+    assert len(rt_up) == len(ku)
+    by_key = {}
+    for k, r in zip(kc, rt_co):
+        by_key.setdefault(k, []).append(r.tobytes())
+    for k, r in zip(ku, rt_up):
+        assert r.tobytes() in by_key[k]
+    # and they are the uploaded leaves' boxes
+    leaves = ref.bvh_nodes[ref.bvh_nodes["tri_count"] > 0]
+    leaf_boxes = {(l["aabbMin"][:3].tobytes(), l["aabbMax"][:3].tobytes()) for l in leaves}
+    for r in rt_up:
+        assert (r["lo"].tobytes(), r["hi"].tobytes()) in leaf_boxes
+    up.close()
+    com.close()
+
+
+def test_as_given_mode_and_environment_independent_default(hiplib, oracle):
+    ref = oracle.build_scene(scenes.cornell_scene())
+    ctx = _upload(ref, as_given=True)
+    assert ctx.tree_kind() == capi.TREE_AS_GIVEN and "requested" in ctx.upload_note()
+    # as given: the arrays come back byte for byte
+    assert ctx.reference_buffer(capi.BUF_BVH_NODES, wire.BVH_NODE).tobytes() == ref.bvh_nodes.tobytes()
+    assert ctx.reference_buffer(capi.BUF_TLAS_NODES, wire.TLAS_NODE).tobytes() == ref.tlas_nodes.tobytes()
+    ctx.close()
+
+
+def _falls_back(ref, match, **changed):
+    arrays = dict(tri_geom=ref.tri_geom, tri_data=ref.tri_data, materials=ref.materials, bvh_nodes=ref.bvh_nodes,
+                  instances=ref.instances, tlas_nodes=ref.tlas_nodes)
+    arrays.update(changed)
+    ctx = host.Context(-1)
+    ctx.upload_reference_layout(arrays["tri_geom"], arrays["tri_data"], arrays["materials"], arrays["bvh_nodes"],
+                                arrays["instances"], arrays["tlas_nodes"])
+    try:
+        assert ctx.tree_kind() == capi.TREE_AS_GIVEN, ctx.upload_note()
+        assert match in ctx.upload_note(), ctx.upload_note()
+    finally:
+        ctx.close()
+
+
+def test_arrays_the_reach_rule_does_not_cover_are_walked_as_given(hiplib, oracle):
+    sc = scenes.demo_scene(600)
+    ref = oracle.build_scene(sc)
+    nodes = ref.bvh_nodes
+    internal = np.flatnonzero(nodes["tri_count"] == 0)
+    leaves = np.flatnonzero(nodes["tri_count"] > 0)
+    deep = [i for i in internal if i not in set(ref.instances["blas_index"])]
+    # a child box that sticks out of its parent's
+    bad = nodes.copy()
+    kid = int(bad["left_child"][deep[0]])
+    bad["aabbMax"][kid][0] += 1000.0
+    _falls_back(ref, "not nested", bvh_nodes=bad)
+    # two leaves that share a triangle
+    bad = nodes.copy()
+    a, b = int(leaves[-1]), int(leaves[-2])
+    bad["first_tri_index"][a] = bad["first_tri_index"][b]
+    bad["tri_count"][a] = 1
+    _falls_back(ref, "two leaves", bvh_nodes=bad)
+    # a subtree reachable twice
+    bad = nodes.copy()
+    bad["right_child"][deep[0]] = bad["left_child"][deep[0]]
+    _falls_back(ref, "reachable twice", bvh_nodes=bad)
+    # an instance whose matrices do not belong together
+    bad = ref.instances.copy()
+    bad["inverse_transform"][1][12] += 3.0
+    _falls_back(ref, "inverse", instances=bad)
+    # an instance missing from the TLAS (its leaf names another one)
+    bad = ref.tlas_nodes.copy()
+    leaf_ids = np.flatnonzero((bad["leftRight"] == 0) & (np.arange(len(bad)) > 0))
+    bad["blas"][leaf_ids[0]] = bad["blas"][leaf_ids[1]]
+    _falls_back(ref, "TLAS lea", tlas_nodes=bad)
+
+
+def test_update_reference_tlas_on_the_native_tree(hiplib, oracle):
+    import copy
+    sc = scenes.instanced_scene(n_side=4, n_unique=2, tris_per_mesh=96)
+    moved = copy.deepcopy(sc)
+    rng = np.random.RandomState(3)
+    for i in (1, 5, 9):
+        t = np.array(moved.instances[i].transform, dtype=np.float32).copy()
+        t[9:] += rng.uniform(-2, 2, 3).astype(np.float32)
+        moved.instances[i].transform = t
+    r0, r1 = oracle.build_scene(sc), oracle.build_scene(moved)
+    ctx = _upload(r0)
+    assert ctx.tree_kind() == capi.TREE_NATIVE_REACH
+    ctx.update_reference_tlas(r1.instances, r1.tlas_nodes)
+    fresh = _upload(r1)
+    for which, dt in ((capi.BUF_INSTANCES, wire.BLAS_INSTANCE), (capi.BUF_TLAS_NODES, wire.TLAS_NODE),
+                      (capi.BUF_REACH_INSTANCES, REACH_INST), (capi.BUF_BVH_NODES, wire.BVH_NODE)):
+        assert ctx.reference_buffer(which, dt).tobytes() == fresh.reference_buffer(which, dt).tobytes(), which
+    # errors leave the scene as it was
+    before = ctx.reference_buffer(capi.BUF_INSTANCES, wire.BLAS_INSTANCE).tobytes()
+    with pytest.raises(capi.JptError, match="count changed"):
+        ctx.update_reference_tlas(r1.instances[:-1], r1.tlas_nodes)
+    other = r1.instances.copy()
+    other["blas_index"][0] = other["blas_index"][-1] if other["blas_index"][0] != other["blas_index"][-1] else 0xFFFF
+    with pytest.raises(capi.JptError, match="another BLAS"):
+        ctx.update_reference_tlas(other, r1.tlas_nodes)
+    bad = r1.tlas_nodes.copy()
+    leaf_ids = np.flatnonzero((bad["leftRight"] == 0) & (np.arange(len(bad)) > 0))
+    bad["blas"][leaf_ids[0]] = bad["blas"][leaf_ids[1]]
+    with pytest.raises(capi.JptError, match="does not fit the native tree"):
+        ctx.update_reference_tlas(r1.instances, bad)
+    assert ctx.reference_buffer(capi.BUF_INSTANCES, wire.BLAS_INSTANCE).tobytes() == before
+    # the commit route's calls are refused on an uploaded scene, and the other way round
+    with pytest.raises(capi.JptError, match="jpt_scene_commit"):
+        ctx.set_instance_transform(0, np.zeros(12, np.float32))
+    com = host.Context(-1)
+    com.build_scene(sc, capi.BUILD_SAH)
+    with pytest.raises(capi.JptError, match="jpt_scene_commit"):
+        com.update_reference_tlas(r1.instances, r1.tlas_nodes)
+    for c in (ctx, fresh, com):
+        c.close()
+
+
+def test_empty_and_single_instance_uploads(hiplib, oracle):
+    import copy
+    sc = scenes.cornell_scene()
+    one = copy.deepcopy(sc)
+    one.instances = one.instances[:1]
+    ref = oracle.build_scene(one)
+    ctx = _upload(ref)
+    assert ctx.tree_kind() == capi.TREE_NATIVE_REACH   # the TLAS root is the one instance's leaf: never box-tested
+    assert len(ctx.reference_buffer(capi.BUF_REACH_INSTANCES, REACH_INST)) == 1
+    ctx.close()
+    none = copy.deepcopy(sc)
+    none.instances = []
+    ref = oracle.build_scene(none)
+    ctx = _upload(ref)
+    assert ctx.tree_kind() == capi.TREE_NATIVE_REACH
+    assert len(ctx.reference_buffer(capi.BUF_TRI_GEOMETRY, wire.TRI_GEOMETRY)) == 0   # no instance names a BLAS
+    ctx.close()
