@@ -170,21 +170,27 @@ def main():
     torch.cuda.set_stream(stream)
     ctx.set_kernel_timing(False)   # per-launch HIP events serialise the launches: they are collected after the timed region
 
-    # gather plumbing (N > 1): the local piece (rgba8 display rows, or float4 sums) viewed as a torch tensor, no copy
-    piece = gathered = None
-    if world > 1:
+    # gather plumbing (N > 1): the local piece (rgba8 display rows, or float4 sums) viewed as a torch tensor, no copy;
+    # made again whenever jpt_set_params changes the framebuffers (the C5 leg)
+    gp = {"piece": None, "gathered": None}
+
+    def setup_gather():
+        if world == 1:
+            return
         ptr, nbytes = ctx.device_ldr() if args.gather == "ldr" else ctx.device_accum()
         typestr, tdtype = ("<i4", torch.int32) if args.gather == "ldr" else ("<f4", torch.float32)
 
         class _View:
             __cuda_array_interface__ = {"shape": (nbytes // 4,), "typestr": typestr, "data": (ptr, False), "version": 2}
 
-        piece = torch.as_tensor(_View(), device=torch.device("cuda", local_rank))
-        if rank == 0:
-            gathered = torch.empty((world, nbytes // 4), dtype=tdtype, device=piece.device)
+        gp["piece"] = torch.as_tensor(_View(), device=torch.device("cuda", local_rank))
+        gp["gathered"] = torch.empty((world, nbytes // 4), dtype=tdtype, device=gp["piece"].device) if rank == 0 else None
 
-    def exchange():
-        """the one exchange of a render: every rank's float4 piece to rank 0, then assembly on rank 0"""
+    setup_gather()
+
+    def gather():
+        """the one exchange of a render: every rank's piece to rank 0"""
+        piece, gathered = gp["piece"], gp["gathered"]
         if backend == "nccl":
             # direct point-to-point gather: every peer sends its piece over its own xGMI link
             partition.gather_to_rank0(piece, dist, rank, world, gathered)
@@ -193,23 +199,50 @@ def main():
             g = partition.gather_to_rank0(piece.cpu(), dist, rank, world)
             if rank == 0:
                 gathered.copy_(g)
+
+    def assemble():
         if rank == 0:
             if args.gather == "ldr":
-                ctx.assemble_ldr_from_ranks(gathered.data_ptr(), world)
+                ctx.assemble_ldr_from_ranks(gp["gathered"].data_ptr(), world)
             else:
-                ctx.assemble_from_ranks(gathered.data_ptr(), world)
+                ctx.assemble_from_ranks(gp["gathered"].data_ptr(), world)
+
+    cur = {"spp": spp}
 
     def step():
         ctx.accum_reset()
-        ctx.render(spp, 1, asynchronous=True)
+        ctx.render(cur["spp"], 1, asynchronous=True)
         if world > 1:
-            exchange()
+            gather()
+            assemble()
 
-    def counted(n_bounces):
+    def phase_split(n=3):
+        """per-rank device time of a step's three phases -- render, gather, assemble -- from events on the context's
+        stream (which orders all three), one step at a time (nothing else in flight); [world, 3] ms on every rank"""
+        acc = np.zeros(3)
+        for _ in range(n):
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+            barrier()
+            ctx.accum_reset()
+            ev[0].record(stream)
+            ctx.render(cur["spp"], 1, asynchronous=True)
+            ev[1].record(stream)
+            gather()
+            ev[2].record(stream)
+            assemble()
+            ev[3].record(stream)
+            barrier()
+            acc += [ev[k].elapsed_time(ev[k + 1]) for k in range(3)]
+        mine = torch.tensor(acc / n, dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        return [[round(float(x), 4) for x in t.tolist()] for t in every]
+
+    def counted(n_bounces, w=None, h=None, n_spp=None):
         """exact event counts of one step (deterministic), outside the timed region; summed over the ranks"""
-        ctx.set_params(W, H, n_bounces, accum_mode)
+        ctx.set_params(w or W, h or H, n_bounces, accum_mode)
         ctx.accum_reset()
-        ctx.render(spp, 1, counted=True)
+        ctx.render(n_spp or spp, 1, counted=True)
         st = ctx.stats()
         t = torch.tensor([st[k] for k in COUNTER_KEYS], dtype=torch.int64, device="cuda" if backend == "nccl" else "cpu")
         if world > 1:
@@ -253,7 +286,7 @@ def main():
     elapsed = timed(args.steps)
     gpu_image = ctx.read_accum() if (world == 1 and rank == 0) else None   # the image the timed region left behind (parity)
     verified = None
-    if args.verify and rank == 0:
+    if (args.verify or world > 1) and rank == 0:   # N > 1: always -- the assembled image of the last timed step against one context's
         got = ctx.read_ldr() if (world > 1 and args.gather == "ldr") else ctx.read_accum()
         solo = host.Context(local_rank)
         solo.build_scene(sc, builder)
@@ -283,6 +316,46 @@ def main():
     else:
         dom, n_dom = "ref_frame_kernel", spp
         dom_ms = float(np.mean(trace_ms)) / n_dom
+
+    # N > 1: what the ranks spend where, and a second timed region at C5's size -- the configuration BASELINE.json tiles
+    # over 8 GPUs (3840x2160, 16 spp, 6 bounces: 8 ms of work on one GPU, against C3's 1 ms and eleven dependent launches)
+    multi = None
+    if world > 1:
+        multi = {"ranks_seen": dist.get_world_size(), "backend": backend}
+        try:
+            multi["rccl_version"] = ".".join(str(x) for x in torch.cuda.nccl.version()) if backend == "nccl" else None
+        except Exception:
+            multi["rccl_version"] = None
+        setup_gather()                      # (counted() re-made the framebuffers)
+        multi["c3_phase_ms_per_rank"] = phase_split()
+        W5, H5, SPP5, B5 = 3840, 2160, 16, 6
+        total5 = counted(B5, W5, H5, SPP5)
+        ctx.set_camera(scenes.camera_block(sc.camera, W5, H5))
+        setup_gather()
+        cur["spp"] = SPP5
+        step()
+        barrier()
+        for _ in range(2):
+            step()
+        barrier()
+        steps5 = max(5, args.steps // 5)
+        elapsed5 = timed(steps5)
+        got5 = (ctx.read_ldr() if args.gather == "ldr" else ctx.read_accum()) if rank == 0 else None
+        multi["c5_phase_ms_per_rank"] = phase_split(2)
+        multi["c5"] = dict(workload="C5: the same scene at %dx%d, %d spp, %d bounces" % (W5, H5, SPP5, B5), rays_per_step=total5["rays"], steps=steps5,
+                           ms_per_step=round(elapsed5 / steps5 * 1e3, 4), value=round(total5["rays"] * steps5 / elapsed5 / 1e6, 3))
+        if rank == 0:
+            solo = host.Context(local_rank)
+            solo.build_scene(sc, builder)
+            solo.set_params(W5, H5, B5, accum_mode)
+            solo.set_camera(scenes.camera_block(sc.camera, W5, H5))
+            solo.render(SPP5, 1)
+            multi["c5"]["verified_bit_identical_to_one_context"] = bool(np.array_equal(got5, solo.read_ldr() if args.gather == "ldr" else solo.read_accum()))
+            solo.close()
+        cur["spp"] = spp
+        ctx.set_params(W, H, bounces, accum_mode)
+        ctx.set_camera(cam)
+        setup_gather()
 
     # the close-up camera on the same context: every pixel sees geometry, so rays/s here is the traversal rate proper
     closeup = None
@@ -355,21 +428,40 @@ def main():
         alg_ref = sum(total[k] * v for k, v in REF_BYTES.items()) + n_pixels * spp * 48
         # HBM traffic of that kernel: PMC counters cannot be read from inside the process, so the per-launch figure comes
         # from the committed rocprofv3 passes of this same command (profiles/)
-        traffic = traffic_src = valu = None
+        traffic = traffic_src = valu = stale = None
+        from tools.csrc_sha import csrc_sha
+        kernels_sha = csrc_sha()
         default_run = (W, H, spp, bounces, args.tris, args.scene, args.builder, world, args.camera, args.kernel, args.route) == \
                       (1920, 1080, 8, 4, 51200, "demo", "sah", 1, "demo", "wavefront", "commit")
         if default_run and os.path.exists(args.pmc_json):
             try:
                 pj = json.load(open(args.pmc_json))
+                if pj.get("_meta", {}).get("csrc_sha") != kernels_sha:
+                    raise LookupError("profiled on other kernels")
                 traffic = int(pj[dom]["hbm_bytes_per_launch"])
                 traffic_src = os.path.relpath(args.pmc_json, ROOT) + ": (2*FETCH_SIZE + WRITE_SIZE) KiB per launch of %s, separate --pmc passes" % dom
+            except LookupError:
+                traffic, stale = None, "profiles/current_pmc.json was collected on other kernel sources than the ones running (csrc hash %s): re-run tools/round_profiles.sh" % kernels_sha
             except Exception:
                 traffic = None
         if default_run and os.path.exists(args.sq_json):
             try:
-                valu = json.load(open(args.sq_json)).get(dom)
+                sj = json.load(open(args.sq_json))
+                if sj.get("_meta", {}).get("csrc_sha") != kernels_sha:
+                    raise LookupError("profiled on other kernels")
+                valu = sj.get(dom)
+            except LookupError:
+                valu, stale = None, "profiles/current_sq.json / current_pmc.json were collected on other kernel sources than the ones running (csrc hash %s): re-run tools/round_profiles.sh" % kernels_sha
             except Exception:
                 valu = None
+        hbm_frac = round(traffic / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if traffic else None
+        valu_issue_frac = (valu or {}).get("valu_issue_frac")
+        # what binds the dominant kernel: the largest of the utilisations this line can state (null when they are not known)
+        binding = None
+        if valu_issue_frac is not None and hbm_frac is not None:
+            binding = "valu_issue" if valu_issue_frac >= hbm_frac else "hbm"
+        sky = total.get("sky_culled", 0)
+        traced = rays - sky
         out = {
             "metric": "Mrays/sec at 1920x1080, 8 spp, 4 bounces",
             "value": round(mrays, 3),
@@ -397,17 +489,22 @@ def main():
                 "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                 "algorithmic_bytes": int(alg), "kernel_ms": round(dom_ms, 4),
                 "traffic": traffic, "traffic_source": traffic_src,
-                "hbm_frac": round(traffic / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if traffic else None,
-                "binding": "valu_issue",
-                # what binds the kernel, from the committed SQ-counter passes of this command (profiles/current_sq.json):
-                # share of the SIMDs' cycles that issue VALU instructions, and share of the 64 lanes those have enabled
-                "valu_issue_frac": (valu or {}).get("valu_busy_frac"),
+                "hbm_frac": hbm_frac,
+                "binding": binding,
+                # from the committed SQ-counter passes of this command (profiles/current_sq.json, stamped with the hash of the
+                # kernel sources they ran on; null + `profiles_stale` when the sources have changed since): share of the chip's
+                # VALU issue capacity the launch used (wave-level instructions x the ISA's priced cycles / (1024 SIMDs x cycles))
+                # and share of the 64 lanes its VALU instructions have enabled
+                "valu_issue_frac": valu_issue_frac,
                 "lane_utilisation": (valu or {}).get("lane_utilisation"),
                 "valu": valu,
+                "profiles_stale": stale,
+                "kernels_sha": kernels_sha,
                 "note": "achieved = bytes the kernel ASKS for (records, triangles, instances, rays in, hits out: exact event counts "
                         "of the bounce launches x record sizes) / launch duration; the scene (6 MB) is L2 / Infinity-Cache resident, "
                         "so these are cache-served requests and hbm_frac (counter traffic / duration / peak) is what reaches HBM. "
-                        "What binds the kernel is VALU issue at about a third of the lanes (valu: committed SQ counters; DESIGN.md section 4).",
+                        "The kernel uses about two thirds of the chip's VALU issue capacity at about a third of its lanes and waits "
+                        "on dependent fetches for the rest (valu: committed SQ counters; DESIGN.md section 4).",
                 "primary_kernel_ms": round(float(np.mean(primary_ms)), 4),
                 "render_ms": round(float(np.mean(render_ms)), 4),
                 "render_ms_note": "one render alone, launches serialised (kernel timing on); ms_per_step is the pipelined rate",
@@ -418,12 +515,27 @@ def main():
             },
             "counters": total,
         }
+        # (`rays` counts every ray_trace() invocation the reference would make; sky_culled of them are primaries
+        # whose pixel lies outside the screen rectangles of the TLAS root's boxes: decided on the host, no kernel walks them)
+        out["traced_rays_per_step"] = traced
+        out["value_traced"] = round(traced * args.steps / elapsed / 1e6, 3)
+        out["value_blocking"] = round(rays / (float(np.mean(render_ms)) * 1e-3) / 1e6, 3) if np.mean(render_ms) > 0 else None
+        out["value_notes"] = ("value = rays_per_step / ms_per_step (queued renders, four in flight); value_traced counts only the rays a "
+                              "kernel walks (rays - sky_culled); value_blocking = rays_per_step / render_ms (one render alone on the device)")
         if closeup is not None:
             out["value_closeup"] = closeup["value"]
             out["closeup"] = closeup
         if dropin is not None:
             out["value_dropin"] = dropin["value"]
             out["dropin"] = dropin
+        if multi is not None:
+            out["value_c5"] = multi["c5"]["value"]
+            out["ms_per_step_c5"] = multi["c5"]["ms_per_step"]
+            out["multi_gpu"] = multi
+            out["multi_gpu"]["phase_columns"] = ["render_ms", "gather_ms", "assemble_ms"]
+            out["multi_gpu"]["note"] = ("phase times: one step at a time, HIP events on each rank's context stream (render = path kernels + accumulation "
+                                        "of the rank's strips; gather = the rank's rows to rank 0; assemble = rank 0's scatter of the gathered rows); "
+                                        "the timed regions queue steps back to back, so ms_per_step is below their sum")
         if verified is not None:
             out["verified_bit_identical_to_one_context"] = verified
         if world == 1 and not args.no_cpu_baseline:

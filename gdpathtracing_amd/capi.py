@@ -20,12 +20,13 @@ KERNEL_WAVEFRONT, KERNEL_REFERENCE_LAYOUT = 0, 1
 SAMPLER_NEAREST_CLAMP, SAMPLER_NEAREST_REPEAT, SAMPLER_LINEAR_CLAMP, SAMPLER_LINEAR_REPEAT = 0, 1, 2, 3
 DENOISE_PROGRESSIVE, DENOISE_TEMPORAL, DENOISE_NONE = 0, 1, 2
 UPLOAD_NATIVE_TREE, UPLOAD_WALK_AS_GIVEN = 0, 1
+STREAM_PRIORITY_DEFAULT, STREAM_PRIORITY_NORMAL, STREAM_PRIORITY_HIGH, STREAM_PRIORITY_LOW = 0, 1, 2, 3
 TREE_NONE, TREE_AS_GIVEN, TREE_REFERENCE_EXACT, TREE_NATIVE_REACH, TREE_NATIVE_WATERTIGHT = range(5)
 BUF_TRI_GEOMETRY, BUF_TRI_DATA, BUF_MATERIALS, BUF_BVH_NODES, BUF_INSTANCES, BUF_TLAS_NODES, BUF_TRIANGLES, BUF_REACH_TRIANGLES, BUF_REACH_INSTANCES = range(9)
 
 # every symbol include/jpt.h declares
 SYMBOLS = [
-    "jpt_abi_version", "jpt_create", "jpt_destroy", "jpt_last_error", "jpt_set_stream", "jpt_get_stream",
+    "jpt_abi_version", "jpt_create", "jpt_destroy", "jpt_last_error", "jpt_set_stream", "jpt_get_stream", "jpt_set_stream_priority",
     "jpt_scene_upload_reference_layout", "jpt_set_upload_mode", "jpt_scene_tree_kind", "jpt_scene_upload_note", "jpt_scene_begin", "jpt_scene_add_mesh", "jpt_scene_add_instance",
     "jpt_scene_set_materials", "jpt_scene_set_textures", "jpt_scene_commit", "jpt_scene_get_reference_buffer",
     "jpt_scene_set_instance_transform", "jpt_scene_update_tlas", "jpt_scene_refit_tlas", "jpt_scene_update_reference_tlas",
@@ -33,8 +34,10 @@ SYMBOLS = [
     "jpt_sync", "jpt_accum_reset", "jpt_set_progressive_frame_count", "jpt_set_denoising_mode", "jpt_set_temporal_params", "jpt_read_ldr_rgba8", "jpt_readback_ldr_begin", "jpt_readback_ldr_end", "jpt_read_accum_f32", "jpt_read_depth_f32",
     "jpt_device_accum", "jpt_assemble_from_ranks", "jpt_device_ldr", "jpt_assemble_ldr_from_ranks", "jpt_local_rows", "jpt_get_stats",
     "jpt_scene_share", "jpt_multi_create", "jpt_multi_destroy", "jpt_multi_last_error", "jpt_multi_world", "jpt_multi_ctx",
-    "jpt_multi_share_scene", "jpt_multi_set_params", "jpt_multi_set_camera", "jpt_multi_accum_reset", "jpt_multi_set_gather",
+    "jpt_multi_share_scene", "jpt_multi_set_instance_transform", "jpt_multi_update_tlas", "jpt_multi_refit_tlas",
+    "jpt_multi_update_reference_tlas", "jpt_multi_set_params", "jpt_multi_set_camera", "jpt_multi_accum_reset", "jpt_multi_set_gather",
     "jpt_multi_render", "jpt_multi_sync", "jpt_multi_read_ldr_rgba8", "jpt_multi_read_accum_f32",
+    "jpt_debug_quantize_nodes4", "jpt_debug_node_step4", "jpt_debug_last_error",
 ]
 
 
@@ -51,7 +54,8 @@ class Stats(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("frames", C.c_uint64), ("blas_expand", C.c_uint64), ("tri_tests", C.c_uint64),
                 ("tlas_expand", C.c_uint64), ("inst_visits", C.c_uint64), ("shaded_hits", C.c_uint64),
                 ("last_render_ms", C.c_double), ("last_trace_ms", C.c_double), ("last_build_ms", C.c_double),
-                ("phase", C.c_uint64 * 8), ("sky_culled", C.c_uint64), ("last_primary_ms", C.c_double)]
+                ("phase", C.c_uint64 * 8), ("sky_culled", C.c_uint64), ("last_primary_ms", C.c_double),
+                ("set_aside", C.c_uint64), ("set_aside_dropped", C.c_uint64)]
 
     def as_dict(self):
         d = {n: getattr(self, n) for n, _ in self._fields_}
@@ -99,6 +103,7 @@ def lib():
     L.jpt_last_error.restype = C.c_char_p
     L.jpt_set_stream.argtypes = [vp, vp]
     L.jpt_get_stream.argtypes = [vp, C.POINTER(vp)]
+    L.jpt_set_stream_priority.argtypes = [vp, i32]
     L.jpt_scene_upload_reference_layout.argtypes = [vp, vp, u32, vp, vp, u32, vp, u32, vp, u32, vp, u32, vp, i32, i32]
     L.jpt_set_upload_mode.argtypes = [vp, i32]
     L.jpt_scene_tree_kind.argtypes = [vp]
@@ -151,6 +156,10 @@ def lib():
     L.jpt_multi_ctx.argtypes = [vp, C.c_int]
     L.jpt_multi_ctx.restype = vp
     L.jpt_multi_share_scene.argtypes = [vp]
+    L.jpt_multi_set_instance_transform.argtypes = [vp, u32, vp]
+    L.jpt_multi_update_tlas.argtypes = [vp]
+    L.jpt_multi_refit_tlas.argtypes = [vp, vp, u32]
+    L.jpt_multi_update_reference_tlas.argtypes = [vp, vp, u32, vp, u32]
     L.jpt_multi_set_params.argtypes = [vp, i32, i32, i32, i32, i32]
     L.jpt_multi_set_camera.argtypes = [vp, vp]
     L.jpt_multi_accum_reset.argtypes = [vp]
@@ -159,6 +168,9 @@ def lib():
     L.jpt_multi_sync.argtypes = [vp]
     L.jpt_multi_read_ldr_rgba8.argtypes = [vp, vp]
     L.jpt_multi_read_accum_f32.argtypes = [vp, vp]
+    L.jpt_debug_quantize_nodes4.argtypes = [vp, u32, vp]
+    L.jpt_debug_node_step4.argtypes = [C.c_int, vp, u32, vp, u32, i32, vp]
+    L.jpt_debug_last_error.restype = C.c_char_p
     _lib = L
     return L
 

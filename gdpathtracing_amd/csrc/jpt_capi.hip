@@ -67,6 +67,7 @@ struct jpt_ctx {
     bool host_scene_ready = false;  // c->ref / c->wide hold a complete scene (also true on host-only contexts)
     bool from_commit = false;       // the scene came from jpt_scene_commit: c->builder holds its meshes and transforms
     int32_t upload_mode = JPT_UPLOAD_NATIVE_TREE;  // jpt_set_upload_mode
+    int32_t slot_priority = JPT_STREAM_PRIORITY_DEFAULT;  // jpt_set_stream_priority
     std::string upload_note;        // why the last reference-layout upload is walked as given (empty: it is not)
     std::vector<RefMaterial> pending_materials;
     std::vector<uint8_t> pending_tex;
@@ -535,6 +536,8 @@ int do_render(jpt_ctx* c, int32_t n_frames, uint32_t first_frame_index, bool cou
         sum.shaded_hits += c->stats.shaded_hits;
         sum.last_render_ms += c->stats.last_render_ms;
         sum.last_trace_ms += c->stats.last_trace_ms;
+        sum.set_aside += c->stats.set_aside;
+        sum.set_aside_dropped += c->stats.set_aside_dropped;
     }
     c->stats.rays = sum.rays;
     c->stats.blas_expand = sum.blas_expand;
@@ -544,6 +547,8 @@ int do_render(jpt_ctx* c, int32_t n_frames, uint32_t first_frame_index, bool cou
     c->stats.shaded_hits = sum.shaded_hits;
     c->stats.last_render_ms = sum.last_render_ms;
     c->stats.last_trace_ms = sum.last_trace_ms;
+    c->stats.set_aside = sum.set_aside;
+    c->stats.set_aside_dropped = sum.set_aside_dropped;
     return JPT_OK;
 }
 
@@ -592,7 +597,10 @@ bool ensure_pipe_slot(jpt_ctx* c, int slot)
         // all slots normal 1.339 / 1.036 ms, all high 1.052 / 1.051, dealt over the three levels 1.230 / 1.212 (the normal-level
         // slot shares a queue with host streams), all low 1.137 / 1.135 (tools/prio_probe.sh, profiles/r02/prio_probe.txt).
         int least = 0, greatest = 0;
-        const int mode = tuning().slot_prio;
+        // (the embedding application decides per context with jpt_set_stream_priority; otherwise JPT_SLOT_PRIO / the default)
+        const int mode = c->slot_priority == JPT_STREAM_PRIORITY_NORMAL ? 0
+                         : c->slot_priority == JPT_STREAM_PRIORITY_HIGH ? 3
+                         : c->slot_priority == JPT_STREAM_PRIORITY_LOW ? 4 : tuning().slot_prio;
         if (mode && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least > greatest) {
             const int levels = least - greatest + 1;
             const int prio = mode == 1 ? greatest + (slot % levels) : (mode == 2 ? (slot < 2 ? greatest : least) : (mode == 4 ? least : greatest));
@@ -801,8 +809,10 @@ int do_render_batch(jpt_ctx* c, int32_t n_frames, uint32_t first_frame_index, bo
         if (wavefront && c->d_workspace.p && n_frames > 0 && c->local_rows > 0) {
             // ray segments traced = sum of the per-bounce queue sizes (always available on this route)
             const size_t per_row = wf2 ? (size_t)wf2_segments() : 1u;
-            c->h_qcount.assign((size_t)nq * per_row, 0u);
+            c->h_qcount.assign((size_t)nq * per_row + 2u, 0u);   // queue sizes, then the set-aside counts
             HIP_TRY(c, hipMemcpy(c->h_qcount.data(), c->d_workspace.p, c->h_qcount.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+            c->stats.set_aside = c->h_qcount[(size_t)nq * per_row];
+            c->stats.set_aside_dropped = c->h_qcount[(size_t)nq * per_row + 1u];
             // every in-image (pixel, frame) has one primary segment; rows 1.. hold the later bounces' queue sizes
             uint64_t rays = (uint64_t)c->width * (uint64_t)c->local_rows * (uint64_t)n_frames;
             for (int b = 1; b <= c->max_bounces; b++)
@@ -954,6 +964,27 @@ int jpt_set_stream(jpt_ctx* c, void* hip_stream)
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         for (int k = 0; k < jpt_ctx::kPipeSlots; k++) c->acc_done_valid[k] = false;
         c->stream = next;
+    }
+    return JPT_OK;
+}
+
+int jpt_set_stream_priority(jpt_ctx* c, int32_t priority)
+{
+    if (!c) return JPT_E_INVALID;
+    if (priority < JPT_STREAM_PRIORITY_DEFAULT || priority > JPT_STREAM_PRIORITY_LOW) return fail(c, JPT_E_INVALID, "unknown stream priority");
+    if (priority == c->slot_priority) return JPT_OK;
+    c->slot_priority = priority;
+    if (c->device < 0) return JPT_OK;
+    // the pipeline slots' streams are made on first use: drop the ones that exist, the next queued render makes new ones
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    for (int k = 0; k < jpt_ctx::kPipeSlots; k++) {
+        if (c->pipe_stream[k]) {
+            (void)hipStreamSynchronize(c->pipe_stream[k]);
+            (void)hipStreamDestroy(c->pipe_stream[k]);
+            c->pipe_stream[k] = nullptr;
+        }
+        c->acc_done_valid[k] = false;
     }
     return JPT_OK;
 }

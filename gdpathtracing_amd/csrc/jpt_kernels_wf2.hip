@@ -121,6 +121,9 @@ struct Wf2Buffers {
     uint32_t* qcount;   // [max_bounces + 2][kSegments] queue sizes; row b = rays traced in bounce b (b >= 1)
     uint32_t* redo_count;  // [0]: paths set aside because the reference cannot reach their hit (wf2_finish) ...
     float4* redo_rec;      // ... two float4 each: the vertex's ray, origin.w = bounce bits, direction.w = path id bits
+    uint32_t redo_cap;     // records redo_rec holds (a few paths in 10^7 are set aside: not one record per path).  A hit
+                           // that finds the buffer full is shaded as found -- the native tree's closest hit, without the
+                           // reference's crack -- and counted in redo_count[1] (jpt_stats.set_aside_dropped)
 };
 
 // n / d for a divisor fixed per launch: one multiply-high with floor(2^32 / d) and one correction step (the
@@ -483,10 +486,19 @@ __global__ __launch_bounds__(kBlock, JPT_SHADE_WAVES) void wf2_shade(SceneShadin
         const float4 tin = bounce > 0 ? wb.thr_q[in][seg_base + i] : make_float4(1.0f, 1.0f, 1.0f, 0.0f);
         const float4 ha = wb.hit_a[seg_base + i];
         const uint32_t hb = wb.hit_b[seg_base + i];
-        bool unreachable;
-        alive = shade_entry<COUNT>(sh, wb, dm, fp, cam_far, bounce, ro, rd, tin, ha, hb, true, unreachable, no, nd, nt, cnt);
-        if (unreachable) {  // a few paths in 10^7: they leave the wavefront here and are finished, exactly, by wf2_finish
-            const size_t k = atomicAdd(&wb.redo_count[0], 1u);
+        // (a loop of at most two turns around ONE inlined shade_entry: the second turn -- the set-aside buffer is full, the
+        // hit is shaded as found -- runs for pathological scenes only)
+#pragma nounroll
+        for (int turn = 0; turn < 2; turn++) {
+            bool unreachable;
+            alive = shade_entry<COUNT>(sh, wb, dm, fp, cam_far, bounce, ro, rd, tin, ha, hb, turn == 0, unreachable, no, nd, nt, cnt);
+            if (!unreachable) break;
+            // a few paths in 10^7: they leave the wavefront here and are finished, exactly, by wf2_finish
+            const uint32_t k = atomicAdd(&wb.redo_count[0], 1u);
+            if (k >= wb.redo_cap) {
+                atomicAdd(&wb.redo_count[1], 1u);
+                continue;
+            }
             float4 rd2 = rd;
             if (bounce > 0) {   // its seed.y (the entry's origin.w) waits in rad[path].w, beside the radiance so far
                 const uint32_t pw = __float_as_uint(rd.w), p = pw & kPathMask;
@@ -496,8 +508,9 @@ __global__ __launch_bounds__(kBlock, JPT_SHADE_WAVES) void wf2_shade(SceneShadin
                 wb.thr[p] = tin;
                 rd2.w = __uint_as_float(p | kHasRadiance);
             }
-            wb.redo_rec[2 * k] = make_float4(ro.x, ro.y, ro.z, __uint_as_float((uint32_t)bounce));
-            wb.redo_rec[2 * k + 1] = rd2;
+            wb.redo_rec[2 * (size_t)k] = make_float4(ro.x, ro.y, ro.z, __uint_as_float((uint32_t)bounce));
+            wb.redo_rec[2 * (size_t)k + 1] = rd2;
+            break;
         }
     }
     // active-ray packing: wave ballot + prefix popcount, one atomic per wave on the SEGMENT's counter (1792
@@ -527,7 +540,7 @@ template <bool COUNT, bool W4>
 __global__ __launch_bounds__(64) void wf2_finish(WideSceneDev sc, SceneShading sh, Wf2Buffers wb, Wf2Dims dm, FrameParams fp, float cam_far,
                                                  DevCounters* __restrict__ counters)
 {
-    const uint32_t n = wb.redo_count[0];
+    const uint32_t n = wb.redo_count[0] < wb.redo_cap ? wb.redo_count[0] : wb.redo_cap;
     if (blockIdx.x * 64u >= n) return;
     constexpr int kDepth = kStackLds + kStackSpill;
     int32_t stack_mem[kDepth];
@@ -732,6 +745,16 @@ static void group_frames(int n_frames, int groups, int g, int& first, int& count
     count = base + (g < extra ? 1 : 0);
 }
 
+// Set-aside records per group: a path is set aside at most once, and a handful per render are (float cracks of the
+// reference's boxes): 1/64 of the paths, at least 4096, instead of one 32-byte record per path (0.5 GB per pipeline slot
+// at C3).  Overflow is counted, not silent: jpt_stats.set_aside_dropped.
+static uint32_t redo_capacity(size_t paths)
+{
+    if (tuning().set_aside_cap >= 0) return (uint32_t)std::min<size_t>((size_t)tuning().set_aside_cap, paths);   // (tests)
+    const size_t c = paths / 64u;
+    return (uint32_t)(c < 4096u ? 4096u : (c > 0x7fffffffu ? 0x7fffffffu : c));
+}
+
 size_t wf2_workspace_bytes(int width, int local_rows, int n_frames, int max_bounces)
 {
     // sized for every layout a render of this size may use (the group count depends on kernel timing, on the
@@ -750,7 +773,7 @@ size_t wf2_workspace_bytes(int width, int local_rows, int n_frames, int max_boun
             b += q * sizeof(uint32_t) + 256;          // hit_b
             b += paths * sizeof(float4) + 256;        // thr
             b += ((size_t)(max_bounces + 2) * kSegments + 64) * sizeof(uint32_t) + 256;   // queue sizes + the set-aside count
-            b += paths * 2 * sizeof(float4) + 256;    // set-aside records (a path is set aside at most once)
+            b += (size_t)redo_capacity(paths) * 2 * sizeof(float4) + 256;    // set-aside records
         }
         const Wf2Dims all = make_dims(width, local_rows, n_frames, full_window(width, local_rows));
         b += (size_t)all.slots_per_frame * (size_t)n_frames * sizeof(float4) + 256;  // rad: [frame][slot], shared by the groups
@@ -811,7 +834,8 @@ void launch_wf2_render(hipStream_t stream, const DeviceScene& ds, const FramePar
         wb.thr_q[1] = (float4*)carve(q * sizeof(float4));
         wb.hit_a = (float4*)carve(q * sizeof(float4));
         wb.hit_b = (uint32_t*)carve(q * sizeof(uint32_t));
-        wb.redo_rec = (float4*)carve(paths * 2 * sizeof(float4));
+        wb.redo_cap = redo_capacity(paths);
+        wb.redo_rec = (float4*)carve((size_t)wb.redo_cap * 2 * sizeof(float4));
         wb.thr = (float4*)carve(paths * sizeof(float4));
         wb.rad = rad_all + (size_t)f0 * dm_all.slots_per_frame;  // this group's frames of the [frame][slot] array
         wb.fin8 = fin8_all + (size_t)f0 * dm_all.slots_per_frame;
@@ -877,7 +901,7 @@ void launch_wf2_render(hipStream_t stream, const DeviceScene& ds, const FramePar
             if (ev) (void)hipEventRecord(ev[2 * (b + 1) + 1], st);
         }
         if (sh.reach_tri && tuning().reach == 2) {  // the paths set aside because the reference cannot reach their hit: finished exactly
-            const dim3 rgrid(16), rblock(64);
+            const dim3 rgrid(64), rblock(64);   // (blocks past the set-aside count exit at once; more records than threads: grid-stride)
             if (counters) {
                 if (w4) hipLaunchKernelGGL((wf2_finish<true, true>), rgrid, rblock, 0, st, sc, sh, wb, dm, gp, cam.far_, counters);
                 else hipLaunchKernelGGL((wf2_finish<true, false>), rgrid, rblock, 0, st, sc, sh, wb, dm, gp, cam.far_, counters);
@@ -902,7 +926,7 @@ void launch_wf2_render(hipStream_t stream, const DeviceScene& ds, const FramePar
             (void)hipEventRecord(async.join[g - 1], async.aux_stream[g - 1]);
             (void)hipStreamWaitEvent(stream, async.join[g - 1], 0);
         }
-        const uint32_t nqc = (uint32_t)nq * kSegments;
+        const uint32_t nqc = (uint32_t)nq * kSegments + 2u;   // (and the two set-aside counts behind the queue sizes)
         for (int g = 1; g < groups; g++)
             hipLaunchKernelGGL(add_queue_counts, dim3((nqc + 255) / 256), dim3(256), 0, stream, gb[0].qcount, gb[g].qcount, nqc);
     }

@@ -149,6 +149,52 @@ int jpt_multi_share_scene(jpt_multi* m)
     return JPT_OK;
 }
 
+// Moving instances: every rank holds a replica of the scene (and, after jpt_scene_share, of the builder that made it), so
+// each of these is the single-context call repeated on every rank -- a rank that kept the old instance level would render
+// its strips of another scene state.
+int jpt_multi_set_instance_transform(jpt_multi* m, uint32_t instance, const float* transform12)
+{
+    if (!m) return JPT_E_INVALID;
+    for (size_t r = 0; r < m->ctx.size(); r++) {
+        const int rc = jpt_scene_set_instance_transform(m->ctx[r], instance, transform12);
+        if (rc != JPT_OK) return mfail_ctx(m, (int)r, rc);
+    }
+    return JPT_OK;
+}
+
+int jpt_multi_update_tlas(jpt_multi* m)
+{
+    if (!m) return JPT_E_INVALID;
+    for (size_t r = 0; r < m->ctx.size(); r++) {
+        (void)hipSetDevice(m->devices[r]);
+        const int rc = jpt_scene_update_tlas(m->ctx[r]);
+        if (rc != JPT_OK) return mfail_ctx(m, (int)r, rc);
+    }
+    return JPT_OK;
+}
+
+int jpt_multi_refit_tlas(jpt_multi* m, const float* transforms12, uint32_t n_instances)
+{
+    if (!m) return JPT_E_INVALID;
+    for (size_t r = 0; r < m->ctx.size(); r++) {
+        (void)hipSetDevice(m->devices[r]);
+        const int rc = jpt_scene_refit_tlas(m->ctx[r], transforms12, n_instances);
+        if (rc != JPT_OK) return mfail_ctx(m, (int)r, rc);
+    }
+    return JPT_OK;
+}
+
+int jpt_multi_update_reference_tlas(jpt_multi* m, const void* blas_instances, uint32_t n_instances, const void* tlas_nodes, uint32_t n_tlas_nodes)
+{
+    if (!m) return JPT_E_INVALID;
+    for (size_t r = 0; r < m->ctx.size(); r++) {
+        (void)hipSetDevice(m->devices[r]);
+        const int rc = jpt_scene_update_reference_tlas(m->ctx[r], blas_instances, n_instances, tlas_nodes, n_tlas_nodes);
+        if (rc != JPT_OK) return mfail_ctx(m, (int)r, rc);
+    }
+    return JPT_OK;
+}
+
 int jpt_multi_set_params(jpt_multi* m, int32_t width, int32_t height, int32_t max_bounces, int32_t accum_mode, int32_t sampler_mode)
 {
     if (!m) return JPT_E_INVALID;

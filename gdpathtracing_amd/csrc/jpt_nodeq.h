@@ -1,10 +1,11 @@
 // jpt_nodeq.h -- the 64-byte quantised form of a four-child record, made from the float form (WideNode4) by one function
 // that the host (upload) and the device (TLAS refit) share.
 //
-// Why: wf2_trace is bound by the CU's vector-memory path, which charges about 16 ns of CU time per wave-level load
-// instruction at the ~24 lanes a record step has enabled (tools/micro/node_fetch.hip: 7.7 ns + 0.33 ns per enabled
-// lane, whatever the table size up to the Infinity Cache's), not by VALU issue and not by bytes: a record step costs
-// what its number of 16-byte loads costs.  The float record needs seven of them; this one needs four.
+// Why: a record step of wf2_trace pays twice -- in VALU issue (the kernel uses about two thirds of the chip's VALU issue
+// capacity, profiles/current_sq.json: valu_issue_frac) and in the CU's vector-memory path, which charges about 16 ns of CU
+// time per wave-level load instruction at the ~24 lanes a record step has enabled (tools/micro/node_fetch.hip: 7.7 ns +
+// 0.33 ns per enabled lane, whatever the table size up to the Infinity Cache's) -- and not in bytes.  The float record
+// needs seven 16-byte loads and 199 VALU instructions per step; this one four loads and 131.
 //
 //   bytes  0..15   origin.xyz (the lo corner of the union of the children's boxes), scale.x
 //         16..31   scale.y, scale.z, lo_x, lo_y        each plane word holds the four children's planes, one byte each
@@ -36,6 +37,17 @@ struct alignas(64) WideNodeQ {
 static_assert(sizeof(WideNodeQ) == 64, "WideNodeQ");
 
 constexpr float kPlaneSlack = 1.0f / 256.0f;
+
+// What the WALK adds to a plane's distance on top of the slack, per axis: kWalkEps * (|b| + |o * rD|), b = the distance of
+// the record's origin plane.  The step evaluates t = q * (scale * rD) + (origin * rD - o * rD) with rD from v_rcp_f32 (1 ulp)
+// and three roundings; the reference's own box test -- the one the reach records repeat -- evaluates (plane - o) * (1 / d)
+// with three others.  Each is off by a few 2^-24 of |b| + |o * rD| of ITS axis, independently per axis, which at a ray
+// origin tens of mesh sizes away exceeds the builder's padding (2e-6 of the mesh's largest coordinate): without this
+// term a ray through the corner of a far, small box could pass the reference's test and fail this one
+// (tests/test_quantized_walk.py).  2^-20 = 16 x 2^-24 covers both evaluations with a factor two to spare.  The slack the
+// walk applies is 1/256 + 1/16384 of a step: the second part covers the rounding of scale * rD times a plane number.
+constexpr float kWalkEps = 1.0f / 1048576.0f;
+constexpr float kWalkSlackOverEps = 4160.0f;   // (1/256 + 1/16384) / kWalkEps, exactly
 
 // smallest power of two >= x (x > 0, finite); tiny or zero extents get the smallest normal number
 JPT_HD float pow2_at_least(float x)

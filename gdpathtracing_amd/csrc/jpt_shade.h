@@ -113,13 +113,15 @@ __device__ __forceinline__ f3 sample_sky(f3 d)  // main.glsl:189-192
 // linear around u*res - 0.5, clamp-to-edge or non-negative modulo, mix() of the four UNORM8 texels, no sRGB decode).
 __device__ __forceinline__ int tex_index(float f, int res, bool repeat)
 {
-    if (f != f || f >= 1073741824.0f || f <= -1073741824.0f) return 0;
-    int i = (int)f;
-    if (repeat) {
-        i %= res;
-        return i < 0 ? i + res : i;
+    if (f != f) return 0;
+    if (!repeat) {   // clamp-to-edge saturates BEFORE the cast: +inf and 1e9 are the last texel, -inf the first
+        if (f >= (float)(res - 1)) return res - 1;
+        return f <= 0.0f ? 0 : (int)f;
     }
-    return i < 0 ? 0 : (i > res - 1 ? res - 1 : i);
+    if (f >= 1073741824.0f || f <= -1073741824.0f) return 0;   // repeat: the modulo of a float this large is not defined by the pin
+    int i = (int)f;
+    i %= res;
+    return i < 0 ? i + res : i;
 }
 __device__ __forceinline__ f3 texel(const SceneShading& sc, int layer, int ix, int iy)
 {

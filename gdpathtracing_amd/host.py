@@ -96,6 +96,10 @@ class Context:
             _ptr(arrs[4]), len(arrs[4]), _ptr(arrs[5]), len(arrs[5]), _ptr(tex),
             0 if tex is None else tex.shape[1], 0 if tex is None else tex.shape[0]), "jpt_scene_upload_reference_layout")
 
+    def set_stream_priority(self, priority: int):
+        """capi.STREAM_PRIORITY_*: the priority level of the streams queued renders run on (jpt_set_stream_priority)."""
+        self._ck(self._lib.jpt_set_stream_priority(self.h, priority), "jpt_set_stream_priority")
+
     def tree_kind(self) -> int:
         """capi.TREE_*: which tree the kernels walk for the current scene."""
         k = self._lib.jpt_scene_tree_kind(self.h)
@@ -415,6 +419,26 @@ class MultiContext:
     def build_scene(self, scene, builder=capi.BUILD_SAH):
         self.ctx(0).build_scene(scene, builder)
         self._ck(self._lib.jpt_multi_share_scene(self.h), "jpt_multi_share_scene")
+
+    def upload_reference_layout(self, *arrays, **kw):
+        self.ctx(0).upload_reference_layout(*arrays, **kw)
+        self._ck(self._lib.jpt_multi_share_scene(self.h), "jpt_multi_share_scene")
+
+    # moving instances: forwarded to every rank's replica
+    def set_instance_transform(self, instance: int, transform12):
+        t = np.ascontiguousarray(transform12, dtype=np.float32).reshape(12)
+        self._ck(self._lib.jpt_multi_set_instance_transform(self.h, instance, _ptr(t)), "jpt_multi_set_instance_transform")
+
+    def update_tlas(self):
+        self._ck(self._lib.jpt_multi_update_tlas(self.h), "jpt_multi_update_tlas")
+
+    def refit_tlas(self, transforms12):
+        t = np.ascontiguousarray(transforms12, dtype=np.float32).reshape(-1, 12)
+        self._ck(self._lib.jpt_multi_refit_tlas(self.h, _ptr(t), t.shape[0]), "jpt_multi_refit_tlas")
+
+    def update_reference_tlas(self, instances, tlas_nodes):
+        a, b = np.ascontiguousarray(instances), np.ascontiguousarray(tlas_nodes)
+        self._ck(self._lib.jpt_multi_update_reference_tlas(self.h, _ptr(a), len(a), _ptr(b), len(b)), "jpt_multi_update_reference_tlas")
 
     def set_params(self, width, height, max_bounces=4, accum_mode=capi.ACCUM_REF_LDR8, sampler_mode=0):
         self._ck(self._lib.jpt_multi_set_params(self.h, width, height, max_bounces, accum_mode, sampler_mode), "jpt_multi_set_params")

@@ -116,6 +116,12 @@ typedef struct {
                                   rectangles of the TLAS root's boxes); they ARE counted in `rays` and `tlas_expand`, as the
                                   reference expands the root for them, but no record is fetched */
     double   last_primary_ms;  /* kernel timing on: the bounce-0 launch alone (last_trace_ms = all traversal launches) */
+    uint64_t set_aside;        /* blocking renders on a native tree with reach records: path vertices whose hit the reference's
+                                  traversal cannot reach (a crack of its boxes), finished exactly after the last bounce */
+    uint64_t set_aside_dropped;/* ... of which: more than the set-aside buffer holds (1/64 of the paths, at least 4096) -- those
+                                  were shaded as found (the native tree's closest hit: the image differs from the reference's
+                                  in those pixels).  0 on every scene measured; a scene that reports more renders exactly with
+                                  JPT_KERNEL_REFERENCE_LAYOUT or JPT_UPLOAD_WALK_AS_GIVEN / JPT_BUILD_REFERENCE_EXACT */
 } jpt_stats;
 
 /* ---- lifetime --------------------------------------------------------------------------------- */
@@ -139,6 +145,20 @@ int jpt_set_stream(jpt_ctx *ctx, void *hip_stream);
  * framework queue its own work -- a collective on the finished rows -- behind the renders (bench.py wraps it in
  * torch.cuda.ExternalStream).  No reference counterpart. */
 int jpt_get_stream(jpt_ctx *ctx, void **hip_stream);
+/* Queued renders (jpt_render_async) run their path kernels on up to four internal streams ("pipeline slots").  The HIP
+ * runtime deals the streams of a process onto a small pool of hardware queues PER PRIORITY LEVEL, and streams that share
+ * a queue run in submission order; so by default the slots are created at the device's HIGHEST stream priority, whose
+ * pool they have to themselves as long as the host, torch and RCCL keep their streams at the normal level (DESIGN.md
+ * section 4: C3 1.05 ms per queued render against 1.34 with everything at the normal level).  That choice also lets the
+ * slots pre-empt the host's own compute work on a shared device.  An embedding application that wants otherwise says so
+ * per context, before its first queued render or at any later time (existing slot streams are drained and re-made):
+ *   DEFAULT  the library's rule (highest level; JPT_SLOT_PRIO in the environment overrides, for tuning runs)
+ *   NORMAL   the level everything else uses: no pre-emption of host work; the queued rate then depends on which streams
+ *            happen to share a hardware queue
+ *   HIGH / LOW   the device's highest / lowest level
+ * No reference counterpart. */
+enum { JPT_STREAM_PRIORITY_DEFAULT = 0, JPT_STREAM_PRIORITY_NORMAL = 1, JPT_STREAM_PRIORITY_HIGH = 2, JPT_STREAM_PRIORITY_LOW = 3 };
+int jpt_set_stream_priority(jpt_ctx *ctx, int32_t priority);
 
 /* ---- scene ingest, route (i): reference layout ------------------------------------------------ */
 
@@ -354,6 +374,15 @@ const char *jpt_multi_last_error(const jpt_multi *m);     /* m may be NULL: erro
 int jpt_multi_world(const jpt_multi *m);
 jpt_ctx *jpt_multi_ctx(jpt_multi *m, int rank);            /* the context of one rank (scene calls, statistics) */
 int jpt_multi_share_scene(jpt_multi *m);                   /* jpt_scene_share(rank r, rank 0) for every other rank */
+/* Moving instances under a jpt_multi: the moving-instance calls above, applied to EVERY rank's replica (a scene call made
+ * on jpt_multi_ctx(m, 0) alone would leave the other ranks rendering their strips of the old scene state).  Same
+ * arguments and results as jpt_scene_set_instance_transform / jpt_scene_update_tlas / jpt_scene_refit_tlas /
+ * jpt_scene_update_reference_tlas; the first failing rank's error is reported. */
+int jpt_multi_set_instance_transform(jpt_multi *m, uint32_t instance, const float *transform12);
+int jpt_multi_update_tlas(jpt_multi *m);
+int jpt_multi_refit_tlas(jpt_multi *m, const float *transforms12, uint32_t n_instances);
+int jpt_multi_update_reference_tlas(jpt_multi *m, const void *blas_instances, uint32_t n_instances,
+                                    const void *tlas_nodes, uint32_t n_tlas_nodes);
 int jpt_multi_set_params(jpt_multi *m, int32_t width, int32_t height, int32_t max_bounces, int32_t accum_mode, int32_t sampler_mode);
 int jpt_multi_set_camera(jpt_multi *m, const void *camera160);
 int jpt_multi_accum_reset(jpt_multi *m);
@@ -365,6 +394,23 @@ int jpt_multi_render(jpt_multi *m, int32_t n_frames, uint32_t first_frame_index)
 int jpt_multi_sync(jpt_multi *m);
 int jpt_multi_read_ldr_rgba8(jpt_multi *m, uint8_t *out);
 int jpt_multi_read_accum_f32(jpt_multi *m, float *out);
+
+/* ---- audit entry points (tests; no reference counterpart) ---------------------------------------------------------------
+ * The native walk's box tests are conservative tests on quantised planes.  These run that one step
+ * on caller-made inputs so its conservativeness can be tested directly (tests/test_quantized_walk.py), not only sampled
+ * through images. */
+/* n_nodes four-child records in the float form (128 bytes each: lo_x[4] lo_y[4] lo_z[4] child[4] hi_x[4] hi_y[4] hi_z[4]
+ * pad[4]; an unused slot has child = INT32_MIN) -> their 64-byte quantised form, with the function uploads use. */
+int jpt_debug_quantize_nodes4(const void *nodes4, uint32_t n_nodes, void *nodesq_out);
+/* One record step per case.  A case is 32 bytes: ray origin xyz, direction xyz (as the walk holds them: the local ray of the
+ * level), the closest distance found so far (hitInfo.t), and the index of the record to expand.  The records' child
+ * references must be k + 1 for slot k.  taken_out[i] gets bit k set when the walk keeps child k (descends into it or
+ * pushes it).  device_id >= 0: the kernel runs the very function the tracing kernels inline.  JPT_DEVICE_HOST_ONLY: a
+ * host restatement of the same arithmetic, with its reciprocals moved host_rcp_ulps ulps away from zero (negative: towards
+ * zero) -- v_rcp_f32 is accurate to 1 ulp. */
+int jpt_debug_node_step4(int device_id, const void *nodes4, uint32_t n_nodes, const void *cases32, uint32_t n_cases,
+                         int32_t host_rcp_ulps, uint8_t *taken_out);
+const char *jpt_debug_last_error(void);
 
 #ifdef __cplusplus
 }

@@ -431,6 +431,10 @@ class GeometryGroup3D {
 
     void set_default_material(const StandardMaterial3D& m) { default_material = m; default_material_set = true; }
     void add_child(const MeshInstance3D& node) { children.push_back(node); }
+    // The scene lives on several devices (PathTracingCameraMulti::init attaches its jpt_multi): build() then commits on
+    // rank 0's context and shares, and update_transforms() reaches EVERY rank's replica (jpt_multi_set_instance_transform,
+    // jpt_multi_update_tlas / jpt_multi_refit_tlas) -- not just the context the scene was built on.
+    void attach_multi(jpt_multi* m) { multi_ = m; }
 
     // geometry_group3d.cpp:228-366: collect instances, dedup meshes / materials by pointer, convert materials,
     // then builder + instances + TLAS + upload (the jpt_scene_* calls)
@@ -519,7 +523,8 @@ class GeometryGroup3D {
             n.global_transform.to_float12(now);
             if (instance >= built_transforms_.size()) throw std::runtime_error("children changed since build(): build() again");
             if (std::memcmp(now, built_transforms_[instance].data(), sizeof now) != 0) {
-                check(ctx_, jpt_scene_set_instance_transform(ctx_, instance, now), "jpt_scene_set_instance_transform");
+                if (multi_) mcheck(jpt_multi_set_instance_transform(multi_, instance, now), "jpt_multi_set_instance_transform");
+                else check(ctx_, jpt_scene_set_instance_transform(ctx_, instance, now), "jpt_scene_set_instance_transform");
                 std::memcpy(built_transforms_[instance].data(), now, sizeof now);
                 moved++;
             }
@@ -530,9 +535,11 @@ class GeometryGroup3D {
                 std::vector<float> all;
                 all.reserve(built_transforms_.size() * 12);
                 for (const auto& t : built_transforms_) all.insert(all.end(), t.begin(), t.end());
-                check(ctx_, jpt_scene_refit_tlas(ctx_, all.data(), (uint32_t)built_transforms_.size()), "jpt_scene_refit_tlas");
+                if (multi_) mcheck(jpt_multi_refit_tlas(multi_, all.data(), (uint32_t)built_transforms_.size()), "jpt_multi_refit_tlas");
+                else check(ctx_, jpt_scene_refit_tlas(ctx_, all.data(), (uint32_t)built_transforms_.size()), "jpt_scene_refit_tlas");
             } else {
-                check(ctx_, jpt_scene_update_tlas(ctx_), "jpt_scene_update_tlas");
+                if (multi_) mcheck(jpt_multi_update_tlas(multi_), "jpt_multi_update_tlas");
+                else check(ctx_, jpt_scene_update_tlas(ctx_), "jpt_scene_update_tlas");
             }
         }
         return moved;
@@ -560,6 +567,11 @@ class GeometryGroup3D {
         check(ctx_, jpt_scene_get_reference_buffer(ctx_, which, out.data(), n, &n), "jpt_scene_get_reference_buffer");
         return out;
     }
+    void mcheck(int rc, const char* what) const
+    {
+        if (rc != JPT_OK) throw std::runtime_error(std::string(what) + ": " + jpt_multi_last_error(multi_));
+    }
+    jpt_multi* multi_ = nullptr;
     std::vector<MeshInstance3D> children;
     std::vector<GpuMaterial> materials_;
     std::vector<std::array<float, 12>> built_transforms_;  // per instance, as handed to the library
@@ -767,6 +779,7 @@ class PathTracingCameraMulti {
         height = h;
         geometry_group->build(jpt_multi_ctx(multi, 0));     // one build ...
         mcheck(jpt_multi_share_scene(multi), "jpt_multi_share_scene");   // ... every device gets the arrays
+        geometry_group->attach_multi(multi);                // ... and later update_transforms() calls reach every device
         projection_matrix = Projection::create_perspective(fov, float(width) / float(height), 0.01f, 1000.0f, false);
         mcheck(jpt_multi_set_params(multi, width, height, max_bounces, accum_mode, JPT_SAMPLER_NEAREST_CLAMP), "jpt_multi_set_params");
         mcheck(jpt_multi_set_gather(multi, gather_display_rows_only ? 1 : 0), "jpt_multi_set_gather");

@@ -279,18 +279,21 @@ static v3 sample_sky(v3 direction)
  *   nearest                  i = floor(x)
  *   linear                   i0 = floor(x - 0.5), i1 = i0 + 1, weight a = (x - 0.5) - floor(x - 0.5)
  *   clamp-to-edge            i = clamp(i, 0, res - 1);     repeat   i = i mod res (non-negative remainder)
- *   NaN or |floor| >= 2^30   index 0 (weight 0)
+ *   NaN                      index 0 (weight 0);  repeat with |floor| >= 2^30: index 0;  clamp-to-edge saturates first,
+ *                            so +inf / 1e9 address the last texel and -inf the first, as Vulkan's clamp does
  *   filter                   mix(mix(t00, t10, a), mix(t01, t11, a), b) per channel, mix = a*(1-t) + b*t (oracle_pins.h);
  *                            texels are UNORM8 -> float by p_from_unorm8, no sRGB decode (path_tracing_camera.cpp:182) */
 static int32_t tex_index(float f, int32_t res, int repeat)
 {
-    if (f != f || f >= 1073741824.0f || f <= -1073741824.0f) return 0;
-    int32_t i = (int32_t)f;   /* f is integral */
-    if (repeat) {
-        i %= res;
-        return i < 0 ? i + res : i;
+    if (f != f) return 0;
+    if (!repeat) {   /* clamp-to-edge saturates BEFORE the cast: +inf and 1e9 are the last texel, -inf the first */
+        if (f >= (float)(res - 1)) return res - 1;
+        return f <= 0.0f ? 0 : (int32_t)f;   /* f is integral */
     }
-    return i < 0 ? 0 : (i > res - 1 ? res - 1 : i);
+    if (f >= 1073741824.0f || f <= -1073741824.0f) return 0;
+    int32_t i = (int32_t)f;
+    i %= res;
+    return i < 0 ? i + res : i;
 }
 static v3 texel(const jpto_scene_view *sc, int32_t layer, int32_t ix, int32_t iy)
 {

@@ -226,7 +226,11 @@ def sample_texture(tex, u, v, layer, mode):
     repeat, linear = bool(mode & 1), bool(mode & 2)
 
     def wrap(i):
-        return int(i) % res if repeat else min(max(int(i), 0), res - 1)
+        if i != i:
+            return 0
+        if not repeat:                 # clamp-to-edge: saturate, then convert (so +-inf are the edge texels)
+            return int(min(max(i, 0.0), float(res - 1)))
+        return 0 if abs(i) >= 2.0 ** 30 else int(i) % res
 
     def texel(ix, iy):
         return tex[layer, iy, ix, :3].astype(np.float64) / 255.0
@@ -237,6 +241,7 @@ def sample_texture(tex, u, v, layer, mode):
     xs, ys = x - 0.5, y - 0.5
     fx, fy = np.floor(xs), np.floor(ys)
     a, b = xs - fx, ys - fy
+    a, b = (0.0 if a != a else a), (0.0 if b != b else b)      # inf - inf: weight 0 (pinned)
     x0, x1, y0, y1 = wrap(fx), wrap(fx + 1), wrap(fy), wrap(fy + 1)
     r0 = texel(x0, y0) * (1 - a) + texel(x1, y0) * a
     r1 = texel(x0, y1) * (1 - a) + texel(x1, y1) * a

@@ -109,11 +109,13 @@ def test_c4_instanced_scene_reduced(oracle, hiplib):
 
 
 @pytest.mark.parametrize("sampler", [capi.SAMPLER_NEAREST_CLAMP, capi.SAMPLER_NEAREST_REPEAT, capi.SAMPLER_LINEAR_CLAMP, capi.SAMPLER_LINEAR_REPEAT])
-def test_texture_scene(oracle, hiplib, sampler):
+@pytest.mark.parametrize("uv_scale", [1.0, 1e9])
+def test_texture_scene(oracle, hiplib, sampler, uv_scale):
     """A textured quad whose uv run from -1.3 to 2.6 (so clamp and repeat differ) with a random two-layer texture array,
-    in the four sampler modes: every kernel and builder equals the oracle bit for bit."""
+    in the four sampler modes: every kernel and builder equals the oracle bit for bit.  uv_scale 1e9: coordinates far past
+    2^30 texels (clamp-to-edge saturates to the edge texel before the integer conversion; repeat addresses texel 0)."""
     quad = scenes.plane_mesh(40.0)
-    quad.surfaces[0].uvs = (quad.surfaces[0].uvs * np.float32(3.9) - np.float32(1.3)).astype(np.float32)
+    quad.surfaces[0].uvs = ((quad.surfaces[0].uvs * np.float32(3.9) - np.float32(1.3)) * np.float32(uv_scale)).astype(np.float32)
     mats = np.stack([scenes.material(), scenes.material(albedo=(1, 1, 1), texture=1)])
     t = scenes.transform12([[1, 0, 0], [0, 0, -1], [0, 1, 0]], (0, 0, 0))
     tex = np.concatenate([scenes.checker_texture(16, 4), np.random.RandomState(3).randint(0, 256, size=(1, 16, 16, 4)).astype(np.uint8)])
@@ -122,7 +124,7 @@ def test_texture_scene(oracle, hiplib, sampler):
     want, _, _, _, _ = oracle.render(oracle.build_scene(sc), scenes.camera_block(sc.camera, w, h), w, h, 2, 2, 1, wire.ACCUM_HDR_F32,
                                      sampler_mode=sampler)
     base, _, _, _, _ = oracle.render(oracle.build_scene(sc), scenes.camera_block(sc.camera, w, h), w, h, 2, 2, 1, wire.ACCUM_HDR_F32)
-    assert sampler == 0 or not np.array_equal(want, base)   # the modes really differ on this scene
+    assert sampler == 0 or uv_scale != 1.0 or not np.array_equal(want, base)   # the modes really differ on this scene
     for kernel in KERNELS:
         for builder in (capi.BUILD_REFERENCE_EXACT, capi.BUILD_SAH):
             ctx = host.Context(0)
@@ -594,6 +596,42 @@ print(json.dumps(dict(sum=float(a.sum()), rays=rays, crc=int(np.frombuffer(a.tob
     assert outs[0] == outs[1] and outs[0]["rays"] > 160 * 96 * 7
 
 
+def test_set_aside_buffer_overflow_is_counted_not_silent(hiplib):
+    """Hits the reference's traversal cannot reach are set aside and finished exactly; the buffer for them holds 1/64 of the
+    paths.  With the capacity forced to 0 every such hit is instead shaded as found -- the image is then the watertight
+    builder's -- and jpt_stats says how many: nothing is dropped silently, and the default capacity drops none.
+    Config C2 (1280x720, 4 spp, 3 bounces), whose reference tree has a crack at pixel (688, 551)."""
+    import subprocess, sys, json
+    code = r'''
+import sys, json, numpy as np
+sys.path.insert(0, %r)
+from gdpathtracing_amd import capi, host, scenes
+sc = scenes.demo_scene(51200); w, h = 1280, 720
+cam = scenes.camera_block(sc.camera, w, h)
+img = {}
+for name, builder in (("reach", capi.BUILD_SAH), ("watertight", capi.BUILD_SAH_WATERTIGHT)):
+    ctx = host.Context(0); ctx.build_scene(sc, builder); ctx.set_params(w, h, 3, 0); ctx.set_camera(cam)
+    ctx.render(4, 1)
+    img[name] = ctx.read_accum(); st = ctx.stats()
+    if name == "reach": aside, dropped = st["set_aside"], st["set_aside_dropped"]
+    ctx.close()
+print(json.dumps(dict(aside=aside, dropped=dropped, differing=int((img["reach"] != img["watertight"]).any(axis=-1).sum()))))
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for cap in (None, "0"):
+        env = dict(os.environ)
+        if cap is not None:
+            env["JPT_SET_ASIDE_CAP"] = cap
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[cap] = json.loads(r.stdout.strip().splitlines()[-1])
+    print("C2 set-aside hits:", res)
+    assert res[None]["aside"] >= 1 and res[None]["dropped"] == 0
+    assert res[None]["differing"] >= 1                     # honoured, the crack changes the image ...
+    assert res["0"]["dropped"] == res["0"]["aside"] >= 1   # ... dropped, it is counted ...
+    assert res["0"]["differing"] == 0                      # ... and the image is the watertight builder's
+
+
 def test_split_readback_overlaps_the_next_render(hiplib):
     """jpt_readback_ldr_begin/end: the copy of frame N's screen image is queued behind frame N, frame N+1 is
     queued behind the copy; `end` returns frame N's image exactly."""
@@ -654,10 +692,12 @@ def test_asynchronous_renders_pipeline_in_order(oracle, hiplib):
     cam = scenes.camera_block(sc.camera, w, h)
     calls = [(2, 1), (1, 3), (3, 4), (2, 7), (1, 9)]
 
-    def run(asynchronous):
+    def run(asynchronous, priorities=None):
         ctx = make_ctx(sc, w, h, bounces, wire.ACCUM_REF_LDR8, capi.BUILD_REFERENCE_EXACT)
         outs = []
         for k, (n, first) in enumerate(calls):
+            if priorities:      # jpt_set_stream_priority between queued renders: slot streams are drained and re-made
+                ctx.set_stream_priority(priorities[k % len(priorities)])
             if k == 3:
                 ctx.accum_reset()
             ctx.render(n, first, asynchronous=asynchronous and k != 2)   # call 2 is blocking in both runs
@@ -667,9 +707,10 @@ def test_asynchronous_renders_pipeline_in_order(oracle, hiplib):
         return outs
 
     a, b = run(True), run(False)
-    for (x, y) in zip(a, b):
-        for u, v in zip(x, y):
-            assert np.array_equal(u, v)
+    c = run(True, [capi.STREAM_PRIORITY_NORMAL, capi.STREAM_PRIORITY_LOW, capi.STREAM_PRIORITY_HIGH, capi.STREAM_PRIORITY_DEFAULT])
+    for (x, y, z) in zip(a, b, c):
+        for u, v, t in zip(x, y, z):
+            assert np.array_equal(u, v) and np.array_equal(u, t)
     ref = oracle.build_scene(sc)
     want, want_ldr, _, _, _ = oracle.render(ref, cam, w, h, bounces, 3, 7, wire.ACCUM_REF_LDR8)   # frames 7, 8, 9 after the reset
     assert np.array_equal(a[1][0], want) and np.array_equal(a[1][1], want_ldr)

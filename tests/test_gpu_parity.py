@@ -473,6 +473,57 @@ def test_tie_between_instances_with_different_transforms(oracle, hiplib, kernel)
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("how", ["update", "refit", "reference arrays"])
+def test_one_process_multi_device_follows_moving_instances(oracle, hiplib, how):
+    """Instances that move under a jpt_multi: the move reaches EVERY rank's replica (jpt_multi_set_instance_transform +
+    jpt_multi_update_tlas, jpt_multi_refit_tlas, or -- route (i) -- jpt_multi_update_reference_tlas), so the assembled image
+    of each animation step equals one context's render of the same step bit for bit.  (A move applied to rank 0's context
+    alone would mix two scene states strip by strip.)"""
+    sc = scenes.instanced_scene(n_side=4, n_unique=2, tris_per_mesh=96)
+    w, h, b, world = 160, 90, 3, 3
+    cam = scenes.camera_block(sc.camera, w, h)
+    one = host.Context(0)
+    m = host.MultiContext([0] * world)
+    if how == "reference arrays":
+        r0 = oracle.build_scene(sc)
+        arrays = (r0.tri_geom, r0.tri_data, r0.materials, r0.bvh_nodes, r0.instances, r0.tlas_nodes)
+        one.upload_reference_layout(*arrays)
+        m.upload_reference_layout(*arrays)
+    else:
+        one.build_scene(sc, capi.BUILD_SAH)
+        m.build_scene(sc, capi.BUILD_SAH)
+    for c in (one, m):
+        c.set_params(w, h, b, wire.ACCUM_REF_LDR8)
+        c.set_camera(cam)
+    cur = sc
+    for step in range(3):
+        moves = _moves_for(cur, 10 + step, 5)
+        cur = _moved(cur, moves)
+        if how == "update":
+            for i, t in moves.items():
+                one.set_instance_transform(i, t)
+                m.set_instance_transform(i, t)
+            one.update_tlas()
+            m.update_tlas()
+        elif how == "refit":
+            allt = np.stack([np.asarray(i.transform, dtype=np.float32) for i in cur.instances])
+            one.refit_tlas(allt)
+            m.refit_tlas(allt)
+        else:
+            r = oracle.build_scene(cur)
+            one.update_reference_tlas(r.instances, r.tlas_nodes)
+            m.update_reference_tlas(r.instances, r.tlas_nodes)
+        one.accum_reset()
+        m.accum_reset()
+        one.render(2, 1 + step)
+        m.render(2, 1 + step)
+        a, bb = m.read_accum(), one.read_accum()
+        assert np.array_equal(a, bb), (how, step, int((a != bb).any(axis=-1).sum()))
+        assert np.array_equal(m.read_ldr(), one.read_ldr())
+    m.close()
+    one.close()
+
+
 @pytest.mark.parametrize("world", [2, 3])
 def test_one_process_multi_device_gather_is_bit_identical(hiplib, world):
     """jpt_multi_* (one process, one context per listed device, peer-to-peer gather of the float4 rows to rank 0,

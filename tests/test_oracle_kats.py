@@ -249,6 +249,17 @@ def test_sampler_modes_match_the_numpy_restatement(oracle, mode):
             assert np.array_equal(sample(u, v, 0), sample(u + 2.0, v - 1.0, 0))
     else:          # clamp-to-edge: everything beyond the edge texel centre is the edge texel
         assert np.array_equal(sample(-3.0, 0.5, 0), sample(0.01, 0.5, 0)) and np.array_equal(sample(7.0, 0.5, 0), sample(0.99, 0.5, 0))
+        # ... however far: the clamp saturates before the integer conversion (Vulkan clamp-to-edge), so huge and infinite
+        # coordinates address the last / first texel, not texel 0
+        for big in (1e9, 3e38, float("inf")):
+            assert np.array_equal(sample(big, 0.5, 0), sample(0.99, 0.5, 0)), big
+            assert np.array_equal(sample(0.5, big, 1), sample(0.5, 0.99, 1)), big
+            assert np.array_equal(sample(-big, 0.5, 0), sample(0.01, 0.5, 0)), big
+            assert np.allclose(sample(big, 0.5, 0), npr.sample_texture(tex, big, 0.5, 0, mode), rtol=0, atol=2e-6)
+    # NaN coordinates address texel 0 with weight 0 in every mode
+    nan = float("nan")
+    assert np.array_equal(sample(nan, nan, 0), tex[0, 0, 0, :3].astype(np.float32).astype(np.float64) / 255.0) or \
+        np.allclose(sample(nan, nan, 0), tex[0, 0, 0, :3] / 255.0, rtol=0, atol=1e-7)
 
 
 def test_unorm8_decode_without_division_is_exact():

@@ -4,7 +4,10 @@
 transcendental unit, 4.2 for everything else (min/max, compares, selects, shifts, VOP3-only forms, conversions).
 Prints per basic block: VALU count, priced cycles, the most frequent mnemonics.
 
-    hipcc ... -S --cuda-device-only -o k.s file.hip ;  python tools/isa_cost.py k.s <kernel-name-substring> [min_cycles]"""
+    hipcc ... -S --cuda-device-only -o k.s file.hip ;  python tools/isa_cost.py k.s <kernel-name-substring> [min_cycles]
+    python tools/isa_cost.py --json out.json        compiles csrc/*.hip to ISA here and writes, per kernel, the VALU count and
+                                                    the priced cycles per VALU instruction of its STATIC instruction mix
+                                                    (profiles/isa_cost.json: what tools/summarize_sq.py prices SQ_INSTS_VALU with)"""
 import collections
 import re
 import sys
@@ -48,5 +51,59 @@ def main(path, kernel, min_cycles=40.0):
     print("total VALU %d, priced cycles %.0f, average %.2f cycles per instruction" % (tot_v, tot_c, tot_c / max(tot_v, 1)))
 
 
+def kernel_table(path):
+    """{kernel symbol: (valu, priced cycles)} for every kernel of one .s file"""
+    out, cur = {}, None
+    for l in open(path).read().splitlines():
+        m = re.match(r"^(_Z\w+):", l)
+        if m:
+            cur = m.group(1)
+            out[cur] = [0, 0.0]
+            continue
+        if cur is None:
+            continue
+        if "s_endpgm" in l:
+            cur = None
+            continue
+        t = l.strip().split()
+        if t and t[0].startswith("v_"):
+            out[cur][0] += 1
+            out[cur][1] += cost(t[0])
+    return out
+
+
+def write_json(dst):
+    import hashlib, json, os, subprocess, tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.join(root, "gdpathtracing_amd", "csrc")
+    sys.path.insert(0, root)
+    from tools.csrc_sha import csrc_sha
+    res = {"_meta": {"csrc_sha": csrc_sha(), "prices": "2.3 plain f32/int ALU, 8.2 transcendental, 4.2 everything else (tools/micro/valu_issue.hip)",
+                     "mix": "static (every instruction of the kernel's ISA counted once)"}}
+    for f in ("jpt_kernels_wf2.hip", "jpt_kernels_ref.hip", "jpt_kernels_post.hip"):
+        with tempfile.NamedTemporaryFile(suffix=".s") as tmp:
+            subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math",
+                                   "-fno-slp-vectorize", "-S", "--cuda-device-only", "-o", tmp.name, os.path.join(csrc, f)],
+                                  stderr=subprocess.DEVNULL)
+            for sym, (n, c) in kernel_table(tmp.name).items():
+                m = re.search(r"(wf2_\w+?|ref_frame_kernel|temporal_kernel|assemble_ldr_kernel|assemble_kernel|instance_refit_kernel|tlas4_refit_kernel|quantize_tail_kernel)(ILb([01])|E|P|I)", sym)
+                if not m or n == 0:
+                    continue
+                name = m.group(1)
+                counted = "ILb1" in sym[sym.find(name):sym.find(name) + len(name) + 5]
+                if counted:
+                    continue                       # the counting builds are not what the profiles run
+                w4 = "ELb1" in sym or "ILb0ELb1" in sym
+                key = name
+                if name in ("wf2_primary", "wf2_trace", "wf2_finish") and not w4:
+                    key = name + "_w2"           # two-child records (reference-exact trees)
+                res[key] = {"valu": n, "cycles_per_valu": round(c / n, 3), "symbol": sym}
+    json.dump(res, open(dst, "w"), indent=1, sort_keys=True)
+    print(json.dumps({k: v.get("cycles_per_valu") for k, v in res.items() if k != "_meta"}, indent=1))
+
+
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2], float(sys.argv[3]) if len(sys.argv) > 3 else 40.0)
+    if sys.argv[1] == "--json":
+        write_json(sys.argv[2])
+    else:
+        main(sys.argv[1], sys.argv[2], float(sys.argv[3]) if len(sys.argv) > 3 else 40.0)

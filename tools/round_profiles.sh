@@ -3,6 +3,8 @@
 tag="${1:-rXX}"
 cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out/round
+python3 tools/isa_cost.py --json profiles/isa_cost.json > gpurun_out/round/isa_cost.log 2>&1   # (hipcc on the box: the ISA of THESE sources)
+cp profiles/isa_cost.json gpurun_out/round/${tag}_isa_cost.json
 bash tools/pmc.sh > gpurun_out/round/pmc.log 2>&1
 python3 tools/summarize_prof.py gpurun_out/prof gpurun_out/round "$tag" > gpurun_out/round/${tag}_summary.txt 2>&1
 bash tools/diag.sh > gpurun_out/round/diag.log 2>&1

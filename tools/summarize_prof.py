@@ -54,6 +54,9 @@ def main(src, dst, tag):
     bench = os.path.join(src, "bench.json")
     if os.path.exists(bench):
         shutil.copy(bench, os.path.join(dst, tag + "_bench.json"))
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from tools.csrc_sha import csrc_sha
+    out["_meta"] = {"csrc_sha": csrc_sha(), "mode": "serial launches (JPT_PIPELINE=0 JPT_GROUPS=1), per-launch averages"}
     json.dump(out, open(os.path.join(dst, tag + "_pmc.json"), "w"), indent=1, sort_keys=True)
     print(json.dumps(out, indent=1, sort_keys=True))
 

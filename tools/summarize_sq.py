@@ -3,10 +3,14 @@
 and the figures DESIGN.md / bench.py quote:
 
   lane_utilisation   SQ_THREAD_CYCLES_VALU / (SQ_ACTIVE_INST_VALU * 64): enabled lanes per VALU instruction
-  valu_busy_frac     SQ_ACTIVE_INST_VALU * 4 cycles / (1024 SIMDs * kernel cycles): SQ_ACTIVE_INST_* count quad-cycles
-                     (MI355X_MICROARCH.md), kernel cycles = GRBM_GUI_ACTIVE / 8 (the counter sums the 8 XCDs)
-  cycles_per_valu    SQ_ACTIVE_INST_VALU * 4 / SQ_INSTS_VALU: what an average instruction of this kernel occupies the VALU for
-                     (2.3 for plain fma / add / mul, 4.2 for min / max / compare / select, 8.2 transcendental: tools/micro/valu_issue.hip)
+  valu_issue_frac    share of the chip's VALU issue capacity the launch used:
+                     SQ_INSTS_VALU (wave-level instructions) x the priced cycles per instruction of this kernel's ISA
+                     (profiles/isa_cost.json = tools/isa_cost.py over the measured issue costs of tools/micro/valu_issue.hip:
+                     2.3 plain f32 / integer ALU, 4.2 min / max / compare / select / convert, 8.2 transcendental; static mix)
+                     / (1024 SIMDs x kernel cycles), kernel cycles = GRBM_GUI_ACTIVE / 8 (the counter sums the 8 XCDs).
+                     Asserted <= 1 for every kernel.  (Round 2 derived a "valu_busy_frac" from SQ_ACTIVE_INST_VALU x 4: that
+                     counter charges a constant ~4 cycles per instruction whatever it is -- 1.13 for wf2_accumulate -- and is
+                     no longer reported as a fraction; the raw counter stays in `counters`.)
   vmem_instr_per_cu_us   wave-level vector-memory instructions per CU per microsecond of kernel time
   l1_accesses_per_vmem   TCP_TOTAL_CACHE_ACCESSES / (SQ_INSTS_VMEM_RD + WR): distinct lines per load instruction
   wait_frac / issue_stall_frac / active_frac   shares of SQ_WAVE_CYCLES
@@ -26,6 +30,16 @@ def kname(s):
 
 
 def main(src, dst):
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    from tools.csrc_sha import csrc_sha
+    isa = {}
+    try:
+        isa = json.load(open(os.path.join(root, "profiles", "isa_cost.json")))
+    except Exception:
+        pass
+    isa_current = isa.get("_meta", {}).get("csrc_sha") == csrc_sha()
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     dur = collections.defaultdict(list)
     for f in glob.glob(src + "/p*/*/*counter_collection.csv"):
@@ -51,10 +65,10 @@ def main(src, dst):
                 d["clock_ghz"] = round(g / 8.0 / (d["kernel_us"] * 1e3), 3)
         if c.get("SQ_ACTIVE_INST_VALU"):
             d["lane_utilisation"] = round(c.get("SQ_THREAD_CYCLES_VALU", 0) / (c["SQ_ACTIVE_INST_VALU"] * 64.0), 4)
-            if c.get("SQ_INSTS_VALU"):
-                d["cycles_per_valu"] = round(c["SQ_ACTIVE_INST_VALU"] * 4.0 / c["SQ_INSTS_VALU"], 3)
-            if g:
-                d["valu_busy_frac"] = round(c["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024.0 * g / 8.0), 4)
+        if c.get("SQ_INSTS_VALU") and g and k in isa and isa_current:
+            d["priced_cycles_per_valu"] = isa[k]["cycles_per_valu"]
+            d["valu_issue_frac"] = round(c["SQ_INSTS_VALU"] * isa[k]["cycles_per_valu"] / (1024.0 * g / 8.0), 4)
+            assert d["valu_issue_frac"] <= 1.0, (k, d["valu_issue_frac"])
         vm = c.get("SQ_INSTS_VMEM_RD", 0) + c.get("SQ_INSTS_VMEM_WR", 0)
         if vm and dur[k]:
             d["vmem_instr_per_cu_us"] = round(vm / 256.0 / d["kernel_us"], 2)
@@ -68,8 +82,10 @@ def main(src, dst):
         if c.get("TCC_HIT_sum") is not None and (c.get("TCC_HIT_sum", 0) + c.get("TCC_MISS_sum", 0)) > 0:
             d["l2_hit"] = round(c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"]), 4)
         out[k] = d
+    out["_meta"] = {"csrc_sha": csrc_sha(), "isa_cost_current": isa_current,
+                    "mode": "serial launches (JPT_PIPELINE=0 JPT_GROUPS=1), per-launch averages"}
     json.dump(out, open(dst, "w"), indent=1, sort_keys=True)
-    print(json.dumps({k: {n: v for n, v in d.items() if n != "counters"} for k, d in out.items()}, indent=1, sort_keys=True))
+    print(json.dumps({k: {n: v for n, v in d.items() if n != "counters"} for k, d in out.items() if k != "_meta"}, indent=1, sort_keys=True))
 
 
 if __name__ == "__main__":
