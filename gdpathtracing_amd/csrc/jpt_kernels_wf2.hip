@@ -195,7 +195,6 @@ __global__ __launch_bounds__(kBlock, JPT_PRIMARY_WAVES) void wf2_primary(WideSce
     __shared__ uint32_t s_cursor, s_out;
     const int lane = threadIdx.x & 63;
     const uint32_t seg = blockIdx.x;
-    // chunks seg, seg + G, seg + 2G, ... belong to this block
     // runs seg, seg + G, seg + 2G, ... of 2^run_shift consecutive chunks belong to this block
     const uint32_t run_mask = (1u << dm.run_shift) - 1u;
     const uint32_t n_runs = (dm.n_chunks + run_mask) >> dm.run_shift;
@@ -368,7 +367,8 @@ __global__ __launch_bounds__(kBlock, JPT_WAVES_PER_SIMD) void wf2_trace(WideScen
 // updated, returns true when the path goes on (no / nd = its next ray).  With reach records (JPT_BUILD_SAH) and
 // check_reach, a hit the reference's own traversal could not have reached -- the world ray fails the world box the
 // reference gives the instance, or the local ray fails the box of the triangle's reference leaf (jpt_types.h) -- is
-// not shaded: `unreachable` comes back true and nothing has been written; the path leaves the wavefront and is finished by wf2_finish.
+// not shaded: the vertex is set aside (redo_rec; its state parked in the path's thr / rad words), `unreachable` comes back
+// true, and the path leaves the wavefront to be finished by wf2_finish.
 template <bool COUNT>
 __device__ __forceinline__ bool shade_entry(const SceneShading& sh, const Wf2Buffers& wb, const Wf2Dims& dm, const FrameParams& fp, float cam_far,
                                             int bounce, const float4 ro, const float4 rd, const float4 tin, const float4 ha, const uint32_t hb,
@@ -418,8 +418,22 @@ __device__ __forceinline__ bool shade_entry(const SceneShading& sh, const Wf2Buf
             bool reached = __float_as_uint(ta.w) != 0u || slab(h.lo, rcp3(h.ld), ta.x, ta.y, ta.z, tb.x, tb.y, tb.z) < 1e30f;
             if (reached && sh.n_instances > 1u) reached = slab(ray.o, rcp3(ray.d), ia.x, ia.y, ia.z, ib.x, ib.y, ib.z) < 1e30f;
             if (!reached) {
-                unreachable = true;
-                return false;
+                // a few paths in 10^7: the path leaves the wavefront here and is finished, exactly, by wf2_finish -- unless
+                // the set-aside buffer is full (pathological scenes): then the hit is shaded as found, and counted
+                const uint32_t k = atomicAdd(&wb.redo_count[0], 1u);
+                if (k < wb.redo_cap) {
+                    float4 rd2 = rd;
+                    if (bounce > 0) {   // its seed.y (the entry's origin.w) waits in rad[path].w, beside the radiance so far
+                        wb.rad[p] = make_float4(r4.x, r4.y, r4.z, ro.w);
+                        wb.thr[p] = tin;
+                        rd2.w = __uint_as_float(p | kHasRadiance);
+                    }
+                    wb.redo_rec[2 * (size_t)k] = make_float4(ro.x, ro.y, ro.z, __uint_as_float((uint32_t)bounce));
+                    wb.redo_rec[2 * (size_t)k + 1] = rd2;
+                    unreachable = true;
+                    return false;
+                }
+                atomicAdd(&wb.redo_count[1], 1u);
             }
         }
     }
@@ -486,32 +500,8 @@ __global__ __launch_bounds__(kBlock, JPT_SHADE_WAVES) void wf2_shade(SceneShadin
         const float4 tin = bounce > 0 ? wb.thr_q[in][seg_base + i] : make_float4(1.0f, 1.0f, 1.0f, 0.0f);
         const float4 ha = wb.hit_a[seg_base + i];
         const uint32_t hb = wb.hit_b[seg_base + i];
-        // (a loop of at most two turns around ONE inlined shade_entry: the second turn -- the set-aside buffer is full, the
-        // hit is shaded as found -- runs for pathological scenes only)
-#pragma nounroll
-        for (int turn = 0; turn < 2; turn++) {
-            bool unreachable;
-            alive = shade_entry<COUNT>(sh, wb, dm, fp, cam_far, bounce, ro, rd, tin, ha, hb, turn == 0, unreachable, no, nd, nt, cnt);
-            if (!unreachable) break;
-            // a few paths in 10^7: they leave the wavefront here and are finished, exactly, by wf2_finish
-            const uint32_t k = atomicAdd(&wb.redo_count[0], 1u);
-            if (k >= wb.redo_cap) {
-                atomicAdd(&wb.redo_count[1], 1u);
-                continue;
-            }
-            float4 rd2 = rd;
-            if (bounce > 0) {   // its seed.y (the entry's origin.w) waits in rad[path].w, beside the radiance so far
-                const uint32_t pw = __float_as_uint(rd.w), p = pw & kPathMask;
-                float4 r4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                if (pw & kHasRadiance) r4 = wb.rad[p];
-                wb.rad[p] = make_float4(r4.x, r4.y, r4.z, ro.w);
-                wb.thr[p] = tin;
-                rd2.w = __uint_as_float(p | kHasRadiance);
-            }
-            wb.redo_rec[2 * (size_t)k] = make_float4(ro.x, ro.y, ro.z, __uint_as_float((uint32_t)bounce));
-            wb.redo_rec[2 * (size_t)k + 1] = rd2;
-            break;
-        }
+        bool unreachable;   // (set aside inside shade_entry: nothing more to do here)
+        alive = shade_entry<COUNT>(sh, wb, dm, fp, cam_far, bounce, ro, rd, tin, ha, hb, true, unreachable, no, nd, nt, cnt);
     }
     // active-ray packing: wave ballot + prefix popcount, one atomic per wave on the SEGMENT's counter (1792
     // different words: no hot address); the order inside the next queue is irrelevant
@@ -603,9 +593,50 @@ __global__ __launch_bounds__(kBlock) void wf2_accumulate(Wf2Buffers wb, Wf2Dims 
     // primary ray of (x, y, frame) (main.glsl:380,395-397 with throughput 1), made up here
     const int py = local_to_global_row(ly, fp);
     const bool culled = !in_window || sky_culled(cull, px, py);
+    // A culled pixel's frames all see the sky, whose colour depends on the ray's d.y alone and changes by a hundredth of an
+    // rgba8 step across a pixel: in REF_LDR8 mode nearly every pixel has ONE rgba8 sky value for all its frames.  The
+    // jittered sample of a frame lies on the quarter circle (px + cos, py + sin), inside the pixel's square, so the four
+    // corner rays bound its d.y (up to the curvature of d.y over one pixel and float rounding: 1e-6 and less); when the
+    // three channels' values * 255 + 0.5 of the four corners lie in the same integer cell at least `kCellMargin` away from
+    // its ends (1000 x those effects), every frame quantises to that cell and the eight primary rays -- seed, sincos, 4 x 4
+    // transform, three divisions, a normalisation each -- need not be made.  Pixels near a cell boundary (a few per cent:
+    // horizontal bands) and cameras whose clip-space w changes sign inside the pixel take the exact per-frame route below.
+    constexpr float kCellMargin = 0.01f;
+    bool sky_constant = false;
+    f3 sky_value = mk3(0.0f, 0.0f, 0.0f);
+    if (culled && fp.accum_mode == 0 && fp.n_frames > 1) {
+        float lo[3] = {1e30f, 1e30f, 1e30f}, hi[3] = {-1e30f, -1e30f, -1e30f};
+        bool sane = true;
+        float w_first = 0.0f;
+        for (int corner = 0; corner < 4; corner++) {
+            float ww;
+            const f3 d = raster_direction(cam, fp.width, fp.height, (float)(px + (corner & 1)), (float)(py + (corner >> 1)), ww);
+            if (corner == 0) w_first = ww;
+            sane = sane && (ww * w_first > 0.0f) && (d.y == d.y);
+            const f3 c = mk3(0.0f, 0.0f, 0.0f) + mk3(1.0f, 1.0f, 1.0f) * sample_sky(d);
+            const float v[3] = {clamp_(c.x, 0.0f, 1.0f) * 255.0f + 0.5f, clamp_(c.y, 0.0f, 1.0f) * 255.0f + 0.5f, clamp_(c.z, 0.0f, 1.0f) * 255.0f + 0.5f};
+            for (int k = 0; k < 3; k++) {
+                lo[k] = fmin_(lo[k], v[k]);
+                hi[k] = fmax_(hi[k], v[k]);
+            }
+        }
+        bool same = sane;
+        float cell[3];
+        for (int k = 0; k < 3; k++) {
+            cell[k] = __builtin_floorf(lo[k]);
+            same = same && (lo[k] - cell[k] >= kCellMargin) && (hi[k] - cell[k] <= 1.0f - kCellMargin) && (hi[k] - lo[k] < 0.5f);
+        }
+        if (same) {
+            sky_constant = true;
+            sky_value = mk3(from_unorm8((uint32_t)cell[0]), from_unorm8((uint32_t)cell[1]), from_unorm8((uint32_t)cell[2]));
+        }
+    }
     for (int f = 0; f < fp.n_frames; f++) {
         f3 cur;
-        if (culled) {
+        if (sky_constant) {
+            cur = sky_value;
+            last = cur;
+        } else if (culled) {
             uint32_t sx, sy;
             const Ray ray = primary_ray(cam, fp.width, fp.height, px, py, fp.frame_index + (uint32_t)f, sx, sy);
             cur = mk3(0.0f, 0.0f, 0.0f) + mk3(1.0f, 1.0f, 1.0f) * sample_sky(ray.d);
@@ -871,7 +902,7 @@ void launch_wf2_render(hipStream_t stream, const DeviceScene& ds, const FramePar
     // the pipeline of one group on one stream
     auto run_group = [&](hipStream_t st, const Wf2Buffers& wb, const Wf2Dims& dm, const FrameParams& gp, hipEvent_t* ev) {
         // queue sizes of bounces >= 1 are accumulated with atomics by wf2_shade: start from zero
-        (void)hipMemsetAsync(wb.qcount + kSegments, 0, ((size_t)(nq - 1) * kSegments + 64) * sizeof(uint32_t), st);  // (and the set-aside count behind them)
+        (void)hipMemsetAsync(wb.qcount + kSegments, 0, ((size_t)(nq - 1) * kSegments + 64) * sizeof(uint32_t), st);  // (and the set-aside counts behind them)
         // Blocks go to the 8 XCDs round-robin by linear index (y * grid.x + x), and the chunks of a segment are far from
         // alike (the first ones are full, the last ones empty): with grid.x a multiple of 8 every XCD would always get
         // the same chunk position.  An odd grid.x deals every position to every XCD (capping C3's grid.x from 37 to 8

@@ -102,6 +102,25 @@ __device__ __forceinline__ Ray primary_ray(const RefCamera& cam, int width, int 
     return ray;
 }
 
+// The ray through an exact raster position (no jitter): the arithmetic of primary_ray from `scx` on.  Used to bound what the
+// jittered rays of a pixel can see (wf2_accumulate); `ww_out` = the clip-space w the position divides by.
+__device__ __forceinline__ f3 raster_direction(const RefCamera& cam, int width, int height, float fx, float fy, float& ww_out)
+{
+    const float scx = fx / (float)width * 2.0f - 1.0f;
+    const float scy = fy / (float)height * 2.0f - 1.0f;
+    const float nx = scx, ny = -scy;
+    const float* m = cam.ivp;
+    float wx = m[0] * nx + m[4] * ny + m[8] + m[12];
+    float wy = m[1] * nx + m[5] * ny + m[9] + m[13];
+    float wz = m[2] * nx + m[6] * ny + m[10] + m[14];
+    const float ww = m[3] * nx + m[7] * ny + m[11] + m[15];
+    ww_out = ww;
+    wx = wx / ww;
+    wy = wy / ww;
+    wz = wz / ww;
+    return normalize3(mk3(wx, wy, wz) - mk3(cam.position.x, cam.position.y, cam.position.z));
+}
+
 __device__ __forceinline__ f3 sample_sky(f3 d)  // main.glsl:189-192
 {
     const float t = 0.5f * (d.y + 1.0f);
