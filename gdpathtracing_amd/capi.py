@@ -30,7 +30,7 @@ SYMBOLS = [
     "jpt_scene_upload_reference_layout", "jpt_set_upload_mode", "jpt_scene_tree_kind", "jpt_scene_upload_note", "jpt_scene_begin", "jpt_scene_add_mesh", "jpt_scene_add_instance",
     "jpt_scene_set_materials", "jpt_scene_set_textures", "jpt_scene_commit", "jpt_scene_get_reference_buffer",
     "jpt_scene_set_instance_transform", "jpt_scene_update_tlas", "jpt_scene_refit_tlas", "jpt_scene_update_reference_tlas",
-    "jpt_set_params", "jpt_set_kernel", "jpt_set_kernel_timing", "jpt_set_partition", "jpt_set_camera", "jpt_render", "jpt_render_counted", "jpt_render_async",
+    "jpt_set_params", "jpt_set_kernel", "jpt_set_debug_steps", "jpt_set_kernel_timing", "jpt_set_partition", "jpt_set_camera", "jpt_render", "jpt_render_counted", "jpt_render_async",
     "jpt_sync", "jpt_accum_reset", "jpt_set_progressive_frame_count", "jpt_set_denoising_mode", "jpt_set_temporal_params", "jpt_read_ldr_rgba8", "jpt_readback_ldr_begin", "jpt_readback_ldr_end", "jpt_read_accum_f32", "jpt_read_depth_f32",
     "jpt_device_accum", "jpt_assemble_from_ranks", "jpt_device_ldr", "jpt_assemble_ldr_from_ranks", "jpt_local_rows", "jpt_get_stats",
     "jpt_scene_share", "jpt_multi_create", "jpt_multi_destroy", "jpt_multi_last_error", "jpt_multi_world", "jpt_multi_ctx",
@@ -124,6 +124,7 @@ def lib():
     L.jpt_set_partition.argtypes = [vp, i32, i32]
     L.jpt_set_kernel.argtypes = [vp, i32]
     L.jpt_set_kernel_timing.argtypes = [vp, i32]
+    L.jpt_set_debug_steps.argtypes = [vp, i32]
     L.jpt_set_camera.argtypes = [vp, vp]
     for n in ("jpt_render", "jpt_render_counted", "jpt_render_async"):
         getattr(L, n).argtypes = [vp, i32, u32]

@@ -98,6 +98,7 @@ struct jpt_ctx {
     RefCamera camera;
     uint32_t frame_count = 0;  // frames accumulated since reset
     int32_t kernel_variant = JPT_KERNEL_WAVEFRONT;
+    bool debug_steps = false;  // jpt_set_debug_steps: the shader's DEBUG_STEPS build, on the audit kernel
     DevBuf<char> d_workspace;
     // render pipelining (jpt_render_async): consecutive asynchronous renders run their path kernels on two helper
     // streams with two workspaces, so one render's launch tails overlap the next render's kernels; the accumulation
@@ -499,7 +500,7 @@ int do_render_batch(jpt_ctx* c, int32_t n_frames, uint32_t first_frame_index, bo
 int32_t frames_per_batch(const jpt_ctx* c, int32_t n_frames)
 {
     const size_t budget = (size_t)tuning().workspace_budget_mb << 20;
-    if (c->kernel_variant == JPT_KERNEL_REFERENCE_LAYOUT || n_frames <= 1) return n_frames;
+    if (c->kernel_variant == JPT_KERNEL_REFERENCE_LAYOUT || c->debug_steps || n_frames <= 1) return n_frames;
     const size_t one = wf2_workspace_bytes(c->width, c->local_rows, 1, c->max_bounces);
     const size_t fit = std::max<size_t>(1, budget / std::max<size_t>(one, 1));
     return (int32_t)std::min<size_t>((size_t)n_frames, fit);
@@ -623,7 +624,7 @@ int do_render_batch(jpt_ctx* c, int32_t n_frames, uint32_t first_frame_index, bo
     if (!c->params_set) return fail(c, JPT_E_STATE, "jpt_set_params not called");
     if (!c->camera_set) return fail(c, JPT_E_STATE, "jpt_set_camera not called");
     if (n_frames < 0) return fail(c, JPT_E_INVALID, "n_frames < 0");
-    if (c->refit_active && c->kernel_variant != JPT_KERNEL_WAVEFRONT)
+    if (c->refit_active && (c->kernel_variant != JPT_KERNEL_WAVEFRONT || c->debug_steps))
         return fail(c, JPT_E_STATE, "jpt_scene_refit_tlas refits the default kernel's records only: call jpt_scene_update_tlas before rendering with another kernel");
     HIP_TRY(c, hipSetDevice(c->device));
     hipStream_t s = c->stream;
@@ -654,7 +655,7 @@ int do_render_batch(jpt_ctx* c, int32_t n_frames, uint32_t first_frame_index, bo
         cnt = c->d_counters.p;
         HIP_TRY(c, hipMemsetAsync(cnt, 0, sizeof(DevCounters), s));
     }
-    const bool wavefront = c->kernel_variant == JPT_KERNEL_WAVEFRONT;
+    const bool wavefront = c->kernel_variant == JPT_KERNEL_WAVEFRONT && !c->debug_steps;   // (DEBUG_STEPS exists in the audit kernel only)
     const bool wf2 = wavefront;
     const int nq = c->max_bounces + 2;
     if (wavefront && c->local_rows > 0 && c->width > 0 && n_frames > 0) {
@@ -676,6 +677,7 @@ int do_render_batch(jpt_ctx* c, int32_t n_frames, uint32_t first_frame_index, bo
         fp.max_bounces = c->max_bounces;
         fp.accum_mode = c->accum_mode;
         fp.display_mode = c->denoise == JPT_DENOISE_PROGRESSIVE ? 0 : 1;
+        fp.debug_steps = c->debug_steps ? 1 : 0;
         if (wavefront) {
             fp.frame_index = first_frame_index;
             fp.frame_count = c->frame_count + 1;
@@ -1547,6 +1549,13 @@ int jpt_set_kernel(jpt_ctx* c, int32_t variant)
     if (!c) return JPT_E_INVALID;
     if (variant != JPT_KERNEL_WAVEFRONT && variant != JPT_KERNEL_REFERENCE_LAYOUT) return fail(c, JPT_E_INVALID, "unknown kernel variant");
     c->kernel_variant = variant;
+    return JPT_OK;
+}
+
+int jpt_set_debug_steps(jpt_ctx* c, int32_t enable)
+{
+    if (!c) return JPT_E_INVALID;
+    c->debug_steps = enable != 0;
     return JPT_OK;
 }
 

@@ -32,6 +32,7 @@ struct FrameParams {
     int32_t depth_frame;        // launch-local index of the frame whose first-hit distance is the depth image (-1: none)
     int32_t display_mode;       // 0: screen = ACES of the running mean (progressive_rendering.glsl:39-45)
                                 // 1: screen = the last frame's own rgba8 store (main.glsl:434), no pass after it
+    int32_t debug_steps = 0;    // the shader's DEBUG_STEPS build (main.glsl:358-361,423-427): audit kernel only
 };
 
 // All device-resident scene data of a context.

@@ -22,6 +22,7 @@ struct RefSceneDev {
 struct RefHit {
     float t, u, v;
     uint32_t tri, inst;
+    uint32_t steps;   // hitInfo.steps: intersectTriangle calls (main.glsl:225)
     bool front;
     f3 lo, ld;  // local ray of the best hit so far (candidate per instance, committed with `inst`)
 };
@@ -44,6 +45,7 @@ __device__ __forceinline__ void intersect_triangle(const RefSceneDev& sc, const 
                                                    bool& improved, DevCounters& cnt)
 {
     if (COUNT) cnt.tri_tests++;
+    hit.steps++;
     const RefTriGeometry& tri = sc.tri_geom[tri_index];
     const f3 v0 = mk3(tri.vertices[0].x, tri.vertices[0].y, tri.vertices[0].z);
     const f3 v1 = mk3(tri.vertices[1].x, tri.vertices[1].y, tri.vertices[1].z);
@@ -115,6 +117,7 @@ template <bool COUNT>
 __device__ __forceinline__ bool ray_trace_tlas(const RefSceneDev& sc, const Ray& ray, RefHit& hit, DevCounters& cnt)
 {
     hit.t = 1e9f;
+    hit.steps = 0;
     if (sc.n_tlas == 0 || sc.n_instances == 0) return false;
     uint32_t stack[64];
     uint32_t sp = 0;
@@ -190,6 +193,13 @@ __global__ __launch_bounds__(256) void ref_frame_kernel(RefSceneDev sc, SceneSha
         float depth = cam.far_;
         f3 radiance = mk3(0.0f, 0.0f, 0.0f);
         f3 throughput = mk3(1.0f, 1.0f, 1.0f);
+        if (fp.debug_steps) {   // #ifdef DEBUG_STEPS (main.glsl:358-361, 423-427): the primary ray's triangle tests / 256, depth = far
+            RefHit hit;
+            if (COUNT) cnt.rays++;
+            (void)ray_trace_tlas<COUNT>(sc, ray, hit, cnt);
+            const float g = clamp_((float)hit.steps / 256.0f, 0.0f, 1.0f);
+            radiance = mk3(g, g, g);
+        } else
         for (int i = 0; i < fp.max_bounces + 1; i++) {  // main.glsl:377
             RefHit hit;
             if (COUNT) cnt.rays++;

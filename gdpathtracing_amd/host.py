@@ -100,6 +100,10 @@ class Context:
         """capi.STREAM_PRIORITY_*: the priority level of the streams queued renders run on (jpt_set_stream_priority)."""
         self._ck(self._lib.jpt_set_stream_priority(self.h, priority), "jpt_set_stream_priority")
 
+    def set_debug_steps(self, enable: bool):
+        """main.glsl's DEBUG_STEPS build: the image is the primary ray's triangle-test count / 256 (jpt_set_debug_steps)."""
+        self._ck(self._lib.jpt_set_debug_steps(self.h, 1 if enable else 0), "jpt_set_debug_steps")
+
     def tree_kind(self) -> int:
         """capi.TREE_*: which tree the kernels walk for the current scene."""
         k = self._lib.jpt_scene_tree_kind(self.h)

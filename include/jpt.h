@@ -267,6 +267,14 @@ int jpt_set_params(jpt_ctx *ctx, int32_t width, int32_t height, int32_t max_boun
 enum { JPT_KERNEL_WAVEFRONT = 0, JPT_KERNEL_REFERENCE_LAYOUT = 1 };
 int jpt_set_kernel(jpt_ctx *ctx, int32_t variant);
 
+/* replaces: building main.glsl with `#define DEBUG_STEPS` (main.glsl:4, commented out as shipped; the reference's one
+ * verification aid): every frame's image is clamp(hitInfo.steps / 256) in all three channels -- the number of
+ * intersectTriangle calls the PRIMARY ray made (main.glsl:225,358-361,423-427) --, one ray per pixel, depth = far; the
+ * post-processing pass runs on it as on any frame.  Rendered by the audit kernel (whatever jpt_set_kernel says), which
+ * walks the scene's tree in reference layout: on the reference's own tree (JPT_UPLOAD_WALK_AS_GIVEN uploads,
+ * JPT_BUILD_REFERENCE_EXACT commits) the counts are the reference's, on a native tree they are that tree's. */
+int jpt_set_debug_steps(jpt_ctx *ctx, int32_t enable);
+
 /* Per-launch timing of the traversal kernels (HIP events recorded around each launch on the context's stream;
  * jpt_stats.last_trace_ms).  Off by default: each event costs a few microseconds between kernels. */
 int jpt_set_kernel_timing(jpt_ctx *ctx, int32_t enable);

@@ -32,7 +32,8 @@
 // the camera's local RenderingDevice, path_tracing_camera.cpp:114,139,211,218): the context hangs off the device
 // pointer in a registry kept by this header and is destroyed with the last ComputeShader that uses it.
 //
-// Two optional `defines` strings are understood (anything else is ignored, like the reference's "#define TESTe"):
+// Three `defines` strings are understood (anything else is ignored, like the reference's "#define TESTe"):
+//   "#define DEBUG_STEPS"         the shader's own debug build (main.glsl:4,358-361): triangle tests of the primary ray / 256
 //   "#define JPT_MAX_BOUNCES n"   path length (default 4 = the literal 5 of main.glsl:377)
 //   "#define JPT_SAMPLER n"       JPT_SAMPLER_* of jpt.h for texture(textureArray, ...) (default NEAREST_CLAMP)
 #pragma once
@@ -120,6 +121,7 @@ class ComputeShader {
             const std::string s = Traits::to_std(d);
             read_define(s, "JPT_MAX_BOUNCES", max_bounces_);
             read_define(s, "JPT_SAMPLER", sampler_);
+            if (s.find("#define DEBUG_STEPS") != std::string::npos) debug_steps_ = true;   // the shader's own switch (main.glsl:4)
         }
         if (!dev_->ctx && jpt_create(0, &dev_->ctx) != JPT_OK) error_ = jpt_last_error(nullptr);
     }
@@ -178,13 +180,17 @@ class ComputeShader {
             }
         // set 1: b0 GpuTriangleGeometry (48 B), b1 GpuTriangleData (80), b2 GpuMaterial (64), b3 BVHNode (48),
         //        b4 BLASInstance (176), b5 TLASNode (32)   (main.glsl:121-155)
-        int rc = jpt_scene_upload_reference_layout(dev_->ctx, b[0]->bytes.data(), (uint32_t)(b[0]->bytes.size() / 48),
+        // (the DEBUG_STEPS build counts the triangle tests of the REFERENCE's tree: walk the uploaded arrays node for node)
+        int rc = jpt_set_upload_mode(dev_->ctx, debug_steps_ ? JPT_UPLOAD_WALK_AS_GIVEN : JPT_UPLOAD_NATIVE_TREE);
+        if (rc == JPT_OK)
+            rc = jpt_scene_upload_reference_layout(dev_->ctx, b[0]->bytes.data(), (uint32_t)(b[0]->bytes.size() / 48),
                                                    b[1]->bytes.data(), b[2]->bytes.data(), (uint32_t)(b[2]->bytes.size() / 64),
                                                    b[3]->bytes.data(), (uint32_t)(b[3]->bytes.size() / 48), b[4]->bytes.data(),
                                                    (uint32_t)(b[4]->bytes.size() / 176), b[5]->bytes.data(),
                                                    (uint32_t)(b[5]->bytes.size() / 32), tex_.empty() ? nullptr : tex_.data(),
                                                    tex_res_, tex_layers_);
         if (rc == JPT_OK) rc = jpt_set_params(dev_->ctx, dev_->width, dev_->height, max_bounces_, JPT_ACCUM_REF_LDR8, sampler_);
+        if (rc == JPT_OK) rc = jpt_set_debug_steps(dev_->ctx, debug_steps_ ? 1 : 0);
         if (rc != JPT_OK) {
             error_ = jpt_last_error(dev_->ctx);
             return;
@@ -284,6 +290,7 @@ class ComputeShader {
     bool progressive_, temporal_;
     bool ready_ = false;
     int max_bounces_ = 4, sampler_ = 0;
+    bool debug_steps_ = false;
     std::vector<std::pair<uint64_t, Slot>> slots_;
     std::vector<uint8_t> tex_;
     int tex_res_ = 0, tex_layers_ = 0;

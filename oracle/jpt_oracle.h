@@ -141,7 +141,10 @@ enum {
      * With this flag the walk ignores every internal box and every distance cull and applies exactly those two tests:
      * the image must equal the normal walk's (tests/test_oracle_render.py), which is what lets a DIFFERENT tree
      * reproduce the reference's image, "cracks" included (gdpathtracing_amd/csrc: reach records). */
-    JPTO_FLAG_REACH_ONLY = 2
+    JPTO_FLAG_REACH_ONLY = 2,
+    /* the shader's DEBUG_STEPS build (main.glsl:4,358-361,423-427; commented out as shipped): the image is
+     * clamp(triangle tests of the primary ray / 256) in all three channels, one ray per pixel, depth = far */
+    JPTO_FLAG_DEBUG_STEPS = 4
 };
 
 /* ---- builder (oracle_bvh.c) ---- */

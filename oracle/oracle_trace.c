@@ -526,6 +526,11 @@ static int ray_trace(ctx_t *cx, const ray_t *ray, shading_t *s)
     hit.steps = 0;
     cx->cnt.rays++;
     int is_hit = (cx->sc->n_tlas > 0 && cx->sc->n_inst > 0) ? ray_trace_tlas(cx, ray, &hit) : 0;
+    if (cx->flags & JPTO_FLAG_DEBUG_STEPS) {   /* #ifdef DEBUG_STEPS (M:358-361) */
+        float g = p_clamp((float)hit.steps / 256.0f, 0.0f, 1.0f);
+        s->emission = v3_make(g, g, g);
+        return 0;
+    }
     if (is_hit) {
         get_shading_data(cx, &hit, s);
         return 1;
@@ -620,7 +625,14 @@ static void trace_rows(const jpto_scene_view *scene, const jpto_camera *camera, 
             uint32_t seed[2];
             primary_ray(camera, width, height, px, py, &ray, seed);
             float depth = camera->far_;
-            v3 radiance = path_trace(&cx, ray, seed, &depth, camera->far_, max_bounces);
+            v3 radiance;
+            if (flags & JPTO_FLAG_DEBUG_STEPS) {   /* M:423-427: one ray_trace, its "emission" is the image; depth stays far */
+                shading_t s;
+                (void)ray_trace(&cx, &ray, &s);
+                radiance = s.emission;
+            } else {
+                radiance = path_trace(&cx, ray, seed, &depth, camera->far_, max_bounces);
+            }
             depth = camera->far_ / (camera->far_ - camera->near_) * (1.0f - camera->near_ / depth);
             size_t idx = (size_t)(py - row_base) * width + px;
             if (radiance_rgba) {

@@ -5,7 +5,7 @@
 // stand-ins of the godot-cpp types the adapter's traits name (godot-cpp is an absent submodule).  The host-side
 // arithmetic between the calls (camera block, frame_count, temporal delta matrix) is jpt_host.hpp's.
 //
-//   gdcs_adapter_test <scene.bin> <prefix> <w> <h> <frames> [mode: 0 progressive, 1 temporal, 2 none] [identity_camera: 0/1]
+//   gdcs_adapter_test <scene.bin> <prefix> <w> <h> <frames> [mode: 0 progressive, 1 temporal, 2 none] [identity_camera: 0/1] [debug_steps: 0/1]
 #include <jpt_gdcs_adapter.hpp>
 #include <jpt_host.hpp>
 
@@ -166,6 +166,7 @@ struct Machine {
     int width = 0, height = 0;
     float fov = 90.0f;
 
+    bool debug_steps = false;   // main.glsl built with its own `#define DEBUG_STEPS` (main.glsl:4)
     standin::Device device;  // the camera's local RenderingDevice: all three shaders are created on it
     std::unique_ptr<Shader> shader[3];
     std::map<int, standin::Rid> rid;  // What -> the RID its creating call returned
@@ -240,7 +241,8 @@ struct Machine {
             if (r.call != CONSTRUCT && !cs) return fail(r, "shader object missing");
             switch (r.call) {
                 case CONSTRUCT:
-                    if (r.pass == MAIN) cs.reset(new Shader(path_of(r.pass), &device, {"#define TESTe"}));
+                    if (r.pass == MAIN && debug_steps) cs.reset(new Shader(path_of(r.pass), &device, {"#define TESTe", "#define DEBUG_STEPS"}));
+                    else if (r.pass == MAIN) cs.reset(new Shader(path_of(r.pass), &device, {"#define TESTe"}));
                     else cs.reset(new Shader(path_of(r.pass), &device));
                     break;
                 case STORAGE: rid[r.what] = cs->create_storage_buffer_uniform(bytes_of(r.what), r.binding, r.set); break;
@@ -307,6 +309,7 @@ int main(int argc, char** argv)
     const int w = std::atoi(argv[3]), h = std::atoi(argv[4]), frames = std::atoi(argv[5]);
     const int mode = argc >= 7 ? std::atoi(argv[6]) : 0;
     const bool identity_camera = argc >= 8 && std::atoi(argv[7]) != 0;
+    const bool debug_steps = argc >= 9 && std::atoi(argv[8]) != 0;
     if (r.get<uint32_t>() != 0x5354504au) return 3;
     std::vector<std::unique_ptr<ArrayMesh>> meshes;
     for (uint32_t m = r.get<uint32_t>(); m > 0; m--) {
@@ -351,6 +354,7 @@ int main(int argc, char** argv)
     m.width = w;
     m.height = h;
     m.fov = fov;
+    m.debug_steps = debug_steps;
     const Projection projection = Projection::create_perspective(fov, float(w) / float(h), 0.01f, 1000.0f, false);  // (path_tracing_camera.cpp:134)
     m.camera.frame_index = 0;   // uninitialised in the reference (render_parameters.h:19)
     m.camera.set_camera_transform(camera_transform.affine_inverse(), projection);   // (path_tracing_camera.cpp:135; overwritten by the first frame)

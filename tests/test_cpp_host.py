@@ -242,6 +242,28 @@ def test_gdcs_adapter_when_the_first_camera_transform_is_the_identity(oracle, gd
 
 
 @pytest.mark.gpu
+def test_gdcs_adapter_debug_steps_define(oracle, gdcs_test):
+    """`new ComputeShader("...main.glsl", rd, {"#define DEBUG_STEPS"})`: the shader's own debug build through the adapter --
+    the uploaded arrays are then walked node for node, so the counts are the reference tree's: equal to the oracle's
+    DEBUG_STEPS render (progressive mode, three frames) bit for bit."""
+    exe, d = gdcs_test
+    sc = scenes.cornell_scene()
+    path = os.path.join(d, "c.jpts")
+    scenes.write_scene_file(sc, path)
+    w, h, frames = 80, 48, 3
+    out = subprocess.run([exe, path, os.path.join(d, "gs"), str(w), str(h), str(frames), "0", "0", "1"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    assert "tree %d" % capi.TREE_AS_GIVEN in out.stdout
+    cam = np.frombuffer(open(os.path.join(d, "gs_camera.bin"), "rb").read(), dtype=wire.CAMERA)[0]
+    got = np.frombuffer(open(os.path.join(d, "gs_accum.bin"), "rb").read(), dtype=np.float32).reshape(h, w, 4)
+    got_ldr = np.frombuffer(open(os.path.join(d, "gs_ldr.bin"), "rb").read(), dtype=np.uint8).reshape(h, w, 4)
+    ref = oracle.build_scene(sc)
+    want, want_ldr, _, _, _ = oracle.render(ref, cam, w, h, 4, frames, 1, wire.ACCUM_REF_LDR8, flags=4)
+    assert np.array_equal(got, want) and np.array_equal(got_ldr, want_ldr)
+    assert got[..., :3].max() > 0
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("denoise", [1, 2])
 def test_gdcs_adapter_other_denoising_modes(oracle, gdcs_test, denoise):
     """The adapter with a third ComputeShader on temporal_reprojection.glsl (TemporalReprojection::init/render call

@@ -557,3 +557,39 @@ def test_one_process_multi_device_gather_is_bit_identical(hiplib, world):
     assert m.ctx(1).stats()["frames"] == 6 and m.ctx(1).local_rows() == len(partition.rows_of_rank(h, 1, world))
     m.close()
     one.close()
+
+
+@pytest.mark.parametrize("route", ["upload as given", "exact", "native"])
+def test_debug_steps_mode(oracle, hiplib, route):
+    """jpt_set_debug_steps = main.glsl's DEBUG_STEPS build: the screen is the primary ray's triangle-test count / 256, through
+    the usual post-processing.  On the reference's own tree (as-given upload, reference-exact commit) the accumulated
+    image equals the oracle's DEBUG_STEPS render bit for bit, whatever kernel is selected (the audit kernel renders it); on
+    the native tree the counts are that tree's (fewer tests), and the mode switches back cleanly."""
+    sc = scenes.demo_scene(3000)
+    w, h, frames = 96, 54, 2
+    cam = scenes.camera_block(sc.camera, w, h)
+    ref = oracle.build_scene(sc)
+    want, want_ldr, _, cnt, _ = oracle.render(ref, cam, w, h, 4, frames, 1, wire.ACCUM_REF_LDR8, flags=4)
+    ctx = host.Context(0)
+    try:
+        if route == "upload as given":
+            ctx.upload_reference_layout(ref.tri_geom, ref.tri_data, ref.materials, ref.bvh_nodes, ref.instances, ref.tlas_nodes, as_given=True)
+        else:
+            ctx.build_scene(sc, capi.BUILD_REFERENCE_EXACT if route == "exact" else capi.BUILD_SAH)
+        ctx.set_params(w, h, 4, wire.ACCUM_REF_LDR8)
+        ctx.set_camera(cam)
+        ctx.set_debug_steps(True)
+        ctx.render(frames, 1, counted=True)
+        got, got_ldr, st = ctx.read_accum(), ctx.read_ldr(), ctx.stats()
+        if route != "native":
+            assert np.array_equal(got, want) and np.array_equal(got_ldr, want_ldr)
+            assert st["tri_tests"] == cnt["tri_tests"] and st["rays"] == w * h * frames
+        else:
+            assert got[..., :3].max() > 0 and st["tri_tests"] < cnt["tri_tests"]   # the native tree tests fewer triangles
+        ctx.set_debug_steps(False)
+        ctx.accum_reset()
+        ctx.render(frames, 1)
+        normal, _, _, _, _ = oracle.render(ref, cam, w, h, 4, frames, 1, wire.ACCUM_REF_LDR8)
+        assert rel_l2(ctx.read_accum(), normal) <= 1e-4
+    finally:
+        ctx.close()

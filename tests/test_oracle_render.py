@@ -129,3 +129,25 @@ def test_committed_fixtures(oracle, name):
     for k in ("accum", "ldr", "depth"):
         assert np.array_equal(got[k], want[k]), k
     assert int(got["rays"]) == int(want["rays"]) and int(got["n_nodes"]) == int(want["n_nodes"])
+
+
+def test_debug_steps_mode_counts_the_primary_rays_triangle_tests(oracle):
+    """main.glsl built with DEBUG_STEPS (main.glsl:4,358-361,423-427): the frame is clamp(hitInfo.steps / 256) per pixel --
+    steps = intersectTriangle calls of the PRIMARY ray --, one ray per pixel, depth = far.  The per-pixel counts add up to
+    the frame's triangle-test counter, and a scene with nothing in it gives black (0 tests)."""
+    sc = scenes.cornell_scene()
+    w, h = 48, 32
+    cam = scenes.camera_block(sc.camera, w, h)
+    ref = oracle.build_scene(sc)
+    rad, depth, cnt = oracle.trace_frame(ref, cam, w, h, 4, flags=4)
+    steps = rad[..., 0] * np.float32(256)
+    assert np.array_equal(steps, np.round(steps)) and np.array_equal(rad[..., 0], rad[..., 1]) and np.array_equal(rad[..., 0], rad[..., 2])
+    assert steps.max() < 256 and int(steps.sum()) == cnt["tri_tests"] > 0
+    assert cnt["rays"] == w * h and cnt["shaded_hits"] == 0                 # one ray per pixel, nothing shaded
+    far, near = np.float32(cam["far"]), np.float32(cam["near"])
+    assert np.all(depth == far / (far - near) * (np.float32(1) - near / far))   # depth stays camera.far
+    import copy
+    empty = copy.deepcopy(sc)
+    empty.instances = []
+    rad0, _, cnt0 = oracle.trace_frame(oracle.build_scene(empty), cam, w, h, 4, flags=4)
+    assert not rad0[..., :3].any() and cnt0["tri_tests"] == 0
