@@ -151,6 +151,7 @@ struct Wf2Dims {
     uint32_t seg_cap;          // entries per segment
     uint32_t run_shift;        // a segment is dealt runs of 2^run_shift consecutive chunks (neighbouring tiles of one frame)
     FastDiv by_tiles_x, by_tiles_per_frame, by_slots_per_frame, by_full_tiles_x;
+    FastDiv by_frames;         // (wf2_accumulate: item -> (pixel, frame))
 };
 
 __device__ __forceinline__ void slot_to_pixel(uint32_t slot, const Wf2Dims& dm, int& px, int& ly)
@@ -570,21 +571,26 @@ __global__ __launch_bounds__(kBlock) void wf2_accumulate(Wf2Buffers wb, Wf2Dims 
                                                          float4* __restrict__ accum, uint32_t* __restrict__ ldr,
                                                          float* __restrict__ depth_out)
 {
-    // one thread per pixel of the context's share of the image, tile by tile; `slot` is the pixel's place in the window
+    // one thread per pixel of the context's share of the image, tile by tile (a wave = one 8 x 8 tile); `slot` is the
+    // pixel's place in the window
+    constexpr int kSharedFrames = 16;                       // most frames per render the shared exact route below holds
+    __shared__ uint32_t s_who[kBlock / 64][64];            // per wave: the pixels that need it, px | py << 16
+    __shared__ uint32_t s_val[kBlock / 64][64 * kSharedFrames];   // ... and their frames' rgba8 sky values
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t full_slot = blockIdx.x * kBlock + threadIdx.x;
     const uint32_t ftile = full_slot >> 6, flane = full_slot & 63u;
     const uint32_t fty = fdiv(ftile, dm.by_full_tiles_x), ftx = ftile - fty * (uint32_t)dm.full_tiles_x;
-    if ((int)fty >= dm.full_tiles_y) return;
+    if ((int)fty >= dm.full_tiles_y) return;   // (the whole wave)
     const int px = (int)(ftx * 8u + (flane & 7u)), ly = (int)(fty * 8u + (flane >> 3));
-    if (px >= fp.width || ly >= fp.local_rows) return;
+    const bool valid = px < fp.width && ly < fp.local_rows;   // (lanes past the image's edge still help with the shared route)
     const int wtx = (int)ftx - dm.tile_x0, wty = (int)fty - dm.tile_y0;
     const bool in_window = wtx >= 0 && wtx < dm.tiles_x && wty >= 0 && wty < dm.tiles_y;
     const uint32_t slot = in_window ? ((uint32_t)wty * (uint32_t)dm.tiles_x + (uint32_t)wtx) * 64u + flane : 0u;
-    const size_t idx = (size_t)ly * fp.width + px;
+    const size_t idx = valid ? (size_t)ly * fp.width + px : 0;
     // fp.frame_count = ProgressiveRendering frame_count of the FIRST frame of this render
     f3 sum = mk3(0.0f, 0.0f, 0.0f);
     bool have_prev = fp.frame_count > 1;
-    if (have_prev) {
+    if (have_prev && valid) {
         const float4 prev = accum[idx];
         sum = mk3(prev.x, prev.y, prev.z);
     }
@@ -592,7 +598,7 @@ __global__ __launch_bounds__(kBlock) void wf2_accumulate(Wf2Buffers wb, Wf2Dims 
     // the primary launch neither traced nor stored the paths of a sky-culled pixel: their radiance is the sky along the
     // primary ray of (x, y, frame) (main.glsl:380,395-397 with throughput 1), made up here
     const int py = local_to_global_row(ly, fp);
-    const bool culled = !in_window || sky_culled(cull, px, py);
+    const bool culled = valid && (!in_window || sky_culled(cull, px, py));
     // A culled pixel's frames all see the sky, whose colour depends on the ray's d.y alone and changes by a hundredth of an
     // rgba8 step across a pixel: in REF_LDR8 mode nearly every pixel has ONE rgba8 sky value for all its frames.  The
     // jittered sample of a frame lies on the quarter circle (px + cos, py + sin), inside the pixel's square, so the four
@@ -604,17 +610,59 @@ __global__ __launch_bounds__(kBlock) void wf2_accumulate(Wf2Buffers wb, Wf2Dims 
     constexpr float kCellMargin = 0.01f;
     bool sky_constant = false;
     f3 sky_value = mk3(0.0f, 0.0f, 0.0f);
-    if (culled && fp.accum_mode == 0 && fp.n_frames > 1) {
+    // values * 255 + 0.5 of the sky along the ray through a raster position, per channel; false: the camera block does not
+    // behave there (the clip-space w changes sign against `w_ref`, or a NaN)
+    auto sky_cells_at = [&](float fx, float fy, float w_ref, float& w_out, float v[3]) -> bool {
+        const f3 d = raster_direction(cam, fp.width, fp.height, fx, fy, w_out);
+        const f3 c = mk3(0.0f, 0.0f, 0.0f) + mk3(1.0f, 1.0f, 1.0f) * sample_sky(d);
+        v[0] = clamp_(c.x, 0.0f, 1.0f) * 255.0f + 0.5f;
+        v[1] = clamp_(c.y, 0.0f, 1.0f) * 255.0f + 0.5f;
+        v[2] = clamp_(c.z, 0.0f, 1.0f) * 255.0f + 0.5f;
+        return (w_out * w_ref > 0.0f) && (d.y == d.y);   // (callers that compare the signs themselves pass w_ref = 1)
+    };
+    const bool want_cells = fp.accum_mode == 0 && fp.n_frames > 1;
+    // First for the whole TILE at once (a wave is one 8 x 8 tile, eight consecutive image rows): its four corner rays, one
+    // per lane group; when they agree on the cells, every culled pixel of the tile has that value.  (The same argument over
+    // eight pixels instead of one: the curvature term is 64 x larger, 5e-5 of a cell, still 200 x inside the margin.)
+    bool tile_constant = false;
+    if (want_cells && __any(culled)) {
+        const int tx0 = (int)ftx * 8, ty0 = local_to_global_row((int)fty * 8, fp);
+        float ww, v[3];
+        {   // (every lane evaluates one of the four corners: lanes 0..3 hold the four)
+            const int corner = lane & 3;
+            bool ok = sky_cells_at((float)(tx0 + 8 * (corner & 1)), (float)(ty0 + 8 * (corner >> 1)), 1.0f, ww, v);
+            ok = (ww == ww) && (v[0] == v[0]) && (ww * __shfl(ww, 0) > 0.0f);   // no NaN, and the four w of one sign
+            bool same = true;
+            f3 val;
+            float cellv[3];
+            for (int k = 0; k < 3; k++) {
+                const float a = __shfl(v[k], 0), b = __shfl(v[k], 1), c2 = __shfl(v[k], 2), d2 = __shfl(v[k], 3);
+                const float lo = fmin_(fmin_(a, b), fmin_(c2, d2)), hi = fmax_(fmax_(a, b), fmax_(c2, d2));
+                cellv[k] = __builtin_floorf(lo);
+                same = same && (lo - cellv[k] >= kCellMargin) && (hi - cellv[k] <= 1.0f - kCellMargin) && (hi - lo < 0.5f);
+            }
+            const unsigned long long okm = __ballot(ok);
+            same = same && ((okm & 0xfull) == 0xfull);
+            if (same) {
+                tile_constant = true;
+                val = mk3(from_unorm8((uint32_t)cellv[0]), from_unorm8((uint32_t)cellv[1]), from_unorm8((uint32_t)cellv[2]));
+                if (culled) {
+                    sky_constant = true;
+                    sky_value = val;
+                }
+            }
+        }
+    }
+    // ... then, in the tiles that straddle a cell boundary, pixel by pixel
+    if (culled && want_cells && !tile_constant) {
         float lo[3] = {1e30f, 1e30f, 1e30f}, hi[3] = {-1e30f, -1e30f, -1e30f};
         bool sane = true;
-        float w_first = 0.0f;
+        float w_first = 1.0f;
         for (int corner = 0; corner < 4; corner++) {
-            float ww;
-            const f3 d = raster_direction(cam, fp.width, fp.height, (float)(px + (corner & 1)), (float)(py + (corner >> 1)), ww);
+            float ww, v[3];
+            const bool ok = sky_cells_at((float)(px + (corner & 1)), (float)(py + (corner >> 1)), w_first, ww, v);
             if (corner == 0) w_first = ww;
-            sane = sane && (ww * w_first > 0.0f) && (d.y == d.y);
-            const f3 c = mk3(0.0f, 0.0f, 0.0f) + mk3(1.0f, 1.0f, 1.0f) * sample_sky(d);
-            const float v[3] = {clamp_(c.x, 0.0f, 1.0f) * 255.0f + 0.5f, clamp_(c.y, 0.0f, 1.0f) * 255.0f + 0.5f, clamp_(c.z, 0.0f, 1.0f) * 255.0f + 0.5f};
+            sane = sane && (corner == 0 ? (ww == ww) : ok);
             for (int k = 0; k < 3; k++) {
                 lo[k] = fmin_(lo[k], v[k]);
                 hi[k] = fmax_(hi[k], v[k]);
@@ -631,10 +679,46 @@ __global__ __launch_bounds__(kBlock) void wf2_accumulate(Wf2Buffers wb, Wf2Dims 
             sky_value = mk3(from_unorm8((uint32_t)cell[0]), from_unorm8((uint32_t)cell[1]), from_unorm8((uint32_t)cell[2]));
         }
     }
+    // The culled pixels that did not pass (near a cell boundary) need their frames' exact values -- eight primary rays
+    // each.  A wave runs that code for all 64 lanes as soon as ONE pixel of its tile needs it, frame after frame; instead
+    // the tile's (pixel, frame) pairs that need it are dealt to the wave's 64 lanes, one pair each, so a tile with eight
+    // such pixels makes one pass (64 pairs), not eight.  The values go through LDS to the pixel that sums them, in frame
+    // order.  (REF_LDR8, 2..kSharedFrames frames per render; otherwise every lane walks its own frames, as before.)
+    const bool shared_route = fp.accum_mode == 0 && fp.n_frames > 1 && fp.n_frames <= kSharedFrames;
+    const bool slow = culled && !sky_constant && shared_route;
+    uint32_t my_rank = 0;
+    {
+        const unsigned long long sm = __ballot(slow);
+        if (sm) {
+            my_rank = lanes_below(sm, lane);
+            if (slow) s_who[wave][my_rank] = (uint32_t)px | ((uint32_t)py << 16);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t total = (uint32_t)__popcll(sm) * (uint32_t)fp.n_frames;
+            for (uint32_t base = 0; base < total; base += 64u) {
+                const uint32_t item = base + (uint32_t)lane;
+                if (item < total) {
+                    const uint32_t p = fdiv(item, dm.by_frames), f = item - p * (uint32_t)fp.n_frames;
+                    const uint32_t who = s_who[wave][p];
+                    uint32_t sx, sy;
+                    const Ray ray = primary_ray(cam, fp.width, fp.height, (int)(who & 0xffffu), (int)(who >> 16), fp.frame_index + f, sx, sy);
+                    const f3 c = mk3(0.0f, 0.0f, 0.0f) + mk3(1.0f, 1.0f, 1.0f) * sample_sky(ray.d);
+                    s_val[wave][item] = unorm8(c.x) | (unorm8(c.y) << 8) | (unorm8(c.z) << 16);   // rgba8 store of main.glsl:434
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    if (!valid) return;
     for (int f = 0; f < fp.n_frames; f++) {
         f3 cur;
         if (sky_constant) {
             cur = sky_value;
+            last = cur;
+        } else if (slow) {   // rgba8 load of progressive_rendering.glsl:33
+            const uint32_t q = s_val[wave][my_rank * (uint32_t)fp.n_frames + (uint32_t)f];
+            cur = mk3(from_unorm8(q & 255u), from_unorm8((q >> 8) & 255u), from_unorm8((q >> 16) & 255u));
             last = cur;
         } else if (culled) {
             uint32_t sx, sy;
@@ -736,6 +820,7 @@ Wf2Dims make_dims(int width, int local_rows, int n_frames, const TileWindow& win
     dm.by_tiles_x = make_fastdiv((uint32_t)dm.tiles_x);
     dm.by_tiles_per_frame = make_fastdiv(dm.tiles_per_frame);
     dm.by_slots_per_frame = make_fastdiv(dm.slots_per_frame);
+    dm.by_frames = make_fastdiv((uint32_t)(n_frames > 0 ? n_frames : 1));
     return dm;
 }
 

@@ -18,7 +18,7 @@ for seed in range(int(os.environ.get('FUZZ_FROM', '8')), int(os.environ.get('FUZ
     for route in ("upload","exact"):
         for kernel in (capi.KERNEL_WAVEFRONT, capi.KERNEL_REFERENCE_LAYOUT):
             print("  ", route, kernel, flush=True); ctx = host.Context(0); ctx.set_kernel(kernel)
-            if route=="upload": ctx.upload_reference_layout(ref.tri_geom,ref.tri_data,ref.materials,ref.bvh_nodes,ref.instances,ref.tlas_nodes,ref.textures)
+            if route=="upload": ctx.upload_reference_layout(ref.tri_geom,ref.tri_data,ref.materials,ref.bvh_nodes,ref.instances,ref.tlas_nodes,ref.textures,as_given=True)   # node for node: ties too
             else: ctx.build_scene(sc, capi.BUILD_REFERENCE_EXACT)
             ctx.set_params(w,h,b,mode); ctx.set_camera(cam)
             ctx.render(f,1+seed,asynchronous=(seed%4==1)); 
@@ -28,10 +28,15 @@ for seed in range(int(os.environ.get('FUZZ_FROM', '8')), int(os.environ.get('FUZ
     if seed%3==0:
         # native tree with reach records against the oracle's reach-only mode (every triangle tested + the two reach tests),
         # native tree alone against the tree-independent mode; in both accumulation modes, blocking and queued
-        for builder, flags in ((capi.BUILD_SAH, 2), (capi.BUILD_SAH_WATERTIGHT, 1)):
+        for builder, flags in ((capi.BUILD_SAH, 2), (capi.BUILD_SAH_WATERTIGHT, 1), ("upload", 2)):   # "upload": route (i) on the native tree
             amode = (seed // 3) % 2
             wantn,wln,wdn,_,_ = ob.render(ref,cam,w,h,b,f,1+seed,amode,flags=flags)
-            ctx = host.Context(0); ctx.build_scene(sc, builder); ctx.set_params(w,h,b,amode); ctx.set_camera(cam)
+            ctx = host.Context(0)
+            if builder == "upload":
+                ctx.upload_reference_layout(ref.tri_geom,ref.tri_data,ref.materials,ref.bvh_nodes,ref.instances,ref.tlas_nodes,ref.textures)
+                assert ctx.tree_kind() == capi.TREE_NATIVE_REACH, ctx.upload_note()
+            else: ctx.build_scene(sc, builder)
+            ctx.set_params(w,h,b,amode); ctx.set_camera(cam)
             ctx.render(f,1+seed,asynchronous=(seed%2==1)); ctx.sync()
             got=ctx.read_accum(); gd=ctx.read_depth(); ctx.close()
             m = ~(np.isnan(got).any(-1)|np.isnan(wantn).any(-1))
