@@ -27,6 +27,7 @@ void RefScene::clear()
     mesh_ref_root.clear();
     up_mesh_root.clear();
     up_blas_index.clear();
+    exact.clear();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -171,15 +172,20 @@ struct ExactBlasBuilder {
 
 // The reference's builder on a copy of one mesh: by_original[i] = box of the reference leaf that ends up holding
 // triangle i of the mesh (`always` when that leaf is the root), root = the reference root's box.
-void reference_leaf_boxes(const std::vector<RefTriangle>& mesh_tris, std::vector<ReachTri>& by_original, ReachInst& root)
+// nodes_out: that tree (indices relative to its root = 0, first_tri_index relative to the mesh's first triangle);
+// order_out[k] = which triangle of the mesh ends up at position k of the reference's order.
+void reference_leaf_boxes(const std::vector<RefTriangle>& mesh_tris, std::vector<ReachTri>& by_original, ReachInst& root,
+                          std::vector<RefBvhNode>& nodes, std::vector<uint32_t>& order_out)
 {
     std::vector<RefTriangle> copy(mesh_tris);
     for (size_t i = 0; i < copy.size(); i++) copy[i]._pad = (uint32_t)i;  // travels with the triangle through the partition swaps
-    std::vector<RefBvhNode> nodes;
+    nodes.clear();
     nodes.reserve(copy.size());
     ExactBlasBuilder eb{nodes, copy};
     (void)eb.build(0, (int)copy.size());
     by_original.assign(copy.size(), ReachTri{});
+    order_out.resize(copy.size());
+    for (size_t k = 0; k < copy.size(); k++) order_out[k] = copy[k]._pad;
     std::memset(&root, 0, sizeof root);
     if (nodes.empty()) return;
     root.root_lo[0] = nodes[0].aabbMin.x; root.root_lo[1] = nodes[0].aabbMin.y; root.root_lo[2] = nodes[0].aabbMin.z;
@@ -710,6 +716,27 @@ bool SceneBuilder::rebuild_instances(BuildMode mode, RefScene& out, std::string&
         for (const PendingInstance& pi : instances_) out.reach_inst.push_back(reach_instance(pi.t12, out.mesh_ref_root[pi.mesh]));
     if (is_native(mode) ? !build_tlas_sah(out.instances, out.tlas_nodes, err) : !build_tlas(out.instances, out.tlas_nodes, err))
         return false;
+    // the shadow's instance level: the records and the TLAS the reference itself would make (bvh.h:81-115, bvh.cpp:264-317)
+    ExactShadow& x = out.exact;
+    x.instances.clear();
+    x.tlas_nodes.clear();
+    x.valid = false;
+    if (mode == BuildMode::Sah && x.mesh_roots.size() == meshes_.size()) {
+        for (const PendingInstance& pi : instances_) {
+            RefInstance inst;
+            std::memset(&inst, 0, sizeof inst);
+            inst.blas_index = x.mesh_roots[pi.mesh];
+            for (int k = 0; k < 3; k++) inst.material[k] = pi.mats[k];
+            const RefBvhNode& root = x.bvh_nodes[inst.blas_index];
+            instance_record(pi.t12, root.aabbMin, root.aabbMax, /*pad_box*/ false, inst);
+            x.instances.push_back(inst);
+        }
+        std::string xerr;
+        x.valid = build_tlas(x.instances, x.tlas_nodes, xerr);
+        x.tri_geom.resize(out.triangles.size());
+        x.tri_native.resize(out.triangles.size(), 0xffffffffu);
+        x.finish(out.triangles.size());
+    }
     return true;
 }
 
@@ -731,9 +758,11 @@ bool SceneBuilder::commit(BuildMode mode, RefScene& out, std::string& err)
                 // to learn which leaf box holds which triangle and what the root box is
                 std::vector<ReachTri> by_original;
                 ReachInst ref_root;
+                std::vector<RefBvhNode> ref_nodes;
+                std::vector<uint32_t> ref_order;
                 std::future<void> reach;
                 if (mode == BuildMode::Sah)
-                    reach = std::async(std::launch::async, [&] { reference_leaf_boxes(pm.tris, by_original, ref_root); });
+                    reach = std::async(std::launch::async, [&] { reference_leaf_boxes(pm.tris, by_original, ref_root, ref_nodes, ref_order); });
                 SahBlasBuilder b{out.bvh_nodes, out.triangles};
                 b.prepare(start, end);
                 root = b.build(0, end - start);
@@ -744,12 +773,39 @@ bool SceneBuilder::commit(BuildMode mode, RefScene& out, std::string& err)
                     for (int i = 0; i < end - start; i++) out.reach_tri[(size_t)(start + i)] = by_original[b.order[(size_t)i]];
                     out.mesh_ref_root.resize(out.mesh_roots.size() + 1);
                     out.mesh_ref_root.back() = ref_root;
+                    // the shadow: the reference's tree of this mesh, its triangle order, and where each of its triangles
+                    // sits in the native order
+                    ExactShadow& x = out.exact;
+                    const uint32_t noff = (uint32_t)x.bvh_nodes.size();
+                    for (RefBvhNode n : ref_nodes) {
+                        if (n.tri_count == 0) {
+                            n.left_child += noff;
+                            n.right_child += noff;
+                        } else {
+                            n.first_tri_index += (uint32_t)start;
+                        }
+                        x.bvh_nodes.push_back(n);
+                    }
+                    std::vector<uint32_t> native_pos((size_t)(end - start));
+                    for (int i = 0; i < end - start; i++) native_pos[b.order[(size_t)i]] = (uint32_t)(start + i);
+                    x.tri_geom.resize((size_t)end);
+                    x.tri_native.resize((size_t)end, 0xffffffffu);
+                    for (int k = 0; k < end - start; k++) {
+                        const RefTriangle& t = pm.tris[ref_order[(size_t)k]];
+                        for (int j = 0; j < 3; j++) x.tri_geom[(size_t)(start + k)].vertices[j] = t.vertices[j];
+                        x.tri_native[(size_t)(start + k)] = native_pos[ref_order[(size_t)k]];
+                    }
+                    x.mesh_roots.push_back(noff);
                 }
             }
         } else {
             if (mode == BuildMode::Sah) {
                 out.mesh_ref_root.resize(out.mesh_roots.size() + 1);
                 std::memset(&out.mesh_ref_root.back(), 0, sizeof(ReachInst));
+                RefBvhNode n;
+                std::memset(&n, 0, sizeof n);
+                out.exact.mesh_roots.push_back((uint32_t)out.exact.bvh_nodes.size());
+                out.exact.bvh_nodes.push_back(n);
             }
             // BuildBVH on an empty mesh returns 0 (bvh.cpp:111-112); keep a valid empty leaf instead
             root = (uint32_t)out.bvh_nodes.size();
@@ -896,6 +952,10 @@ bool native_instances_from_uploaded(const std::vector<RefInstance>& up_inst, con
     out.reach_inst = std::move(reach);
     out.tlas_nodes = std::move(tlas);
     out.up_blas_index = std::move(up_index);
+    // the shadow's instance level is the uploaded one
+    out.exact.instances = up_inst;
+    out.exact.tlas_nodes = up_tlas;
+    if (out.exact.valid) out.exact.finish(out.triangles.size());   // (a TLAS update of an uploaded scene; the upload itself finishes below)
     return true;
 }
 
@@ -910,6 +970,7 @@ bool native_from_uploaded(const RefScene& up, RefScene& out, std::string& why)
     }
     std::vector<uint8_t> node_seen(nn, 0);
     std::vector<uint32_t> tri_leaf(nt, kNone);  // the uploaded leaf that holds each triangle
+    std::vector<uint32_t> up_to_native(nt, kNone);
     for (const RefInstance& in : up.instances) {
         const uint32_t up_root = in.blas_index;
         if (std::find(out.up_mesh_root.begin(), out.up_mesh_root.end(), up_root) != out.up_mesh_root.end()) continue;
@@ -989,6 +1050,7 @@ bool native_from_uploaded(const RefScene& up, RefScene& out, std::string& why)
             b.apply_order(start, end);
             out.reach_tri.resize((size_t)end);
             for (int i = 0; i < end - start; i++) {
+                up_to_native[mesh_tris[b.order[(size_t)i]]] = (uint32_t)(start + i);
                 const uint32_t leaf = tri_leaf[mesh_tris[b.order[(size_t)i]]];
                 const RefBvhNode& ln = up.bvh_nodes[leaf];
                 ReachTri r;
@@ -1015,6 +1077,13 @@ bool native_from_uploaded(const RefScene& up, RefScene& out, std::string& why)
     }
     out.reach_tri.resize(out.triangles.size());
     if (!native_instances_from_uploaded(up.instances, up.tlas_nodes, out, why)) return false;
+    // the shadow: the uploaded trees themselves, and where each uploaded triangle sits in the native order
+    out.exact.bvh_nodes = up.bvh_nodes;
+    out.exact.tri_geom = up.tri_geom;
+    out.exact.tri_native = std::move(up_to_native);
+    out.exact.mesh_roots = out.up_mesh_root;
+    out.exact.valid = true;
+    out.exact.finish(out.triangles.size());
     split_triangles(out);
     out.materials = up.materials;
     out.textures = up.textures;
@@ -1228,6 +1297,91 @@ bool flatten(const RefScene& ref, WideScene& out, std::string& err)
         return false;
     }
     return true;
+}
+
+// the index arrays of the restricted walk (jpt_builder.h); `resolvable` stays false when the trees are not in the shape
+// the walk indexes -- BLAS subtrees numbered in pre-order (left child = parent + 1: what bvh.cpp:108-185 emits), every
+// instance in exactly one TLAS leaf reachable from slot 0
+void ExactShadow::finish(size_t n_native)
+{
+    resolvable = false;
+    native_ref.assign(n_native, 0xffffffffu);
+    tri_leaf.assign(tri_geom.size(), 0xffffffffu);
+    subtree_end.assign(bvh_nodes.size(), 0u);
+    tlas_parent.assign(tlas_nodes.size(), 0xffffffffu);
+    inst_tlas_leaf.assign(instances.size(), 0xffffffffu);
+    if (!valid) return;
+    for (size_t t = 0; t < tri_native.size(); t++)
+        if (tri_native[t] < n_native) native_ref[tri_native[t]] = (uint32_t)t;
+    // BLAS: pre-order check and subtree ends, one explicit-stack pass per root
+    std::vector<uint8_t> done(bvh_nodes.size(), 0);
+    for (uint32_t root : mesh_roots) {
+        if (root >= bvh_nodes.size()) return;
+        if (done[root]) continue;
+        std::vector<uint32_t> open;   // nodes whose subtree is being numbered
+        uint32_t next = root;         // the id the next visited node must have
+        std::vector<uint32_t> todo{root};
+        while (!todo.empty()) {
+            const uint32_t n = todo.back();
+            todo.pop_back();
+            if (n != next || n >= bvh_nodes.size() || done[n]) return;   // not pre-order
+            done[n] = 1;
+            next++;
+            const RefBvhNode& node = bvh_nodes[n];
+            if (node.tri_count > 0) {
+                for (uint32_t k = 0; k < node.tri_count; k++) {
+                    const size_t t = (size_t)node.first_tri_index + k;
+                    if (t >= tri_leaf.size()) return;
+                    tri_leaf[t] = n;
+                }
+            } else if (!(node.left_child == 0 && node.right_child == 0)) {
+                if (node.left_child != n + 1) return;
+                todo.push_back(node.right_child);
+                todo.push_back(node.left_child);
+            }
+        }
+        // ends: a node's subtree ends where the next node that is not its descendant begins; in pre-order that is the
+        // right sibling of the nearest ancestor-or-self that is a left child, else the end of the root's range
+        std::vector<std::pair<uint32_t, uint32_t>> st{{root, next}};
+        while (!st.empty()) {
+            const uint32_t n = st.back().first, e = st.back().second;
+            st.pop_back();
+            subtree_end[n] = e;
+            const RefBvhNode& node = bvh_nodes[n];
+            if (node.tri_count == 0 && !(node.left_child == 0 && node.right_child == 0)) {
+                if (!(node.right_child > node.left_child && node.right_child < e)) return;
+                st.emplace_back(node.left_child, node.right_child);
+                st.emplace_back(node.right_child, e);
+            }
+        }
+    }
+    // TLAS: parents and the leaf of every instance
+    if (!instances.empty()) {
+        if (tlas_nodes.empty()) return;
+        std::vector<uint32_t> todo{0u};
+        tlas_parent[0] = 0u;
+        std::vector<uint8_t> seen(tlas_nodes.size(), 0);
+        while (!todo.empty()) {
+            const uint32_t n = todo.back();
+            todo.pop_back();
+            if (seen[n]) return;
+            seen[n] = 1;
+            const RefTlasNode& node = tlas_nodes[n];
+            if (node.leftRight == 0u) {
+                if (node.blas >= instances.size() || inst_tlas_leaf[node.blas] != 0xffffffffu) return;
+                inst_tlas_leaf[node.blas] = n;
+                continue;
+            }
+            const uint32_t l = node.leftRight & 0xffffu, r = node.leftRight >> 16;
+            if (l >= tlas_nodes.size() || r >= tlas_nodes.size()) return;
+            tlas_parent[l] = tlas_parent[r] = n;
+            todo.push_back(r);
+            todo.push_back(l);
+        }
+        for (uint32_t leaf : inst_tlas_leaf)
+            if (leaf == 0xffffffffu) return;
+    }
+    resolvable = true;
 }
 
 namespace {

@@ -26,6 +26,38 @@ struct SurfaceView {  // one ArrayMesh surface (bvh.cpp:192-198)
     int32_t n_vertices, n_indices;
 };
 
+// The reference's OWN trees, kept beside a native scene ("shadow").  Of two triangles at exactly the same distance the
+// reference keeps the one its walk tests LATER (`t > hitInfo.t` rejects, main.glsl:247), and a box entered at exactly
+// hitInfo.t is not entered at all (:290): which triangle survives an exact tie is a property of the reference's visiting
+// order, which a native tree does not have.  The native walk flags such hits; wf2_finish then repeats the reference's walk
+// -- its nodes, its order, its arithmetic -- restricted to the ANCESTORS of the leaves that hold the tying triangles
+// (everything else can only contribute farther hits, which never keep a box that holds a tying triangle from being
+// entered), and takes what that walk keeps.  On route (ii) the trees come from the run of the reference's builder that also
+// yields the reach records; on route (i) they are the uploaded arrays themselves.
+struct ExactShadow {
+    std::vector<RefBvhNode> bvh_nodes;
+    std::vector<RefTriGeometry> tri_geom;   // in the reference's triangle order
+    std::vector<uint32_t> tri_native;       // reference triangle -> the same triangle's index in the native order (~0u: none)
+    std::vector<RefInstance> instances;     // the reference's records (blas_index into bvh_nodes above)
+    std::vector<RefTlasNode> tlas_nodes;
+    std::vector<uint32_t> mesh_roots;       // per unique mesh: its root in bvh_nodes
+    // derived by finish() -- what the restricted walk needs to tell ancestors from the rest:
+    std::vector<uint32_t> native_ref;       // native triangle -> reference triangle
+    std::vector<uint32_t> tri_leaf;         // reference triangle -> the BVH node (a leaf) that holds it
+    std::vector<uint32_t> subtree_end;      // per BVH node: one past the last node of its subtree (the trees are in pre-order)
+    std::vector<uint32_t> tlas_parent;      // per TLAS node reachable from slot 0: its parent (slot 0: itself)
+    std::vector<uint32_t> inst_tlas_leaf;   // per instance: its TLAS leaf
+    bool valid = false;                     // trees present ...
+    bool resolvable = false;                // ... and in the shape finish() can index (pre-order BLASes, every instance in one TLAS leaf)
+    void clear()
+    {
+        bvh_nodes.clear(); tri_geom.clear(); tri_native.clear(); instances.clear(); tlas_nodes.clear(); mesh_roots.clear();
+        native_ref.clear(); tri_leaf.clear(); subtree_end.clear(); tlas_parent.clear(); inst_tlas_leaf.clear();
+        valid = resolvable = false;
+    }
+    void finish(size_t n_native_triangles);
+};
+
 // Scene in the reference layout: exactly the vectors GeometryGroup3D keeps (geometry_group3d.h:40-60).
 struct RefScene {
     std::vector<RefTriangle> triangles;       // builder-internal (empty after a reference-layout upload)
@@ -48,6 +80,7 @@ struct RefScene {
     // BLASInstance records against
     std::vector<uint32_t> up_mesh_root;
     std::vector<uint32_t> up_blas_index;
+    ExactShadow exact;                        // BuildMode::Sah and native uploads
     void clear();
 };
 

@@ -86,6 +86,12 @@ struct jpt_ctx {
     DevBuf<WideInstance> d_winst, d_winst4;
     DevBuf<WideNode4> d_nodes4;   // four-child records: BLAS part, then room for the TLAS part (one index space)
     DevBuf<WideNodeQ> d_nodesq;   // their quantised form (jpt_nodeq.h), same indices: what the kernels walk
+    // the reference's own trees beside a native scene (ExactShadow): two-child records + the triangle map
+    DevBuf<RefBvhNode> d_x_bvh;
+    DevBuf<RefTriGeometry> d_x_tri_geom;
+    DevBuf<RefInstance> d_x_inst;
+    DevBuf<RefTlasNode> d_x_tlas;
+    DevBuf<uint32_t> d_x_tri_native, d_x_native_ref, d_x_tri_leaf, d_x_subtree_end, d_x_tlas_parent, d_x_inst_leaf;
     DevBuf<ReachTri> d_reach_tri;   // reach records (JPT_BUILD_SAH): per triangle / per instance (one per copy of the instance level)
     DevBuf<ReachInst> d_reach_inst;
     BuildMode build_mode = BuildMode::ReferenceExact;
@@ -284,6 +290,44 @@ int upload_nodes4(jpt_ctx* c, bool tlas_only)
     return JPT_OK;
 }
 
+// The shadow (the reference's own trees beside a native scene, ExactShadow) -> the device, for jpt_tie_walk.h.
+// `instances_only`: the BLAS part is there already (a TLAS update).  Not having a shadow is not an error: exact distance
+// ties are then decided by the order of the native walk.
+int upload_shadow(jpt_ctx* c, bool instances_only)
+{
+    TieShadowDev& d = c->ds.x;
+    d.ok = false;
+    const ExactShadow& x = c->ref.exact;
+    if (!tuning().exact_shadow || !x.valid || !x.resolvable || !c->native_tree || c->ref.reach_tri.empty() || c->device < 0 || x.instances.empty())
+        return JPT_OK;
+    hipStream_t s = c->stream;
+    if (!instances_only) {
+        HIP_TRY(c, c->d_x_bvh.upload(x.bvh_nodes, s));
+        HIP_TRY(c, c->d_x_tri_geom.upload(x.tri_geom, s));
+        HIP_TRY(c, c->d_x_tri_native.upload(x.tri_native, s));
+        HIP_TRY(c, c->d_x_native_ref.upload(x.native_ref, s));
+        HIP_TRY(c, c->d_x_tri_leaf.upload(x.tri_leaf, s));
+        HIP_TRY(c, c->d_x_subtree_end.upload(x.subtree_end, s));
+    }
+    HIP_TRY(c, c->d_x_inst.upload(x.instances, s));
+    HIP_TRY(c, c->d_x_tlas.upload(x.tlas_nodes, s));
+    HIP_TRY(c, c->d_x_tlas_parent.upload(x.tlas_parent, s));
+    HIP_TRY(c, c->d_x_inst_leaf.upload(x.inst_tlas_leaf, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    d.bvh = c->d_x_bvh.p;
+    d.tri_geom = c->d_x_tri_geom.p;
+    d.instances = c->d_x_inst.p;
+    d.tlas = c->d_x_tlas.p;
+    d.tri_native = c->d_x_tri_native.p;
+    d.native_ref = c->d_x_native_ref.p;
+    d.tri_leaf = c->d_x_tri_leaf.p;
+    d.subtree_end = c->d_x_subtree_end.p;
+    d.tlas_parent = c->d_x_tlas_parent.p;
+    d.inst_tlas_leaf = c->d_x_inst_leaf.p;
+    d.ok = true;
+    return JPT_OK;
+}
+
 // host RefScene (+ flatten) -> device
 int upload_scene(jpt_ctx* c)
 {
@@ -373,6 +417,10 @@ int upload_scene(jpt_ctx* c)
     d.n_tlas_nodes = (uint32_t)c->wide.tlas_nodes.size();
     d.use4 = use4;
     d.wide_instances4 = c->d_winst4.p;
+    {
+        const int rcx = upload_shadow(c, false);
+        if (rcx != JPT_OK) return rcx;
+    }
     c->scene_ready = true;
     return JPT_OK;
 }
@@ -1236,7 +1284,7 @@ int upload_tlas_update(jpt_ctx* c)
     d.tlas_root = c->wide.tlas_root;
     d.n_tlas_nodes = (uint32_t)c->wide.tlas_nodes.size();
     d.wide_instances4 = c->d_winst4.p;
-    return JPT_OK;
+    return upload_shadow(c, true);
 }
 
 }  // namespace
@@ -1395,6 +1443,7 @@ int jpt_scene_refit_tlas(jpt_ctx* c, const float* transforms12, uint32_t n_insta
         c->cull_boxes_current = false;
     }
     c->refit_active = true;
+    c->ds.x.ok = false;   // the shadow's instance level is the last host update's: set-aside paths are finished on the native tree until the next one
     c->stats.last_build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return JPT_OK;
 }

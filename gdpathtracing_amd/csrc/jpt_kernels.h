@@ -35,6 +35,21 @@ struct FrameParams {
     int32_t debug_steps = 0;    // the shader's DEBUG_STEPS build (main.glsl:358-361,423-427): audit kernel only
 };
 
+// device view of ExactShadow (jpt_builder.h)
+struct TieShadowDev {
+    const RefBvhNode* __restrict__ bvh = nullptr;
+    const RefTriGeometry* __restrict__ tri_geom = nullptr;   // reference order
+    const RefInstance* __restrict__ instances = nullptr;
+    const RefTlasNode* __restrict__ tlas = nullptr;
+    const uint32_t* __restrict__ tri_native = nullptr;       // reference triangle -> native triangle
+    const uint32_t* __restrict__ native_ref = nullptr;       // native triangle -> reference triangle
+    const uint32_t* __restrict__ tri_leaf = nullptr;         // reference triangle -> its leaf node
+    const uint32_t* __restrict__ subtree_end = nullptr;      // BVH node -> one past its subtree (pre-order numbering)
+    const uint32_t* __restrict__ tlas_parent = nullptr;
+    const uint32_t* __restrict__ inst_tlas_leaf = nullptr;
+    bool ok = false;
+};
+
 // All device-resident scene data of a context.
 struct DeviceScene {
     // reference layout (drop-in route + cold shading data)
@@ -65,6 +80,10 @@ struct DeviceScene {
     // reach records (jpt_types.h): null unless the scene was committed with JPT_BUILD_SAH
     const ReachTri* reach_tri = nullptr;
     const ReachInst* reach_inst = nullptr;
+    // the reference's own trees beside a native scene (ExactShadow, jpt_builder.h): what wf2_finish decides exact distance
+    // ties on (jpt_tie_walk.h).  x.ok false: not available (a watertight scene, a device refit since the last host update,
+    // uploaded trees that are not numbered in pre-order) -- ties are then left to the order of the native walk.
+    TieShadowDev x;
 
     SceneShading shading() const
     {
@@ -78,6 +97,7 @@ struct DeviceScene {
         s.sampler_mode = sampler_mode;
         s.reach_tri = reach_tri;
         s.reach_inst = reach_inst;
+        s.retrace_ties = x.ok && reach_tri != nullptr;
         s.tex_res = tex_res;
         s.n_layers = n_layers;
         return s;

@@ -23,6 +23,7 @@
 #include <cstdlib>
 
 #include "jpt_trace_core.h"
+#include "jpt_tie_walk.h"
 #include "jpt_tuning.h"
 
 // the primary kernel carries the ray set-up and the sky-cull test besides the walk: 74 VGPRs on its own.  Round 1 (float
@@ -418,6 +419,9 @@ __device__ __forceinline__ bool shade_entry(const SceneShading& sh, const Wf2Buf
         if (check) {
             bool reached = __float_as_uint(ta.w) != 0u || slab(h.lo, rcp3(h.ld), ta.x, ta.y, ta.z, tb.x, tb.y, tb.z) < 1e30f;
             if (reached && sh.n_instances > 1u) reached = slab(ray.o, rcp3(ray.d), ia.x, ia.y, ia.z, ib.x, ib.y, ib.z) < 1e30f;
+            // (an exact distance tie is as undecidable on the native tree as a crack: with the reference's trees at hand
+            // it is decided where the reference decides it)
+            if (sh.retrace_ties && (hb & kHitTied) != 0u) reached = false;
             if (!reached) {
                 // a few paths in 10^7: the path leaves the wavefront here and is finished, exactly, by wf2_finish -- unless
                 // the set-aside buffer is full (pathological scenes): then the hit is shaded as found, and counted
@@ -527,17 +531,24 @@ __global__ __launch_bounds__(kBlock, JPT_SHADE_WAVES) void wf2_shade(SceneShadin
 // the closest hit among the triangles the reference can reach, i.e. the reference's answer) and shaded bounce after
 // bounce by the same shade_entry, its state passing through the path's own thr / rad words.  A handful of paths per
 // render, so one small grid of single-wave blocks with the whole stack in scratch; one launch per render.
-template <bool COUNT, bool W4>
-__global__ __launch_bounds__(64) void wf2_finish(WideSceneDev sc, SceneShading sh, Wf2Buffers wb, Wf2Dims dm, FrameParams fp, float cam_far,
+template <bool COUNT, bool W4, bool EXACT>
+__global__ __launch_bounds__(64) void wf2_finish(WideSceneDev sc, TieShadowDev sx, SceneShading sh, Wf2Buffers wb, Wf2Dims dm, FrameParams fp, float cam_far,
                                                  DevCounters* __restrict__ counters)
 {
     const uint32_t n = wb.redo_count[0] < wb.redo_cap ? wb.redo_count[0] : wb.redo_cap;
-    if (blockIdx.x * 64u >= n) return;
+    if (blockIdx.x >= n) return;
     constexpr int kDepth = kStackLds + kStackSpill;
     int32_t stack_mem[kDepth];
-    const typename Traversal<COUNT, W4, true>::Stack st{nullptr, stack_mem, 0, 0, kDepth};
+    // Every segment of a set-aside path is traced on the native tree with the two reach tests applied inside the walk: the
+    // closest hit among the triangles the reference can reach.  EXACT (`sx` = the reference's own trees): when that walk
+    // met a second reachable triangle at exactly the closest distance, the tie is decided where the reference decides it
+    // (jpt_tie_walk.h).
+    using Walk = Traversal<COUNT, W4, true>;
+    const typename Walk::Stack st{nullptr, stack_mem, 0, 0, kDepth};
     DevCounters cnt = {};
-    for (uint32_t k = blockIdx.x * 64u + threadIdx.x; k < n; k += gridDim.x * 64u) {
+    // (records are dealt to the BLOCKS first -- record k to block k % grid, lane k / grid: a handful of set-aside paths run as
+    // one lane each of as many waves, side by side, instead of as divergent lanes of one wave, one after another)
+    for (uint32_t k = threadIdx.x * gridDim.x + blockIdx.x; k < n; k += gridDim.x * 64u) {
         float4 ro = wb.redo_rec[2 * (size_t)k], rd = wb.redo_rec[2 * (size_t)k + 1];
         const int first = (int)__float_as_uint(ro.w);
         float4 tin = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
@@ -546,14 +557,27 @@ __global__ __launch_bounds__(64) void wf2_finish(WideSceneDev sc, SceneShading s
             tin = wb.thr[__float_as_uint(rd.w) & kPathMask];
         }
         for (int bounce = first;; bounce++) {
-            Traversal<COUNT, W4, true> tr;
-            tr.begin(sc, mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z));
+            const f3 o3 = mk3(ro.x, ro.y, ro.z), d3 = mk3(rd.x, rd.y, rd.z);
+            Walk tr;
+            tr.begin(sc, o3, d3);
             while (tr.step(sc, st, cnt)) {
+            }
+            TraceHit hit = tr.hit;
+            if (EXACT && hit.t < 1e9f && (hit.inst & kHitTied) != 0u) {
+                TieLeaves tl;
+                tie_leaves<COUNT, W4>(sc, sx, st, o3, d3, hit.t, tl, cnt);
+                TraceHit xh;
+                if (!tl.overflow && tl.n > 0 && tie_walk(sx, tl, o3, d3, xh) && xh.t == hit.t) {
+                    // (xh.t differs only if a float accident kept the reference's walk from the tying leaves: then the native
+                    // walk's answer stands)
+                    hit = xh;
+                    hit.tri = sx.tri_native[xh.tri];   // shading and reach records are in the native order
+                }
             }
             // (the ray-segment count the host reads is the sum of the queue sizes: this path's later segments are in no queue)
             if (bounce > first) atomicAdd(&wb.qcount[(size_t)bounce * kSegments], 1u);
-            const float4 ha = make_float4(tr.hit.t, tr.hit.u, tr.hit.v, __uint_as_float(tr.hit.tri));
-            const uint32_t hb = tr.hit.inst | (tr.hit.front ? 0x80000000u : 0u);
+            const float4 ha = make_float4(hit.t, hit.u, hit.v, __uint_as_float(hit.tri));
+            const uint32_t hb = (hit.inst & ~kHitTied) | (hit.front ? 0x80000000u : 0u);
             bool unreachable;
             float4 no, nd, nt;
             if (!shade_entry<COUNT>(sh, wb, dm, fp, cam_far, bounce, ro, rd, tin, ha, hb, false, unreachable, no, nd, nt, cnt)) break;
@@ -861,14 +885,15 @@ static void group_frames(int n_frames, int groups, int g, int& first, int& count
     count = base + (g < extra ? 1 : 0);
 }
 
-// Set-aside records per group: a path is set aside at most once, and a handful per render are (float cracks of the
-// reference's boxes): 1/64 of the paths, at least 4096, instead of one 32-byte record per path (0.5 GB per pipeline slot
-// at C3).  Overflow is counted, not silent: jpt_stats.set_aside_dropped.
+// Set-aside records per group: a path is set aside at most once, and few are (float cracks of the reference's boxes: a
+// handful per render; exact distance ties: rare outside scenes built of coincident geometry): 1/64 of the paths, at least
+// 65 536 (2 MB) and never more than the paths, instead of one 32-byte record per path (0.5 GB per pipeline slot at C3).
+// Overflow is counted, not silent: jpt_stats.set_aside_dropped.
 static uint32_t redo_capacity(size_t paths)
 {
     if (tuning().set_aside_cap >= 0) return (uint32_t)std::min<size_t>((size_t)tuning().set_aside_cap, paths);   // (tests)
-    const size_t c = paths / 64u;
-    return (uint32_t)(c < 4096u ? 4096u : (c > 0x7fffffffu ? 0x7fffffffu : c));
+    const size_t c = std::min(paths, std::max<size_t>(paths / 64u, 65536u));
+    return (uint32_t)(c > 0x7fffffffu ? 0x7fffffffu : c);
 }
 
 size_t wf2_workspace_bytes(int width, int local_rows, int n_frames, int max_bounces)
@@ -1016,14 +1041,18 @@ void launch_wf2_render(hipStream_t stream, const DeviceScene& ds, const FramePar
             }
             if (ev) (void)hipEventRecord(ev[2 * (b + 1) + 1], st);
         }
-        if (sh.reach_tri && tuning().reach == 2) {  // the paths set aside because the reference cannot reach their hit: finished exactly
-            const dim3 rgrid(64), rblock(64);   // (blocks past the set-aside count exit at once; more records than threads: grid-stride)
-            if (counters) {
-                if (w4) hipLaunchKernelGGL((wf2_finish<true, true>), rgrid, rblock, 0, st, sc, sh, wb, dm, gp, cam.far_, counters);
-                else hipLaunchKernelGGL((wf2_finish<true, false>), rgrid, rblock, 0, st, sc, sh, wb, dm, gp, cam.far_, counters);
+        if (sh.reach_tri && tuning().reach == 2) {  // the paths set aside because their hit is undecidable on the native tree: finished exactly
+            const dim3 rgrid(256), rblock(64);   // (blocks past the set-aside count exit at once; more records than threads: grid-stride)
+            const TieShadowDev& sx = ds.x;
+            if (sx.ok && w4) {
+                if (counters) hipLaunchKernelGGL((wf2_finish<true, true, true>), rgrid, rblock, 0, st, sc, sx, sh, wb, dm, gp, cam.far_, counters);
+                else hipLaunchKernelGGL((wf2_finish<false, true, true>), rgrid, rblock, 0, st, sc, sx, sh, wb, dm, gp, cam.far_, counters);
+            } else if (counters) {
+                if (w4) hipLaunchKernelGGL((wf2_finish<true, true, false>), rgrid, rblock, 0, st, sc, sx, sh, wb, dm, gp, cam.far_, counters);
+                else hipLaunchKernelGGL((wf2_finish<true, false, false>), rgrid, rblock, 0, st, sc, sx, sh, wb, dm, gp, cam.far_, counters);
             } else {
-                if (w4) hipLaunchKernelGGL((wf2_finish<false, true>), rgrid, rblock, 0, st, sc, sh, wb, dm, gp, cam.far_, counters);
-                else hipLaunchKernelGGL((wf2_finish<false, false>), rgrid, rblock, 0, st, sc, sh, wb, dm, gp, cam.far_, counters);
+                if (w4) hipLaunchKernelGGL((wf2_finish<false, true, false>), rgrid, rblock, 0, st, sc, sx, sh, wb, dm, gp, cam.far_, counters);
+                else hipLaunchKernelGGL((wf2_finish<false, false, false>), rgrid, rblock, 0, st, sc, sx, sh, wb, dm, gp, cam.far_, counters);
             }
         }
     };

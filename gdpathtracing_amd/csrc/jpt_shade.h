@@ -37,6 +37,8 @@ struct SceneShading {  // cold, once-per-hit data: kept in the reference layout
     const uint8_t* __restrict__ tex;
     const ReachTri* __restrict__ reach_tri;    // reach records (jpt_types.h), null when the scene has none
     const ReachInst* __restrict__ reach_inst;
+    bool retrace_ties;                         // the reference's own trees are on the device: a hit the walk flagged as an exact
+                                               // distance tie is set aside and traced again on them (wf2_finish)
     uint32_t n_materials, n_instances;
     int32_t tex_res, n_layers;
     int32_t sampler_mode;  // JPT_SAMPLER_*: bit 0 repeat, bit 1 linear

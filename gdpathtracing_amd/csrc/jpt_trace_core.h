@@ -59,6 +59,11 @@ __device__ __forceinline__ float slab(const f3& o, const f3& rD, float mnx, floa
 // 246-252).  The two differ only after a tie between instances.
 constexpr int kInstBits = 15;
 constexpr uint32_t kInstMask = (1u << kInstBits) - 1u;
+// Bit 30: the triangle kept has EXACTLY the distance of a triangle found before it (four-child records).  Which of the two
+// the reference keeps depends on the order of ITS walk (`t > hitInfo.t` rejects, so the later test wins, main.glsl:247; and a
+// box entered at exactly hitInfo.t is not entered, :290): the native walk cannot know, it only says so.  Cleared when a
+// strictly closer triangle is found.
+constexpr uint32_t kHitTied = 1u << 30;
 
 struct TraceHit {
     float t, u, v;
@@ -316,7 +321,7 @@ struct Traversal {
                 // before the branch so that the record stays three 16-byte loads: inside it the compiler splits them.)
                 if (!out) {
                     const bool closer = t < hit.t;
-                    hit.inst = ((closer ? cur_inst : hit.inst) & kInstMask) | (cur_inst << kInstBits);
+                    hit.inst = ((closer ? cur_inst : hit.inst) & kInstMask) | (cur_inst << kInstBits) | (closer ? 0u : kHitTied);
                     hit.t = t;
                     hit.u = u;
                     hit.v = v;
@@ -366,6 +371,13 @@ struct Traversal {
             if (sc.n_instances > 1u) {
                 const float4 a = ld4(&sc.reach_inst[cur_inst].lo[0]), b = ld4(&sc.reach_inst[cur_inst].hi[0]);
                 if (!(slab(wo, wrD, a.x, a.y, a.z, b.x, b.y, b.z) < 1e30f)) {
+                    // not entered: the next record off the stack may be a TLAS record, whose box tests read the current-level
+                    // ray -- which pop_next left as the PREVIOUS instance's local ray, counting on this entry to replace it
+                    if (kLean) {
+                        o = wo;
+                        d = wd;
+                        set_level();
+                    }
                     have = false;
                     return;
                 }

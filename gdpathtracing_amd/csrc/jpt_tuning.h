@@ -26,6 +26,8 @@ struct Tuning {
     int trace_chain = 0;           // JPT_TRACE_CHAIN=1..4: segments per block of the tracing launches (0: the library's rule)
     int max_leaf = 2;              // JPT_MAX_LEAF: native builder leaf size
     bool upload_as_given = false;  // JPT_UPLOAD_WALK=given: reference-layout uploads are walked node for node as uploaded (audits)
+    bool exact_shadow = true;      // JPT_EXACT_SHADOW=0: no copy of the reference's trees beside a native scene (set-aside paths are
+                                   // finished on the native tree with the reach tests inside the walk; exact ties not re-traced)
     long set_aside_cap = -1;       // JPT_SET_ASIDE_CAP: records of the set-aside buffer (-1: the library's rule; tests force 0)
     int reach = 2;                 // JPT_REACH=0: ignore the reach records; 1: check but never redo (timing experiments only)
 };
@@ -56,6 +58,7 @@ inline const Tuning& tuning()
         v.trace_chain = geti("JPT_TRACE_CHAIN", 0);
         v.max_leaf = geti("JPT_MAX_LEAF", 2);
         v.reach = geti("JPT_REACH", 2);
+        v.exact_shadow = geti("JPT_EXACT_SHADOW", 1) != 0;
         if (const char* e = std::getenv("JPT_SET_ASIDE_CAP")) v.set_aside_cap = std::atol(e);
         if (const char* e = std::getenv("JPT_UPLOAD_WALK")) v.upload_as_given = e[0] == 'g' || e[0] == 'G';
         if (v.max_leaf < 1) v.max_leaf = 1;

@@ -116,9 +116,11 @@ typedef struct {
                                   rectangles of the TLAS root's boxes); they ARE counted in `rays` and `tlas_expand`, as the
                                   reference expands the root for them, but no record is fetched */
     double   last_primary_ms;  /* kernel timing on: the bounce-0 launch alone (last_trace_ms = all traversal launches) */
-    uint64_t set_aside;        /* blocking renders on a native tree with reach records: path vertices whose hit the reference's
-                                  traversal cannot reach (a crack of its boxes), finished exactly after the last bounce */
-    uint64_t set_aside_dropped;/* ... of which: more than the set-aside buffer holds (1/64 of the paths, at least 4096) -- those
+    uint64_t set_aside;        /* blocking renders on a native tree with reach records: path vertices whose hit is undecidable on
+                                  the native tree -- the reference's traversal cannot reach it (a crack of its boxes), or
+                                  another triangle lies at exactly the same distance --, traced again on the reference's own
+                                  trees after the last bounce */
+    uint64_t set_aside_dropped;/* ... of which: more than the set-aside buffer holds (1/64 of the paths, at least 65 536) -- those
                                   were shaded as found (the native tree's closest hit: the image differs from the reference's
                                   in those pixels).  0 on every scene measured; a scene that reports more renders exactly with
                                   JPT_KERNEL_REFERENCE_LAYOUT or JPT_UPLOAD_WALK_AS_GIVEN / JPT_BUILD_REFERENCE_EXACT */

@@ -143,3 +143,40 @@ def test_native_tree_with_reach_records_answers_like_the_reference(oracle, hipli
     assert np.array_equal(nan_got, nan_want)
     assert ndiff == 0
     assert rel_l2(got[ok2], walk[ok2]) <= 1e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("route", ["commit", "upload"])
+@pytest.mark.parametrize("seed", SEEDS)
+def test_native_tree_against_the_reference_walk_with_coincident_triangles(oracle, hiplib, seed, route):
+    """Soups WITH coincident triangles: exact distance ties everywhere, where `t > hitInfo.t` rejects and the later-tested
+    triangle wins (main.glsl:247) -- the order of the reference's own walk decides.  The native walk flags every hit that ties
+    with an earlier one, and wf2_finish decides those on the reference's own trees (kept beside the native ones), walking
+    only the ancestors of the tying leaves (jpt_tie_walk.h): the native routes land on the oracle's NORMAL walk of the
+    reference tree, bit for bit -- not only on its order-free modes.  (Seed 2, pixel (41, 50), is also the regression test
+    of a walk that kept the previous instance's local ray after a rejected instance entry.)"""
+    sc = scenes.random_scene(seed, coincident=True)
+    w, h, bounces, frames = 96, 64, 3, 2
+    cam = scenes.camera_block(sc.camera, w, h)
+    ref = oracle.build_scene(sc)
+    want, _, want_depth, _, _ = oracle.render(ref, cam, w, h, bounces, frames, 1, wire.ACCUM_HDR_F32)
+    ctx = host.Context(0)
+    try:
+        if route == "upload":
+            ctx.upload_reference_layout(ref.tri_geom, ref.tri_data, ref.materials, ref.bvh_nodes, ref.instances, ref.tlas_nodes, ref.textures)
+        else:
+            ctx.build_scene(sc, capi.BUILD_SAH)
+        ctx.set_params(w, h, bounces, wire.ACCUM_HDR_F32)
+        ctx.set_camera(cam)
+        ctx.render(frames, 1)
+        got, got_depth, st = ctx.read_accum(), ctx.read_depth(), ctx.stats()
+    finally:
+        ctx.close()
+    nan_got, nan_want = np.isnan(got).any(axis=-1), np.isnan(want).any(axis=-1)
+    ok = ~(nan_got | nan_want)
+    ndiff = int((got[ok] != want[ok]).any(axis=-1).sum())
+    print("coincident soup", seed, route, "set aside", st["set_aside"], "dropped", st["set_aside_dropped"], "differing pixels", ndiff,
+          "rel_l2", rel_l2(got[ok], want[ok]))
+    assert st["set_aside_dropped"] == 0
+    assert np.array_equal(nan_got, nan_want)
+    assert ndiff == 0

@@ -237,12 +237,12 @@ def test_other_baseline_configs_at_full_size(oracle, hiplib, config):
     got = fast.read_accum()
     ys, xs = np.nonzero((got != want).any(axis=-1))
     err = rel_l2(got, want)
-    print(config, "native tree + reach records: differing pixels", len(ys), "rel_l2", err)
+    print(config, "native tree + reach records: differing pixels", len(ys), "rel_l2", err, "set aside", fast.stats()["set_aside"])
     assert err <= 1e-4
-    # C2: identical.  C4 (1 024 instances, 25.9 M rays): what remains beside the cracks is the order of the walk -- exact
-    # distance ties between different triangles, and the `d < hitInfo.t` culls (a box skipped because another triangle at
-    # nearly the same distance was found first) -- one pixel in the last bits of one sample
-    assert len(ys) <= (0 if config == "C2" else 2), "pixels %s differ from the reference tree's image" % list(zip(xs.tolist(), ys.tolist()))[:8]
+    # Identical, C4 (1 024 instances, 25.9 M rays) included: beside the cracks its image depends on the ORDER of the
+    # reference's walk -- exact distance ties between different triangles -- and those few dozen vertices are decided on the
+    # reference's own trees (jpt_tie_walk.h; one pixel differed before)
+    assert len(ys) == 0, "pixels %s differ from the reference tree's image" % list(zip(xs.tolist(), ys.tolist()))[:8]
     assert fast.stats()["rays"] == cnt["rays"] or config != "C2"
     fast.close()
     # The same through the drop-in route (reference-layout upload -> native tree + reach records from the uploaded boxes)
@@ -251,8 +251,7 @@ def test_other_baseline_configs_at_full_size(oracle, hiplib, config):
     got = up.read_accum()
     ys, xs = np.nonzero((got != want).any(axis=-1))
     print(config, "reference-layout upload on the native tree: differing pixels", len(ys), "rel_l2", rel_l2(got, want))
-    assert rel_l2(got, want) <= 1e-4
-    assert len(ys) <= (0 if config == "C2" else 2), "pixels %s differ from the reference tree's image" % list(zip(xs.tolist(), ys.tolist()))[:8]
+    assert len(ys) == 0, "pixels %s differ from the reference tree's image" % list(zip(xs.tolist(), ys.tolist()))[:8]
     up.close()
     # The native builder ALONE (JPT_BUILD_SAH_WATERTIGHT) does not reproduce the cracks: it differs from the reference
     # in those pixels and only there, and its value is the tree-independent answer -- the oracle with every box
@@ -531,19 +530,25 @@ def test_unique_triangle_scene_reduced(oracle, hiplib):
 
 def test_unique_triangle_scene_full_size(oracle, hiplib):
     """S-unique at 1 000 012 unique triangles (~110 MB of flattened records: past L2, inside the Infinity Cache),
-    1920x1080, 2 spp, 4 bounces.  Properties: a 2-way partition reproduces the whole image; the audit kernel agrees bit
-    for bit; a band of rows equals the oracle walking the reference tree of the same million triangles; every pixel's
-    first ray hits (the camera sits in the box opening), so the depth image holds no `far`."""
+    1920x1080, 2 spp, 4 bounces.  Properties: a 2-way partition reproduces the whole image; the audit kernel agrees (bit for
+    bit but for the handful of pixels where two triangles tie exactly: the default kernel decides those on the reference's
+    own trees, the audit kernel walks the native tree alone); a band of rows equals the oracle walking the reference tree
+    of the same million triangles; every pixel's first ray hits (the camera sits in the box opening), so the depth
+    image holds no `far`."""
     sc = scenes.unique_scene()
     assert sc.n_unique_tris > 1_000_000
     w, h, spp, b = 1920, 1080, 2, 4
     ctx = make_ctx(sc, w, h, b, wire.ACCUM_REF_LDR8)
     ctx.render(spp, 1)
     full, depth, rays = ctx.read_accum(), ctx.read_depth(), ctx.stats()["rays"]
+    aside = ctx.stats()["set_aside"]
     ctx.set_kernel(capi.KERNEL_REFERENCE_LAYOUT)
     ctx.accum_reset()
     ctx.render(spp, 1)
-    assert np.array_equal(ctx.read_accum(), full)
+    audit = ctx.read_accum()
+    ndiff = int((audit != full).any(axis=-1).sum())
+    print("unique scene: set aside", aside, "| pixels where the audit kernel (native tree alone) differs", ndiff, "rel_l2", rel_l2(audit, full))
+    assert ndiff <= aside   # (every such pixel is a path the default kernel finished on the reference's trees; the oracle comparison is below)
     ctx.close()
     assert rays > 2.2 * w * h * spp                     # paths go on bouncing inside the box
     cam = scenes.camera_block(sc.camera, w, h)

@@ -415,13 +415,20 @@ def test_duplicated_instance_keeps_the_first_visited_one(oracle, hiplib, kernel)
     cam = scenes.camera_block(sc.camera, w, h)
     ref = oracle.build_scene(sc)
     want, want_ldr, want_depth, cnt, _ = oracle.render(ref, cam, w, h, bounces, frames, 1, wire.ACCUM_HDR_F32)
-    for route in ("upload", "exact"):
+    # which instance wins an exact tie depends on the visiting order: the reference's trees node for node ("upload",
+    # "exact") -- or, on the native routes of the default kernel, the re-trace of every hit the walk flags as tied on the
+    # reference's own trees, which are kept beside the native ones
+    routes = ("upload", "exact") + (("native upload", "native commit") if kernel == capi.KERNEL_WAVEFRONT else ())
+    for route in routes:
         ctx = host.Context(0)
         try:
             ctx.set_kernel(kernel)
             if route == "upload":
-                # (which instance wins an exact tie depends on the visiting order: the uploaded trees, node for node)
                 ctx.upload_reference_layout(ref.tri_geom, ref.tri_data, ref.materials, ref.bvh_nodes, ref.instances, ref.tlas_nodes, as_given=True)
+            elif route == "native upload":
+                ctx.upload_reference_layout(ref.tri_geom, ref.tri_data, ref.materials, ref.bvh_nodes, ref.instances, ref.tlas_nodes)
+            elif route == "native commit":
+                ctx.build_scene(sc, capi.BUILD_SAH)
             else:
                 ctx.build_scene(sc, capi.BUILD_REFERENCE_EXACT)
             ctx.set_params(w, h, bounces, wire.ACCUM_HDR_F32)
@@ -431,7 +438,10 @@ def test_duplicated_instance_keeps_the_first_visited_one(oracle, hiplib, kernel)
         finally:
             ctx.close()
         assert np.array_equal(got, want), route
-        assert st["shaded_hits"] == cnt["shaded_hits"] and st["tri_tests"] == cnt["tri_tests"]
+        if not route.startswith("native"):
+            assert st["shaded_hits"] == cnt["shaded_hits"] and st["tri_tests"] == cnt["tri_tests"]
+        else:
+            assert st["set_aside"] > 0 and st["set_aside_dropped"] == 0   # the ties were found and re-traced
 
 
 @pytest.mark.parametrize("kernel", KERNELS)
@@ -453,13 +463,20 @@ def test_tie_between_instances_with_different_transforms(oracle, hiplib, kernel)
     camb = scenes.camera_block(sc.camera, w, h)
     ref = oracle.build_scene(sc)
     want, want_ldr, want_depth, cnt, _ = oracle.render(ref, camb, w, h, bounces, frames, 1, wire.ACCUM_HDR_F32)
-    for route in ("upload", "exact"):
+    # which instance wins an exact tie depends on the visiting order: the reference's trees node for node ("upload",
+    # "exact") -- or, on the native routes of the default kernel, the re-trace of every hit the walk flags as tied on the
+    # reference's own trees, which are kept beside the native ones
+    routes = ("upload", "exact") + (("native upload", "native commit") if kernel == capi.KERNEL_WAVEFRONT else ())
+    for route in routes:
         ctx = host.Context(0)
         try:
             ctx.set_kernel(kernel)
             if route == "upload":
-                # (which instance wins an exact tie depends on the visiting order: the uploaded trees, node for node)
                 ctx.upload_reference_layout(ref.tri_geom, ref.tri_data, ref.materials, ref.bvh_nodes, ref.instances, ref.tlas_nodes, as_given=True)
+            elif route == "native upload":
+                ctx.upload_reference_layout(ref.tri_geom, ref.tri_data, ref.materials, ref.bvh_nodes, ref.instances, ref.tlas_nodes)
+            elif route == "native commit":
+                ctx.build_scene(sc, capi.BUILD_SAH)
             else:
                 ctx.build_scene(sc, capi.BUILD_REFERENCE_EXACT)
             ctx.set_params(w, h, bounces, wire.ACCUM_HDR_F32)

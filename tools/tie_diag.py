@@ -1,0 +1,29 @@
+# where a coincident-triangle soup still differs from the oracle's walk of the reference tree: per bounce count and route
+import os, sys; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from gdpathtracing_amd import capi, host, scenes, wire
+from oracle import binding as ob
+seed = int(os.environ.get("SEED", "2"))
+sc = scenes.random_scene(seed, coincident=True)
+w, h = 96, 64
+cam = scenes.camera_block(sc.camera, w, h)
+ref = ob.build_scene(sc)
+only = os.environ.get("ONLY")   # e.g. commit,1,1
+for route in ("commit", "upload"):
+    for bounces in (0, 1, 2, 3):
+        for frames in (1, 2):
+            if only and only != "%s,%d,%d" % (route, bounces, frames): continue
+            want, _, wd, _, _ = ob.render(ref, cam, w, h, bounces, frames, 1, wire.ACCUM_HDR_F32)
+            ctx = host.Context(0)
+            if route == "upload": ctx.upload_reference_layout(ref.tri_geom, ref.tri_data, ref.materials, ref.bvh_nodes, ref.instances, ref.tlas_nodes, ref.textures)
+            else: ctx.build_scene(sc, capi.BUILD_SAH)
+            ctx.set_params(w, h, bounces, wire.ACCUM_HDR_F32); ctx.set_camera(cam); ctx.render(frames, 1)
+            got, gd, st = ctx.read_accum(), ctx.read_depth(), ctx.stats(); ctx.close()
+            ok = ~(np.isnan(got).any(-1) | np.isnan(want).any(-1))
+            bad = ok & (got != want).any(-1)
+            ys, xs = np.nonzero(bad.reshape(h, w)) if bad.ndim == 1 else np.nonzero(bad)
+            print(route, "bounces", bounces, "frames", frames, "set aside", st["set_aside"], "differing", int(bad.sum()), list(zip(xs.tolist(), ys.tolist()))[:4],
+                  "depth differs", int((~np.isclose(gd, wd, rtol=0, atol=0, equal_nan=True)).sum()), flush=True)
+            if bad.sum():
+                g = got.reshape(h, w, 4); ww = want.reshape(h, w, 4)
+                for x, y in list(zip(xs.tolist(), ys.tolist()))[:2]: print("   ", (x, y), g[y, x], ww[y, x])
