@@ -538,7 +538,7 @@ __global__ __launch_bounds__(64) void wf2_finish(WideSceneDev sc, TieShadowDev s
     const uint32_t n = wb.redo_count[0] < wb.redo_cap ? wb.redo_count[0] : wb.redo_cap;
     if (blockIdx.x >= n) return;
     constexpr int kDepth = kStackLds + kStackSpill;
-    int32_t stack_mem[kDepth];
+    int32_t stack_mem[kDepth];   // (the whole stack in scratch; in LDS instead: no difference, profiles/r03/r03z_finish_probe.txt)
     // Every segment of a set-aside path is traced on the native tree with the two reach tests applied inside the walk: the
     // closest hit among the triangles the reference can reach.  EXACT (`sx` = the reference's own trees): when that walk
     // met a second reachable triangle at exactly the closest distance, the tie is decided where the reference decides it
