@@ -26,7 +26,7 @@ BUF_TRI_GEOMETRY, BUF_TRI_DATA, BUF_MATERIALS, BUF_BVH_NODES, BUF_INSTANCES, BUF
 
 # every symbol include/jpt.h declares
 SYMBOLS = [
-    "jpt_abi_version", "jpt_create", "jpt_destroy", "jpt_last_error", "jpt_set_stream", "jpt_get_stream", "jpt_set_stream_priority",
+    "jpt_abi_version", "jpt_create", "jpt_destroy", "jpt_last_error", "jpt_set_stream", "jpt_get_stream", "jpt_set_stream_priority", "jpt_set_memory_policy", "jpt_get_workspace_bytes",
     "jpt_scene_upload_reference_layout", "jpt_set_upload_mode", "jpt_scene_tree_kind", "jpt_scene_upload_note", "jpt_scene_begin", "jpt_scene_add_mesh", "jpt_scene_add_instance",
     "jpt_scene_set_materials", "jpt_scene_set_textures", "jpt_scene_commit", "jpt_scene_get_reference_buffer",
     "jpt_scene_set_instance_transform", "jpt_scene_update_tlas", "jpt_scene_refit_tlas", "jpt_scene_update_reference_tlas",
@@ -104,6 +104,8 @@ def lib():
     L.jpt_set_stream.argtypes = [vp, vp]
     L.jpt_get_stream.argtypes = [vp, C.POINTER(vp)]
     L.jpt_set_stream_priority.argtypes = [vp, i32]
+    L.jpt_set_memory_policy.argtypes = [vp, i32, C.c_uint64]
+    L.jpt_get_workspace_bytes.argtypes = [vp, C.POINTER(C.c_uint64)]
     L.jpt_scene_upload_reference_layout.argtypes = [vp, vp, u32, vp, vp, u32, vp, u32, vp, u32, vp, u32, vp, i32, i32]
     L.jpt_set_upload_mode.argtypes = [vp, i32]
     L.jpt_scene_tree_kind.argtypes = [vp]

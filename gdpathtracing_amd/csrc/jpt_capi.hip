@@ -68,6 +68,8 @@ struct jpt_ctx {
     bool from_commit = false;       // the scene came from jpt_scene_commit: c->builder holds its meshes and transforms
     int32_t upload_mode = JPT_UPLOAD_NATIVE_TREE;  // jpt_set_upload_mode
     int32_t slot_priority = JPT_STREAM_PRIORITY_DEFAULT;  // jpt_set_stream_priority
+    int32_t max_slots = 0;              // jpt_set_memory_policy: renders in flight (0: the library's rule)
+    uint64_t workspace_budget = 0;      // ... and bytes per workspace (0: tuning().workspace_budget_mb)
     std::string upload_note;        // why the last reference-layout upload is walked as given (empty: it is not)
     std::vector<RefMaterial> pending_materials;
     std::vector<uint8_t> pending_tex;
@@ -547,7 +549,7 @@ int do_render_batch(jpt_ctx* c, int32_t n_frames, uint32_t first_frame_index, bo
 // frames of one wavefront render that fit the workspace budget (all frames of a batch are in flight at once)
 int32_t frames_per_batch(const jpt_ctx* c, int32_t n_frames)
 {
-    const size_t budget = (size_t)tuning().workspace_budget_mb << 20;
+    const size_t budget = c->workspace_budget ? (size_t)c->workspace_budget : (size_t)tuning().workspace_budget_mb << 20;
     if (c->kernel_variant == JPT_KERNEL_REFERENCE_LAYOUT || c->debug_steps || n_frames <= 1) return n_frames;
     const size_t one = wf2_workspace_bytes(c->width, c->local_rows, 1, c->max_bounces);
     const size_t fit = std::max<size_t>(1, budget / std::max<size_t>(one, 1));
@@ -742,7 +744,8 @@ int do_render_batch(jpt_ctx* c, int32_t n_frames, uint32_t first_frame_index, bo
             const bool pipelining = tuning().pipelining;
             // renders in flight (JPT_PIPE_SLOTS overrides): a render is eleven dependent launches of >= 25-30 us each
             // however little work it holds, so several of them are needed to fill the chip
-            const int forced_slots = [] {
+            const int forced_slots = [c] {
+                if (c->max_slots > 0) return c->max_slots;   // the embedding application's cap (jpt_set_memory_policy)
                 const int k = tuning().pipe_slots;
                 return k <= 0 ? 0 : (k < 2 ? 2 : (k > jpt_ctx::kPipeSlots ? jpt_ctx::kPipeSlots : k));
             }();
@@ -791,7 +794,7 @@ int do_render_batch(jpt_ctx* c, int32_t n_frames, uint32_t first_frame_index, bo
                 // 3840x2160x16 spp 11.56 ms against 11.96 with two groups, instanced scene 3.80 against 4.05)
                 Wf2Async one_group = c->async;
                 one_group.aux_stream[0] = nullptr;
-                one_group.trace_chain = huge ? 1 : 4;
+                one_group.trace_chain = (huge || pipe_slots == 1) ? 1 : 4;   // (a single render in flight: full-width launches)
                 const bool acc_on_slot = tuning().acc_on_slot;
                 if (acc_on_slot) {
                     // The accumulation runs on the slot's stream too, after whatever `s` holds now (the previous render's
@@ -1036,6 +1039,40 @@ int jpt_set_stream_priority(jpt_ctx* c, int32_t priority)
         }
         c->acc_done_valid[k] = false;
     }
+    return JPT_OK;
+}
+
+int jpt_set_memory_policy(jpt_ctx* c, int32_t renders_in_flight, uint64_t workspace_budget_bytes)
+{
+    if (!c) return JPT_E_INVALID;
+    if (renders_in_flight < 0 || renders_in_flight > jpt_ctx::kPipeSlots) return fail(c, JPT_E_INVALID, "renders_in_flight must be 0 (the library's rule) or 1..4");
+    c->max_slots = renders_in_flight;
+    c->workspace_budget = workspace_budget_bytes;
+    if (c->device < 0) return JPT_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    // drain, then give back what the new policy no longer allows: the workspaces of slots past the cap, and any workspace
+    // larger than the new budget (the next render allocates what it needs)
+    for (int k = 0; k < jpt_ctx::kPipeSlots; k++)
+        if (c->pipe_stream[k]) HIP_TRY(c, hipStreamSynchronize(c->pipe_stream[k]));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    const int keep = renders_in_flight > 0 ? renders_in_flight : jpt_ctx::kPipeSlots;
+    for (int k = 0; k < jpt_ctx::kPipeSlots; k++) {
+        DevBuf<char>& w = k ? c->d_workspace_more[k - 1] : c->d_workspace;
+        if (k >= keep || (workspace_budget_bytes && w.n > workspace_budget_bytes)) {
+            w.release();
+            c->acc_done_valid[k] = false;
+        }
+    }
+    c->async_seq = 0;   // the next queued render starts at slot 0 again
+    return JPT_OK;
+}
+
+int jpt_get_workspace_bytes(jpt_ctx* c, uint64_t* bytes_out)
+{
+    if (!c || !bytes_out) return JPT_E_INVALID;
+    uint64_t n = c->d_workspace.n;
+    for (int k = 0; k + 1 < jpt_ctx::kPipeSlots; k++) n += c->d_workspace_more[k].n;
+    *bytes_out = n;
     return JPT_OK;
 }
 

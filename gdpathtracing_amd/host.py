@@ -96,6 +96,16 @@ class Context:
             _ptr(arrs[4]), len(arrs[4]), _ptr(arrs[5]), len(arrs[5]), _ptr(tex),
             0 if tex is None else tex.shape[1], 0 if tex is None else tex.shape[0]), "jpt_scene_upload_reference_layout")
 
+    def set_memory_policy(self, renders_in_flight: int = 0, workspace_budget_bytes: int = 0):
+        """Cap on the device memory spent on renders in flight: 1..4 workspaces (0: the library's rule) and the most bytes
+        one workspace may take (0: 24 GiB) -- jpt_set_memory_policy."""
+        self._ck(self._lib.jpt_set_memory_policy(self.h, renders_in_flight, workspace_budget_bytes), "jpt_set_memory_policy")
+
+    def workspace_bytes(self) -> int:
+        n = C.c_uint64(0)
+        self._ck(self._lib.jpt_get_workspace_bytes(self.h, C.byref(n)), "jpt_get_workspace_bytes")
+        return int(n.value)
+
     def set_stream_priority(self, priority: int):
         """capi.STREAM_PRIORITY_*: the priority level of the streams queued renders run on (jpt_set_stream_priority)."""
         self._ck(self._lib.jpt_set_stream_priority(self.h, priority), "jpt_set_stream_priority")

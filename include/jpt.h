@@ -162,6 +162,20 @@ int jpt_get_stream(jpt_ctx *ctx, void **hip_stream);
 enum { JPT_STREAM_PRIORITY_DEFAULT = 0, JPT_STREAM_PRIORITY_NORMAL = 1, JPT_STREAM_PRIORITY_HIGH = 2, JPT_STREAM_PRIORITY_LOW = 3 };
 int jpt_set_stream_priority(jpt_ctx *ctx, int32_t priority);
 
+/* Device memory a context may spend on renders in flight.  A wavefront render keeps 168 bytes per path (pixel x frame of
+ * the render window) in a workspace, and queued renders (jpt_render_async) use up to four workspaces at once -- 11 GB for
+ * four 1920x1080x8-spp renders: fine on a 288 GB device the library has to itself, the first thing an application sharing
+ * the GPU with its own renderer will want to cap.
+ *   renders_in_flight  1..4 workspaces / pipeline slots; 0: the library's rule (4; 2 when one workspace exceeds 24 GiB).
+ *                      1 serialises queued renders (about 1.5 x the time per render at C3's size).
+ *   workspace_budget_bytes  most bytes ONE workspace may take; a render with more frames than fit runs as batches of
+ *                      frames in frame order, same image (0: the library's rule, 24 GiB).
+ * Takes effect with the next render; workspaces no longer allowed are freed at once (the call waits for renders in
+ * flight).  jpt_get_workspace_bytes reports what is allocated now.  No reference counterpart (the reference's
+ * workspace is the two images of one frame). */
+int jpt_set_memory_policy(jpt_ctx *ctx, int32_t renders_in_flight, uint64_t workspace_budget_bytes);
+int jpt_get_workspace_bytes(jpt_ctx *ctx, uint64_t *bytes_out);
+
 /* ---- scene ingest, route (i): reference layout ------------------------------------------------ */
 
 /* replaces: the six cs->create_storage_buffer_uniform(geometry_group->get_*_buffer(), b, 1) calls and

@@ -721,6 +721,43 @@ def test_asynchronous_renders_pipeline_in_order(oracle, hiplib):
     assert np.array_equal(a[1][0], want) and np.array_equal(a[1][1], want_ldr)
 
 
+def test_memory_policy_caps_the_workspaces_and_keeps_the_image(hiplib):
+    """jpt_set_memory_policy: queued renders with four, two and one workspace in flight, and with a budget per workspace
+    that forces batches of frames, leave the same accumulation buffer; jpt_get_workspace_bytes shows the cap taking
+    effect (workspaces past it are freed by the call)."""
+    sc = scenes.demo_scene(2500)
+    w, h, bounces, spp = 320, 180, 3, 6
+    cam = scenes.camera_block(sc.camera, w, h)
+
+    def run(slots, budget):
+        ctx = make_ctx(sc, w, h, bounces, wire.ACCUM_REF_LDR8, capi.BUILD_SAH)
+        if slots or budget:
+            ctx.set_memory_policy(slots, budget)
+        for k in range(6):
+            ctx.render(spp, 1 + spp * k, asynchronous=True)
+        ctx.sync()
+        out, used = ctx.read_accum(), ctx.workspace_bytes()
+        ctx.set_memory_policy(1, budget)
+        after = ctx.workspace_bytes()
+        ctx.render(spp, 1 + spp * 6, asynchronous=True)       # still renders after the cap moved
+        ctx.sync()
+        ctx.close()
+        return out, used, after
+
+    full, used4, after4 = run(0, 0)
+    one_ws = used4 // 4
+    assert used4 == 4 * one_ws and after4 == one_ws            # four equal workspaces; the cap to one freed three
+    two, used2, _ = run(2, 0)
+    one, used1, _ = run(1, 0)
+    assert used2 == 2 * one_ws and used1 == one_ws
+    batched, used_b, _ = run(4, one_ws // 3)                    # two of six frames fit the budget: three batches per render
+    assert used_b <= 4 * (one_ws // 3)
+    for other in (two, one, batched):
+        assert np.array_equal(full, other)
+    with pytest.raises(RuntimeError):
+        make_ctx(sc, w, h, bounces, wire.ACCUM_REF_LDR8, capi.BUILD_SAH).set_memory_policy(5, 0)
+
+
 def test_foreign_work_on_the_context_stream_sees_each_queued_render(hiplib):
     """jpt_get_stream: work a framework queues on the context's stream between asynchronous renders (bench.py's
     gather) is ordered after the render before it and before the render after it -- although the renders' kernels,
