@@ -327,6 +327,7 @@ int upload_shadow(jpt_ctx* c, bool instances_only)
     d.tlas_parent = c->d_x_tlas_parent.p;
     d.inst_tlas_leaf = c->d_x_inst_leaf.p;
     d.ok = true;
+    d.tlas_current = true;
     return JPT_OK;
 }
 
@@ -1480,7 +1481,7 @@ int jpt_scene_refit_tlas(jpt_ctx* c, const float* transforms12, uint32_t n_insta
         c->cull_boxes_current = false;
     }
     c->refit_active = true;
-    c->ds.x.ok = false;   // the shadow's instance level is the last host update's: set-aside paths are finished on the native tree until the next one
+    c->ds.x.tlas_current = false;   // the copy of the reference's instance level is the last HOST update's: until the next one exact ties are decided inside one instance only (jpt_tie_walk.h)
     c->stats.last_build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return JPT_OK;
 }

@@ -48,6 +48,7 @@ struct TieShadowDev {
     const uint32_t* __restrict__ tlas_parent = nullptr;
     const uint32_t* __restrict__ inst_tlas_leaf = nullptr;
     bool ok = false;
+    bool tlas_current = false;   // false after a device refit: `instances` and `tlas` are those of the last HOST update
 };
 
 // All device-resident scene data of a context.
@@ -81,8 +82,8 @@ struct DeviceScene {
     const ReachTri* reach_tri = nullptr;
     const ReachInst* reach_inst = nullptr;
     // the reference's own trees beside a native scene (ExactShadow, jpt_builder.h): what wf2_finish decides exact distance
-    // ties on (jpt_tie_walk.h).  x.ok false: not available (a watertight scene, a device refit since the last host update,
-    // uploaded trees that are not numbered in pre-order) -- ties are then left to the order of the native walk.
+    // ties on (jpt_tie_walk.h).  x.ok false: not available (a watertight scene, uploaded trees that are not numbered in
+    // pre-order) -- ties are then left to the order of the native walk.
     TieShadowDev x;
 
     SceneShading shading() const

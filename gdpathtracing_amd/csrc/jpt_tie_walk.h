@@ -73,9 +73,93 @@ __device__ __forceinline__ void tie_leaves(const WideSceneDev& sc, const TieShad
 }
 
 // step 2: main.glsl:305-350 / :270-303 / :224-257 on the reference's arrays, through the ancestors of `tl` only.  false: the
-// walk could not be set up (too many TLAS nodes on the way): the caller keeps what it has.
-__device__ __forceinline__ bool tie_walk(const TieShadowDev& x, const TieLeaves& tl, f3 wo, f3 wd, TraceHit& hit)
+// walk could not be set up (too many TLAS nodes on the way; an out-of-date TLAS and ties in more than one instance): the
+// caller keeps what it has.
+// `inst_records`: the instances' CURRENT records (the shading pass's array: after a device refit the copy's own are out of
+// date).  `tlas_current` false -- a device refit since the last host update, the reference's TLAS of the moved scene is not
+// known -- limits the walk to ties inside ONE instance, which the instance level has no say in: the BLAS part alone.
+__device__ __forceinline__ bool tie_walk(const TieShadowDev& x, const RefInstance* __restrict__ inst_records, bool tlas_current, const TieLeaves& tl,
+                                         f3 wo, f3 wd, TraceHit& hit)
 {
+    hit.t = 1e9f;
+    hit.u = hit.v = 0.0f;
+    hit.tri = 0u;
+    hit.front = false;
+    uint32_t blas_of_hit = 0u, found_in = 0u;
+    float minT = 1e9f;
+    uint32_t bs[64];
+    // main.glsl:316-327: one instance's BLAS, through the ancestors of its tying leaves
+    auto visit_instance = [&](uint32_t inst) {
+        const RefInstance& b = inst_records[inst];
+        const f3 o = xform_point(b.inverse_transform, wo), d = xform_dir(b.inverse_transform, wd);
+        const f3 rD = rcp3(d);
+        int bsp = 0;
+        bs[bsp++] = x.instances[inst].blas_index;   // (the mesh an instance shows does not change when it moves)
+        while (bsp > 0) {
+            const RefBvhNode& bn = x.bvh[bs[--bsp]];
+            if (bn.tri_count > 0u) {
+                for (uint32_t i = 0; i < bn.tri_count; i++) {
+                    const uint32_t ti = bn.first_tri_index + i;
+                    const RefTriGeometry& tri = x.tri_geom[ti];
+                    const f3 v0 = mk3(tri.vertices[0].x, tri.vertices[0].y, tri.vertices[0].z);
+                    const f3 v1 = mk3(tri.vertices[1].x, tri.vertices[1].y, tri.vertices[1].z);
+                    const f3 v2 = mk3(tri.vertices[2].x, tri.vertices[2].y, tri.vertices[2].z);
+                    const f3 edge1 = v1 - v0, edge2 = v2 - v0;
+                    const f3 pvec = cross3(d, edge2);
+                    const float det = dot3(edge1, pvec);
+                    if (__builtin_fabsf(det) < 1e-5f) continue;
+                    const float invDet = 1.0f / det;
+                    const f3 tvec = o - v0;
+                    const float u = dot3(tvec, pvec) * invDet;
+                    if (u < 0.0f || u > 1.0f) continue;
+                    const f3 qvec = cross3(tvec, edge1);
+                    const float v = dot3(d, qvec) * invDet;
+                    if (v < 0.0f || u + v > 1.0f) continue;
+                    const float t = dot3(edge2, qvec) * invDet;
+                    if (t < 0.0f || t > hit.t) continue;
+                    hit.t = t;
+                    hit.u = u;
+                    hit.v = v;
+                    hit.tri = ti;
+                    hit.front = dot3(cross3(edge1, edge2), d) > 0.0f;
+                    found_in = inst;
+                }
+                continue;
+            }
+            const uint32_t li = bn.left_child, ri = bn.right_child;
+            const RefBvhNode& cl = x.bvh[li];
+            const RefBvhNode& cr = x.bvh[ri];
+            const float d1 = slab(o, rD, cl.aabbMin.x, cl.aabbMin.y, cl.aabbMin.z, cl.aabbMax.x, cl.aabbMax.y, cl.aabbMax.z);
+            const float d2 = slab(o, rD, cr.aabbMin.x, cr.aabbMin.y, cr.aabbMin.z, cr.aabbMax.x, cr.aabbMax.y, cr.aabbMax.z);
+            // (a subtree is on the way iff a tying leaf of this instance is numbered inside it)
+            const uint32_t le = x.subtree_end[li], re = x.subtree_end[ri];
+            bool lw = false, rw = false;
+            for (int k = 0; k < tl.n; k++) {
+                const bool here = tl.inst[k] == inst;
+                lw = lw || (here && tl.leaf[k] >= li && tl.leaf[k] < le);
+                rw = rw || (here && tl.leaf[k] >= ri && tl.leaf[k] < re);
+            }
+            const bool leftValid = d1 < hit.t && lw, rightValid = d2 < hit.t && rw;
+            if (d1 < d2) {
+                if (rightValid && bsp < 64) bs[bsp++] = ri;
+                if (leftValid && bsp < 64) bs[bsp++] = li;
+            } else {
+                if (leftValid && bsp < 64) bs[bsp++] = li;
+                if (rightValid && bsp < 64) bs[bsp++] = ri;
+            }
+        }
+        if (hit.t < minT) {   // main.glsl:324-327
+            blas_of_hit = inst;
+            minT = hit.t;
+        }
+    };
+    if (!tlas_current) {
+        for (int k = 1; k < tl.n; k++)
+            if (tl.inst[k] != tl.inst[0]) return false;
+        visit_instance(tl.inst[0]);
+        hit.inst = (blas_of_hit & kInstMask) | (found_in << kInstBits);
+        return true;
+    }
     // TLAS nodes on the way to the tying instances
     uint32_t way[kTieTlas];
     int n_way = 0;
@@ -96,83 +180,15 @@ __device__ __forceinline__ bool tie_walk(const TieShadowDev& x, const TieLeaves&
         for (int j = 0; j < n_way; j++) r = r || way[j] == node;
         return r;
     };
-    hit.t = 1e9f;
-    hit.u = hit.v = 0.0f;
-    hit.tri = 0u;
-    hit.front = false;
-    uint32_t blas_of_hit = 0u, found_in = 0u;
     const f3 wrD = rcp3(wd);
-    uint32_t ts[64], bs[64];
+    uint32_t ts[64];
     int tsp = 0;
     ts[tsp++] = 0u;
-    float minT = 1e9f;
     while (tsp > 0) {
         const RefTlasNode& node = x.tlas[ts[--tsp]];
         const uint32_t lr = node.leftRight;
         if (lr == 0u) {
-            const uint32_t inst = node.blas;
-            const RefInstance& b = x.instances[inst];
-            const f3 o = xform_point(b.inverse_transform, wo), d = xform_dir(b.inverse_transform, wd);
-            const f3 rD = rcp3(d);
-            int bsp = 0;
-            bs[bsp++] = b.blas_index;
-            while (bsp > 0) {
-                const RefBvhNode& bn = x.bvh[bs[--bsp]];
-                if (bn.tri_count > 0u) {
-                    for (uint32_t i = 0; i < bn.tri_count; i++) {
-                        const uint32_t ti = bn.first_tri_index + i;
-                        const RefTriGeometry& tri = x.tri_geom[ti];
-                        const f3 v0 = mk3(tri.vertices[0].x, tri.vertices[0].y, tri.vertices[0].z);
-                        const f3 v1 = mk3(tri.vertices[1].x, tri.vertices[1].y, tri.vertices[1].z);
-                        const f3 v2 = mk3(tri.vertices[2].x, tri.vertices[2].y, tri.vertices[2].z);
-                        const f3 edge1 = v1 - v0, edge2 = v2 - v0;
-                        const f3 pvec = cross3(d, edge2);
-                        const float det = dot3(edge1, pvec);
-                        if (__builtin_fabsf(det) < 1e-5f) continue;
-                        const float invDet = 1.0f / det;
-                        const f3 tvec = o - v0;
-                        const float u = dot3(tvec, pvec) * invDet;
-                        if (u < 0.0f || u > 1.0f) continue;
-                        const f3 qvec = cross3(tvec, edge1);
-                        const float v = dot3(d, qvec) * invDet;
-                        if (v < 0.0f || u + v > 1.0f) continue;
-                        const float t = dot3(edge2, qvec) * invDet;
-                        if (t < 0.0f || t > hit.t) continue;
-                        hit.t = t;
-                        hit.u = u;
-                        hit.v = v;
-                        hit.tri = ti;
-                        hit.front = dot3(cross3(edge1, edge2), d) > 0.0f;
-                        found_in = inst;
-                    }
-                    continue;
-                }
-                const uint32_t li = bn.left_child, ri = bn.right_child;
-                const RefBvhNode& cl = x.bvh[li];
-                const RefBvhNode& cr = x.bvh[ri];
-                const float d1 = slab(o, rD, cl.aabbMin.x, cl.aabbMin.y, cl.aabbMin.z, cl.aabbMax.x, cl.aabbMax.y, cl.aabbMax.z);
-                const float d2 = slab(o, rD, cr.aabbMin.x, cr.aabbMin.y, cr.aabbMin.z, cr.aabbMax.x, cr.aabbMax.y, cr.aabbMax.z);
-                // (a subtree is on the way iff a tying leaf of this instance is numbered inside it)
-                const uint32_t le = x.subtree_end[li], re = x.subtree_end[ri];
-                bool lw = false, rw = false;
-                for (int k = 0; k < tl.n; k++) {
-                    const bool here = tl.inst[k] == inst;
-                    lw = lw || (here && tl.leaf[k] >= li && tl.leaf[k] < le);
-                    rw = rw || (here && tl.leaf[k] >= ri && tl.leaf[k] < re);
-                }
-                const bool leftValid = d1 < hit.t && lw, rightValid = d2 < hit.t && rw;
-                if (d1 < d2) {
-                    if (rightValid && bsp < 64) bs[bsp++] = ri;
-                    if (leftValid && bsp < 64) bs[bsp++] = li;
-                } else {
-                    if (leftValid && bsp < 64) bs[bsp++] = li;
-                    if (rightValid && bsp < 64) bs[bsp++] = ri;
-                }
-            }
-            if (hit.t < minT) {   // main.glsl:324-327
-                blas_of_hit = inst;
-                minT = hit.t;
-            }
+            visit_instance(node.blas);
             continue;
         }
         const uint32_t left = lr & 0xffffu, right = lr >> 16;

@@ -320,6 +320,60 @@ def test_reference_tlas_update_route(oracle, hiplib, as_given):
     assert np.array_equal(got, want) and np.array_equal(got_ldr, want_ldr)
 
 
+@pytest.mark.parametrize("route", ["commit", "upload"])
+@pytest.mark.parametrize("seed", [1, 4])
+def test_exact_ties_stay_decided_after_instances_move(oracle, hiplib, seed, route):
+    """The reference's own trees beside the native scene (where exact distance ties are decided, jpt_tie_walk.h) follow the
+    instances: after jpt_scene_update_tlas / jpt_scene_update_reference_tlas a soup of coincident triangles still renders
+    bit for bit like the oracle's normal walk of the moved scene's reference tree.  After a DEVICE refit the copy's instance
+    level is out of date until the next host update -- the reference's TLAS of the moved scene is not known -- and ties are
+    decided inside one instance only (the BLAS part of the walk, with the refitted instance records): coincident triangles
+    of one mesh, which is what these soups hold, still come out exactly."""
+    sc = scenes.random_scene(seed, coincident=True)
+    w, h, bounces, frames = 96, 64, 3, 2
+    cam = scenes.camera_block(sc.camera, w, h)
+    moves = _moves_for(sc, 11 + seed, 4)
+    moved = _moved(sc, moves)
+    r0, r1 = oracle.build_scene(sc), oracle.build_scene(moved)
+    want, _, want_depth, _, _ = oracle.render(r1, cam, w, h, bounces, frames, 1, wire.ACCUM_HDR_F32)
+    ctx = host.Context(0)
+    try:
+        if route == "upload":
+            ctx.upload_reference_layout(r0.tri_geom, r0.tri_data, r0.materials, r0.bvh_nodes, r0.instances, r0.tlas_nodes, r0.textures)
+        else:
+            ctx.build_scene(sc, capi.BUILD_SAH)
+        ctx.set_params(w, h, bounces, wire.ACCUM_HDR_F32)
+        ctx.set_camera(cam)
+        ctx.render(frames, 1)
+        if route == "upload":
+            ctx.update_reference_tlas(r1.instances, r1.tlas_nodes)
+        else:
+            for i, t in moves.items():
+                ctx.set_instance_transform(i, t)
+            ctx.update_tlas()
+        ctx.accum_reset()
+        ctx.render(frames, 1)
+        got, got_depth, st = ctx.read_accum(), ctx.read_depth(), ctx.stats()
+        refit = None
+        if route == "commit":
+            ctx.refit_tlas(np.stack([np.asarray(i.transform, dtype=np.float32) for i in moved.instances]))
+            ctx.accum_reset()
+            ctx.render(frames, 1)
+            refit = ctx.read_accum()
+    finally:
+        ctx.close()
+    nan_got, nan_want = np.isnan(got).any(axis=-1), np.isnan(want).any(axis=-1)
+    ok = ~(nan_got | nan_want)
+    print("moved coincident soup", seed, route, "set aside", st["set_aside"], "differing pixels", int((got[ok] != want[ok]).any(axis=-1).sum()))
+    assert st["set_aside"] > 0 and st["set_aside_dropped"] == 0
+    assert np.array_equal(nan_got, nan_want) and np.array_equal(got[ok], want[ok])
+    assert np.array_equal(got_depth, want_depth, equal_nan=True)
+    if refit is not None:
+        ok2 = ok & ~np.isnan(refit).any(axis=-1)
+        print("   after a device refit to the same transforms: differing pixels", int((refit[ok2] != want[ok2]).any(axis=-1).sum()), "rel_l2", rel_l2(refit[ok2], want[ok2]))
+        assert np.array_equal(refit[ok2], want[ok2])
+
+
 # ---- primary rays that cannot reach any root box are not traced (SkyCull) ------------------------------------------
 
 def _look_at(eye, target, up=(0.0, 1.0, 0.0)):
