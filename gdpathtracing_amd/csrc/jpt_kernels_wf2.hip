@@ -567,7 +567,7 @@ __global__ __launch_bounds__(64) void wf2_finish(WideSceneDev sc, TieShadowDev s
                 TieLeaves tl;
                 tie_leaves<COUNT, W4>(sc, sx, st, o3, d3, hit.t, tl, cnt);
                 TraceHit xh;
-                if (!tl.overflow && tl.n > 0 && tie_walk(sx, sh.instances, sx.tlas_current, tl, o3, d3, xh) && xh.t == hit.t) {
+                if (tl.n > 0 && tie_walk(sx, sh.instances, sx.tlas_current, tl, o3, d3, xh) && xh.t == hit.t) {
                     // (xh.t differs only if a float accident kept the reference's walk from the tying leaves: then the native
                     // walk's answer stands)
                     hit = xh;

@@ -20,7 +20,7 @@ namespace jpt {
 
 #if defined(__HIPCC__)
 
-constexpr int kTieLeaves = 8;    // most tying leaves a vertex may have (more: the native walk's answer stands)
+constexpr int kTieLeaves = 8;    // most tying leaves a vertex may have (more: the reference's whole walk, see tie_walk)
 constexpr int kTieTlas = 96;     // most TLAS nodes on the way to them
 
 struct TieLeaves {
@@ -78,9 +78,12 @@ __device__ __forceinline__ void tie_leaves(const WideSceneDev& sc, const TieShad
 // `inst_records`: the instances' CURRENT records (the shading pass's array: after a device refit the copy's own are out of
 // date).  `tlas_current` false -- a device refit since the last host update, the reference's TLAS of the moved scene is not
 // known -- limits the walk to ties inside ONE instance, which the instance level has no say in: the BLAS part alone.
+// `tl.overflow` (more tying leaves than the list holds: many coincident copies of a triangle): no restriction at all -- the
+// reference's whole walk, slow and exact.
 __device__ __forceinline__ bool tie_walk(const TieShadowDev& x, const RefInstance* __restrict__ inst_records, bool tlas_current, const TieLeaves& tl,
                                          f3 wo, f3 wd, TraceHit& hit)
 {
+    const bool everything = tl.overflow;
     hit.t = 1e9f;
     hit.u = hit.v = 0.0f;
     hit.tri = 0u;
@@ -133,7 +136,7 @@ __device__ __forceinline__ bool tie_walk(const TieShadowDev& x, const RefInstanc
             const float d2 = slab(o, rD, cr.aabbMin.x, cr.aabbMin.y, cr.aabbMin.z, cr.aabbMax.x, cr.aabbMax.y, cr.aabbMax.z);
             // (a subtree is on the way iff a tying leaf of this instance is numbered inside it)
             const uint32_t le = x.subtree_end[li], re = x.subtree_end[ri];
-            bool lw = false, rw = false;
+            bool lw = everything, rw = everything;
             for (int k = 0; k < tl.n; k++) {
                 const bool here = tl.inst[k] == inst;
                 lw = lw || (here && tl.leaf[k] >= li && tl.leaf[k] < le);
@@ -154,6 +157,7 @@ __device__ __forceinline__ bool tie_walk(const TieShadowDev& x, const RefInstanc
         }
     };
     if (!tlas_current) {
+        if (everything) return false;
         for (int k = 1; k < tl.n; k++)
             if (tl.inst[k] != tl.inst[0]) return false;
         visit_instance(tl.inst[0]);
@@ -163,7 +167,7 @@ __device__ __forceinline__ bool tie_walk(const TieShadowDev& x, const RefInstanc
     // TLAS nodes on the way to the tying instances
     uint32_t way[kTieTlas];
     int n_way = 0;
-    for (int k = 0; k < tl.n; k++) {
+    for (int k = 0; k < tl.n && !everything; k++) {
         uint32_t node = x.inst_tlas_leaf[tl.inst[k]];
         for (;;) {
             bool seen = false;
@@ -176,7 +180,7 @@ __device__ __forceinline__ bool tie_walk(const TieShadowDev& x, const RefInstanc
         }
     }
     auto on_way = [&](uint32_t node) {
-        bool r = false;
+        bool r = everything;
         for (int j = 0; j < n_way; j++) r = r || way[j] == node;
         return r;
     };

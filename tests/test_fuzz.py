@@ -180,3 +180,42 @@ def test_native_tree_against_the_reference_walk_with_coincident_triangles(oracle
     assert st["set_aside_dropped"] == 0
     assert np.array_equal(nan_got, nan_want)
     assert ndiff == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("route", ["commit", "upload"])
+def test_many_coincident_copies_fall_back_to_the_whole_reference_walk(oracle, hiplib, route):
+    """Forty coincident copies of one large triangle (different normals and uvs, so the winner shows) in every mesh of a
+    soup.  The reference's builder puts at most four triangles in a leaf (bvh.cpp:125), so a ray through them ties in at
+    least ten leaves: more than the tie walk's list holds (8).  Such a vertex is decided by the reference's WHOLE walk of
+    its own trees (jpt_tie_walk.h, `overflow`) -- slow, exact: the native routes still equal the oracle's normal walk bit
+    for bit."""
+    import copy
+    sc = copy.deepcopy(scenes.random_scene(3, n_meshes=2, n_instances=4, tris_per_surface=60, coincident=True))
+    for mesh in sc.meshes:
+        surf = mesh.surfaces[0]
+        v = np.asarray(surf.vertices, dtype=np.float32).reshape(-1, 3, 3).copy()
+        v[4:44] = np.array([[-1.5, -1.2, 0.1], [1.6, -1.1, -0.2], [0.1, 1.7, 0.3]], dtype=np.float32)
+        surf.vertices = v.reshape(-1, 3)
+    w, h, bounces, frames = 96, 64, 2, 2
+    cam = scenes.camera_block(sc.camera, w, h)
+    ref = oracle.build_scene(sc)
+    want, _, want_depth, _, _ = oracle.render(ref, cam, w, h, bounces, frames, 1, wire.ACCUM_HDR_F32)
+    ctx = host.Context(0)
+    try:
+        if route == "upload":
+            ctx.upload_reference_layout(ref.tri_geom, ref.tri_data, ref.materials, ref.bvh_nodes, ref.instances, ref.tlas_nodes, ref.textures)
+        else:
+            ctx.build_scene(sc, capi.BUILD_SAH)
+        ctx.set_params(w, h, bounces, wire.ACCUM_HDR_F32)
+        ctx.set_camera(cam)
+        ctx.render(frames, 1)
+        got, got_depth, st = ctx.read_accum(), ctx.read_depth(), ctx.stats()
+    finally:
+        ctx.close()
+    nan_got, nan_want = np.isnan(got).any(axis=-1), np.isnan(want).any(axis=-1)
+    ok = ~(nan_got | nan_want)
+    print("forty coincident copies", route, "set aside", st["set_aside"], "differing pixels", int((got[ok] != want[ok]).any(axis=-1).sum()))
+    assert st["set_aside"] > 300 and st["set_aside_dropped"] == 0
+    assert np.array_equal(nan_got, nan_want) and np.array_equal(got[ok], want[ok])
+    assert np.array_equal(got_depth, want_depth, equal_nan=True)
