@@ -73,8 +73,7 @@ __device__ __forceinline__ void tie_leaves(const WideSceneDev& sc, const TieShad
 }
 
 // step 2: main.glsl:305-350 / :270-303 / :224-257 on the reference's arrays, through the ancestors of `tl` only.  false: the
-// walk could not be set up (too many TLAS nodes on the way; an out-of-date TLAS and ties in more than one instance): the
-// caller keeps what it has.
+// walk could not be set up (an out-of-date TLAS and ties in more than one instance): the caller keeps what it has.
 // `inst_records`: the instances' CURRENT records (the shading pass's array: after a device refit the copy's own are out of
 // date).  `tlas_current` false -- a device refit since the last host update, the reference's TLAS of the moved scene is not
 // known -- limits the walk to ties inside ONE instance, which the instance level has no say in: the BLAS part alone.
@@ -83,7 +82,7 @@ __device__ __forceinline__ void tie_leaves(const WideSceneDev& sc, const TieShad
 __device__ __forceinline__ bool tie_walk(const TieShadowDev& x, const RefInstance* __restrict__ inst_records, bool tlas_current, const TieLeaves& tl,
                                          f3 wo, f3 wd, TraceHit& hit)
 {
-    const bool everything = tl.overflow;
+    bool everything = tl.overflow;   // (also: more TLAS nodes on the way than `way` holds)
     hit.t = 1e9f;
     hit.u = hit.v = 0.0f;
     hit.tri = 0u;
@@ -173,7 +172,10 @@ __device__ __forceinline__ bool tie_walk(const TieShadowDev& x, const RefInstanc
             bool seen = false;
             for (int j = 0; j < n_way; j++) seen = seen || way[j] == node;
             if (seen) break;   // (and with it everything above)
-            if (n_way == kTieTlas) return false;
+            if (n_way == kTieTlas) {
+                everything = true;
+                break;
+            }
             way[n_way++] = node;
             if (node == 0u) break;
             node = x.tlas_parent[node];
