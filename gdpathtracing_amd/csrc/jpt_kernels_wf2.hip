@@ -213,12 +213,38 @@ __global__ __launch_bounds__(kBlock, JPT_PRIMARY_WAVES) void wf2_primary(WideSce
     DevCounters cnt = {};
     Traversal<COUNT, W4> tr;
     bool active = false, exhausted = false;
+    bool unsaved = false;   // this lane's finished walk has not left its result yet (see wf2_trace: written when the wave refills)
     uint32_t path = 0;
+    auto save_results = [&]() {
+        // hits are packed into the segment's bounce-0 queue (main.glsl:349), one counter update per wave
+        const bool is_hit = unsaved && tr.hit.t < 1e9f;
+        const unsigned long long hm = __ballot(is_hit);
+        if (hm) {
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(&s_out, (uint32_t)__popcll(hm));
+            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+            if (is_hit) {
+                const uint32_t j = base + lanes_below(hm, lane);
+                wb.ray_o[0][seg_base + j] = make_float4(tr.wo.x, tr.wo.y, tr.wo.z, 0.0f);
+                wb.ray_d[0][seg_base + j] = make_float4(tr.wd.x, tr.wd.y, tr.wd.z, __uint_as_float(path));
+                wb.hit_a[seg_base + j] = make_float4(tr.hit.t, tr.hit.u, tr.hit.v, __uint_as_float(tr.hit.tri));
+                wb.hit_b[seg_base + j] = tr.hit.inst | (tr.hit.front ? 0x80000000u : 0u);
+            }
+        }
+        if (unsaved && !is_hit) {   // sky: radiance += 1 * sampleSky(d), path over (main.glsl:380,395-397)
+            const uint32_t f = fdiv(path, dm.by_slots_per_frame);
+            const f3 sky = mk3(0.0f, 0.0f, 0.0f) + mk3(1.0f, 1.0f, 1.0f) * sample_sky(tr.wd);
+            store_final(wb, fp.accum_mode, path, sky);
+            if ((int)f == fp.depth_frame) wb.first_depth[path - f * dm.slots_per_frame] = cam.far_;
+        }
+        unsaved = false;
+    };
 
     for (;;) {
         const unsigned long long idle = __ballot(!active);
         const int n_idle = __popcll(idle);
         if (!exhausted && n_idle >= tune.refill_idle) {
+            if (__any(unsaved)) save_results();
             uint32_t start = 0;
             if (lane == 0) start = atomicAdd(&s_cursor, (uint32_t)n_idle);
             start = (uint32_t)__builtin_amdgcn_readfirstlane((int)start);
@@ -261,22 +287,11 @@ __global__ __launch_bounds__(kBlock, JPT_PRIMARY_WAVES) void wf2_primary(WideSce
         {
             if (walk_round<COUNT, W4>(tr, active, sc, my_stack, cnt, tune)) {
                 active = false;
-                const uint32_t f = fdiv(path, dm.by_slots_per_frame);
-                const bool last_frame = (int)f == fp.depth_frame;
-                if (tr.hit.t < 1e9f) {  // main.glsl:349: packed into the segment's bounce-0 queue
-                    const uint32_t j = atomicAdd(&s_out, 1u);
-                    wb.ray_o[0][seg_base + j] = make_float4(tr.wo.x, tr.wo.y, tr.wo.z, 0.0f);
-                    wb.ray_d[0][seg_base + j] = make_float4(tr.wd.x, tr.wd.y, tr.wd.z, __uint_as_float(path));
-                    wb.hit_a[seg_base + j] = make_float4(tr.hit.t, tr.hit.u, tr.hit.v, __uint_as_float(tr.hit.tri));
-                    wb.hit_b[seg_base + j] = tr.hit.inst | (tr.hit.front ? 0x80000000u : 0u);
-                } else {                // sky: radiance += 1 * sampleSky(d), path over (main.glsl:380,395-397)
-                    const f3 sky = mk3(0.0f, 0.0f, 0.0f) + mk3(1.0f, 1.0f, 1.0f) * sample_sky(tr.wd);
-                    store_final(wb, fp.accum_mode, path, sky);
-                    if (last_frame) wb.first_depth[path - f * dm.slots_per_frame] = cam.far_;
-                }
+                unsaved = true;
             }
         }
     }
+    if (__any(unsaved)) save_results();
     __syncthreads();
     if (threadIdx.x == 0) wb.qcount[0 * kSegments + seg] = s_out;
     if (COUNT) flush_counters(cnt, counters);
@@ -317,12 +332,27 @@ __global__ __launch_bounds__(kBlock, JPT_WAVES_PER_SIMD) void wf2_trace(WideScen
     DevCounters cnt = {};
     Traversal<COUNT, W4> tr;
     bool active = false, exhausted = false;
+#ifndef JPT_LATE_HIT_STORE
+#define JPT_LATE_HIT_STORE 1
+#endif
+    bool unsaved = false;   // this lane's finished walk has not written its hit yet
     size_t my_loc = 0;
+    // A finished walk's hit stays in the lane's registers until the lane takes its next ray: the hits are written when the
+    // wave refills (two dozen lanes at once) instead of in the round each walk happens to end in (some lane does in
+    // nearly every round: a dozen instructions per round for one or two lanes' stores).
+    auto save_hit = [&]() {
+        wb.hit_a[my_loc] = make_float4(tr.hit.t, tr.hit.u, tr.hit.v, __uint_as_float(tr.hit.tri));
+        wb.hit_b[my_loc] = tr.hit.inst | (tr.hit.front ? 0x80000000u : 0u);
+    };
 
     for (;;) {
         const unsigned long long idle = __ballot(!active);
         const int n_idle = __popcll(idle);
         if (!exhausted && n_idle >= tune.refill_idle) {
+            if (JPT_LATE_HIT_STORE && unsaved) {
+                save_hit();
+                unsaved = false;
+            }
             uint32_t start = 0;
             if (lane == 0) start = atomicAdd(&s_cursor, (uint32_t)n_idle);
             start = (uint32_t)__builtin_amdgcn_readfirstlane((int)start);
@@ -352,11 +382,12 @@ __global__ __launch_bounds__(kBlock, JPT_WAVES_PER_SIMD) void wf2_trace(WideScen
         {
             if (walk_round<COUNT, W4>(tr, active, sc, my_stack, cnt, tune)) {
                 active = false;
-                wb.hit_a[my_loc] = make_float4(tr.hit.t, tr.hit.u, tr.hit.v, __uint_as_float(tr.hit.tri));
-                wb.hit_b[my_loc] = tr.hit.inst | (tr.hit.front ? 0x80000000u : 0u);
+                if (JPT_LATE_HIT_STORE) unsaved = true;
+                else save_hit();
             }
         }
     }
+    if (JPT_LATE_HIT_STORE && unsaved) save_hit();
     if (COUNT) flush_counters(cnt, counters);
 }
 
