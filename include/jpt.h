@@ -70,7 +70,10 @@ enum {
                                       ("reach records"): a hit found on the native tree is checked against the two box
                                       tests that decide whether the reference's traversal reaches that triangle at all
                                       (main.glsl:259-350), so the image equals the reference's even where float rounding
-                                      lets a reference ray slip through its own boxes */
+                                      lets a reference ray slip through its own boxes.  The reference's
+                                      trees are kept beside the native ones: a hit that ties with another at exactly the
+                                      same distance -- whose winner is a matter of the reference's visiting order,
+                                      main.glsl:247 -- is decided by the reference's own walk */
     JPT_BUILD_SAH_WATERTIGHT = 2   /* the native builder alone (half the build time): every triangle hit is found; differs
                                       from the reference's image in the few pixels per 10^7 paths where the reference's
                                       tree has such a crack */
@@ -185,7 +188,8 @@ int jpt_get_workspace_bytes(jpt_ctx *ctx, uint64_t *bytes_out);
  * triangles of every BLAS an instance names), and the uploaded boxes that decide what the reference's traversal can reach
  * -- each triangle's BVHNode leaf (tri_count > 0), each instance's TLAS leaf -- become the reach records that keep the
  * image the reference's (see JPT_BUILD_SAH): the addon keeps GeometryGroup3D::build() and renders at the native route's
- * rate.  No builder of the reference is re-run.  Arrays that are not such a tree (a node or triangle reachable twice,
+ * rate; the uploaded trees themselves are kept on the device too, and decide exact distance ties (see JPT_BUILD_SAH).
+ * No builder of the reference is re-run.  Arrays that are not such a tree (a node or triangle reachable twice,
  * boxes that are not nested, an instance in no / several TLAS leaves, transform and inverse_transform that do not belong
  * together) are walked node for node as uploaded, like JPT_UPLOAD_WALK_AS_GIVEN; jpt_scene_upload_note says why.
  * After a native upload jpt_scene_get_reference_buffer returns the native trees in reference layout (triangles in the
@@ -203,7 +207,7 @@ int jpt_scene_upload_reference_layout(jpt_ctx *ctx,
 enum {
     JPT_UPLOAD_NATIVE_TREE = 0,   /* default: native tree + reach records from the uploaded leaf / instance boxes */
     JPT_UPLOAD_WALK_AS_GIVEN = 1  /* audit route: the uploaded BVHNode / TLASNode arrays are walked node for node, in the
-                                     reference's visit order (event counters and exact-tie winners equal the reference's);
+                                     reference's visit order (the six event counters equal the reference's too);
                                      ~20x slower on the demo scene, whose reference boxes are inflated to the origin */
 };
 int jpt_set_upload_mode(jpt_ctx *ctx, int32_t mode);
