@@ -819,8 +819,28 @@ int do_render_batch(jpt_ctx* c, int32_t n_frames, uint32_t first_frame_index, bo
                 // (launch_wf2_render splits the frames into groups only if the helper streams exist)
                 const int want_groups = wf2_wanted_groups(n_frames, (size_t)c->width * (size_t)c->local_rows * (size_t)n_frames);
                 if (want_groups > 1 && !need_ev && !counted) (void)ensure_group_streams(c, want_groups);
+                // A SMALL render that runs alone (the addon's use: one blocking 1-spp frame per Godot frame): two chained
+                // segments per tracing block.  With a few rays per lane a segment's queue runs dry almost at once; half as
+                // many waves with queues twice as deep keep their lanes fuller (C2 0.779 -> 0.738 ms, a 1-spp 1080p frame
+                // 0.673 -> 0.648).  Not for windows of millions of paths (C3 in one group: 1.39 -> 1.51 ms) nor for scenes
+                // past the caches, which are bound by the latency of their fetches and want every wave they can get (1 M
+                // triangles, 2 spp: 9.49 -> 9.93 ms): one segment per block (profiles/r03/r03ao_lone_chain.txt).
+                Wf2Async lone = c->async;
+                {
+                    FrameParams wfp;
+                    wfp.width = c->width;
+                    wfp.height = c->height;
+                    wfp.local_rows = c->local_rows;
+                    wfp.rank = c->rank;
+                    wfp.world = c->world;
+                    const uint64_t window_paths =
+                        ((uint64_t)c->width * (uint64_t)c->local_rows - wf2_pixels_outside_window(c->async.cull, wfp)) * (uint64_t)n_frames;
+                    const size_t walked_bytes = c->wide.blas_nodes4.size() * sizeof(WideNodeQ) + c->wide.tris.size() * sizeof(WideTri);
+                    const bool small = window_paths <= 1500000u && walked_bytes <= ((size_t)32 << 20);
+                    lone.trace_chain = (c->native_tree && !c->ref_is_exact && small) ? 2 : 1;
+                }
                 launch_wf2_render(s, c->ds, fp, c->camera, c->d_workspace.p, c->d_accum.p, c->d_ldr.p, c->d_depth.p, cnt,
-                                  need_ev ? c->trace_events.data() : nullptr, c->async);
+                                  need_ev ? c->trace_events.data() : nullptr, lone);
             }
         } else {
             for (int32_t f = 0; f < n_frames; f++) {
