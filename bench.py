@@ -310,6 +310,13 @@ def main():
         primary_ms.append(st["last_primary_ms"])
         render_ms.append(st["last_render_ms"])   # device time of ONE render on its own (no overlap with a neighbour)
     ctx.set_kernel_timing(False)
+    # One render at a time as the library runs it when nothing is queued behind it (no per-launch events: frame groups and
+    # chained segments by the library's rule) -- what the addon's blocking render() per Godot frame gets
+    blocking_ms = []
+    for k in range(7):
+        ctx.accum_reset()
+        ctx.render(spp, 1)
+        if k >= 2: blocking_ms.append(ctx.stats()["last_render_ms"])   # (the first ones create the frame groups' streams)
     if args.kernel == "wavefront":
         dom, n_dom = "wf2_trace", max(bounces, 1)
         dom_ms = (float(np.mean(trace_ms)) - float(np.mean(primary_ms))) / n_dom    # average duration of ONE wf2_trace launch
@@ -508,6 +515,7 @@ def main():
                 "primary_kernel_ms": round(float(np.mean(primary_ms)), 4),
                 "render_ms": round(float(np.mean(render_ms)), 4),
                 "render_ms_note": "one render alone, launches serialised (kernel timing on); ms_per_step is the pipelined rate",
+                "blocking_render_ms": round(float(np.mean(blocking_ms)), 4),
                 # what a render must move through HBM whatever the caches do -- the framebuffers it leaves
                 # behind (float4 sums, rgba8 screen, r32f depth), per render, not per launch
                 "compulsory_framebuffer_bytes_per_render": int(n_pixels * (16 + 4 + 4)),
@@ -519,9 +527,11 @@ def main():
         # whose pixel lies outside the screen rectangles of the TLAS root's boxes: decided on the host, no kernel walks them)
         out["traced_rays_per_step"] = traced
         out["value_traced"] = round(traced * args.steps / elapsed / 1e6, 3)
-        out["value_blocking"] = round(rays / (float(np.mean(render_ms)) * 1e-3) / 1e6, 3) if np.mean(render_ms) > 0 else None
+        out["value_blocking"] = round(rays / (float(np.mean(blocking_ms)) * 1e-3) / 1e6, 3) if np.mean(blocking_ms) > 0 else None
         out["value_notes"] = ("value = rays_per_step / ms_per_step (queued renders, four in flight); value_traced counts only the rays a "
-                              "kernel walks (rays - sky_culled); value_blocking = rays_per_step / render_ms (one render alone on the device)")
+                              "kernel walks (rays - sky_culled); value_blocking = rays_per_step / roofline.blocking_render_ms (the device "
+                              "time of one render with nothing queued behind it, as the library runs it; roofline.render_ms is the same "
+                              "render with its launches serialised for per-kernel timing)")
         if closeup is not None:
             out["value_closeup"] = closeup["value"]
             out["closeup"] = closeup
