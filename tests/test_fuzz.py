@@ -2,6 +2,8 @@
 multi-surface meshes, sheared / mirrored instances, random materials and textures).
 CPU part: the library's reference-exact builder against the oracle's builder, byte for byte.
 GPU part: every device route against the oracle's image."""
+import os
+
 import numpy as np
 import pytest
 
@@ -219,3 +221,19 @@ def test_many_coincident_copies_fall_back_to_the_whole_reference_walk(oracle, hi
     assert st["set_aside"] > 300 and st["set_aside_dropped"] == 0
     assert np.array_equal(nan_got, nan_want) and np.array_equal(got[ok], want[ok])
     assert np.array_equal(got_depth, want_depth, equal_nan=True)
+
+
+@pytest.mark.gpu
+def test_extended_fuzz_slice(hiplib):
+    """tests/tools/fuzz_more.py on seeds 8..39 (the whole tool runs 1 280 seeds by hand: profiles/r03/r03ab_fuzz_more.txt): varying
+    sizes, bounce and frame counts, accumulation modes, queued and blocking renders; every reference-tree route and both
+    native routes bit for bit against the oracle's walk of the reference tree, the watertight builder against the
+    tree-independent mode."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, FUZZ_FROM="8", FUZZ_TO="40")
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "tools", "fuzz_more.py")], capture_output=True, text=True, env=env, cwd=root, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    last = r.stdout.strip().splitlines()[-1]
+    print(last)
+    assert last.startswith("extended fuzz done") and last.endswith("mismatches: 0"), r.stdout[-2000:]

@@ -430,7 +430,7 @@ def test_far_camera_up_to_17000_scene_sizes(oracle, hiplib, distance):
     tie exactly and the later-tested one wins (main.glsl:247).  Left to the native tree's order that showed from 17 000
     scene sizes on (5 of 11 115 hit pixels at 50 000 units in round 2); decided on the reference's own trees
     (jpt_tie_walk.h) the native route equals the oracle's walk of the reference tree bit for bit up to there -- the demo
-    scene seen from 50 000 units through a 0.007 degree lens.  (tools/far_probe.py goes on to 500 000 units, where the
+    scene seen from 50 000 units through a 0.007 degree lens.  (tests/tools/far_probe.py goes on to 500 000 units, where the
     oracle's own modes disagree in a quarter of the pixels.)"""
     sc = scenes.demo_scene(1500)
     fov = float(np.degrees(2.0 * np.arctan(3.2 / distance)))

@@ -2,8 +2,8 @@
 away hit distances are coarse, different triangles tie exactly, and the order of the tests decides: DESIGN.md section 8.)
 Demo scene seen from 50 .. 500 000 units through a lens narrow enough to fill the frame;
 native route (reach records) against the oracle's walk of the reference tree, and against the watertight / NO_CULL pair.
-gpurun -- python tools/far_probe.py"""
-import os, sys; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+gpurun -- python tests/tools/far_probe.py"""
+import os, sys; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from gdpathtracing_amd import capi, host, scenes, wire
 from oracle import binding as ob

@@ -1,5 +1,5 @@
 # where a coincident-triangle soup still differs from the oracle's walk of the reference tree: per bounce count and route
-import os, sys; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import os, sys; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from gdpathtracing_amd import capi, host, scenes, wire
 from oracle import binding as ob
