@@ -4,6 +4,8 @@
 // bit-comparable with the oracle including exact-t ties.  The fast route is jpt_kernels_wide.hip.
 #include "jpt_kernels.h"
 #include "jpt_shade.h"
+#include "jpt_tie_walk.h"
+#include "jpt_tuning.h"
 
 namespace jpt {
 
@@ -24,6 +26,7 @@ struct RefHit {
     uint32_t tri, inst;
     uint32_t steps;   // hitInfo.steps: intersectTriangle calls (main.glsl:225)
     bool front;
+    bool tied;        // the triangle kept has EXACTLY the distance of one accepted before it (see kHitTied, jpt_trace_core.h)
     f3 lo, ld;  // local ray of the best hit so far (candidate per instance, committed with `inst`)
 };
 
@@ -40,9 +43,12 @@ __device__ __forceinline__ float intersect_aabb(const Ray& ray, f3 bmin, f3 bmax
 }
 
 // main.glsl:224-257
+// `ties` (native trees whose scene keeps the reference's own trees beside it): with hitInfo.t preset to a tying distance
+// the walk notes, per accepted triangle, the REFERENCE leaf that holds it (jpt_tie_walk.h, step 1)
 template <bool COUNT>
 __device__ __forceinline__ void intersect_triangle(const RefSceneDev& sc, const Ray& ray, uint32_t tri_index, RefHit& hit,
-                                                   bool& improved, DevCounters& cnt)
+                                                   bool& improved, DevCounters& cnt, const TieShadowDev* ties = nullptr,
+                                                   TieLeaves* tl = nullptr, uint32_t inst = 0u)
 {
     if (COUNT) cnt.tri_tests++;
     hit.steps++;
@@ -68,18 +74,24 @@ __device__ __forceinline__ void intersect_triangle(const RefSceneDev& sc, const 
         const ReachTri& r = sc.reach_tri[tri_index];
         if (!r.always && !(intersect_aabb(ray, mk3(r.lo[0], r.lo[1], r.lo[2]), mk3(r.hi[0], r.hi[1], r.hi[2])) < 1e30f)) return;
     }
+    hit.tied = !(t < hit.t) && hit.t < 1e9f;
     hit.t = t;
     hit.tri = tri_index;
     hit.u = u;
     hit.v = v;
     hit.front = dot3(cross3(edge1, edge2), ray.d) > 0.0f;
     improved = true;
+    if (tl) {
+        const uint32_t rt = ties->native_ref[tri_index];
+        if (rt != 0xffffffffu) tl->add(ties->tri_leaf[rt], inst);
+    }
 }
 
 // main.glsl:270-303
 template <bool COUNT>
 __device__ __forceinline__ void ray_trace_blas(const RefSceneDev& sc, uint32_t root, const Ray& ray, RefHit& hit,
-                                               bool& improved, DevCounters& cnt)
+                                               bool& improved, DevCounters& cnt, const TieShadowDev* ties = nullptr,
+                                               TieLeaves* tl = nullptr, uint32_t inst = 0u)
 {
     uint32_t stack[64];
     uint32_t sp = 0;
@@ -89,7 +101,7 @@ __device__ __forceinline__ void ray_trace_blas(const RefSceneDev& sc, uint32_t r
         const uint32_t tri_count = node.tri_count;
         if (tri_count > 0) {
             const uint32_t first = node.first_tri_index;
-            for (uint32_t i = 0; i < tri_count; i++) intersect_triangle<COUNT>(sc, ray, first + i, hit, improved, cnt);
+            for (uint32_t i = 0; i < tri_count; i++) intersect_triangle<COUNT>(sc, ray, first + i, hit, improved, cnt, ties, tl, inst);
             continue;
         }
         if (COUNT) cnt.blas_expand++;
@@ -114,9 +126,11 @@ __device__ __forceinline__ void ray_trace_blas(const RefSceneDev& sc, uint32_t r
 
 // main.glsl:305-350
 template <bool COUNT>
-__device__ __forceinline__ bool ray_trace_tlas(const RefSceneDev& sc, const Ray& ray, RefHit& hit, DevCounters& cnt)
+__device__ __forceinline__ bool ray_trace_tlas(const RefSceneDev& sc, const Ray& ray, RefHit& hit, DevCounters& cnt,
+                                               const TieShadowDev* ties = nullptr, TieLeaves* tl = nullptr, float preset_t = 1e9f)
 {
-    hit.t = 1e9f;
+    hit.t = preset_t;
+    hit.tied = false;
     hit.steps = 0;
     if (sc.n_tlas == 0 || sc.n_instances == 0) return false;
     uint32_t stack[64];
@@ -139,7 +153,7 @@ __device__ __forceinline__ bool ray_trace_tlas(const RefSceneDev& sc, const Ray&
             b_ray.d = xform_dir(b.inverse_transform, ray.d);
             b_ray.rD = rcp3(b_ray.d);
             bool improved = false;
-            ray_trace_blas<COUNT>(sc, b.blas_index, b_ray, hit, improved, cnt);
+            ray_trace_blas<COUNT>(sc, b.blas_index, b_ray, hit, improved, cnt, ties, tl, inst);
             // hitInfo.position / out_dir come from the local ray of the last accepted triangle (main.glsl:249,253)
             if (improved) {
                 hit.lo = b_ray.o;
@@ -176,8 +190,8 @@ __device__ __forceinline__ bool ray_trace_tlas(const RefSceneDev& sc, const Ray&
 
 // One dispatch of main.glsl (main.glsl:404-436) fused with one dispatch of progressive_rendering.glsl
 // (:28-46) for the pixels of this context's partition.
-template <bool COUNT>
-__global__ __launch_bounds__(256) void ref_frame_kernel(RefSceneDev sc, SceneShading sh, FrameParams fp, RefCamera cam,
+template <bool COUNT, bool TIES>
+__global__ __launch_bounds__(256) void ref_frame_kernel(RefSceneDev sc, TieShadowDev shadow, SceneShading sh, FrameParams fp, RefCamera cam,
                                                         float4* __restrict__ accum, uint32_t* __restrict__ ldr,
                                                         float* __restrict__ depth_out, DevCounters* __restrict__ counters)
 {
@@ -207,6 +221,27 @@ __global__ __launch_bounds__(256) void ref_frame_kernel(RefSceneDev sc, SceneSha
             if (!is_hit) {
                 radiance = radiance + throughput * sample_sky(ray.d);
                 break;
+            }
+            if (TIES && hit.tied) {
+                // an exact distance tie: decided where the reference decides it (jpt_tie_walk.h) -- the leaves that hold
+                // the tying triangles from one more walk with hitInfo.t preset, then the reference's own walk through
+                // their ancestors (event counters: not those of a reference tree anyway)
+                TieLeaves tl;
+                RefHit again;
+                DevCounters none = {};
+                (void)ray_trace_tlas<false>(sc, ray, again, none, &shadow, &tl, hit.t);
+                TraceHit xh;
+                if (tl.n > 0 && tie_walk(shadow, sh.instances, shadow.tlas_current, tl, ray.o, ray.d, xh) && xh.t == hit.t) {
+                    const uint32_t found_in = (xh.inst >> kInstBits) & kInstMask;
+                    hit.u = xh.u;
+                    hit.v = xh.v;
+                    hit.tri = shadow.tri_native[xh.tri];
+                    hit.front = xh.front;
+                    hit.inst = xh.inst & kInstMask;
+                    const RefInstance& fb = sc.instances[found_in];
+                    hit.lo = xform_point(fb.inverse_transform, ray.o);
+                    hit.ld = xform_dir(fb.inverse_transform, ray.d);
+                }
             }
             if (COUNT) cnt.shaded_hits++;
             Hit h;
@@ -238,10 +273,14 @@ void launch_ref_frame(hipStream_t stream, const DeviceScene& ds, const FramePara
     sc.reach_inst = ds.reach_inst;
     const SceneShading sh = ds.shading();
     dim3 grid((fp.width + 31) / 32, (fp.local_rows + 7) / 8), block(256);
-    if (counters)
-        hipLaunchKernelGGL(ref_frame_kernel<true>, grid, block, 0, stream, sc, sh, fp, cam, accum, ldr, depth, counters);
-    else
-        hipLaunchKernelGGL(ref_frame_kernel<false>, grid, block, 0, stream, sc, sh, fp, cam, accum, ldr, depth, counters);
+    const bool ties = ds.x.ok && ds.reach_tri != nullptr && !fp.debug_steps && tuning().exact_shadow;
+    if (ties) {
+        if (counters) hipLaunchKernelGGL((ref_frame_kernel<true, true>), grid, block, 0, stream, sc, ds.x, sh, fp, cam, accum, ldr, depth, counters);
+        else hipLaunchKernelGGL((ref_frame_kernel<false, true>), grid, block, 0, stream, sc, ds.x, sh, fp, cam, accum, ldr, depth, counters);
+    } else {
+        if (counters) hipLaunchKernelGGL((ref_frame_kernel<true, false>), grid, block, 0, stream, sc, ds.x, sh, fp, cam, accum, ldr, depth, counters);
+        else hipLaunchKernelGGL((ref_frame_kernel<false, false>), grid, block, 0, stream, sc, ds.x, sh, fp, cam, accum, ldr, depth, counters);
+    }
 }
 
 }  // namespace jpt

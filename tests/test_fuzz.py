@@ -148,9 +148,10 @@ def test_native_tree_with_reach_records_answers_like_the_reference(oracle, hipli
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("kernel", [capi.KERNEL_WAVEFRONT, capi.KERNEL_REFERENCE_LAYOUT])
 @pytest.mark.parametrize("route", ["commit", "upload"])
 @pytest.mark.parametrize("seed", SEEDS)
-def test_native_tree_against_the_reference_walk_with_coincident_triangles(oracle, hiplib, seed, route):
+def test_native_tree_against_the_reference_walk_with_coincident_triangles(oracle, hiplib, seed, route, kernel):
     """Soups WITH coincident triangles: exact distance ties everywhere, where `t > hitInfo.t` rejects and the later-tested
     triangle wins (main.glsl:247) -- the order of the reference's own walk decides.  The native walk flags every hit that ties
     with an earlier one, and wf2_finish decides those on the reference's own trees (kept beside the native ones), walking
@@ -164,6 +165,7 @@ def test_native_tree_against_the_reference_walk_with_coincident_triangles(oracle
     want, _, want_depth, _, _ = oracle.render(ref, cam, w, h, bounces, frames, 1, wire.ACCUM_HDR_F32)
     ctx = host.Context(0)
     try:
+        ctx.set_kernel(kernel)   # (the audit kernel decides its ties the same way)
         if route == "upload":
             ctx.upload_reference_layout(ref.tri_geom, ref.tri_data, ref.materials, ref.bvh_nodes, ref.instances, ref.tlas_nodes, ref.textures)
         else:
@@ -177,7 +179,7 @@ def test_native_tree_against_the_reference_walk_with_coincident_triangles(oracle
     nan_got, nan_want = np.isnan(got).any(axis=-1), np.isnan(want).any(axis=-1)
     ok = ~(nan_got | nan_want)
     ndiff = int((got[ok] != want[ok]).any(axis=-1).sum())
-    print("coincident soup", seed, route, "set aside", st["set_aside"], "dropped", st["set_aside_dropped"], "differing pixels", ndiff,
+    print("coincident soup", seed, route, "kernel", kernel, "set aside", st["set_aside"], "dropped", st["set_aside_dropped"], "differing pixels", ndiff,
           "rel_l2", rel_l2(got[ok], want[ok]))
     assert st["set_aside_dropped"] == 0
     assert np.array_equal(nan_got, nan_want)

@@ -29,10 +29,11 @@ for seed in range(int(os.environ.get('FUZZ_FROM', '8')), int(os.environ.get('FUZ
     # reference tree, on every seed -- two thirds of them with coincident triangles, whose winner is a matter of visiting order;
     # the watertight builder against the tree-independent mode on the seeds without coincident triangles
     for builder, flags in ((capi.BUILD_SAH, 0), ("upload", 0), (capi.BUILD_SAH_WATERTIGHT, 1)):
-        if flags == 1 and seed % 3 != 0: continue
-        amode = (seed // 3) % 2
-        wantn,wln,wdn,_,_ = (want,wl,wd,None,None) if (flags == 0 and amode == mode) else ob.render(ref,cam,w,h,b,f,1+seed,amode,flags=flags)
-        ctx = host.Context(0)
+      if flags == 1 and seed % 3 != 0: continue
+      amode = (seed // 3) % 2
+      wantn,wln,wdn,_,_ = (want,wl,wd,None,None) if (flags == 0 and amode == mode) else ob.render(ref,cam,w,h,b,f,1+seed,amode,flags=flags)
+      for kernel in (capi.KERNEL_WAVEFRONT, capi.KERNEL_REFERENCE_LAYOUT):   # (the audit kernel decides its ties the same way)
+        ctx = host.Context(0); ctx.set_kernel(kernel)
         if builder == "upload":
             ctx.upload_reference_layout(ref.tri_geom,ref.tri_data,ref.materials,ref.bvh_nodes,ref.instances,ref.tlas_nodes,ref.textures)
             assert ctx.tree_kind() == capi.TREE_NATIVE_REACH, ctx.upload_note()
@@ -42,5 +43,5 @@ for seed in range(int(os.environ.get('FUZZ_FROM', '8')), int(os.environ.get('FUZ
         got=ctx.read_accum(); gd=ctx.read_depth(); st=ctx.stats(); ctx.close(); n_native+=1; n_aside+=st["set_aside"]
         m = ~(np.isnan(got).any(-1)|np.isnan(wantn).any(-1))
         if not (np.array_equal(np.isnan(got).any(-1),np.isnan(wantn).any(-1)) and np.array_equal(got[m],wantn[m]) and np.array_equal(gd,wdn,equal_nan=True)):
-            bad+=1; print("NATIVE MISMATCH seed",seed,"builder",builder,"pixels",int((got[m]!=wantn[m]).any(-1).sum()),"set aside",st["set_aside"],"dropped",st["set_aside_dropped"])
+            bad+=1; print("NATIVE MISMATCH seed",seed,"builder",builder,"kernel",kernel,"pixels",int((got[m]!=wantn[m]).any(-1).sum()),"set aside",st["set_aside"],"dropped",st["set_aside_dropped"])
 print("extended fuzz done: %d reference-tree renders, %d native-tree renders (%d vertices set aside: cracks and exact ties), mismatches: %d" % (n_ref, n_native, n_aside, bad))
