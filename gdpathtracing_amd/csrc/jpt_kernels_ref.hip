@@ -191,7 +191,7 @@ __device__ __forceinline__ bool ray_trace_tlas(const RefSceneDev& sc, const Ray&
 // One dispatch of main.glsl (main.glsl:404-436) fused with one dispatch of progressive_rendering.glsl
 // (:28-46) for the pixels of this context's partition.
 template <bool COUNT, bool TIES>
-__global__ __launch_bounds__(256) void ref_frame_kernel(RefSceneDev sc, TieShadowDev shadow, SceneShading sh, FrameParams fp, RefCamera cam,
+__global__ __launch_bounds__(256, 5) void ref_frame_kernel(RefSceneDev sc, TieShadowDev shadow, SceneShading sh, FrameParams fp, RefCamera cam,
                                                         float4* __restrict__ accum, uint32_t* __restrict__ ldr,
                                                         float* __restrict__ depth_out, DevCounters* __restrict__ counters)
 {
