@@ -10,7 +10,9 @@ Scene, camera and RNG streams are synthetic and deterministic (gdpathtracing_amd
 resident in HBM before the timed region starts.
 
   python bench.py --gpus 1 --steps K --warmup W
-  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W     (the driver's form)
+  python bench.py --gpus N ...                    starts that torch.distributed.run itself, as a child process
+  python bench.py --gpus N --launcher multi ...   ONE process, one context per device (jpt_multi_*, peer-to-peer pushes)
 
 Rank 0 prints ONE JSON line.  `value` = ray segments actually traced by all ranks / max-over-ranks time.
 At N = 1 the line also carries
@@ -56,6 +58,130 @@ def rel_l2(a, b):
     return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
 
 
+def self_launch(n):
+    """python -m torch.distributed.run --nnodes=1 --nproc-per-node n ... bench.py <the same arguments>, as a child process"""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL between processes needs it on this driver
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in p.stdout.splitlines():
+        if ln.startswith("{"):
+            line = ln
+        else:
+            sys.stderr.write(ln + "\n")
+    if line is not None:
+        print(line)
+        sys.stdout.flush()
+    elif p.returncode == 0:
+        sys.stderr.write("bench.py: the launched ranks printed no JSON line\n")
+        return 1
+    return p.returncode
+
+
+def main_multi(args):
+    """--launcher multi: the same workload from ONE process through jpt_multi_* (include/jpt.h): a context per device, every
+    render fanned out, each peer pushing its float4 rows to device 0 on a copy stream of its own, assembly on device 0.  One
+    JSON line in the same format; `value` = ray segments of all ranks / wall time of K queued steps."""
+    import torch
+    from gdpathtracing_amd import capi, host, scenes
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    n = args.gpus
+    have = torch.cuda.device_count()
+    devices = [r % have for r in range(n)]     # fewer GPUs than ranks: a rehearsal, ranks share devices (copies are device-local)
+    if args.scene == "demo":
+        sc = scenes.demo_scene(args.tris)
+    elif args.scene == "cornell":
+        sc = scenes.cornell_scene()
+    elif args.scene == "unique":
+        sc = scenes.unique_scene(args.tris if args.tris != 51200 else 1_000_000)
+    else:
+        sc = scenes.instanced_scene()
+    accum_mode = capi.ACCUM_REF_LDR8 if args.accum == "ldr8" else capi.ACCUM_HDR_F32
+    builder = {"sah": capi.BUILD_SAH, "exact": capi.BUILD_REFERENCE_EXACT, "watertight": capi.BUILD_SAH_WATERTIGHT}[args.builder]
+    m = host.MultiContext(devices)
+    t0 = time.time()
+    m.build_scene(sc, builder)
+    build_s = time.time() - t0
+    m.set_gather(args.gather == "ldr")
+
+    def sync_all():
+        m.sync()
+        for d in sorted(set(devices)):
+            torch.cuda.synchronize(d)
+
+    def leg(w, h, spp, bounces, steps, warmup):
+        cam = scenes.camera_block(sc.camera, w, h)
+        m.set_params(w, h, bounces, accum_mode)
+        m.set_camera(cam)
+        rays = 0
+        for r in range(n):                       # exact event counts, rank by rank (deterministic)
+            c = m.ctx(r)
+            c.accum_reset()
+            c.render(spp, 1, counted=True)
+            rays += c.stats()["rays"]
+
+        def step():
+            m.accum_reset()
+            m.render(spp, 1)
+
+        step()
+        sync_all()
+        for _ in range(warmup):
+            step()
+        sync_all()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        sync_all()
+        elapsed = time.perf_counter() - t0
+        plan = m.gather_plan()
+        got = m.read_ldr() if args.gather == "ldr" else m.read_accum()
+        solo = host.Context(devices[0])
+        solo.build_scene(sc, builder)
+        solo.set_params(w, h, bounces, accum_mode)
+        solo.set_camera(cam)
+        solo.render(spp, 1)
+        same = bool(np.array_equal(got, solo.read_ldr() if args.gather == "ldr" else solo.read_accum()))
+        solo.close()
+        return dict(rays_per_step=rays, steps=steps, ms_per_step=round(elapsed / steps * 1e3, 4), value=round(rays * steps / elapsed / 1e6, 3),
+                    verified_bit_identical_to_one_context=same, gather_plan=plan)
+
+    c3 = leg(args.width, args.height, args.spp, args.bounces, args.steps, args.warmup)
+    c5 = leg(3840, 2160, 16, 6, max(5, args.steps // 5), 2)
+    c5["workload"] = "C5: the same scene at 3840x2160, 16 spp, 6 bounces"
+    out = {
+        "metric": "Mrays/sec at 1920x1080, 8 spp, 4 bounces", "value": c3["value"], "unit": "Mrays/s", "n_gpus": n, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": c3["ms_per_step"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic", "launcher": "multi",
+        "config": {"workload": "C3: S-demo (open Cornell cube + light + 2 instances of a %d-tri procedural mesh), %dx%d, %d spp, %d bounces, accum=%s, builder=%s"
+                               % (args.tris, args.width, args.height, args.spp, args.bounces, args.accum, args.builder),
+                   "unique_tris": sc.n_unique_tris, "instances": len(sc.instances), "rays_per_step": c3["rays_per_step"],
+                   "parallelism": "screen strips x%d, ONE process (jpt_multi): each peer pushes its %s rows to device 0 on its own copy stream, "
+                                  "assembly on device 0" % (n, "rgba8 display" if args.gather == "ldr" else "float4 accumulation"),
+                   "scene_build_s": round(build_s, 4)},
+        "verified_bit_identical_to_one_context": c3["verified_bit_identical_to_one_context"],
+        "value_c5": c5["value"], "ms_per_step_c5": c5["ms_per_step"],
+        "multi_gpu": {"ranks_seen": n, "devices": devices, "distinct_devices": len(set(devices)), "backend": "hipMemcpyPeerAsync (one process)",
+                      "gather_plan": c3["gather_plan"], "c5": c5,
+                      "note": "ranks share a device when the box has fewer GPUs than ranks: a rehearsal of the protocol, not a link rate"
+                              if len(set(devices)) < n else "one device per rank"},
+    }
+    print(json.dumps(out))
+    m.close()
+    ok = c3["verified_bit_identical_to_one_context"] and c5["verified_bit_identical_to_one_context"]
+    if not ok:
+        sys.stderr.write("bench.py: the assembled image differs from one context's\n")
+    return 0 if ok else 3
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -87,12 +213,24 @@ def main():
                     help="N > 1: what crosses the links each render -- the float4 accumulation rows (16 B/pixel: the exchange "
                          "BASELINE.json's north_star names, the default) or only the rgba8 display rows (4 B/pixel, what the "
                          "reference reads back)")
+    ap.add_argument("--launcher", choices=["torchrun", "multi"], default="torchrun",
+                    help="N > 1: torchrun = one process per GPU under torch.distributed (RCCL gather; started as a child process "
+                         "when WORLD_SIZE is not set) -- the driver's mode; multi = ONE process, one context per device through "
+                         "jpt_multi_* (what the addon's C++ host uses): every peer pushes its rows to device 0 on its own copy stream")
     ap.add_argument("--cpu-sample", default="auto")
     ap.add_argument("--pmc-json", default=os.path.join(ROOT, "profiles", "current_pmc.json"),
                     help="per-launch HBM bytes of each kernel from the committed rocprofv3 --pmc passes (tools/pmc.sh)")
     ap.add_argument("--sq-json", default=os.path.join(ROOT, "profiles", "current_sq.json"),
                     help="per-launch SQ counters of each kernel from the committed rocprofv3 --pmc passes (tools/diag.sh)")
     args = ap.parse_args()
+
+    # `python bench.py --gpus N` on its own (no torch.distributed.run around it, WORLD_SIZE unset): start the per-GPU
+    # processes ourselves.  A CHILD process (never exec: nothing in this process may have touched the GPU, and nothing has --
+    # torch is not imported yet), its one JSON line relayed, its exit status ours.  VERDICT r03 weak 3b.
+    if args.gpus > 1 and args.launcher == "torchrun" and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus))
+    if args.gpus > 1 and args.launcher == "multi" and "WORLD_SIZE" not in os.environ:
+        sys.exit(main_multi(args))
 
     import torch
     from gdpathtracing_amd import capi, host, partition, scenes
@@ -101,9 +239,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
-        args.gpus = world
+        args.gpus = world          # (under torch.distributed.run the launcher's world size is the truth)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     # JPT_BENCH_BACKEND=gloo is a functional rehearsal of the N > 1 flow on a box with fewer GPUs than ranks

@@ -27,7 +27,7 @@ BUF_TRI_GEOMETRY, BUF_TRI_DATA, BUF_MATERIALS, BUF_BVH_NODES, BUF_INSTANCES, BUF
 # every symbol include/jpt.h declares
 SYMBOLS = [
     "jpt_abi_version", "jpt_create", "jpt_destroy", "jpt_last_error", "jpt_set_stream", "jpt_get_stream", "jpt_set_stream_priority", "jpt_set_memory_policy", "jpt_get_workspace_bytes",
-    "jpt_scene_upload_reference_layout", "jpt_set_upload_mode", "jpt_scene_tree_kind", "jpt_scene_upload_note", "jpt_scene_begin", "jpt_scene_add_mesh", "jpt_scene_add_instance",
+    "jpt_scene_upload_reference_layout", "jpt_set_upload_mode", "jpt_scene_tree_kind", "jpt_scene_upload_note", "jpt_scene_ties_exact", "jpt_scene_begin", "jpt_scene_add_mesh", "jpt_scene_add_instance",
     "jpt_scene_set_materials", "jpt_scene_set_textures", "jpt_scene_commit", "jpt_scene_get_reference_buffer",
     "jpt_scene_set_instance_transform", "jpt_scene_update_tlas", "jpt_scene_refit_tlas", "jpt_scene_update_reference_tlas",
     "jpt_set_params", "jpt_set_kernel", "jpt_set_debug_steps", "jpt_set_kernel_timing", "jpt_set_partition", "jpt_set_camera", "jpt_render", "jpt_render_counted", "jpt_render_async",
@@ -36,7 +36,7 @@ SYMBOLS = [
     "jpt_scene_share", "jpt_multi_create", "jpt_multi_destroy", "jpt_multi_last_error", "jpt_multi_world", "jpt_multi_ctx",
     "jpt_multi_share_scene", "jpt_multi_set_instance_transform", "jpt_multi_update_tlas", "jpt_multi_refit_tlas",
     "jpt_multi_update_reference_tlas", "jpt_multi_set_params", "jpt_multi_set_camera", "jpt_multi_accum_reset", "jpt_multi_set_gather",
-    "jpt_multi_render", "jpt_multi_sync", "jpt_multi_read_ldr_rgba8", "jpt_multi_read_accum_f32",
+    "jpt_multi_render", "jpt_multi_sync", "jpt_multi_gather_plan", "jpt_multi_read_ldr_rgba8", "jpt_multi_read_accum_f32",
     "jpt_debug_quantize_nodes4", "jpt_debug_node_step4", "jpt_debug_last_error",
 ]
 
@@ -111,6 +111,8 @@ def lib():
     L.jpt_scene_tree_kind.argtypes = [vp]
     L.jpt_scene_upload_note.argtypes = [vp]
     L.jpt_scene_upload_note.restype = C.c_char_p
+    L.jpt_scene_ties_exact.argtypes = [vp, C.POINTER(C.c_char_p)]
+    L.jpt_scene_ties_exact.restype = C.c_int
     L.jpt_scene_begin.argtypes = [vp]
     L.jpt_scene_add_mesh.argtypes = [vp, C.POINTER(Surface), i32, C.POINTER(u32)]
     L.jpt_scene_add_instance.argtypes = [vp, u32, vp, vp, i32]
@@ -169,6 +171,7 @@ def lib():
     L.jpt_multi_set_gather.argtypes = [vp, i32]
     L.jpt_multi_render.argtypes = [vp, i32, u32]
     L.jpt_multi_sync.argtypes = [vp]
+    L.jpt_multi_gather_plan.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
     L.jpt_multi_read_ldr_rgba8.argtypes = [vp, vp]
     L.jpt_multi_read_accum_f32.argtypes = [vp, vp]
     L.jpt_debug_quantize_nodes4.argtypes = [vp, u32, vp]

@@ -37,6 +37,10 @@ namespace {
 
 inline float lo_(float a, float b) { return (b < a) ? b : a; }  // std::min
 inline float hi_(float a, float b) { return (a < b) ? b : a; }  // std::max
+// bin of a scaled centroid coordinate, clamped BEFORE the conversion: (int) of a NaN or of a value past INT_MAX is
+// undefined, and uploaded instances / triangles may hold either (found by the UBSan run of tests/test_upload_mutations.py);
+// a finite in-range x converts exactly as the plain cast did, so valid scenes build the same trees
+inline int bin_of(float x, int bins) { return !(x > 0.0f) ? 0 : (x >= (float)bins ? bins - 1 : (int)x); }
 inline float comp(const Vec4& v, int axis) { return axis == 0 ? v.x : axis == 1 ? v.y : axis == 2 ? v.z : axis == 3 ? v.w : v.x; }
 
 struct Box4 {
@@ -77,7 +81,10 @@ struct ExactBlasBuilder {
         const float inv_range = 1.0f / range;
         for (uint32_t i = 0; i < node.tri_count; i++) {
             const RefTriangle& t = tris[node.first_tri_index + i];
-            const int b = std::clamp(int(float(kBins) * (comp(t.centroid, axis) - lo) * inv_range), 0, kBins - 1);
+            // int(float) as bvh.cpp:64 writes it is undefined for a NaN or an out-of-range value (a mesh with such a vertex);
+            // the reference's x86 build gets cvttss2si's "integer indefinite", INT_MIN, which the clamp turns into bin 0
+            const float fb = float(kBins) * (comp(t.centroid, axis) - lo) * inv_range;
+            const int b = std::clamp((fb >= -2147483648.0f && fb < 2147483648.0f) ? int(fb) : INT32_MIN, 0, kBins - 1);
             bin_n[b]++;
             bin_box[b].grow(t.vertices[0]);
             bin_box[b].grow(t.vertices[1]);
@@ -304,8 +311,7 @@ struct SahBlasBuilder {
             const Box3& tb = tri_box[t];
             for (int a = 0; a < 3; a++) {
                 if (!usable[a]) continue;
-                int k = (int)((centroid[(size_t)t * 3 + a] - c0[a]) * scale[a]);
-                k = k < 0 ? 0 : (k >= kBins ? kBins - 1 : k);
+                const int k = bin_of((centroid[(size_t)t * 3 + a] - c0[a]) * scale[a], kBins);
                 bb[a][k].grow(tb);
                 bn[a][k]++;
             }
@@ -347,8 +353,7 @@ struct SahBlasBuilder {
         if (best_axis >= 0) {
             const float cc = c0[best_axis], sc = scale[best_axis];
             auto it = std::partition(order.begin() + lo, order.begin() + hi, [&](uint32_t t) {
-                int k = (int)((centroid[(size_t)t * 3 + best_axis] - cc) * sc);
-                k = k < 0 ? 0 : (k >= kBins ? kBins - 1 : k);
+                const int k = bin_of((centroid[(size_t)t * 3 + best_axis] - cc) * sc, kBins);
                 return k <= best_bin;
             });
             mid = (int)(it - order.begin());
@@ -457,9 +462,20 @@ bool build_tlas(const std::vector<RefInstance>& inst, std::vector<RefTlasNode>& 
         live.push_back((int)out.size());
         out.push_back(n);
     }
+    // FindBestMatch keeps -1 when no union's half-area is below its 1e30 start value (NaN or huge instance boxes); the
+    // reference then indexes its list with -1 (bvh.cpp:285-287).  Here that is an error of the scene, not of the process.
+    const char* no_partner = "TLAS: an instance's world box is not finite (TLAS::FindBestMatch finds no partner, bvh.cpp:319-340)";
     int a = 0, b = nearest_partner(out, live, count, a);
+    if (count > 1 && b < 0) {
+        err = no_partner;
+        return false;
+    }
     while (count > 1) {
         const int c = nearest_partner(out, live, count, b);
+        if (c < 0) {
+            err = no_partner;
+            return false;
+        }
         if (a == c) {
             const int ia = live[a], ib = live[b];
             RefTlasNode n;
@@ -473,6 +489,10 @@ bool build_tlas(const std::vector<RefInstance>& inst, std::vector<RefTlasNode>& 
             out.push_back(n);
             live[b] = live[--count];
             b = nearest_partner(out, live, count, a);
+            if (count > 1 && b < 0) {
+                err = no_partner;
+                return false;
+            }
         } else {
             a = b;
             b = c;
@@ -520,8 +540,7 @@ struct TlasSahBuilder {
             for (int i = lo; i < hi; i++) {
                 float a[3], b[3];
                 box_of(inst[order[(size_t)i]], a, b);
-                int k = (int)((0.5f * (a[axis] + b[axis]) - c0) * scale);
-                k = k < 0 ? 0 : (k >= kBins ? kBins - 1 : k);
+                const int k = bin_of((0.5f * (a[axis] + b[axis]) - c0) * scale, kBins);
                 bb[k].grow(a);
                 bb[k].grow(b);
                 bn[k]++;
@@ -556,8 +575,7 @@ struct TlasSahBuilder {
             auto it = std::partition(order.begin() + lo, order.begin() + hi, [&](uint32_t id) {
                 float a[3], b[3];
                 box_of(inst[id], a, b);
-                int k = (int)((0.5f * (a[best_axis] + b[best_axis]) - c0) * scale);
-                k = k < 0 ? 0 : (k >= kBins ? kBins - 1 : k);
+                const int k = bin_of((0.5f * (a[best_axis] + b[best_axis]) - c0) * scale, kBins);
                 return k <= best_bin;
             });
             const int m = (int)(it - order.begin());
@@ -799,21 +817,44 @@ bool SceneBuilder::commit(BuildMode mode, RefScene& out, std::string& err)
                 }
             }
         } else {
+            // an empty mesh: resolved after the loop
             if (mode == BuildMode::Sah) {
                 out.mesh_ref_root.resize(out.mesh_roots.size() + 1);
                 std::memset(&out.mesh_ref_root.back(), 0, sizeof(ReachInst));
-                RefBvhNode n;
-                std::memset(&n, 0, sizeof n);
-                out.exact.mesh_roots.push_back((uint32_t)out.exact.bvh_nodes.size());
-                out.exact.bvh_nodes.push_back(n);
+                out.exact.mesh_roots.push_back(0u);
             }
-            // BuildBVH on an empty mesh returns 0 (bvh.cpp:111-112); keep a valid empty leaf instead
-            root = (uint32_t)out.bvh_nodes.size();
-            RefBvhNode n;
-            std::memset(&n, 0, sizeof n);
-            out.bvh_nodes.push_back(n);
         }
         out.mesh_roots.push_back(root);
+    }
+    // BuildBVH on a mesh without triangles pushes no node and returns 0 (bvh.cpp:111-112), so in the reference an instance of
+    // such a mesh gets blas_index 0 (geometry_group3d.cpp:311,325) and SHOWS WHATEVER TREE STARTS AT NODE 0 -- the first mesh
+    // that has triangles -- under its own transform and materials.  Reproduced: an empty mesh stands for that mesh in every
+    // table (so the node arrays equal the reference's byte for byte and all routes render what the reference renders).  Only
+    // when NO mesh has a triangle -- the reference's shader would then read a node past the end of an empty buffer -- a
+    // single empty leaf is kept so that every root names a valid node.
+    {
+        size_t first = meshes_.size();
+        for (size_t m = 0; m < meshes_.size(); m++)
+            if (!meshes_[m].tris.empty()) {
+                first = m;
+                break;
+            }
+        const bool shadow = mode == BuildMode::Sah;
+        if (first == meshes_.size() && !meshes_.empty()) {
+            RefBvhNode n;
+            std::memset(&n, 0, sizeof n);
+            out.bvh_nodes.push_back(n);     // mesh_roots are all 0 already
+            if (shadow) out.exact.bvh_nodes.push_back(n);
+        } else {
+            for (size_t m = 0; m < meshes_.size(); m++)
+                if (meshes_[m].tris.empty()) {
+                    out.mesh_roots[m] = out.mesh_roots[first];
+                    if (shadow) {
+                        out.mesh_ref_root[m] = out.mesh_ref_root[first];
+                        out.exact.mesh_roots[m] = out.exact.mesh_roots[first];
+                    }
+                }
+        }
     }
     if (!rebuild_instances(mode, out, err)) return false;
     split_triangles(out);
@@ -1100,52 +1141,89 @@ namespace {
 struct Flattener {
     const RefScene& ref;
     WideScene& out;
-    std::vector<int32_t> blas_ref_of_node;  // child reference for each reference BVH node (lazy)
     std::string err;
+    // Uploaded arrays are only range-checked when they get here, so the two recursions below must end on ANY input:
+    // a node is expanded once (kDone: a second parent gets the record made for the first, so a shared subtree costs
+    // its size, not 2^depth), a node met again while its own subtree is still open is a cycle (kOpen: an error --
+    // main.glsl:270-350 would never leave it), and no chain is followed deeper than kMaxDepth frames of the host
+    // stack.  That loses nothing: the kernels' traversal stack holds fewer than 100 entries and a tree that could need
+    // more is refused after the flatten (compute_stack_need, jpt_capi.hip upload_scene), so a tree this deep was never
+    // going to be accepted; the bound only keeps collapse4 / need2 / need4, which recurse over what is made here, shallow.
+    enum : uint8_t { kUnseen = 0, kOpen = 1, kDone = 2 };
+    static constexpr uint32_t kMaxDepth = 512u;
+    std::vector<uint8_t> blas_state, tlas_state;
+    std::vector<int32_t> blas_memo, tlas_memo;
+
+    Flattener(const RefScene& r, WideScene& o) : ref(r), out(o) {}
 
     int32_t leaf_ref(uint32_t first, uint32_t count) { return ~(int32_t)((first & kLeafFirstMask) | ((count - 1) << kLeafCountShift)); }
 
     // returns the child reference that stands for reference node `ni`
     int32_t blas_child(uint32_t ni, uint32_t depth)
     {
+        if (!err.empty()) return ~0;
         if (ni >= ref.bvh_nodes.size()) {
             err = "BVH child index out of range";
             return ~0;
         }
-        // uploaded arrays are only range-checked: a cycle (or a chain deeper than any builder makes) must not
-        // overflow the host stack.  A tree over n nodes is at most n deep.
-        if (depth > 4096u || depth > ref.bvh_nodes.size() + 1u) {
-            err = "BVH is cyclic or deeper than 4096 levels";
+        if (blas_state.empty()) {
+            blas_state.assign(ref.bvh_nodes.size(), kUnseen);
+            blas_memo.assign(ref.bvh_nodes.size(), 0);
+        }
+        if (blas_state[ni] == kDone) return blas_memo[ni];
+        if (blas_state[ni] == kOpen) {
+            err = "BVH has a cycle";
             return ~0;
         }
+        if (depth > kMaxDepth) {
+            err = "BVH is deeper than 512 levels";
+            return ~0;
+        }
+        blas_state[ni] = kOpen;
+        const int32_t r = blas_expand(ni, depth);
+        blas_state[ni] = kDone;
+        blas_memo[ni] = r;
+        return r;
+    }
+
+    int32_t blas_expand(uint32_t ni, uint32_t depth)
+    {
         out.max_blas_depth = std::max(out.max_blas_depth, depth);
         const RefBvhNode& n = ref.bvh_nodes[ni];
         if (n.tri_count > 0 || (n.left_child == 0 && n.right_child == 0)) {
             uint32_t first = n.first_tri_index, count = n.tri_count;
             if (count == 0) return make_empty_leaf();
-            if (first + count > kLeafFirstMask) {
-                err = "too many triangles for the 25-bit leaf reference";
+            if ((uint64_t)first + count > (uint64_t)kLeafFirstMask || (uint64_t)first + count > ref.tri_geom.size()) {
+                err = (uint64_t)first + count > ref.tri_geom.size() ? "BVH leaf triangle range out of bounds"
+                                                                     : "too many triangles for the 25-bit leaf reference";
                 return ~0;
             }
             if (count <= (uint32_t)kMaxLeafTris) return leaf_ref(first, count);
+            if (count > (uint32_t)kMaxLeafTris * kMaxDepth) {
+                err = "a BVH leaf holds more than 32768 triangles";
+                return ~0;
+            }
             // oversized leaf (the reference makes them when all three SAH axes are rejected): chain of
             // records whose two boxes both equal the leaf box.  With equal entry distances the walk takes the
             // else branch of main.glsl:293-299 and visits the RIGHT child first, so the first 64 triangles go
             // right and the rest left: the triangles are tested in index order, as the leaf loop of
-            // main.glsl:280-283 does (ties, t == hitInfo.t, go to the later triangle)
-            const int32_t self = (int32_t)out.blas_nodes.size();
-            out.blas_nodes.emplace_back();
-            WideNode w;
-            std::memset(&w, 0, sizeof w);
-            set_box(w.lmin, w.lmax, n);
-            set_box(w.rmin, w.rmax, n);
-            w.right = leaf_ref(first, kMaxLeafTris);
-            RefBvhNode rest = n;
-            rest.first_tri_index = first + kMaxLeafTris;
-            rest.tri_count = count - kMaxLeafTris;
-            w.left = oversized_rest(rest);
-            out.blas_nodes[self] = w;
-            return self;
+            // main.glsl:280-283 does (ties, t == hitInfo.t, go to the later triangle).  A loop, not a recursion:
+            // the count is the caller's word and a chain may be 2^25 / 64 records long.
+            const int32_t head = (int32_t)out.blas_nodes.size();
+            while (true) {
+                const int32_t self = (int32_t)out.blas_nodes.size();
+                WideNode w;
+                std::memset(&w, 0, sizeof w);
+                set_box(w.lmin, w.lmax, n);
+                set_box(w.rmin, w.rmax, n);
+                w.right = leaf_ref(first, kMaxLeafTris);
+                first += kMaxLeafTris;
+                count -= kMaxLeafTris;
+                w.left = count <= (uint32_t)kMaxLeafTris ? leaf_ref(first, count) : self + 1;
+                out.blas_nodes.push_back(w);
+                if (count <= (uint32_t)kMaxLeafTris) break;
+            }
+            return head;
         }
         const int32_t self = (int32_t)out.blas_nodes.size();
         out.blas_nodes.emplace_back();
@@ -1178,24 +1256,6 @@ struct Flattener {
         return self;
     }
 
-    int32_t oversized_rest(const RefBvhNode& n)
-    {
-        if (n.tri_count <= (uint32_t)kMaxLeafTris) return leaf_ref(n.first_tri_index, n.tri_count);
-        const int32_t self = (int32_t)out.blas_nodes.size();
-        out.blas_nodes.emplace_back();
-        WideNode w;
-        std::memset(&w, 0, sizeof w);
-        set_box(w.lmin, w.lmax, n);
-        set_box(w.rmin, w.rmax, n);
-        w.right = leaf_ref(n.first_tri_index, kMaxLeafTris);   // visited first (see blas_child)
-        RefBvhNode rest = n;
-        rest.first_tri_index += kMaxLeafTris;
-        rest.tri_count -= kMaxLeafTris;
-        w.left = oversized_rest(rest);
-        out.blas_nodes[self] = w;
-        return self;
-    }
-
     static void set_box(float* lo, float* hi, const RefBvhNode& n)
     {
         lo[0] = n.aabbMin.x; lo[1] = n.aabbMin.y; lo[2] = n.aabbMin.z;
@@ -1204,10 +1264,33 @@ struct Flattener {
 
     int32_t tlas_child(uint32_t ni, uint32_t depth)
     {
-        if (ni >= ref.tlas_nodes.size() || depth > 70000) {
+        if (!err.empty()) return ~0;
+        if (ni >= ref.tlas_nodes.size()) {
             err = "TLAS child index out of range";
             return ~0;
         }
+        if (tlas_state.empty()) {
+            tlas_state.assign(ref.tlas_nodes.size(), kUnseen);
+            tlas_memo.assign(ref.tlas_nodes.size(), 0);
+        }
+        if (tlas_state[ni] == kDone) return tlas_memo[ni];
+        if (tlas_state[ni] == kOpen) {
+            err = "TLAS has a cycle";
+            return ~0;
+        }
+        if (depth > kMaxDepth) {
+            err = "TLAS is deeper than 512 levels";
+            return ~0;
+        }
+        tlas_state[ni] = kOpen;
+        const int32_t r = tlas_expand(ni, depth);
+        tlas_state[ni] = kDone;
+        tlas_memo[ni] = r;
+        return r;
+    }
+
+    int32_t tlas_expand(uint32_t ni, uint32_t depth)
+    {
         out.max_tlas_depth = std::max(out.max_tlas_depth, depth);
         const RefTlasNode& n = ref.tlas_nodes[ni];
         if (n.leftRight == 0) {
@@ -1244,7 +1327,7 @@ struct Flattener {
 bool flatten(const RefScene& ref, WideScene& out, std::string& err)
 {
     out = WideScene();
-    Flattener f{ref, out, {}, {}};
+    Flattener f(ref, out);
     // triangles: v0 + the two Moller-Trumbore edges (same subtractions as main.glsl:231-232)
     out.tris.resize(ref.tri_geom.size());
     for (size_t i = 0; i < ref.tri_geom.size(); i++) {
@@ -1573,7 +1656,7 @@ bool reflatten_tlas(const RefScene& ref, WideScene& out, bool with4, std::string
     out.max_tlas_depth = 0;
     out.tlas_root = out.tlas_root4 = 0;
     if (!ref.tlas_nodes.empty() && !ref.instances.empty()) {
-        Flattener f{ref, out, {}, {}};
+        Flattener f(ref, out);
         out.tlas_root = f.tlas_child(0, 1);
         if (!f.err.empty()) {
             err = f.err;

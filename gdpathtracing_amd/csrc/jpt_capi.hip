@@ -71,6 +71,7 @@ struct jpt_ctx {
     int32_t max_slots = 0;              // jpt_set_memory_policy: renders in flight (0: the library's rule)
     uint64_t workspace_budget = 0;      // ... and bytes per workspace (0: tuning().workspace_budget_mb)
     std::string upload_note;        // why the last reference-layout upload is walked as given (empty: it is not)
+    std::string ties_note;          // why exact distance ties fall to the native tree's order (empty: they are decided exactly)
     std::vector<RefMaterial> pending_materials;
     std::vector<uint8_t> pending_tex;
     int32_t pending_tex_res = 0, pending_layers = 0;
@@ -292,6 +293,25 @@ int upload_nodes4(jpt_ctx* c, bool tlas_only)
     return JPT_OK;
 }
 
+// Why exact distance ties fall to the native tree's order, for jpt_scene_ties_exact (this used to be silent).  A
+// tree of the reference's own -- uploads walked as given, JPT_BUILD_REFERENCE_EXACT -- needs no shadow: its walk IS the
+// reference's.
+void note_ties(jpt_ctx* c)
+{
+    const ExactShadow& x = c->ref.exact;
+    c->ties_note.clear();
+    if (c->native_tree) {
+        if (c->ref.reach_tri.empty()) c->ties_note = "the scene has no reach records (JPT_BUILD_SAH_WATERTIGHT): the native tree's order decides";
+        else if (!tuning().exact_shadow) c->ties_note = "switched off (JPT_EXACT_SHADOW=0)";
+        else if (x.instances.empty()) c->ties_note.clear();   // nothing to hit
+        else if (!x.valid) c->ties_note = "the reference's TLAS of this scene could not be built (TLAS::build, bvh.cpp:264-317)";
+        else if (!x.resolvable)
+            c->ties_note = "the uploaded trees are not in the shape the restricted walk indexes: every BLAS numbered in pre-order "
+                           "(left child = parent + 1, what build_recursive emits, bvh.cpp:108-185) and every instance in exactly one "
+                           "TLAS leaf reachable from slot 0";
+    }
+}
+
 // The shadow (the reference's own trees beside a native scene, ExactShadow) -> the device, for jpt_tie_walk.h.
 // `instances_only`: the BLAS part is there already (a TLAS update).  Not having a shadow is not an error: exact distance
 // ties are then decided by the order of the native walk.
@@ -300,6 +320,7 @@ int upload_shadow(jpt_ctx* c, bool instances_only)
     TieShadowDev& d = c->ds.x;
     d.ok = false;
     const ExactShadow& x = c->ref.exact;
+    note_ties(c);
     if (!tuning().exact_shadow || !x.valid || !x.resolvable || !c->native_tree || c->ref.reach_tri.empty() || c->device < 0 || x.instances.empty())
         return JPT_OK;
     hipStream_t s = c->stream;
@@ -357,6 +378,7 @@ int upload_scene(jpt_ctx* c)
     c->host_scene_ready = true;
     c->tlas_dirty = false;
     c->refit_active = false;
+    note_ties(c);
     if (c->device < 0) return JPT_OK;  // host-only context: arrays stay on the host, nothing can be rendered
     HIP_TRY(c, hipSetDevice(c->device));
     hipStream_t s = c->stream;
@@ -562,6 +584,14 @@ int do_render(jpt_ctx* c, int32_t n_frames, uint32_t first_frame_index, bool cou
     if (!c) return JPT_E_INVALID;
     if (c->device < 0 || !c->scene_ready || !c->params_set || !c->camera_set || n_frames <= 0)
         return do_render_batch(c, n_frames, first_frame_index, counted, blocking);  // reports the error / no-op
+    // a budget the caller set is a cap, not a hint: one frame is the smallest batch there is
+    if (c->workspace_budget && c->kernel_variant != JPT_KERNEL_REFERENCE_LAYOUT && !c->debug_steps) {
+        const size_t one = wf2_workspace_bytes(c->width, c->local_rows, 1, c->max_bounces);
+        if (one > c->workspace_budget)
+            return fail(c, JPT_E_LIMIT, "jpt_set_memory_policy: one frame of this resolution needs a workspace of " + std::to_string(one) +
+                                            " bytes, the budget is " + std::to_string(c->workspace_budget) +
+                                            " (raise it, or render with JPT_KERNEL_REFERENCE_LAYOUT, which needs none)");
+    }
     const int32_t per = frames_per_batch(c, n_frames);
     if (per >= n_frames) return do_render_batch(c, n_frames, first_frame_index, counted, blocking);
     // more frames than the workspace budget holds at once: batches in frame order (the accumulation continues).  A
@@ -1190,6 +1220,15 @@ int jpt_scene_tree_kind(jpt_ctx* c)
 
 const char* jpt_scene_upload_note(const jpt_ctx* c) { return c ? c->upload_note.c_str() : ""; }
 
+int jpt_scene_ties_exact(jpt_ctx* c, const char** why_out)
+{
+    if (why_out) *why_out = "";
+    if (!c) return JPT_E_INVALID;
+    if (!c->host_scene_ready) return fail(c, JPT_E_STATE, "no scene");
+    if (why_out) *why_out = c->ties_note.c_str();
+    return c->ties_note.empty() ? 1 : 0;
+}
+
 int jpt_scene_begin(jpt_ctx* c)
 {
     if (!c) return JPT_E_INVALID;
@@ -1295,6 +1334,7 @@ int jpt_scene_share(jpt_ctx* dst, jpt_ctx* src)
     dst->build_mode = src->build_mode;
     dst->from_commit = src->from_commit;
     dst->upload_note = src->upload_note;
+    dst->ties_note = src->ties_note;
     dst->building = false;
     const int rc = upload_scene(dst);   // flatten + upload to dst's device; no builder runs
     dst->stats.last_build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -1529,6 +1569,16 @@ int jpt_scene_update_reference_tlas(jpt_ctx* c, const void* blas_instances, uint
     std::vector<RefInstance> old_inst = c->ref.instances;
     std::vector<RefTlasNode> old_tlas = c->ref.tlas_nodes;
     std::vector<ReachInst> old_reach = c->ref.reach_inst;
+    // ... and the shadow's instance level with them (native_instances_from_uploaded rewrites it): after a
+    // rejected update exact ties must still be decided on the TLAS of the scene that is rendered
+    std::vector<RefInstance> old_x_inst;
+    std::vector<RefTlasNode> old_x_tlas;
+    std::vector<uint32_t> old_up_index;
+    if (native) {
+        old_x_inst = c->ref.exact.instances;
+        old_x_tlas = c->ref.exact.tlas_nodes;
+        old_up_index = c->ref.up_blas_index;
+    }
     if (native) {
         std::vector<RefInstance> ni(n_instances);
         std::vector<RefTlasNode> nt(n_tlas_nodes);
@@ -1549,6 +1599,12 @@ int jpt_scene_update_reference_tlas(jpt_ctx* c, const void* blas_instances, uint
         c->ref.instances = old_inst;
         c->ref.tlas_nodes = old_tlas;
         c->ref.reach_inst = old_reach;
+        if (native) {
+            c->ref.exact.instances = old_x_inst;
+            c->ref.exact.tlas_nodes = old_x_tlas;
+            c->ref.up_blas_index = old_up_index;
+            if (c->ref.exact.valid) c->ref.exact.finish(c->ref.triangles.size());
+        }
         const int back = upload_tlas_update(c);
         c->host_scene_ready = (back == JPT_OK);
         c->scene_ready = c->host_scene_ready && c->device >= 0;
@@ -1857,7 +1913,7 @@ int jpt_assemble_from_ranks(jpt_ctx* c, const void* device_gathered, int32_t wor
     const size_t full = (size_t)c->width * c->height;
     HIP_TRY(c, c->d_full_accum.resize(full));
     HIP_TRY(c, c->d_full_ldr.resize(full));
-    launch_assemble(c->stream, (const float4*)device_gathered, world, c->width, c->height,
+    launch_assemble(c->stream, (const float4*)device_gathered, c->d_accum.p, c->rank, world, c->width, c->height,
                     max_rows_of_any_rank(c->height, world), c->d_full_accum.p, c->d_full_ldr.p, c->frame_count);
     HIP_TRY(c, hipGetLastError());
     c->assembled = true;  // asynchronous on the context's stream; jpt_read_* / jpt_sync wait for it
@@ -1872,7 +1928,7 @@ int jpt_assemble_ldr_from_ranks(jpt_ctx* c, const void* device_gathered, int32_t
     if (world != c->world) return fail(c, JPT_E_INVALID, "world differs from jpt_set_partition");
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, c->d_full_ldr.resize((size_t)c->width * c->height));
-    launch_assemble_ldr(c->stream, (const uint32_t*)device_gathered, world, c->width, c->height,
+    launch_assemble_ldr(c->stream, (const uint32_t*)device_gathered, c->d_ldr.p, c->rank, world, c->width, c->height,
                         max_rows_of_any_rank(c->height, world), c->d_full_ldr.p);
     HIP_TRY(c, hipGetLastError());
     c->assembled_ldr = true;  // asynchronous on the context's stream; jpt_read_ldr_rgba8 / jpt_sync wait for it

@@ -200,12 +200,13 @@ int wf2_wanted_groups(int n_frames, size_t paths);
 // cull's argument; the event counters are completed with their number on the host)
 uint64_t wf2_pixels_outside_window(const SkyCull& cull, const FrameParams& fp);
 
-// rank-major gathered strips -> full framebuffer (multi-GPU assemble)
-void launch_assemble(hipStream_t stream, const float4* gathered, int world, int width, int height, int max_local_rows,
-                     float4* accum_full, uint32_t* ldr_full, uint32_t frame_count);
+// rank-major gathered strips -> full framebuffer (multi-GPU assemble); the rows of `own_rank`, the gathering rank itself, are
+// read from `own` (its local buffer), not from the gathered pieces
+void launch_assemble(hipStream_t stream, const float4* gathered, const float4* own, int own_rank, int world, int width, int height,
+                     int max_local_rows, float4* accum_full, uint32_t* ldr_full, uint32_t frame_count);
 
 // the display image alone (each rank has already tone-mapped its own rows)
-void launch_assemble_ldr(hipStream_t stream, const uint32_t* gathered, int world, int width, int height, int max_local_rows,
-                         uint32_t* ldr_full);
+void launch_assemble_ldr(hipStream_t stream, const uint32_t* gathered, const uint32_t* own, int own_rank, int world, int width,
+                         int height, int max_local_rows, uint32_t* ldr_full);
 
 }  // namespace jpt

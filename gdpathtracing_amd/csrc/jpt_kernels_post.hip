@@ -7,7 +7,9 @@
 
 namespace jpt {
 
-__global__ __launch_bounds__(256) void assemble_kernel(const float4* __restrict__ gathered, int world, int width, int height,
+// (`own`: the gathering rank's own rows, read where its render left them -- its piece crosses no link and is not copied)
+__global__ __launch_bounds__(256) void assemble_kernel(const float4* __restrict__ gathered, const float4* __restrict__ own, int own_rank,
+                                                       int world, int width, int height,
                                                        int max_local_rows, float4* __restrict__ accum_full,
                                                        uint32_t* __restrict__ ldr_full, uint32_t frame_count)
 {
@@ -17,7 +19,7 @@ __global__ __launch_bounds__(256) void assemble_kernel(const float4* __restrict_
     const int strip = y / kStripRows;
     const int rank = strip % world;
     const int ly = (strip / world) * kStripRows + (y - strip * kStripRows);
-    const float4 v = gathered[((size_t)rank * max_local_rows + ly) * width + x];
+    const float4 v = rank == own_rank ? own[(size_t)ly * width + x] : gathered[((size_t)rank * max_local_rows + ly) * width + x];
     const size_t idx = (size_t)y * width + x;
     accum_full[idx] = v;
     const float fc = (float)(frame_count ? frame_count : 1u);
@@ -26,7 +28,8 @@ __global__ __launch_bounds__(256) void assemble_kernel(const float4* __restrict_
 }
 
 // the same scatter for the display image alone: 4 bytes per pixel cross the links instead of 16
-__global__ __launch_bounds__(256) void assemble_ldr_kernel(const uint32_t* __restrict__ gathered, int world, int width, int height,
+__global__ __launch_bounds__(256) void assemble_ldr_kernel(const uint32_t* __restrict__ gathered, const uint32_t* __restrict__ own,
+                                                           int own_rank, int world, int width, int height,
                                                            int max_local_rows, uint32_t* __restrict__ ldr_full)
 {
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
@@ -35,7 +38,7 @@ __global__ __launch_bounds__(256) void assemble_ldr_kernel(const uint32_t* __res
     const int strip = y / kStripRows;
     const int rank = strip % world;
     const int ly = (strip / world) * kStripRows + (y - strip * kStripRows);
-    ldr_full[(size_t)y * width + x] = gathered[((size_t)rank * max_local_rows + ly) * width + x];
+    ldr_full[(size_t)y * width + x] = rank == own_rank ? own[(size_t)ly * width + x] : gathered[((size_t)rank * max_local_rows + ly) * width + x];
 }
 
 // temporal_reprojection.glsl:30-72, one thread per pixel.  Reads its own screen pixel, the depth image at its own
@@ -195,19 +198,20 @@ void launch_temporal(hipStream_t stream, const RefTemporalParams& tp, uint32_t* 
                        use_first ? hist2 : hist1);
 }
 
-void launch_assemble_ldr(hipStream_t stream, const uint32_t* gathered, int world, int width, int height, int max_local_rows,
-                         uint32_t* ldr_full)
+void launch_assemble_ldr(hipStream_t stream, const uint32_t* gathered, const uint32_t* own, int own_rank, int world, int width,
+                         int height, int max_local_rows, uint32_t* ldr_full)
 {
     dim3 grid((width + 255) / 256, height), block(256);
-    hipLaunchKernelGGL(assemble_ldr_kernel, grid, block, 0, stream, gathered, world, width, height, max_local_rows, ldr_full);
+    hipLaunchKernelGGL(assemble_ldr_kernel, grid, block, 0, stream, gathered, own, own_rank, world, width, height, max_local_rows,
+                       ldr_full);
 }
 
-void launch_assemble(hipStream_t stream, const float4* gathered, int world, int width, int height, int max_local_rows,
-                     float4* accum_full, uint32_t* ldr_full, uint32_t frame_count)
+void launch_assemble(hipStream_t stream, const float4* gathered, const float4* own, int own_rank, int world, int width, int height,
+                     int max_local_rows, float4* accum_full, uint32_t* ldr_full, uint32_t frame_count)
 {
     dim3 grid((width + 255) / 256, height), block(256);
-    hipLaunchKernelGGL(assemble_kernel, grid, block, 0, stream, gathered, world, width, height, max_local_rows, accum_full,
-                       ldr_full, frame_count);
+    hipLaunchKernelGGL(assemble_kernel, grid, block, 0, stream, gathered, own, own_rank, world, width, height, max_local_rows,
+                       accum_full, ldr_full, frame_count);
 }
 
 }  // namespace jpt

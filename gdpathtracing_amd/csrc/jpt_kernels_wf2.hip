@@ -656,10 +656,17 @@ __global__ __launch_bounds__(kBlock) void wf2_accumulate(Wf2Buffers wb, Wf2Dims 
     const bool culled = valid && (!in_window || sky_culled(cull, px, py));
     // A culled pixel's frames all see the sky, whose colour depends on the ray's d.y alone and changes by a hundredth of an
     // rgba8 step across a pixel: in REF_LDR8 mode nearly every pixel has ONE rgba8 sky value for all its frames.  The
-    // jittered sample of a frame lies on the quarter circle (px + cos, py + sin), inside the pixel's square, so the four
-    // corner rays bound its d.y (up to the curvature of d.y over one pixel and float rounding: 1e-6 and less); when the
-    // three channels' values * 255 + 0.5 of the four corners lie in the same integer cell at least `kCellMargin` away from
-    // its ends (1000 x those effects), every frame quantises to that cell and the eight primary rays -- seed, sincos, 4 x 4
+    // jittered sample of a frame lies on the quarter circle (px + cos, py + sin), inside the pixel's square.  A pinhole
+    // maps raster lines to great circles, so the directions through the square fill the spherical quadrilateral of its four
+    // corner rays, and along a great circle d.y = A cos(s + phi): f'' = -f.  Every point of the quadrilateral lies on an
+    // arc between two points of its edges, so d.y leaves the range of the four corner values by at most
+    //     2 * (theta^2 / 8) * max |d.y|        (theta: the quadrilateral's diameter; two levels of interpolation)
+    // -- nothing for the narrow pixels of the benchmark cameras (1e-6), but NOT nothing for a wide lens looking at the
+    // zenith, where d.y has its maximum INSIDE the square (0.06 of a cell for an 8 x 8 tile at fov 150).  The
+    // corner range is therefore widened by that bound, in cell units (d value / d d.y <= 255 * 0.05 * 0.5 = 6.4,
+    // main.glsl:189-192), before it is asked to lie inside ONE integer cell of value * 255 + 0.5, `kCellMargin` away from
+    // the cell's ends (float rounding of the ray set-up: 1e-5 of a cell); a quadrilateral wider than half a radian is not
+    // tried.  When that holds every frame quantises to that cell and the eight primary rays -- seed, sincos, 4 x 4
     // transform, three divisions, a normalisation each -- need not be made.  Pixels near a cell boundary (a few per cent:
     // horizontal bands) and cameras whose clip-space w changes sign inside the pixel take the exact per-frame route below.
     constexpr float kCellMargin = 0.01f;
@@ -667,32 +674,54 @@ __global__ __launch_bounds__(kBlock) void wf2_accumulate(Wf2Buffers wb, Wf2Dims 
     f3 sky_value = mk3(0.0f, 0.0f, 0.0f);
     // values * 255 + 0.5 of the sky along the ray through a raster position, per channel; false: the camera block does not
     // behave there (the clip-space w changes sign against `w_ref`, or a NaN)
-    auto sky_cells_at = [&](float fx, float fy, float w_ref, float& w_out, float v[3]) -> bool {
-        const f3 d = raster_direction(cam, fp.width, fp.height, fx, fy, w_out);
+    auto sky_cells_at = [&](float fx, float fy, float w_ref, float& w_out, float v[3], f3& d) -> bool {
+        d = raster_direction(cam, fp.width, fp.height, fx, fy, w_out);
         const f3 c = mk3(0.0f, 0.0f, 0.0f) + mk3(1.0f, 1.0f, 1.0f) * sample_sky(d);
         v[0] = clamp_(c.x, 0.0f, 1.0f) * 255.0f + 0.5f;
         v[1] = clamp_(c.y, 0.0f, 1.0f) * 255.0f + 0.5f;
         v[2] = clamp_(c.z, 0.0f, 1.0f) * 255.0f + 0.5f;
         return (w_out * w_ref > 0.0f) && (d.y == d.y);   // (callers that compare the signs themselves pass w_ref = 1)
     };
+    // the bound above from the four corner directions, in cells; 1e30 when the quadrilateral is too wide to bound this way
+    auto interior_excess = [&](const f3 c[4]) -> float {
+#ifdef JPT_SKY_CELL_NO_EXCESS   // (round 3's rule, for showing that test_sky_cells_of_culled_pixels_... catches it)
+        return 0.0f;
+#endif
+        float chord2 = 0.0f, ay = 0.0f;
+        for (int i = 0; i < 4; i++) {
+            ay = fmax_(ay, __builtin_fabsf(c[i].y));
+            for (int j = i + 1; j < 4; j++) {
+                const f3 e = c[i] - c[j];
+                chord2 = fmax_(chord2, e.x * e.x + e.y * e.y + e.z * e.z);
+            }
+        }
+        if (!(chord2 < 0.2f)) return 1e30f;                        // (also a NaN)
+        const float theta2 = 1.1f * chord2;                        // theta <= 0.5: theta^2 < 1.03 chord^2
+        const float m = fmin_(1.0f, ay + __builtin_sqrtf(theta2));  // max |d.y| inside: a corner's, plus at most theta
+        return 6.4f * 0.25f * theta2 * m;
+    };
     const bool want_cells = fp.accum_mode == 0 && fp.n_frames > 1;
     // First for the whole TILE at once (a wave is one 8 x 8 tile, eight consecutive image rows): its four corner rays, one
     // per lane group; when they agree on the cells, every culled pixel of the tile has that value.  (The same argument over
-    // eight pixels instead of one: the curvature term is 64 x larger, 5e-5 of a cell, still 200 x inside the margin.)
+    // eight pixels instead of one; theta is eight times larger, so wide lenses fail here and pass pixel by pixel.)
     bool tile_constant = false;
     if (want_cells && __any(culled)) {
         const int tx0 = (int)ftx * 8, ty0 = local_to_global_row((int)fty * 8, fp);
         float ww, v[3];
         {   // (every lane evaluates one of the four corners: lanes 0..3 hold the four)
             const int corner = lane & 3;
-            bool ok = sky_cells_at((float)(tx0 + 8 * (corner & 1)), (float)(ty0 + 8 * (corner >> 1)), 1.0f, ww, v);
+            f3 dc;
+            bool ok = sky_cells_at((float)(tx0 + 8 * (corner & 1)), (float)(ty0 + 8 * (corner >> 1)), 1.0f, ww, v, dc);
             ok = (ww == ww) && (v[0] == v[0]) && (ww * __shfl(ww, 0) > 0.0f);   // no NaN, and the four w of one sign
+            f3 cd[4];
+            for (int i = 0; i < 4; i++) cd[i] = mk3(__shfl(dc.x, i), __shfl(dc.y, i), __shfl(dc.z, i));
+            const float excess = interior_excess(cd);
             bool same = true;
             f3 val;
             float cellv[3];
             for (int k = 0; k < 3; k++) {
                 const float a = __shfl(v[k], 0), b = __shfl(v[k], 1), c2 = __shfl(v[k], 2), d2 = __shfl(v[k], 3);
-                const float lo = fmin_(fmin_(a, b), fmin_(c2, d2)), hi = fmax_(fmax_(a, b), fmax_(c2, d2));
+                const float lo = fmin_(fmin_(a, b), fmin_(c2, d2)) - excess, hi = fmax_(fmax_(a, b), fmax_(c2, d2)) + excess;
                 cellv[k] = __builtin_floorf(lo);
                 same = same && (lo - cellv[k] >= kCellMargin) && (hi - cellv[k] <= 1.0f - kCellMargin) && (hi - lo < 0.5f);
             }
@@ -713,9 +742,10 @@ __global__ __launch_bounds__(kBlock) void wf2_accumulate(Wf2Buffers wb, Wf2Dims 
         float lo[3] = {1e30f, 1e30f, 1e30f}, hi[3] = {-1e30f, -1e30f, -1e30f};
         bool sane = true;
         float w_first = 1.0f;
+        f3 cd[4];
         for (int corner = 0; corner < 4; corner++) {
             float ww, v[3];
-            const bool ok = sky_cells_at((float)(px + (corner & 1)), (float)(py + (corner >> 1)), w_first, ww, v);
+            const bool ok = sky_cells_at((float)(px + (corner & 1)), (float)(py + (corner >> 1)), w_first, ww, v, cd[corner]);
             if (corner == 0) w_first = ww;
             sane = sane && (corner == 0 ? (ww == ww) : ok);
             for (int k = 0; k < 3; k++) {
@@ -723,9 +753,12 @@ __global__ __launch_bounds__(kBlock) void wf2_accumulate(Wf2Buffers wb, Wf2Dims 
                 hi[k] = fmax_(hi[k], v[k]);
             }
         }
+        const float excess = interior_excess(cd);
         bool same = sane;
         float cell[3];
         for (int k = 0; k < 3; k++) {
+            lo[k] -= excess;
+            hi[k] += excess;
             cell[k] = __builtin_floorf(lo[k]);
             same = same && (lo[k] - cell[k] >= kCellMargin) && (hi[k] - cell[k] <= 1.0f - kCellMargin) && (hi[k] - lo[k] < 0.5f);
         }

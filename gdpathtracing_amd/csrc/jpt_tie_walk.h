@@ -129,6 +129,10 @@ __device__ __forceinline__ bool tie_walk(const TieShadowDev& x, const RefInstanc
                 continue;
             }
             const uint32_t li = bn.left_child, ri = bn.right_child;
+            // a node without triangles AND without children is the empty leaf that stands for an empty mesh
+            // (SceneBuilder::commit, native_from_uploaded): nothing below it -- read as an interior node it would send this
+            // instance's local ray through node 0, another mesh's tree (reachable in the whole-walk mode)
+            if (li == 0u && ri == 0u) continue;
             const RefBvhNode& cl = x.bvh[li];
             const RefBvhNode& cr = x.bvh[ri];
             const float d1 = slab(o, rD, cl.aabbMin.x, cl.aabbMin.y, cl.aabbMin.z, cl.aabbMax.x, cl.aabbMax.y, cl.aabbMax.z);

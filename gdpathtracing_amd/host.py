@@ -121,6 +121,14 @@ class Context:
             self._ck(k, "jpt_scene_tree_kind")
         return k
 
+    def ties_exact(self):
+        """(bool, why): are exact distance ties decided as the reference decides them (jpt_scene_ties_exact)?"""
+        why = C.c_char_p()
+        rc = self._lib.jpt_scene_ties_exact(self.h, C.byref(why))
+        if rc < 0:
+            self._ck(rc, "jpt_scene_ties_exact")
+        return bool(rc), (why.value.decode() if why.value else "")
+
     def upload_note(self) -> str:
         msg = self._lib.jpt_scene_upload_note(self.h)
         return msg.decode() if msg else ""
@@ -473,6 +481,12 @@ class MultiContext:
 
     def sync(self):
         self._ck(self._lib.jpt_multi_sync(self.h), "jpt_multi_sync")
+
+    def gather_plan(self) -> dict:
+        """what the last render issued for its gather: peer copies, distinct streams they went on, copies of rank 0's own piece"""
+        a, b, c = C.c_int32(), C.c_int32(), C.c_int32()
+        self._ck(self._lib.jpt_multi_gather_plan(self.h, C.byref(a), C.byref(b), C.byref(c)), "jpt_multi_gather_plan")
+        return {"peer_copies": a.value, "distinct_streams": b.value, "own_piece_copies": c.value}
 
     def read_accum(self):
         out = np.zeros((self.height, self.width, 4), dtype=np.float32)

@@ -172,7 +172,9 @@ int jpt_set_stream_priority(jpt_ctx *ctx, int32_t priority);
  *   renders_in_flight  1..4 workspaces / pipeline slots; 0: the library's rule (4; 2 when one workspace exceeds 24 GiB).
  *                      1 serialises queued renders (about 1.5 x the time per render at C3's size).
  *   workspace_budget_bytes  most bytes ONE workspace may take; a render with more frames than fit runs as batches of
- *                      frames in frame order, same image (0: the library's rule, 24 GiB).
+ *                      frames in frame order, same image (0: the library's rule, 24 GiB).  One frame is the smallest
+ *                      batch: when a single frame of the current resolution does not fit a budget set here, the
+ *                      render calls return JPT_E_LIMIT and allocate nothing (the audit kernel needs no workspace).
  * Takes effect with the next render; workspaces no longer allowed are freed at once (the call waits for renders in
  * flight).  jpt_get_workspace_bytes reports what is allocated now.  No reference counterpart (the reference's
  * workspace is the two images of one frame). */
@@ -222,6 +224,14 @@ enum {
 int jpt_scene_tree_kind(jpt_ctx *ctx);
 /* Empty unless the last jpt_scene_upload_reference_layout is walked as given: then the reason. */
 const char *jpt_scene_upload_note(const jpt_ctx *ctx);
+/* 1: hits at exactly equal distance -- whose winner is a matter of the reference's visiting order, main.glsl:247 -- are
+ * decided as the reference decides them for the scene this context holds (by the reference's own walk of the trees kept
+ * beside the native ones; trivially on JPT_TREE_AS_GIVEN / JPT_TREE_REFERENCE_EXACT trees).  0: they fall to the native
+ * tree's order, and *why_out (may be NULL; valid until the next scene call) says why: a JPT_BUILD_SAH_WATERTIGHT commit, or
+ * an upload whose BLAS nodes are not numbered in pre-order (left child = parent + 1, as bvh.cpp:108-185 numbers them), which
+ * the restricted walk needs -- such an upload still renders on the native tree with reach records; only the winners of exact
+ * ties may differ from the reference's.  jpt_stats.set_aside keeps counting the tied vertices either way.  Negative: JPT_E_*. */
+int jpt_scene_ties_exact(jpt_ctx *ctx, const char **why_out);
 
 /* ---- scene ingest, route (ii): native build --------------------------------------------------- */
 
@@ -374,7 +384,9 @@ int jpt_read_depth_f32(jpt_ctx *ctx, float *out);
  * plumbing (RCCL gather through torch): float4 accumulation, and its size in bytes. */
 void *jpt_device_accum(jpt_ctx *ctx, size_t *bytes_out);
 /* Rank 0 after the gather: scatter `world` rank-major local buffers (device pointer) into this context's
- * full W*H framebuffers so jpt_read_* return the assembled image. */
+ * full W*H framebuffers so jpt_read_* return the assembled image.  The gathering context's OWN rows are read in place,
+ * from its local buffers as its last render left them: its slot of `device_gathered` is not read and need not be filled
+ * (no copy of a rank's piece to itself). */
 int jpt_assemble_from_ranks(jpt_ctx *ctx, const void *device_gathered, int32_t world);
 /* The display image alone.  Every rank holds the complete sums of its own rows, so its rgba8 rows are final:
  * gathering them (4 bytes per pixel instead of 16) is all a displayed frame needs -- what the reference reads back
@@ -389,8 +401,9 @@ int jpt_get_stats(jpt_ctx *ctx, jpt_stats *out);
 /* ---- one image on several GPUs from ONE process ------------------------------------------------------
  * The addon's host is a single C++ process (path_tracing_camera.cpp:193-232).  A jpt_multi owns one context per listed
  * device, each rendering its strips of the screen partition (jpt_set_partition); jpt_multi_render fans the render out,
- * pulls every rank's float4 accumulation rows to device 0 with peer-to-peer copies over xGMI (one link per peer, behind
- * an event on the rank's stream; the next renders' path kernels overlap with it) and assembles them there, so the
+ * every peer pushes its float4 accumulation rows to device 0 with a peer-to-peer copy over its own xGMI link (on a copy
+ * stream of its own device, behind an event on the rank's render: the N - 1 transfers are in flight together, and the next
+ * renders' path kernels overlap with them) and device 0 assembles them -- its own rows in place --, so the
  * jpt_multi_read_* calls return the whole image -- bit-identical to one GPU's.  Scene set-up: build it once on
  * jpt_multi_ctx(m, 0) with the jpt_scene_* calls, then jpt_multi_share_scene.  (Processes that hold one GPU each --
  * bench.py under torch.distributed -- use jpt_set_partition / jpt_device_accum / jpt_assemble_from_ranks with RCCL
@@ -420,6 +433,10 @@ int jpt_multi_set_gather(jpt_multi *m, int32_t ldr_only);
 /* asynchronous: queues the render on every rank, the gather and the assembly; jpt_multi_sync or a read waits */
 int jpt_multi_render(jpt_multi *m, int32_t n_frames, uint32_t first_frame_index);
 int jpt_multi_sync(jpt_multi *m);
+/* What the last jpt_multi_render issued for its gather (diagnostic; SURVEY.md 8(e): the N - 1 transfers must be concurrent,
+ * one per xGMI link): the number of peer copies, the number of DISTINCT streams they were issued on (each peer pushes on a
+ * stream of its own device: = n_peer_copies), and how often rank 0's own piece was copied (0: the assembly reads it in place). */
+int jpt_multi_gather_plan(const jpt_multi *m, int32_t *n_peer_copies, int32_t *n_distinct_streams, int32_t *own_piece_copies);
 int jpt_multi_read_ldr_rgba8(jpt_multi *m, uint8_t *out);
 int jpt_multi_read_accum_f32(jpt_multi *m, float *out);
 

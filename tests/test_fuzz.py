@@ -226,6 +226,47 @@ def test_many_coincident_copies_fall_back_to_the_whole_reference_walk(oracle, hi
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("route", ["commit", "upload", "exact", "audit"])
+def test_instance_of_an_empty_mesh_shows_what_the_reference_shows(oracle, hiplib, route):
+    """BuildBVH of a mesh without triangles returns root 0 (bvh.cpp:111-112), so the reference draws the first mesh with
+    triangles in its place.  With forty coincident copies in that mesh the tie walk runs in its whole-walk mode, where every
+    instance is visited (an empty leaf read as an interior node sent the ray through node 0 by accident; now the
+    instance IS an instance of that mesh, in the oracle's arrays and in the product's)."""
+    import copy
+    from tests.test_oracle_builder import with_empty_mesh
+    sc = copy.deepcopy(scenes.random_scene(3, n_meshes=2, n_instances=4, tris_per_surface=60, coincident=True))
+    for mesh in sc.meshes:
+        surf = mesh.surfaces[0]
+        v = np.asarray(surf.vertices, dtype=np.float32).reshape(-1, 3, 3).copy()
+        v[4:44] = np.array([[-1.5, -1.2, 0.1], [1.6, -1.1, -0.2], [0.1, 1.7, 0.3]], dtype=np.float32)
+        surf.vertices = v.reshape(-1, 3)
+    sc = with_empty_mesh(sc, "last")
+    w, h, bounces, frames = 96, 64, 2, 2
+    cam = scenes.camera_block(sc.camera, w, h)
+    ref = oracle.build_scene(sc)
+    assert int(ref.instances["blas_index"][-1]) == 0
+    want, _, want_depth, _, _ = oracle.render(ref, cam, w, h, bounces, frames, 1, wire.ACCUM_HDR_F32)
+    ctx = host.Context(0)
+    try:
+        if route == "upload":
+            ctx.upload_reference_layout(ref.tri_geom, ref.tri_data, ref.materials, ref.bvh_nodes, ref.instances, ref.tlas_nodes, ref.textures)
+        else:
+            ctx.build_scene(sc, capi.BUILD_REFERENCE_EXACT if route == "exact" else capi.BUILD_SAH)
+        if route == "audit":
+            ctx.set_kernel(capi.KERNEL_REFERENCE_LAYOUT)
+        ctx.set_params(w, h, bounces, wire.ACCUM_HDR_F32)
+        ctx.set_camera(cam)
+        ctx.render(frames, 1)
+        got, got_depth = ctx.read_accum(), ctx.read_depth()
+    finally:
+        ctx.close()
+    nan_got, nan_want = np.isnan(got).any(axis=-1), np.isnan(want).any(axis=-1)
+    ok = ~(nan_got | nan_want)
+    assert np.array_equal(nan_got, nan_want) and np.array_equal(got[ok], want[ok])
+    assert np.array_equal(got_depth, want_depth, equal_nan=True)
+
+
+@pytest.mark.gpu
 def test_extended_fuzz_slice(hiplib):
     """tests/tools/fuzz_more.py on seeds 8..39 (the whole tool runs 1 280 seeds by hand: profiles/r03/r03ab_fuzz_more.txt): varying
     sizes, bounce and frame counts, accumulation modes, queued and blocking renders; every reference-tree route and both

@@ -755,6 +755,21 @@ def test_memory_policy_caps_the_workspaces_and_keeps_the_image(hiplib):
         assert np.array_equal(full, other)
     with pytest.raises(RuntimeError):
         make_ctx(sc, w, h, bounces, wire.ACCUM_REF_LDR8, capi.BUILD_SAH).set_memory_policy(5, 0)
+    # a budget below ONE frame's workspace is refused by the render (JPT_E_LIMIT), nothing is allocated past it;
+    # the audit kernel, which needs no workspace, still renders
+    ctx = make_ctx(sc, w, h, bounces, wire.ACCUM_REF_LDR8, capi.BUILD_SAH)
+    ctx.set_memory_policy(0, one_ws // (spp * 2))
+    for asynchronous in (False, True):
+        with pytest.raises(capi.JptError) as e:
+            ctx.render(spp, 1, asynchronous=asynchronous)
+        assert "(-3)" in str(e.value) and "budget" in str(e.value)
+    assert ctx.workspace_bytes() == 0
+    ctx.set_kernel(capi.KERNEL_REFERENCE_LAYOUT)
+    ctx.render(spp, 1)
+    ctx.set_kernel(capi.KERNEL_WAVEFRONT)
+    ctx.set_memory_policy(0, 0)
+    ctx.render(spp, 1)
+    ctx.close()
 
 
 def test_foreign_work_on_the_context_stream_sees_each_queued_render(hiplib):
@@ -830,3 +845,30 @@ def test_c4_device_refit_at_full_size(hiplib):
     ctx.render(frames, 1)
     assert np.array_equal(ctx.read_accum(), want) and np.array_equal(ctx.read_depth(), want_depth)
     ctx.close()
+
+
+@pytest.mark.parametrize("launcher", ["torchrun", "multi"])
+def test_bench_self_launch_two_ranks_on_one_gpu(hiplib, launcher):
+    """`python3 bench.py --gpus 2` with WORLD_SIZE unset (VERDICT r03 weak 3b / task 2): the default launcher starts
+    torch.distributed.run itself as a child process (gloo here: two ranks share the box's one GPU), `--launcher multi` runs
+    the one-process jpt_multi route.  Either way: rc 0, ONE JSON line, two ranks seen, both assembled images (C3's size and
+    C5's) bit-identical to one context's."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["JPT_BENCH_BACKEND"] = "gloo"
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "1", "--tris", "5000"]
+    if launcher == "multi":
+        cmd += ["--launcher", "multi"]
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1500)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["multi_gpu"]["ranks_seen"] == 2
+    assert d["verified_bit_identical_to_one_context"] is True
+    assert d["multi_gpu"]["c5"]["verified_bit_identical_to_one_context"] is True
+    if launcher == "multi":
+        assert d["multi_gpu"]["gather_plan"] == {"peer_copies": 1, "distinct_streams": 1, "own_piece_copies": 0}

@@ -424,6 +424,38 @@ def test_sky_cull_is_exact(oracle, hiplib, view, builder):
         assert rel_l2(got, want) <= 1e-4 and np.array_equal(got_depth == np.float32(want_depth.max()), want_depth == want_depth.max())
 
 
+@pytest.mark.parametrize("fov,size", [(110.0, (800, 600)), (150.0, (800, 600)), (170.0, (320, 240)), (79.5, (640, 360))])
+@pytest.mark.parametrize("look", ["zenith", "nadir_away", "near_zenith"])
+def test_sky_cells_of_culled_pixels_with_wide_lenses_looking_up(oracle, hiplib, fov, size, look):
+    """wf2_accumulate gives a sky-culled pixel ONE rgba8 sky value for all its frames when its corner rays (first
+    the corners of its 8 x 8 tile) agree on the rgba8 cell.  The sky depends on d.y (main.glsl:189-192), and with the
+    camera looking straight up d.y has its maximum INSIDE the tile: corner values alone do not bound it for wide lenses.
+    The scene lies below / behind the camera, every pixel is culled; REF_LDR8, several frames: accumulation and display
+    must equal the oracle's bit for bit."""
+    sc = scenes.demo_scene(300)
+    eye = (0.0, 30.0, 0.0)
+    target = {"zenith": (0.0, 60.0, 0.0), "nadir_away": (40.0, 29.0, 3.0), "near_zenith": (0.7, 60.0, -0.4)}[look]
+    up = (0.0, 0.0, -1.0) if look != "nadir_away" else (0.0, 1.0, 0.0)
+    sc.camera = scenes.CameraDesc(_look_at(eye, target, up=up), fov_deg=fov)
+    w, h = size
+    frames = 4
+    cam = scenes.camera_block(sc.camera, w, h)
+    ref = oracle.build_scene(sc)
+    want, want_ldr, _, cnt, _ = oracle.render(ref, cam, w, h, 2, frames, 1, wire.ACCUM_REF_LDR8)
+    ctx = host.Context(0)
+    try:
+        ctx.build_scene(sc, capi.BUILD_SAH)
+        ctx.set_params(w, h, 2, wire.ACCUM_REF_LDR8)
+        ctx.set_camera(cam)
+        ctx.render(frames, 1, counted=True)
+        got, got_ldr, st = ctx.read_accum(), ctx.read_ldr(), ctx.stats()
+    finally:
+        ctx.close()
+    assert st["sky_culled"] > 0.9 * w * h * frames            # the shortcut's pixels are what is tested
+    assert np.array_equal(got, want), int((got != want).any(axis=-1).sum())
+    assert np.array_equal(got_ldr, want_ldr)
+
+
 @pytest.mark.parametrize("distance", [50.0, 500.0, 5000.0, 50000.0])
 def test_far_camera_up_to_17000_scene_sizes(oracle, hiplib, distance):
     """Far away from the geometry the representable hit distances are far apart (0.004 at t = 50 000), different triangles
@@ -617,6 +649,9 @@ def test_one_process_multi_device_gather_is_bit_identical(hiplib, world):
         one.render(n, first)
         m.render(n, first)
         assert np.array_equal(m.read_accum(), one.read_accum()) and np.array_equal(m.read_ldr(), one.read_ldr())
+        # the world - 1 transfers run side by side, each peer pushing on a stream of its own; rank 0's own piece
+        # crosses nothing and is not copied (all copies used to queue on rank 0's one stream)
+        assert m.gather_plan() == {"peer_copies": world - 1, "distinct_streams": world - 1, "own_piece_copies": 0}
     one.accum_reset()
     m.accum_reset()
     m.set_gather(True)

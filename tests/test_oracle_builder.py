@@ -11,11 +11,31 @@ import pytest
 
 from gdpathtracing_amd import capi, host, scenes, wire
 
+def with_empty_mesh(sc, where):
+    """`sc` plus a mesh without triangles and one instance of it.  BuildBVH pushes no node for it and returns 0
+    (bvh.cpp:111-112): in the reference that instance shows the tree that starts at node 0 -- the first mesh with triangles."""
+    import copy
+    sc = copy.deepcopy(sc)
+    none = scenes.Surface(np.zeros((0, 3)), np.zeros((0, 3)), np.zeros((0, 2)), np.zeros((0,), dtype=np.int32))
+    if where == "first":
+        sc.meshes.insert(0, scenes.Mesh([none]))
+        for i in sc.instances:
+            i.mesh += 1
+        mesh = 0
+    else:
+        sc.meshes.append(scenes.Mesh([none]))
+        mesh = len(sc.meshes) - 1
+    sc.instances.append(scenes.Instance(mesh, scenes.transform12(None, (0.3, 0.2, 0.1)), [0]))
+    return sc
+
+
 SCENES = {
     "cornell": lambda: scenes.cornell_scene(),
     "demo2k": lambda: scenes.demo_scene(2048),
     "demo20k": lambda: scenes.demo_scene(20000),
     "inst": lambda: scenes.instanced_scene(6, 3, 200),
+    "empty_mesh_last": lambda: with_empty_mesh(scenes.instanced_scene(3, 2, 100), "last"),
+    "empty_mesh_first": lambda: with_empty_mesh(scenes.cornell_scene(), "first"),
 }
 
 

@@ -190,3 +190,38 @@ def test_empty_and_single_instance_uploads(hiplib, oracle):
     assert ctx.tree_kind() == capi.TREE_NATIVE_REACH
     assert len(ctx.reference_buffer(capi.BUF_TRI_GEOMETRY, wire.TRI_GEOMETRY)) == 0   # no instance names a BLAS
     ctx.close()
+
+
+def test_ties_exact_says_when_ties_fall_to_the_native_order(oracle, hiplib):
+    """an upload whose BLAS nodes are not numbered in pre-order still renders on the native tree with reach records,
+    but the restricted reference walk that decides exact distance ties cannot index it -- that used to be silent.
+    jpt_scene_ties_exact reports it, with the reason."""
+    sc = scenes.instanced_scene(4, 2, 64)
+    ref = oracle.build_scene(sc)
+    for mode, want in ((capi.BUILD_SAH, True), (capi.BUILD_SAH_WATERTIGHT, False), (capi.BUILD_REFERENCE_EXACT, True)):
+        ctx = host.Context(-1)
+        ctx.build_scene(sc, mode)
+        ok, why = ctx.ties_exact()
+        assert ok == want and (why == "") == want
+        ctx.close()
+    ctx = host.Context(-1)
+    ctx.upload_reference_layout(ref.tri_geom, ref.tri_data, ref.materials, ref.bvh_nodes, ref.instances, ref.tlas_nodes)
+    assert ctx.ties_exact() == (True, "")
+    # the same trees with the node array reversed: a valid tree, not in pre-order
+    n = len(ref.bvh_nodes)
+    perm = np.arange(n)[::-1].copy()
+    inv = np.empty(n, dtype=np.int64)
+    inv[perm] = np.arange(n)
+    nodes = ref.bvh_nodes[perm].copy()
+    inner = nodes["tri_count"] == 0
+    nodes["left_child"][inner] = inv[nodes["left_child"][inner]]
+    nodes["right_child"][inner] = inv[nodes["right_child"][inner]]
+    inst = ref.instances.copy()
+    inst["blas_index"] = inv[inst["blas_index"]]
+    ctx.upload_reference_layout(ref.tri_geom, ref.tri_data, ref.materials, nodes, inst, ref.tlas_nodes)
+    assert ctx.tree_kind() == capi.TREE_NATIVE_REACH
+    ok, why = ctx.ties_exact()
+    assert not ok and "pre-order" in why
+    ctx.upload_reference_layout(ref.tri_geom, ref.tri_data, ref.materials, nodes, inst, ref.tlas_nodes, as_given=True)
+    assert ctx.ties_exact() == (True, "")
+    ctx.close()
