@@ -576,6 +576,18 @@ def main():
         kernels_sha = csrc_sha()
         default_run = (W, H, spp, bounces, args.tris, args.scene, args.builder, world, args.camera, args.kernel, args.route) == \
                       (1920, 1080, 8, 4, 51200, "demo", "sah", 1, "demo", "wavefront", "commit")
+        # the other profiled workloads (tools/workload_profiles.sh): same size and settings, another scene / camera; their
+        # counter passes are in profiles/current_{pmc,sq}_<workload>.json
+        workload_key = None
+        if (W, H, spp, bounces, args.builder, world, args.kernel, args.route) == (1920, 1080, 8, 4, "sah", 1, "wavefront", "commit"):
+            workload_key = {("demo", "demo", 51200): "c3", ("demo", "closeup", 51200): "closeup", ("inst", "demo", 51200): "c4",
+                            ("unique", "demo", 51200): "unique", ("unique", "demo", 4000000): "unique4m"}.get((args.scene, args.camera, args.tris))
+        if workload_key not in (None, "c3"):
+            default_run = True
+            if args.pmc_json == os.path.join(ROOT, "profiles", "current_pmc.json"):
+                args.pmc_json = os.path.join(ROOT, "profiles", "current_pmc_%s.json" % workload_key)
+            if args.sq_json == os.path.join(ROOT, "profiles", "current_sq.json"):
+                args.sq_json = os.path.join(ROOT, "profiles", "current_sq_%s.json" % workload_key)
         if default_run and os.path.exists(args.pmc_json):
             try:
                 pj = json.load(open(args.pmc_json))
@@ -600,9 +612,17 @@ def main():
         hbm_frac = round(traffic / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if traffic else None
         valu_issue_frac = (valu or {}).get("valu_issue_frac")
         # what binds the dominant kernel: the largest of the utilisations this line can state (null when they are not known)
+        # ... one of: "hbm" (counter traffic / duration >= 0.6 of the 8 TB/s peak: 6.3 TB/s is what the chip sustains), "valu_issue"
+        # (>= 0.6 of the issue capacity), else "dependent_fetch_latency" -- neither the memory system nor the ALUs are busy, the
+        # waves sit in s_waitcnt on the next record of their rays' chains (wait_frac says for what share of their cycles)
         binding = None
         if valu_issue_frac is not None and hbm_frac is not None:
-            binding = "valu_issue" if valu_issue_frac >= hbm_frac else "hbm"
+            if hbm_frac >= 0.6 and hbm_frac >= valu_issue_frac:
+                binding = "hbm"
+            elif valu_issue_frac >= 0.6:
+                binding = "valu_issue"
+            else:
+                binding = "dependent_fetch_latency"
         sky = total.get("sky_culled", 0)
         traced = rays - sky
         out = {
@@ -634,6 +654,7 @@ def main():
                 "traffic": traffic, "traffic_source": traffic_src,
                 "hbm_frac": hbm_frac,
                 "binding": binding,
+                "wait_frac": (valu or {}).get("wait_frac"), "l2_hit": (valu or {}).get("l2_hit"),
                 # from the committed SQ-counter passes of this command (profiles/current_sq.json, stamped with the hash of the
                 # kernel sources they ran on; null + `profiles_stale` when the sources have changed since): share of the chip's
                 # VALU issue capacity the launch used (wave-level instructions x the ISA's priced cycles / (1024 SIMDs x cycles))

@@ -55,11 +55,13 @@ class Stats(C.Structure):
                 ("tlas_expand", C.c_uint64), ("inst_visits", C.c_uint64), ("shaded_hits", C.c_uint64),
                 ("last_render_ms", C.c_double), ("last_trace_ms", C.c_double), ("last_build_ms", C.c_double),
                 ("phase", C.c_uint64 * 8), ("sky_culled", C.c_uint64), ("last_primary_ms", C.c_double),
-                ("set_aside", C.c_uint64), ("set_aside_dropped", C.c_uint64)]
+                ("set_aside", C.c_uint64), ("set_aside_dropped", C.c_uint64),
+                ("walk_steps_max", C.c_uint64), ("walk_steps_hist", C.c_uint64 * 8)]
 
     def as_dict(self):
         d = {n: getattr(self, n) for n, _ in self._fields_}
         d["phase"] = list(self.phase)
+        d["walk_steps_hist"] = list(self.walk_steps_hist)
         return d
 
 

@@ -441,6 +441,7 @@ int upload_scene(jpt_ctx* c)
     d.n_blas_nodes = (uint32_t)c->wide.blas_nodes.size();
     d.n_tlas_nodes = (uint32_t)c->wide.tlas_nodes.size();
     d.use4 = use4;
+    d.stack_need4 = c->wide.stack_need4;
     d.wide_instances4 = c->d_winst4.p;
     {
         const int rcx = upload_shadow(c, false);
@@ -947,6 +948,8 @@ int do_render_batch(jpt_ctx* c, int32_t n_frames, uint32_t first_frame_index, bo
             c->stats.shaded_hits = h.shaded_hits;
             for (int k = 0; k < 8; k++) c->stats.phase[k] = h.phase[k];
             c->stats.sky_culled = h.phase[7];
+            c->stats.walk_steps_max = h.walk_max;
+            for (int k = 0; k < 8; k++) c->stats.walk_steps_hist[k] = h.walk_hist[k];
         }
     }
     return JPT_OK;
@@ -1355,6 +1358,7 @@ int upload_tlas_update(jpt_ctx* c)
         return fail(c, JPT_E_LIMIT, "acceleration structure too deep after the TLAS update: a traversal could need " +
                                         std::to_string(need) + " stack entries, the kernels hold " + std::to_string(trace_stack_capacity()));
     }
+    c->ds.stack_need4 = c->wide.stack_need4;
     if (c->device < 0) return JPT_OK;
     HIP_TRY(c, hipSetDevice(c->device));
     hipStream_t s = c->stream;

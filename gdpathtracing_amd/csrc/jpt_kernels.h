@@ -18,6 +18,10 @@ struct DevCounters {  // SURVEY.md 8(d) event counters
     // in a wave and how many lanes took part -- [0] rounds, [1] node iterations, [2] lanes in them, [3] leaf
     // phases, [4] lanes in them, [5] instance phases, [6] lanes in them, [7] primary rays finished by the sky cull
     unsigned long long phase[8];
+    // ... and the length of the walks: the most record steps (internal records + leaves + instance entries) any one ray took, and
+    // how many rays took < 16, < 64, < 256, < 1024, < 4096, < 16384, < 65536, more (a launch cannot end before its longest ray)
+    unsigned long long walk_max;
+    unsigned long long walk_hist[8];
 };
 
 struct FrameParams {
@@ -73,6 +77,7 @@ struct DeviceScene {
     uint32_t n_blas_nodes = 0, n_tlas_nodes = 0;
     // four-child collapse of the same trees (native builder only; null otherwise)
     bool use4 = false;
+    uint32_t stack_need4 = 0;                // worst-case pending entries of a walk over the four-child records (compute_stack_need)
     const WideNode4* nodes4 = nullptr;       // BLAS records followed by the TLAS records, one index space (float form: the
                                              // device refit of the TLAS works on these) ...
     const WideNodeQ* nodesq = nullptr;       // ... and their 64-byte quantised form, same indices: what the kernels walk
@@ -147,6 +152,16 @@ __device__ __forceinline__ void flush_counters(const DevCounters& c, DevCounters
     if (c.shaded_hits) atomicAdd(&out->shaded_hits, c.shaded_hits);
     for (int k = 0; k < 8; k++)
         if (c.phase[k]) atomicAdd(&out->phase[k], c.phase[k]);
+    if (c.walk_max) atomicMax(&out->walk_max, c.walk_max);
+    for (int k = 0; k < 8; k++)
+        if (c.walk_hist[k]) atomicAdd(&out->walk_hist[k], c.walk_hist[k]);
+}
+__device__ __forceinline__ void count_walk(DevCounters& c, uint32_t steps)
+{
+    if (steps > c.walk_max) c.walk_max = steps;
+    int b = 0;
+    for (uint32_t lim = 16u; b < 7 && steps >= lim; lim <<= 2) b++;
+    c.walk_hist[b]++;
 }
 #endif
 
@@ -195,6 +210,7 @@ void launch_temporal(hipStream_t stream, const RefTemporalParams& tp, uint32_t* 
                      float4* hist2);
 
 int wf2_wanted_groups(int n_frames, size_t paths);
+uint32_t wf2_rg_stack_capacity();   // stack entries of the regrouped bounce launches (JPT_TRACE_REGROUP), LDS + global
 // pixels of this context's share of the image that lie outside the render's window (the tile-aligned bounding rectangle
 // of the sky cull's screen rectangles): the primary launch does not even enumerate them (their rays are sky by the
 // cull's argument; the event counters are completed with their number on the host)

@@ -52,7 +52,7 @@ struct WfTune {
 // leaf wait), (2) triangle leaves, (3) instance entries.  Returns true for lanes whose walk is complete.
 template <bool COUNT, bool W4>
 __device__ __forceinline__ bool walk_round(Traversal<COUNT, W4>& tr, bool active, const WideSceneDev& sc,
-                                           const typename Traversal<COUNT, W4>::Stack& st, DevCounters& cnt, const WfTune& tune)
+                                           const typename Traversal<COUNT, W4>::Stack& st, DevCounters& cnt, const WfTune& tune, uint32_t& steps)
 {
     const int kNodeMinLanes = tune.node_min_lanes;
     const bool lane0 = (threadIdx.x & 63) == 0;
@@ -77,6 +77,7 @@ __device__ __forceinline__ bool walk_round(Traversal<COUNT, W4>& tr, bool active
             cnt.phase[2] += (unsigned long long)__popcll(m);
         }
         if (want) tr.node_step(sc, st, cnt);
+        if (COUNT && want) steps++;
     }
     bool wl = active && tr.wants_leaf();
     bool wi = active && tr.wants_instance();
@@ -101,6 +102,7 @@ __device__ __forceinline__ bool walk_round(Traversal<COUNT, W4>& tr, bool active
     }
     if (wl) tr.leaf_step(sc, cnt);
     if (wi) tr.instance_step(sc, st, cnt);
+    if (COUNT && (wl || wi)) steps++;
     return active && tr.finished();
 }
 
@@ -122,6 +124,8 @@ struct Wf2Buffers {
     uint32_t* qcount;   // [max_bounces + 2][kSegments] queue sizes; row b = rays traced in bounce b (b >= 1)
     uint32_t* redo_count;  // [0]: paths set aside because the reference cannot reach their hit (wf2_finish) ...
     float4* redo_rec;      // ... two float4 each: the vertex's ray, origin.w = bounce bits, direction.w = path id bits
+    uint32_t* rg_cursor;   // regrouped tracing launches (wf2_trace_rg): [max_bounces + 2][kSegments] queue cursors, shared by the waves of a queue
+    int32_t* rg_spill;     // ... and the stack entries past the LDS part: [block][pool slot][entry]
     uint32_t redo_cap;     // records redo_rec holds (a few paths in 10^7 are set aside: not one record per path).  A hit
                            // that finds the buffer full is shaded as found -- the native tree's closest hit, without the
                            // reference's crack -- and counted in redo_count[1] (jpt_stats.set_aside_dropped)
@@ -215,6 +219,7 @@ __global__ __launch_bounds__(kBlock, JPT_PRIMARY_WAVES) void wf2_primary(WideSce
     bool active = false, exhausted = false;
     bool unsaved = false;   // this lane's finished walk has not left its result yet (see wf2_trace: written when the wave refills)
     uint32_t path = 0;
+    uint32_t walk_steps = 0;   // (counting builds: record steps of this lane's ray)
     auto save_results = [&]() {
         // hits are packed into the segment's bounce-0 queue (main.glsl:349), one counter update per wave
         const bool is_hit = unsaved && tr.hit.t < 1e9f;
@@ -275,6 +280,7 @@ __global__ __launch_bounds__(kBlock, JPT_PRIMARY_WAVES) void wf2_primary(WideSce
                             const Ray ray = primary_ray(cam, fp.width, fp.height, px, py, fp.frame_index + f, sx, sy);
                             tr.begin(sc, ray.o, ray.d);
                             active = true;
+                            walk_steps = 0;
                         }
                     }
                 }
@@ -285,9 +291,10 @@ __global__ __launch_bounds__(kBlock, JPT_PRIMARY_WAVES) void wf2_primary(WideSce
             continue;
         }
         {
-            if (walk_round<COUNT, W4>(tr, active, sc, my_stack, cnt, tune)) {
+            if (walk_round<COUNT, W4>(tr, active, sc, my_stack, cnt, tune, walk_steps)) {
                 active = false;
                 unsaved = true;
+                if (COUNT) count_walk(cnt, walk_steps);
             }
         }
     }
@@ -337,6 +344,7 @@ __global__ __launch_bounds__(kBlock, JPT_WAVES_PER_SIMD) void wf2_trace(WideScen
 #endif
     bool unsaved = false;   // this lane's finished walk has not written its hit yet
     size_t my_loc = 0;
+    uint32_t walk_steps = 0;   // (counting builds: record steps of this lane's ray)
     // A finished walk's hit stays in the lane's registers until the lane takes its next ray: the hits are written when the
     // wave refills (two dozen lanes at once) instead of in the round each walk happens to end in (some lane does in
     // nearly every round: a dozen instructions per round for one or two lanes' stores).
@@ -372,6 +380,7 @@ __global__ __launch_bounds__(kBlock, JPT_WAVES_PER_SIMD) void wf2_trace(WideScen
                     tr.begin(sc, mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z));
                     my_loc = loc;
                     active = true;
+                    walk_steps = 0;
                 }
             }
         }
@@ -380,14 +389,290 @@ __global__ __launch_bounds__(kBlock, JPT_WAVES_PER_SIMD) void wf2_trace(WideScen
             continue;
         }
         {
-            if (walk_round<COUNT, W4>(tr, active, sc, my_stack, cnt, tune)) {
+            if (walk_round<COUNT, W4>(tr, active, sc, my_stack, cnt, tune, walk_steps)) {
                 active = false;
                 if (JPT_LATE_HIT_STORE) unsaved = true;
                 else save_hit();
+                if (COUNT) count_walk(cnt, walk_steps);
             }
         }
     }
     if (JPT_LATE_HIT_STORE && unsaved) save_hit();
+    if (COUNT) flush_counters(cnt, counters);
+}
+
+// ---- bounces >= 1, REGROUPED (JPT_TRACE_REGROUP=1; VERDICT r03 task 1) -------------------------------------------------
+//
+// wf2_trace binds a ray to a lane for its whole walk: a record step runs with the 28-39 of 64 lanes whose ray happens to want
+// one, a leaf turn with 16-29.  Here a ray is bound to nothing.  A wave (= a block) keeps kRgPool rays'
+// walk state in LDS -- level ray, closest hit, current record, a short stack: 56 + 4 * kRgStack bytes per ray -- and four byte
+// lists of pool slots: rays that want a record step (NODE), a triangle leaf (LEAF), the world ray (TOP: an instance entry, or
+// a TLAS record after an instance was left) and slots without a ray (FREE).  Each turn the wave takes up to 64 slots off ONE
+// list, pulls their state into registers, runs that one kind of step with every lane occupied, writes the state back and
+// files each slot under what its ray wants next (ballot + prefix popcount per list; everything is wave-synchronous: no
+// barrier, no atomic but the queue cursor).  Per ray the sequence of steps -- the functions of jpt_trace_core.h, the same
+// stack discipline -- is exactly wf2_trace's, so the hits are bit-identical; only which rays share a wave-level step changes.
+// A finished ray's hit stays in its slot until the slot is refilled (written 64 at a time, like wf2_trace's late store).
+#ifndef JPT_RG_POOL
+#define JPT_RG_POOL 160
+#endif
+#ifndef JPT_RG_STACK
+#define JPT_RG_STACK 8
+#endif
+constexpr int kRgPool = JPT_RG_POOL;      // rays in flight per wave (slot ids are bytes)
+constexpr int kRgStack = JPT_RG_STACK;    // stack entries per ray in LDS ...
+constexpr int kRgSpill = 64 - JPT_RG_STACK;   // ... and past them in global memory: 64 in all (the reference's own stack size, main.glsl:272,307)
+static_assert(kRgPool >= 64 && kRgPool <= 256 && kRgPool % 4 == 0, "pool slots are addressed by bytes; a refill takes 64");
+constexpr uint32_t kRgPending = 1u << 25;  // meta word: the slot holds a finished ray's hit that is not written yet
+enum { kRgNode = 0, kRgLeaf = 1, kRgTop = 2, kRgFree = 3 };
+
+struct RgPoolLds {
+    float4 a[kRgPool];                 // level ray origin.xyz, hit.t
+    float4 b[kRgPool];                 // level ray direction.xyz, current record (bits)
+    float4 c[kRgPool];                 // hit.u, hit.v, hit.tri (bits), hit.inst | front << 31 (bits)
+    uint32_t m[kRgPool];               // sp (0..7) | in_blas (8) | cur_inst (9..23) | kRgPending
+    uint32_t loc[kRgPool];             // the ray's queue entry (world ray in, hit out)
+    int32_t stack[kRgStack * kRgPool]; // [entry][slot]
+    uint8_t list[4][256];              // rings of slot ids
+};
+
+constexpr uint32_t kRgMaxBlocks = 2u * kSegments;   // grid cap of a regrouped launch (the spill area is sized for it)
+size_t wf2_rg_spill_bytes(uint32_t blocks) { return (size_t)blocks * kRgPool * kRgSpill * sizeof(int32_t); }
+
+template <bool COUNT>
+__global__ __launch_bounds__(64) void wf2_trace_rg(WideSceneDev sc, Wf2Buffers wb, Wf2Dims dm, int bounce, int chain, int waves_per_queue,
+                                                   DevCounters* __restrict__ counters)
+{
+    __shared__ RgPoolLds P;
+    using Walk = Traversal<COUNT, true>;
+    const int lane = threadIdx.x;
+    const uint32_t seg0 = (blockIdx.x / (uint32_t)waves_per_queue) * (uint32_t)chain;
+    uint32_t end[kMaxChain];
+    uint32_t n = 0;
+    for (int k = 0; k < kMaxChain; k++) {
+        if (k < chain && seg0 + (uint32_t)k < kSegments) n += wb.qcount[(size_t)bounce * kSegments + seg0 + (uint32_t)k];
+        end[k] = n;
+    }
+    if (n == 0) return;
+    uint32_t* __restrict__ cursor = wb.rg_cursor + (size_t)bounce * kSegments + seg0;
+    const float4* __restrict__ qo = wb.ray_o[bounce & 1];
+    const float4* __restrict__ qd = wb.ray_d[bounce & 1];
+    int32_t* __restrict__ spill_base = wb.rg_spill + (size_t)blockIdx.x * kRgPool * kRgSpill;
+    DevCounters cnt = {};
+    // all slots free, nothing pending
+    for (int s = lane; s < kRgPool; s += 64) {
+        P.m[s] = 0u;
+        P.list[kRgFree][s] = (uint8_t)s;
+    }
+    uint32_t hn = 0, hl = 0, ht = 0, hf = 0;            // list heads (free-running; the rings hold 256)
+    uint32_t cn = 0, cl = 0, ct = 0, cf = kRgPool;      // list sizes
+    // 64 queue entries are reserved one refill ahead: the atomic's round trip is over when its result is needed
+    uint32_t next_start = 0;
+    if (lane == 0) next_start = atomicAdd(cursor, 64u);
+    bool exhausted = false;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    auto append = [&](int kind, bool pred, uint32_t id, uint32_t head, uint32_t& count) {
+        const unsigned long long mk = __ballot(pred);
+        if (mk) {
+            if (pred) P.list[kind][(head + count + lanes_below(mk, lane)) & 255u] = (uint8_t)id;
+            count += (uint32_t)__popcll(mk);
+        }
+    };
+    auto stack_of = [&](uint32_t id) {
+        return typename Walk::Stack{&P.stack[id], spill_base + (size_t)id * kRgSpill, kRgPool, kRgStack, kRgSpill};
+    };
+    auto write_hit = [&](uint32_t id) {
+        const float4 a = P.a[id], c = P.c[id];
+        const size_t loc = P.loc[id];
+        wb.hit_a[loc] = make_float4(a.w, c.x, c.y, c.z);
+        wb.hit_b[loc] = __float_as_uint(c.w);
+    };
+    // after a step: the next record off the ray's stack if the step left none, then the slot goes to the list of what the ray
+    // wants next (pop_next of jpt_trace_core.h; a ray that left an instance wants the world ray back: TOP)
+    auto file_slot = [&](bool on, uint32_t id, Walk& tr, const typename Walk::Stack& st) {
+        bool fin = false, left_instance = false;
+        if (on && !tr.have) {
+            if (tr.sp == 0) {
+                fin = true;
+            } else {
+                tr.cur = tr.pop(st);
+                if (tr.cur == kSentinel) {
+                    tr.in_blas = false;
+                    left_instance = true;
+                    if (tr.sp == 0) fin = true;
+                    else tr.cur = tr.pop(st);
+                }
+            }
+        }
+        if (on) {
+            P.b[id].w = __int_as_float(tr.cur);
+            P.m[id] = (uint32_t)tr.sp | (tr.in_blas ? 256u : 0u) | (tr.cur_inst << 9) | (fin ? kRgPending : 0u);
+        }
+        const bool go = on && !fin;
+        const bool to_top = go && !tr.in_blas && (tr.cur < 0 || left_instance);
+        const bool to_node = go && tr.cur >= 0 && !to_top;
+        const bool to_leaf = go && tr.cur < 0 && tr.in_blas;
+        append(kRgNode, to_node, id, hn, cn);
+        append(kRgLeaf, to_leaf, id, hl, cl);
+        append(kRgTop, to_top, id, ht, ct);
+        append(kRgFree, on && fin, id, hf, cf);
+    };
+
+    for (;;) {
+        int kind;
+        uint32_t take;
+        if (!exhausted && cf >= 64u) {
+            kind = kRgFree;
+            take = 64u;
+        } else {
+            // a full chunk if any list has one, else the longest list
+            const uint32_t best = cn >= cl ? (cn >= ct ? cn : ct) : (cl >= ct ? cl : ct);
+            if (best == 0u) break;   // (nothing in flight, and no refill: the queue is exhausted)
+            kind = cn >= 64u ? kRgNode : (cl >= 64u ? kRgLeaf : (ct >= 64u ? kRgTop : (best == cn ? kRgNode : (best == cl ? kRgLeaf : kRgTop))));
+            const uint32_t have_n = kind == kRgNode ? cn : (kind == kRgLeaf ? cl : ct);
+            take = have_n < 64u ? have_n : 64u;
+        }
+        const bool on = (uint32_t)lane < take;
+        if (kind == kRgFree) {
+            // refill: the reserved queue entries go into free slots (whose previous rays' hits are written out first)
+            const uint32_t start = (uint32_t)__builtin_amdgcn_readfirstlane((int)next_start);
+            const uint32_t avail = start < n ? (n - start < 64u ? n - start : 64u) : 0u;
+            if (start + 64u >= n) exhausted = true;
+            else if (lane == 0) next_start = atomicAdd(cursor, 64u);
+            const bool mine = (uint32_t)lane < avail;
+            uint32_t id = 0;
+            bool trivial = false;
+            if (mine) {
+                id = P.list[kRgFree][(hf + (uint32_t)lane) & 255u];
+                if (P.m[id] & kRgPending) write_hit(id);
+                const uint32_t idx = start + (uint32_t)lane;
+                uint32_t k = 0, first = 0;
+                for (int j = 0; j < kMaxChain - 1; j++)
+                    if (idx >= end[j]) {
+                        k = (uint32_t)j + 1u;
+                        first = end[j];
+                    }
+                const size_t loc = (size_t)(seg0 + k) * dm.seg_cap + (idx - first);
+                const float4 ro = qo[loc], rd = qd[loc];
+                // Traversal::begin: the walk starts at the TLAS root with the world ray; hit.t = 1e9 (main.glsl:354)
+                trivial = sc.n_instances == 0u;
+                P.a[id] = make_float4(ro.x, ro.y, ro.z, 1e9f);
+                P.b[id] = make_float4(rd.x, rd.y, rd.z, __int_as_float(sc.tlas_root));
+                P.c[id] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                P.m[id] = trivial ? kRgPending : 0u;
+                P.loc[id] = (uint32_t)loc;
+            }
+            hf += avail;
+            cf -= avail;
+            append(kRgNode, mine && !trivial && sc.tlas_root >= 0, id, hn, cn);
+            append(kRgTop, mine && !trivial && sc.tlas_root < 0, id, ht, ct);
+            append(kRgFree, mine && trivial, id, hf, cf);
+        } else if (kind == kRgNode) {
+            uint32_t id = 0;
+            Walk tr;
+            if (on) id = P.list[kRgNode][(hn + (uint32_t)lane) & 255u];
+            hn += take;
+            cn -= take;
+            const typename Walk::Stack st = stack_of(id);
+            tr.have = true;
+            if (on) {
+                const float4 a = P.a[id], b = P.b[id];
+                const uint32_t m = P.m[id];
+                tr.o = mk3(a.x, a.y, a.z);
+                tr.d = mk3(b.x, b.y, b.z);
+                tr.hit.t = a.w;
+                tr.cur = __float_as_int(b.w);
+                tr.sp = (int)(m & 255u);
+                tr.in_blas = (m & 256u) != 0u;
+                tr.cur_inst = (m >> 9) & kInstMask;
+                tr.set_level();
+                tr.node_step4(sc, st, cnt);
+            }
+            if (COUNT && lane == 0) {
+                cnt.phase[0]++;
+                cnt.phase[1]++;
+                cnt.phase[2] += take;
+            }
+            file_slot(on, id, tr, st);
+        } else if (kind == kRgLeaf) {
+            uint32_t id = 0;
+            Walk tr;
+            if (on) id = P.list[kRgLeaf][(hl + (uint32_t)lane) & 255u];
+            hl += take;
+            cl -= take;
+            const typename Walk::Stack st = stack_of(id);
+            tr.have = true;
+            if (on) {
+                const float4 a = P.a[id], b = P.b[id], c = P.c[id];
+                const uint32_t m = P.m[id];
+                tr.o = mk3(a.x, a.y, a.z);
+                tr.d = mk3(b.x, b.y, b.z);
+                tr.hit.t = a.w;
+                tr.hit.u = c.x;
+                tr.hit.v = c.y;
+                tr.hit.tri = __float_as_uint(c.z);
+                tr.hit.inst = __float_as_uint(c.w) & 0x7fffffffu;
+                tr.hit.front = (__float_as_uint(c.w) >> 31) != 0u;
+                tr.cur = __float_as_int(b.w);
+                tr.sp = (int)(m & 255u);
+                tr.in_blas = true;
+                tr.cur_inst = (m >> 9) & kInstMask;
+                tr.leaf_step(sc, cnt);
+                P.a[id].w = tr.hit.t;
+                P.c[id] = make_float4(tr.hit.u, tr.hit.v, __uint_as_float(tr.hit.tri), __uint_as_float(tr.hit.inst | (tr.hit.front ? 0x80000000u : 0u)));
+            }
+            if (COUNT && lane == 0) {
+                cnt.phase[0]++;
+                cnt.phase[3]++;
+                cnt.phase[4] += take;
+            }
+            file_slot(on, id, tr, st);
+        } else {
+            uint32_t id = 0;
+            Walk tr;
+            if (on) id = P.list[kRgTop][(ht + (uint32_t)lane) & 255u];
+            ht += take;
+            ct -= take;
+            const typename Walk::Stack st = stack_of(id);
+            tr.have = true;
+            if (on) {
+                const uint32_t m = P.m[id];
+                const size_t loc = P.loc[id];
+                const float4 ro = qo[loc], rd = qd[loc];
+                tr.wo = mk3(ro.x, ro.y, ro.z);
+                tr.wd = mk3(rd.x, rd.y, rd.z);
+                tr.cur = __float_as_int(P.b[id].w);
+                tr.sp = (int)(m & 255u);
+                tr.in_blas = false;
+                tr.cur_inst = (m >> 9) & kInstMask;
+                if (tr.cur < 0) {
+                    tr.instance_step(sc, st, cnt);   // the instance's local ray, a sentinel on the stack, the BLAS root
+                } else {
+                    tr.o = tr.wo;                    // a TLAS record after an instance: its box tests read the world ray
+                    tr.d = tr.wd;
+                }
+                P.a[id].x = tr.o.x;
+                P.a[id].y = tr.o.y;
+                P.a[id].z = tr.o.z;
+                P.b[id].x = tr.d.x;
+                P.b[id].y = tr.d.y;
+                P.b[id].z = tr.d.z;
+            }
+            if (COUNT && lane == 0) {
+                cnt.phase[0]++;
+                cnt.phase[5]++;
+                cnt.phase[6] += take;
+            }
+            file_slot(on, id, tr, st);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    // the hits still waiting in their slots
+    for (int s = lane; s < kRgPool; s += 64)
+        if (P.m[s] & kRgPending) write_hit((uint32_t)s);
     if (COUNT) flush_counters(cnt, counters);
 }
 
@@ -916,6 +1201,7 @@ Wf2Dims make_dims(int width, int local_rows, int n_frames, const TileWindow& win
 
 uint32_t wf2_segments() { return kSegments; }
 uint32_t trace_stack_capacity() { return (uint32_t)(kStackLds + kStackSpill); }
+uint32_t wf2_rg_stack_capacity() { return (uint32_t)(kRgStack + kRgSpill); }
 
 // Frame groups.  Every launch of the pipeline ends with a tail: a few long rays in a few waves while the rest of the
 // chip has nothing left to do (a ray's latency under full load is ~20 us on average, ~100 us for the longest; C3's ten
@@ -977,7 +1263,8 @@ size_t wf2_workspace_bytes(int width, int local_rows, int n_frames, int max_boun
             b += q * sizeof(float4) + 256;            // hit_a
             b += q * sizeof(uint32_t) + 256;          // hit_b
             b += paths * sizeof(float4) + 256;        // thr
-            b += ((size_t)(max_bounces + 2) * kSegments + 64) * sizeof(uint32_t) + 256;   // queue sizes + the set-aside count
+            b += ((size_t)(max_bounces + 2) * kSegments * 2 + 64) * sizeof(uint32_t) + 256;   // queue sizes + the set-aside count + the regrouped launches' cursors
+            if (tuning().trace_regroup) b += wf2_rg_spill_bytes(kRgMaxBlocks) + 256;
             b += (size_t)redo_capacity(paths) * 2 * sizeof(float4) + 256;    // set-aside records
         }
         const Wf2Dims all = make_dims(width, local_rows, n_frames, full_window(width, local_rows));
@@ -1018,8 +1305,10 @@ void launch_wf2_render(hipStream_t stream, const DeviceScene& ds, const FramePar
     Wf2Dims gdm[kMaxGroups];
     FrameParams gfp[kMaxGroups];
     for (int g = 0; g < groups; g++) {  // group 0 first: the host reads it
-        gb[g].qcount = (uint32_t*)carve(((size_t)nq * kSegments + 64) * sizeof(uint32_t));
+        gb[g].qcount = (uint32_t*)carve(((size_t)nq * kSegments * 2 + 64) * sizeof(uint32_t));
         gb[g].redo_count = gb[g].qcount + (size_t)nq * kSegments;
+        gb[g].rg_cursor = gb[g].redo_count + 64;
+        gb[g].rg_spill = tuning().trace_regroup ? (int32_t*)carve(wf2_rg_spill_bytes(kRgMaxBlocks)) : nullptr;
     }
     float4* rad_all = (float4*)carve((size_t)dm_all.slots_per_frame * (size_t)fp.n_frames * sizeof(float4));
     uint32_t* fin8_all = (uint32_t*)carve((size_t)dm_all.slots_per_frame * (size_t)fp.n_frames * sizeof(uint32_t));
@@ -1073,10 +1362,24 @@ void launch_wf2_render(hipStream_t stream, const DeviceScene& ds, const FramePar
     }();
     const dim3 tgrid((kSegments + (uint32_t)chain - 1u) / (uint32_t)chain);
     const dim3 pgrid(kSegments);
+    // JPT_TRACE_REGROUP=1: the bounce launches as wf2_trace_rg -- four-child records only, and only while the scene's worst-case
+    // stack fits the regrouped walk's 64 entries (else wf2_trace, whose stack holds trace_stack_capacity()).  A wave keeps
+    // kRgPool rays in 15 KB of LDS, so ten waves fit a CU: a launch that has the chip to itself wants ~2 560 waves, a queued
+    // render (four in flight) a quarter of that.
+    const bool regroup = tuning().trace_regroup && w4 && ds.stack_need4 <= wf2_rg_stack_capacity() && gb[0].rg_spill != nullptr;
+    const int rg_waves = [&] {
+        const uint32_t queues = tgrid.x;
+        const uint32_t target = async.trace_chain >= 4 ? 640u : (groups == 2 ? 1280u : 2560u);
+        uint32_t wv = tuning().rg_waves > 0 ? (uint32_t)tuning().rg_waves : (target + queues - 1u) / queues;
+        if (wv < 1u) wv = 1u;
+        while (wv > 1u && wv * queues > kRgMaxBlocks) wv--;
+        return (int)wv;
+    }();
+    const uint32_t rg_blocks = tgrid.x * (uint32_t)rg_waves;
     // the pipeline of one group on one stream
     auto run_group = [&](hipStream_t st, const Wf2Buffers& wb, const Wf2Dims& dm, const FrameParams& gp, hipEvent_t* ev) {
         // queue sizes of bounces >= 1 are accumulated with atomics by wf2_shade: start from zero
-        (void)hipMemsetAsync(wb.qcount + kSegments, 0, ((size_t)(nq - 1) * kSegments + 64) * sizeof(uint32_t), st);  // (and the set-aside counts behind them)
+        (void)hipMemsetAsync(wb.qcount + kSegments, 0, ((size_t)(nq - 1) * kSegments + 64 + (size_t)nq * kSegments) * sizeof(uint32_t), st);  // (and the set-aside counts and the regrouped launches' cursors behind them)
         // Blocks go to the 8 XCDs round-robin by linear index (y * grid.x + x), and the chunks of a segment are far from
         // alike (the first ones are full, the last ones empty): with grid.x a multiple of 8 every XCD would always get
         // the same chunk position.  An odd grid.x deals every position to every XCD (capping C3's grid.x from 37 to 8
@@ -1096,7 +1399,10 @@ void launch_wf2_render(hipStream_t stream, const DeviceScene& ds, const FramePar
             else hipLaunchKernelGGL(wf2_shade<false>, sgrid, block, 0, st, sh, wb, dm, gp, cam.far_, b, counters);
             if (b == gp.max_bounces) break;
             if (ev) (void)hipEventRecord(ev[2 * (b + 1)], st);
-            if (counters) {
+            if (regroup) {
+                if (counters) hipLaunchKernelGGL(wf2_trace_rg<true>, dim3(rg_blocks), dim3(64), 0, st, sc, wb, dm, b + 1, chain, rg_waves, counters);
+                else hipLaunchKernelGGL(wf2_trace_rg<false>, dim3(rg_blocks), dim3(64), 0, st, sc, wb, dm, b + 1, chain, rg_waves, counters);
+            } else if (counters) {
                 if (w4) hipLaunchKernelGGL((wf2_trace<true, true>), tgrid, block, 0, st, sc, wb, dm, b + 1, tune, chain, counters);
                 else hipLaunchKernelGGL((wf2_trace<true, false>), tgrid, block, 0, st, sc, wb, dm, b + 1, tune, chain, counters);
             } else {

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define JPT_ABI_VERSION 3
+#define JPT_ABI_VERSION 4
 
 typedef struct jpt_ctx jpt_ctx;
 
@@ -127,6 +127,10 @@ typedef struct {
                                   were shaded as found (the native tree's closest hit: the image differs from the reference's
                                   in those pixels).  0 on every scene measured; a scene that reports more renders exactly with
                                   JPT_KERNEL_REFERENCE_LAYOUT or JPT_UPLOAD_WALK_AS_GIVEN / JPT_BUILD_REFERENCE_EXACT */
+    /* ABI 4 -- counting renders with the wavefront kernels: how long the walks are.  A launch cannot end before its longest
+     * ray does, one dependent fetch after another (launch tails). */
+    uint64_t walk_steps_max;    /* most record steps (internal records + leaf turns + instance entries) one ray took */
+    uint64_t walk_steps_hist[8];/* rays that took < 16, < 64, < 256, < 1024, < 4096, < 16384, < 65536, more steps */
 } jpt_stats;
 
 /* ---- lifetime --------------------------------------------------------------------------------- */
