@@ -45,6 +45,7 @@ struct WfTune {
     int leaf_min_lanes;  // a leaf / instance phase with fewer takers than this is put off to the next round, as long as
     int inst_min_lanes;  // other lanes of the wave can make progress meanwhile
     int phase_frac16;    // ... and never more than this many sixteenths of the wave's active rays
+    int coop_rounds;     // COOP launches: a ray still walking this many rounds after its block's queue ran dry is handed to wf2_long
 };
 
 // One round of the walk for every active lane of the wave, "while-while" style so that lanes in different
@@ -124,6 +125,9 @@ struct Wf2Buffers {
     uint32_t* qcount;   // [max_bounces + 2][kSegments] queue sizes; row b = rays traced in bounce b (b >= 1)
     uint32_t* redo_count;  // [0]: paths set aside because the reference cannot reach their hit (wf2_finish) ...
     float4* redo_rec;      // ... two float4 each: the vertex's ray, origin.w = bounce bits, direction.w = path id bits
+    uint32_t* long_count;  // COOP launches: [max_bounces + 2] rays handed over to wf2_long by the launch of that bounce ...
+    uint2* long_list;      // ... each (path, segment) for the primary launch, (queue entry, 0) for a bounce launch; consumed by the
+    uint32_t long_cap;     //     wf2_long launch that follows, so one list serves all launches of a render
     uint32_t* rg_cursor;   // regrouped tracing launches (wf2_trace_rg): [max_bounces + 2][kSegments] queue cursors, shared by the waves of a queue
     int32_t* rg_spill;     // ... and the stack entries past the LDS part: [block][pool slot][entry]
     uint32_t redo_cap;     // records redo_rec holds (a few paths in 10^7 are set aside: not one record per path).  A hit
@@ -191,9 +195,145 @@ __device__ __forceinline__ uint32_t lanes_below(unsigned long long mask, int lan
     return (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
 }
 
+// ---- a long walk, finished by a whole wave -----------------------------------------------------------------------------
+//
+// A launch cannot end before its longest ray does, and a lone ray advances one dependent fetch at a time (~0.8 us a step on an
+// otherwise idle chip).  On the 1 M-triangle scene 40 of 16.6 M primary rays take 1 000 - 5 310 record steps (99.99 % take
+// fewer than 256): the primary launch spent 4.4 of its 7.6 ms waiting for them, one frame alone took 4.5 ms against 0.5 ms per
+// further frame (profiles/r04/r04g_tail_probe.txt, r04h_walk_hist.txt; round 3 had taken this launch for latency-bound as a
+// whole).  The COOP instantiations of the tracing kernels hand such a ray over: a ray that is still walking `coop_rounds`
+// rounds after its block's queue ran dry is dropped where it is and listed (a global list, one atomic per such ray), and the
+// small launch that follows, wf2_long, walks every listed ray AGAIN FROM THE ROOT with all 64 lanes of a wave: a lane walks
+// one subtree with its private stack, gives the entry on top of that stack to the wave's pool (LDS) whenever lanes are
+// idle, idle lanes take entries from the pool (an entry carries its level: TLAS, or the instance it belongs to), and after
+// every round all lanes adopt the closest distance any of them has found, so every lane culls with it.  The closest hit does
+// not depend on the order of the tests; two lanes that both keep a triangle at the final distance are an exact tie and
+// flagged as one (kHitTied), like two such triangles met by one walk.  5 310 dependent steps become ~150 rounds: S-unique's
+// primary launch 8.9 -> 4.2 ms, its bounce launches 3.4 -> 2.6 ms, a blocking render 20.1 -> 14.4 ms (profiles/r04/
+// r04l_coop_ab.txt).  Used for scenes of >= 200 000 triangles: on the small scenes no ray is long, the launches' tails are
+// the drain of ordinary rays, and the empty follow-up launches alone cost a blocking C3 render 15 % (r04m_coop_small_scenes.txt).
+constexpr int kCoopPool = 64;      // pool entries per wave (two words each)
+constexpr uint32_t kLongGrid = 2048;       // blocks (= waves) of a wf2_long launch
+constexpr uint32_t kCoopListCap = 8192;   // rays one launch can hand over (the rest keep walking on their lanes)
+
+__device__ __forceinline__ float wave_min_f(float v)
+{
+    for (int off = 32; off > 0; off >>= 1) v = fmin_(v, __shfl_xor(v, off));
+    return v;
+}
+
+template <bool COUNT>
+__device__ __forceinline__ TraceHit coop_walk(const WideSceneDev& sc, const typename Traversal<COUNT, true>::Stack st, int32_t* __restrict__ pool,
+                                           f3 ro, f3 rd, DevCounters& cnt)
+{
+    using Walk = Traversal<COUNT, true>;
+    const int lane = threadIdx.x & 63;
+    constexpr uint32_t kNone = 0xffffffffu;   // hit.tri of a lane that holds no triangle of its own at hit.t
+    Walk tr;
+    tr.begin(sc, ro, rd);
+    tr.hit.tri = kNone;
+    bool active = lane == 0 && tr.have;
+    if (lane != 0) tr.have = false;
+    uint32_t n_pool = 0;
+    for (;;) {
+        // idle lanes take pool entries (newest first)
+        {
+            const unsigned long long idle = __ballot(!active);
+            const uint32_t n_idle = (uint32_t)__popcll(idle);
+            const uint32_t take = n_pool < n_idle ? n_pool : n_idle;
+            if (take) {
+                const uint32_t r = lanes_below(idle, lane);
+                if (!active && r < take) {
+                    const int32_t ref = pool[2u * (n_pool - 1u - r)];
+                    const uint32_t ctx = (uint32_t)pool[2u * (n_pool - 1u - r) + 1u];
+                    tr.sp = 0;
+                    tr.cur = ref;
+                    tr.have = true;
+                    tr.in_blas = (ctx & 1u) != 0u;
+                    tr.cur_inst = ctx >> 1;
+                    if (tr.in_blas) {   // the instance's local ray (instance_step's arithmetic, main.glsl:319-320)
+                        const WideInstance* ip = sc.instances + tr.cur_inst;
+                        const float4 m0 = ld4(&ip->inv[0]), m1 = ld4(&ip->inv[4]), m2 = ld4(&ip->inv[8]);
+                        tr.o = mk3(m0.x * ro.x + m0.w * ro.y + m1.z * ro.z + m2.y, m0.y * ro.x + m1.x * ro.y + m1.w * ro.z + m2.z,
+                                   m0.z * ro.x + m1.y * ro.y + m2.x * ro.z + m2.w);
+                        tr.d = mk3(m0.x * rd.x + m0.w * rd.y + m1.z * rd.z, m0.y * rd.x + m1.x * rd.y + m1.w * rd.z,
+                                   m0.z * rd.x + m1.y * rd.y + m2.x * rd.z);
+                    } else {
+                        tr.o = ro;
+                        tr.d = rd;
+                    }
+                    tr.set_level();
+                    active = true;
+                }
+                n_pool -= take;
+            }
+        }
+        if (!__any(active)) break;   // (and the pool is empty: an idle lane would have taken from it)
+        if (active && !tr.step(sc, st, cnt)) active = false;
+        // every lane culls with the closest distance found anywhere; a lane whose own triangle is farther no longer holds one
+        {
+            const float t = wave_min_f(tr.hit.t);
+            if (t < tr.hit.t) {
+                tr.hit.t = t;
+                tr.hit.tri = kNone;
+                tr.hit.inst = 0u;
+            }
+        }
+        // while lanes are idle, lanes with pending entries give the one on top of their stack to the pool (never the sentinel
+        // that marks "leave the instance": what lies above it belongs to the instance the lane is in)
+        {
+            const uint32_t n_idle = (uint32_t)__popcll(__ballot(!active));
+            const uint32_t want = n_idle > n_pool ? n_idle - n_pool : 0u;
+            if (want) {
+                int32_t top = kSentinel;
+                const bool may = active && tr.sp > 0;
+                if (may) {   // peek
+                    const int row = tr.sp - 1;
+                    top = row < st.lds_entries ? st.lds[row * st.stride] : (row < st.lds_entries + st.spill_entries ? st.spill[row - st.lds_entries] : kSentinel);
+                }
+                const bool give = may && top != kSentinel;
+                const unsigned long long gm = __ballot(give);
+                const uint32_t r = lanes_below(gm, lane);
+                const uint32_t room = (uint32_t)kCoopPool - n_pool;
+                const uint32_t lim = want < room ? want : room;
+                if (give && r < lim) {
+                    tr.sp--;
+                    pool[2u * (n_pool + r)] = top;
+                    pool[2u * (n_pool + r) + 1u] = (int32_t)((tr.in_blas ? 1u : 0u) | (tr.cur_inst << 1));
+                }
+                const uint32_t given = (uint32_t)__popcll(gm);
+                n_pool += given < lim ? given : lim;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    // the closest hit: the lanes that hold a triangle at the final distance
+    const float best = wave_min_f(tr.hit.t);
+    const unsigned long long win = __ballot(tr.hit.tri != kNone && tr.hit.t == best);
+    TraceHit out;
+    out.t = 1e9f;
+    out.u = out.v = 0.0f;
+    out.tri = out.inst = 0u;
+    out.front = false;
+    if (win && best < 1e9f) {
+        const int w = __ffsll((long long)win) - 1;
+        out.t = best;
+        out.u = __shfl(tr.hit.u, w);
+        out.v = __shfl(tr.hit.v, w);
+        out.tri = (uint32_t)__shfl((int)tr.hit.tri, w);
+        out.front = __shfl((int)tr.hit.front, w) != 0;
+        const uint32_t wi = (uint32_t)__shfl((int)tr.hit.inst, w);
+        const uint32_t found_in = (wi >> kInstBits) & kInstMask;
+        const bool tied = __popcll(win) > 1 || (wi & kHitTied) != 0u;
+        out.inst = found_in | (found_in << kInstBits) | (tied ? kHitTied : 0u);
+    }
+    return out;
+}
+
 // ---- bounce 0: generate + trace ------------------------------------------------------------------------
 
-template <bool COUNT, bool W4>
+template <bool COUNT, bool W4, bool COOP = false>
 __global__ __launch_bounds__(kBlock, JPT_PRIMARY_WAVES) void wf2_primary(WideSceneDev sc, Wf2Buffers wb, Wf2Dims dm, FrameParams fp, RefCamera cam,
                                                       WfTune tune, SkyCull cull, DevCounters* __restrict__ counters)
 {
@@ -214,6 +354,7 @@ __global__ __launch_bounds__(kBlock, JPT_PRIMARY_WAVES) void wf2_primary(WideSce
     int32_t spill[kStackSpill];
     const typename Traversal<COUNT, W4>::Stack my_stack{&stack[threadIdx.x], spill, kTraceBlock, kStackLds};
     const size_t seg_base = (size_t)seg * dm.seg_cap;
+    uint32_t dry_rounds = 0;   // (COOP: rounds of this wave since the block's queue ran dry; wave-uniform)
     DevCounters cnt = {};
     Traversal<COUNT, W4> tr;
     bool active = false, exhausted = false;
@@ -296,6 +437,17 @@ __global__ __launch_bounds__(kBlock, JPT_PRIMARY_WAVES) void wf2_primary(WideSce
                 unsaved = true;
                 if (COUNT) count_walk(cnt, walk_steps);
             }
+            if constexpr (COOP && W4) {
+                // the block's queue has been exhausted for kCoopRounds rounds and this ray is still walking: hand it over to
+                // wf2_long (see coop_walk).  (A wave-uniform count of rounds since the queue ran dry, not a per-lane one.)
+                if (exhausted && ++dry_rounds >= (uint32_t)tune.coop_rounds && active) {
+                    const uint32_t k = atomicAdd(&wb.long_count[0], 1u);
+                    if (k < wb.long_cap) {
+                        wb.long_list[k] = make_uint2(path, seg);
+                        active = false;
+                    }
+                }
+            }
         }
     }
     if (__any(unsaved)) save_results();
@@ -314,7 +466,7 @@ __global__ __launch_bounds__(kBlock, JPT_PRIMARY_WAVES) void wf2_primary(WideSce
 #define JPT_MAX_CHAIN 4
 #endif
 constexpr int kMaxChain = JPT_MAX_CHAIN;
-template <bool COUNT, bool W4>
+template <bool COUNT, bool W4, bool COOP = false>
 __global__ __launch_bounds__(kBlock, JPT_WAVES_PER_SIMD) void wf2_trace(WideSceneDev sc, Wf2Buffers wb, Wf2Dims dm, int bounce, WfTune tune,
                                                     int chain, DevCounters* __restrict__ counters)
 {
@@ -334,6 +486,7 @@ __global__ __launch_bounds__(kBlock, JPT_WAVES_PER_SIMD) void wf2_trace(WideScen
     __syncthreads();
     int32_t spill[kStackSpill];
     const typename Traversal<COUNT, W4>::Stack my_stack{&stack[threadIdx.x], spill, kTraceBlock, kStackLds};
+    uint32_t dry_rounds = 0;   // (COOP: rounds of this wave since the block's queue ran dry; wave-uniform)
     const float4* __restrict__ qo = wb.ray_o[bounce & 1];
     const float4* __restrict__ qd = wb.ray_d[bounce & 1];
     DevCounters cnt = {};
@@ -395,9 +548,68 @@ __global__ __launch_bounds__(kBlock, JPT_WAVES_PER_SIMD) void wf2_trace(WideScen
                 else save_hit();
                 if (COUNT) count_walk(cnt, walk_steps);
             }
+            if constexpr (COOP && W4) {
+                if (exhausted && ++dry_rounds >= (uint32_t)tune.coop_rounds && active) {
+                    const uint32_t k = atomicAdd(&wb.long_count[bounce], 1u);
+                    if (k < wb.long_cap) {
+                        wb.long_list[k] = make_uint2((uint32_t)my_loc, 0u);
+                        active = false;
+                    }
+                }
+            }
         }
     }
     if (JPT_LATE_HIT_STORE && unsaved) save_hit();
+    if (COUNT) flush_counters(cnt, counters);
+}
+
+// the rays a COOP launch handed over, each walked by a whole wave (coop_walk); results stored the way the launch stores them
+template <bool COUNT, bool PRIMARY>
+__global__ __launch_bounds__(64) void wf2_long(WideSceneDev sc, Wf2Buffers wb, Wf2Dims dm, FrameParams fp, RefCamera cam, int bounce,
+                                               DevCounters* __restrict__ counters)
+{
+    const uint32_t n_all = wb.long_count[bounce];
+    const uint32_t n = n_all < wb.long_cap ? n_all : wb.long_cap;
+    if (blockIdx.x >= n) return;
+    __shared__ int32_t stack[kStackLds * 64];
+    __shared__ int32_t s_pool[2 * kCoopPool];
+    int32_t spill[kStackSpill];
+    const typename Traversal<COUNT, true>::Stack my_stack{&stack[threadIdx.x], spill, 64, kStackLds};
+    const int lane = threadIdx.x;
+    DevCounters cnt = {};
+    for (uint32_t k = blockIdx.x; k < n; k += gridDim.x) {
+        const uint2 rec = wb.long_list[k];
+        if (PRIMARY) {
+            const uint32_t path = rec.x, seg = rec.y;
+            const uint32_t f = fdiv(path, dm.by_slots_per_frame);
+            int px, ly;
+            slot_to_pixel(path - f * dm.slots_per_frame, dm, px, ly);
+            uint32_t sx, sy;
+            const Ray ray = primary_ray(cam, fp.width, fp.height, px, local_to_global_row(ly, fp), fp.frame_index + f, sx, sy);
+            const TraceHit h = coop_walk<COUNT>(sc, my_stack, s_pool, ray.o, ray.d, cnt);
+            if (lane == 0) {
+                if (h.t < 1e9f) {   // into the segment's bounce-0 queue (wf2_primary has left its size in qcount)
+                    const size_t j = (size_t)seg * dm.seg_cap + atomicAdd(&wb.qcount[0 * kSegments + seg], 1u);
+                    wb.ray_o[0][j] = make_float4(ray.o.x, ray.o.y, ray.o.z, 0.0f);
+                    wb.ray_d[0][j] = make_float4(ray.d.x, ray.d.y, ray.d.z, __uint_as_float(path));
+                    wb.hit_a[j] = make_float4(h.t, h.u, h.v, __uint_as_float(h.tri));
+                    wb.hit_b[j] = h.inst | (h.front ? 0x80000000u : 0u);
+                } else {            // sky (main.glsl:380,395-397)
+                    const f3 sky = mk3(0.0f, 0.0f, 0.0f) + mk3(1.0f, 1.0f, 1.0f) * sample_sky(ray.d);
+                    store_final(wb, fp.accum_mode, path, sky);
+                    if ((int)f == fp.depth_frame) wb.first_depth[path - f * dm.slots_per_frame] = cam.far_;
+                }
+            }
+        } else {
+            const size_t loc = rec.x;
+            const float4 ro = wb.ray_o[bounce & 1][loc], rd = wb.ray_d[bounce & 1][loc];
+            const TraceHit h = coop_walk<COUNT>(sc, my_stack, s_pool, mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), cnt);
+            if (lane == 0) {
+                wb.hit_a[loc] = make_float4(h.t, h.u, h.v, __uint_as_float(h.tri));
+                wb.hit_b[loc] = h.inst | (h.front ? 0x80000000u : 0u);
+            }
+        }
+    }
     if (COUNT) flush_counters(cnt, counters);
 }
 
@@ -1263,7 +1475,8 @@ size_t wf2_workspace_bytes(int width, int local_rows, int n_frames, int max_boun
             b += q * sizeof(float4) + 256;            // hit_a
             b += q * sizeof(uint32_t) + 256;          // hit_b
             b += paths * sizeof(float4) + 256;        // thr
-            b += ((size_t)(max_bounces + 2) * kSegments * 2 + 64) * sizeof(uint32_t) + 256;   // queue sizes + the set-aside count + the regrouped launches' cursors
+            b += ((size_t)(max_bounces + 2) * kSegments * 2 + 192) * sizeof(uint32_t) + 256;   // queue sizes + the set-aside count + the regrouped launches' cursors + the hand-over counts
+            b += (size_t)kCoopListCap * sizeof(uint2) + 256;                                     // rays handed over to wf2_long
             if (tuning().trace_regroup) b += wf2_rg_spill_bytes(kRgMaxBlocks) + 256;
             b += (size_t)redo_capacity(paths) * 2 * sizeof(float4) + 256;    // set-aside records
         }
@@ -1305,9 +1518,12 @@ void launch_wf2_render(hipStream_t stream, const DeviceScene& ds, const FramePar
     Wf2Dims gdm[kMaxGroups];
     FrameParams gfp[kMaxGroups];
     for (int g = 0; g < groups; g++) {  // group 0 first: the host reads it
-        gb[g].qcount = (uint32_t*)carve(((size_t)nq * kSegments * 2 + 64) * sizeof(uint32_t));
+        gb[g].qcount = (uint32_t*)carve(((size_t)nq * kSegments * 2 + 192) * sizeof(uint32_t));
         gb[g].redo_count = gb[g].qcount + (size_t)nq * kSegments;
         gb[g].rg_cursor = gb[g].redo_count + 64;
+        gb[g].long_count = gb[g].rg_cursor + (size_t)nq * kSegments;   // (128 words: one count per launch, max_bounces <= 64)
+        gb[g].long_list = (uint2*)carve((size_t)kCoopListCap * sizeof(uint2));
+        gb[g].long_cap = kCoopListCap;
         gb[g].rg_spill = tuning().trace_regroup ? (int32_t*)carve(wf2_rg_spill_bytes(kRgMaxBlocks)) : nullptr;
     }
     float4* rad_all = (float4*)carve((size_t)dm_all.slots_per_frame * (size_t)fp.n_frames * sizeof(float4));
@@ -1354,7 +1570,7 @@ void launch_wf2_render(hipStream_t stream, const DeviceScene& ds, const FramePar
     SceneShading sh = ds.shading();
     if (tuning().reach == 0) sh.reach_tri = nullptr;
     const dim3 block(kBlock);
-    const WfTune tune{tuning().refill_idle, tuning().node_min_lanes, tuning().leaf_min_lanes, tuning().inst_min_lanes, tuning().phase_frac16};
+    const WfTune tune{tuning().refill_idle, tuning().node_min_lanes, tuning().leaf_min_lanes, tuning().inst_min_lanes, tuning().phase_frac16, tuning().coop_rounds};
 
     const int chain = [&] {  // JPT_TRACE_CHAIN overrides (tuning runs); two frame groups share the chip: half-width launches
         const int c = tuning().trace_chain > 0 ? tuning().trace_chain : (groups == 2 ? 2 : async.trace_chain);
@@ -1366,6 +1582,8 @@ void launch_wf2_render(hipStream_t stream, const DeviceScene& ds, const FramePar
     // stack fits the regrouped walk's 64 entries (else wf2_trace, whose stack holds trace_stack_capacity()).  A wave keeps
     // kRgPool rays in 15 KB of LDS, so ten waves fit a CU: a launch that has the chip to itself wants ~2 560 waves, a queued
     // render (four in flight) a quarter of that.
+    // long walks handed over to a whole wave (coop_walk): scenes large enough to have them (JPT_COOP overrides)
+    const bool coop = w4 && (tuning().coop < 0 ? ds.n_tris >= 200000u : tuning().coop != 0);
     const bool regroup = tuning().trace_regroup && w4 && ds.stack_need4 <= wf2_rg_stack_capacity() && gb[0].rg_spill != nullptr;
     const int rg_waves = [&] {
         const uint32_t queues = tgrid.x;
@@ -1379,19 +1597,26 @@ void launch_wf2_render(hipStream_t stream, const DeviceScene& ds, const FramePar
     // the pipeline of one group on one stream
     auto run_group = [&](hipStream_t st, const Wf2Buffers& wb, const Wf2Dims& dm, const FrameParams& gp, hipEvent_t* ev) {
         // queue sizes of bounces >= 1 are accumulated with atomics by wf2_shade: start from zero
-        (void)hipMemsetAsync(wb.qcount + kSegments, 0, ((size_t)(nq - 1) * kSegments + 64 + (size_t)nq * kSegments) * sizeof(uint32_t), st);  // (and the set-aside counts and the regrouped launches' cursors behind them)
+        (void)hipMemsetAsync(wb.qcount + kSegments, 0, ((size_t)(nq - 1) * kSegments + 64 + (size_t)nq * kSegments + 128) * sizeof(uint32_t), st);  // (and the set-aside counts and the regrouped launches' cursors behind them)
         // Blocks go to the 8 XCDs round-robin by linear index (y * grid.x + x), and the chunks of a segment are far from
         // alike (the first ones are full, the last ones empty): with grid.x a multiple of 8 every XCD would always get
         // the same chunk position.  An odd grid.x deals every position to every XCD (capping C3's grid.x from 37 to 8
         // cost 9 %).
         const dim3 sgrid(((dm.seg_cap + kBlock - 1) / kBlock) | 1u, kSegments);
         if (ev) (void)hipEventRecord(ev[0], st);
-        if (counters) {
+        if (coop) {
+            if (counters) hipLaunchKernelGGL((wf2_primary<true, true, true>), pgrid, block, 0, st, sc, wb, dm, gp, cam, tune, async.cull, counters);
+            else hipLaunchKernelGGL((wf2_primary<false, true, true>), pgrid, block, 0, st, sc, wb, dm, gp, cam, tune, async.cull, counters);
+        } else if (counters) {
             if (w4) hipLaunchKernelGGL((wf2_primary<true, true>), pgrid, block, 0, st, sc, wb, dm, gp, cam, tune, async.cull, counters);
             else hipLaunchKernelGGL((wf2_primary<true, false>), pgrid, block, 0, st, sc, wb, dm, gp, cam, tune, async.cull, counters);
         } else {
             if (w4) hipLaunchKernelGGL((wf2_primary<false, true>), pgrid, block, 0, st, sc, wb, dm, gp, cam, tune, async.cull, counters);
             else hipLaunchKernelGGL((wf2_primary<false, false>), pgrid, block, 0, st, sc, wb, dm, gp, cam, tune, async.cull, counters);
+        }
+        if (coop) {   // the rays the launch handed over, each by a whole wave (blocks past their number exit at once)
+            if (counters) hipLaunchKernelGGL((wf2_long<true, true>), dim3(kLongGrid), dim3(64), 0, st, sc, wb, dm, gp, cam, 0, counters);
+            else hipLaunchKernelGGL((wf2_long<false, true>), dim3(kLongGrid), dim3(64), 0, st, sc, wb, dm, gp, cam, 0, counters);
         }
         if (ev) (void)hipEventRecord(ev[1], st);
         for (int b = 0; b <= gp.max_bounces; b++) {
@@ -1402,12 +1627,19 @@ void launch_wf2_render(hipStream_t stream, const DeviceScene& ds, const FramePar
             if (regroup) {
                 if (counters) hipLaunchKernelGGL(wf2_trace_rg<true>, dim3(rg_blocks), dim3(64), 0, st, sc, wb, dm, b + 1, chain, rg_waves, counters);
                 else hipLaunchKernelGGL(wf2_trace_rg<false>, dim3(rg_blocks), dim3(64), 0, st, sc, wb, dm, b + 1, chain, rg_waves, counters);
+            } else if (coop) {
+                if (counters) hipLaunchKernelGGL((wf2_trace<true, true, true>), tgrid, block, 0, st, sc, wb, dm, b + 1, tune, chain, counters);
+                else hipLaunchKernelGGL((wf2_trace<false, true, true>), tgrid, block, 0, st, sc, wb, dm, b + 1, tune, chain, counters);
             } else if (counters) {
                 if (w4) hipLaunchKernelGGL((wf2_trace<true, true>), tgrid, block, 0, st, sc, wb, dm, b + 1, tune, chain, counters);
                 else hipLaunchKernelGGL((wf2_trace<true, false>), tgrid, block, 0, st, sc, wb, dm, b + 1, tune, chain, counters);
             } else {
                 if (w4) hipLaunchKernelGGL((wf2_trace<false, true>), tgrid, block, 0, st, sc, wb, dm, b + 1, tune, chain, counters);
                 else hipLaunchKernelGGL((wf2_trace<false, false>), tgrid, block, 0, st, sc, wb, dm, b + 1, tune, chain, counters);
+            }
+            if (coop && !regroup) {
+                if (counters) hipLaunchKernelGGL((wf2_long<true, false>), dim3(kLongGrid), dim3(64), 0, st, sc, wb, dm, gp, cam, b + 1, counters);
+                else hipLaunchKernelGGL((wf2_long<false, false>), dim3(kLongGrid), dim3(64), 0, st, sc, wb, dm, gp, cam, b + 1, counters);
             }
             if (ev) (void)hipEventRecord(ev[2 * (b + 1) + 1], st);
         }

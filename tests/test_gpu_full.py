@@ -872,3 +872,24 @@ def test_bench_self_launch_two_ranks_on_one_gpu(hiplib, launcher):
     assert d["multi_gpu"]["c5"]["verified_bit_identical_to_one_context"] is True
     if launcher == "multi":
         assert d["multi_gpu"]["gather_plan"] == {"peer_copies": 1, "distinct_streams": 1, "own_piece_copies": 0}
+
+
+@pytest.mark.parametrize("switch", ["JPT_COOP=1 JPT_COOP_ROUNDS=2", "JPT_TRACE_REGROUP=1", "JPT_TRACE_REGROUP=1 JPT_COOP=1 JPT_COOP_ROUNDS=2"])
+def test_alternative_tracing_launches_are_bit_identical(hiplib, switch):
+    """The tuning switches are read once per process, so the alternative launches run the parity tests in a child process:
+    JPT_COOP=1 with an eager hand-over (most tail rays of every launch are walked by wf2_long / coop_walk, which large
+    scenes get by default for their few very long rays) and JPT_TRACE_REGROUP=1 (wf2_trace_rg: ray state in LDS, compacted
+    lists per step kind -- kept as a measured, rejected variant).  Same images bit for bit as the default launches: a subset
+    of the parity suite, against the oracle."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for kv in switch.split():
+        k, v = kv.split("=")
+        env[k] = v
+    p = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_parity.py"), os.path.join(root, "tests", "test_fuzz.py"),
+                        "-m", "gpu", "-x", "-q", "-k", "c1_cornell or demo_scene_multi_frame or coincident or tie_between or duplicated or native_tree"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=1500)
+    assert p.returncode == 0, p.stdout[-3000:]
+    assert " passed" in p.stdout and "failed" not in p.stdout
