@@ -39,6 +39,10 @@ namespace {
 
 constexpr int kBlock = kTraceBlock;
 constexpr uint32_t kSegments = 256u * JPT_WAVES_PER_SIMD;  // persistent grid: one 256-thread block per CU per wave/SIMD
+#ifndef JPT_LEAF_INNER
+#define JPT_LEAF_INNER 0
+#endif
+constexpr int kLeafInner = JPT_LEAF_INNER;
 struct WfTune {
     int refill_idle;     // refill when at least this many lanes of a wave are idle
     int node_min_lanes;  // leave the node loop when fewer lanes than this still descend
@@ -79,6 +83,22 @@ __device__ __forceinline__ bool walk_round(Traversal<COUNT, W4>& tr, bool active
         }
         if (want) tr.node_step(sc, st, cnt);
         if (COUNT && want) steps++;
+        // -DJPT_LEAF_INNER=n (VERDICT r03 task 1, "leaves inside the record loop"; a build-time constant: as a run-time knob the
+        // dormant code alone cost the loop two registers and a spill): when at least n lanes have arrived at a leaf, the
+        // leaves are tested here, inside the loop, and those lanes rejoin the descent at once instead of waiting for the loop
+        // to run down to node_min_lanes.  0 (default): off -- measured, profiles/r04/r04n_leaf_inner.txt.
+        if (W4 && kLeafInner > 0) {
+            const bool wl_in = active && tr.wants_leaf();
+            const unsigned long long lm = __ballot(wl_in);
+            if (__popcll(lm) >= kLeafInner) {
+                if (COUNT && lane0) {
+                    cnt.phase[3]++;
+                    cnt.phase[4] += (unsigned long long)__popcll(lm);
+                }
+                if (wl_in) tr.leaf_step(sc, cnt);
+                if (COUNT && wl_in) steps++;
+            }
+        }
     }
     bool wl = active && tr.wants_leaf();
     bool wi = active && tr.wants_instance();

@@ -167,14 +167,16 @@ def primary_rays(cam, w, h, px, py, frame):
     return np.broadcast_to(cpos, world.shape).astype(F), np_path._normalize(world - cpos[None, :]), seed
 
 
-def main(dist=500000.0, n_bounces=2):
+def main(dist=500000.0, n_bounces=2, w=192, h=108, frames=(1, 2), quiet=False):
+    """returns (explained, exact ties, unexplained, rays compared)"""
     sc = scenes.demo_scene(1500)
     ref = ob.build_scene(sc)
-    w, h = 192, 108
+    say = (lambda *a, **k: None) if quiet else print
+    compared = 0
     fov = float(np.degrees(2.0 * np.arctan(3.2 / dist)))
     sc.camera = scenes.CameraDesc(scenes.transform12(None, (0.3, 0.2, dist)), fov_deg=fov)
     explained = unexplained = ties = 0
-    for frame in (1, 2):
+    for frame in frames:
         cam = scenes.camera_block(sc.camera, w, h)
         cam["frame_index"] = frame
         ys, xs = np.mgrid[0:h, 0:w]     # every pixel: both modes are replayed for each primary ray
@@ -183,6 +185,7 @@ def main(dist=500000.0, n_bounces=2):
             rays_o, rays_d, seed = primary_rays(cam, w, h, px, py, frame)
         for bounce in range(n_bounces + 1):
             keep, hv, n_diff = [], [], 0
+            compared += len(px)
             for k in range(len(px)):
                 o, d = rays_o[k], rays_d[k]
                 t_ref, tri_ref, inst_ref, seen, ex = walk(ref, o, d, False)
@@ -197,7 +200,7 @@ def main(dist=500000.0, n_bounces=2):
                     frame, bounce, px[k], py[k], tri_ref, inst_ref, t_ref, tri_rch, inst_rch, t_rch)
                 if t_rch == t_ref:
                     ties += 1
-                    print(line + "  -> an exact tie decided by order (the tie walk's business on the device)", flush=True)
+                    say(line + "  -> an exact tie decided by order (the tie walk's business on the device)", flush=True)
                     continue
                 # the reach rule keeps something strictly closer that the reference walk never tested: which box hid it?
                 culprit = None
@@ -208,14 +211,14 @@ def main(dist=500000.0, n_bounces=2):
                         break
                 if culprit and culprit[1] >= culprit[2] and t_rch <= culprit[2]:
                     explained += 1
-                    print(line + "\n      box of node %d on its chain: entry distance %.9g >= hitInfo.t %.9g when its parent was expanded, although its own "
+                    say(line + "\n      box of node %d on its chain: entry distance %.9g >= hitInfo.t %.9g when its parent was expanded, although its own "
                           "triangle's t is %.9g (entry - t = %.3g = %.1f ulp of t; |origin| = %.6g): culled by `d < hitInfo.t` (main.glsl:290-291)" % (
                               culprit[0], culprit[1], culprit[2], t_rch, float(culprit[1]) - float(t_rch),
                               (float(culprit[1]) - float(t_rch)) / float(np.spacing(F(t_rch))), float(np.abs(o).max())), flush=True)
                 else:
                     unexplained += 1
-                    print(line + "\n      NOT explained by a culled chain box: %r" % (culprit,), flush=True)
-            print("frame %d bounce %d: %d rays, %d where the reference walk and the reach rule keep different triangles" % (
+                    say(line + "\n      NOT explained by a culled chain box: %r" % (culprit,), flush=True)
+            say("frame %d bounce %d: %d rays, %d where the reference walk and the reach rule keep different triangles" % (
                 frame, bounce, len(px), n_diff), flush=True)
             if bounce == n_bounces or not keep:
                 break
@@ -237,8 +240,9 @@ def main(dist=500000.0, n_bounces=2):
                 go = ~(lambert_in <= 0)
             px, py, seed = px[keep][go], py[keep][go], seed2[go]
             rays_o, rays_d = new_o[go].astype(F), new_d[go].astype(F)
-    print("summary at distance %g: %d rays explained by a chain box whose float entry distance exceeds its own triangle's t and reaches "
-          "hitInfo.t; %d exact ties; %d unexplained" % (dist, explained, ties, unexplained))
+    say("summary at distance %g: %d rays explained by a chain box whose float entry distance exceeds its own triangle's t and reaches "
+        "hitInfo.t; %d exact ties; %d unexplained" % (dist, explained, ties, unexplained))
+    return explained, ties, unexplained, compared
 
 
 if __name__ == "__main__":
