@@ -181,6 +181,12 @@ struct Wf2Dims {
     uint32_t run_shift;        // a segment is dealt runs of 2^run_shift consecutive chunks (neighbouring tiles of one frame)
     FastDiv by_tiles_x, by_tiles_per_frame, by_slots_per_frame, by_full_tiles_x;
     FastDiv by_frames;         // (wf2_accumulate: item -> (pixel, frame))
+    // XCD bands (JPT_XCD_BAND_ROWS > 0): blocks b and b + 8 share an XCD and its 4 MB L2 (dispatch is round-robin); the runs of a
+    // frame are cut into bands of band_runs consecutive runs (a few tile rows) and band q of every frame belongs to the
+    // blocks with seg % 8 == q % 8, so an XCD's rays start in its own stripes of the screen.  0: runs dealt round-robin to
+    // all segments (every XCD sees every part of the screen).
+    uint32_t band_runs, runs_per_frame, bands_per_frame;
+    FastDiv by_band_runs;
 };
 
 __device__ __forceinline__ void slot_to_pixel(uint32_t slot, const Wf2Dims& dm, int& px, int& ly)
@@ -364,7 +370,22 @@ __global__ __launch_bounds__(kBlock, JPT_PRIMARY_WAVES) void wf2_primary(WideSce
     // runs seg, seg + G, seg + 2G, ... of 2^run_shift consecutive chunks belong to this block
     const uint32_t run_mask = (1u << dm.run_shift) - 1u;
     const uint32_t n_runs = (dm.n_chunks + run_mask) >> dm.run_shift;
-    const uint32_t my_runs = seg < n_runs ? (n_runs - seg + kSegments - 1u) / kSegments : 0u;
+    uint32_t my_runs = seg < n_runs ? (n_runs - seg + kSegments - 1u) / kSegments : 0u;
+    // XCD bands: this block is member k of the 224 blocks with label x = seg % 8; they share the runs of the bands q = x, x + 8, ...
+    // of every frame, run m of them (frame-major) going to member m % 224
+    const uint32_t xb = seg & 7u, kb = seg >> 3;
+    constexpr uint32_t kPerLabel = kSegments / 8u;
+    uint32_t runs_x_frame = 0;   // runs of label x in one frame
+    FastDiv by_runs_x_frame = {1u, 0u};
+    if (dm.band_runs) {
+        const uint32_t nbx = dm.bands_per_frame > xb ? (dm.bands_per_frame - xb + 7u) >> 3 : 0u;
+        const uint32_t short_by = ((dm.bands_per_frame - 1u) & 7u) == xb ? dm.bands_per_frame * dm.band_runs - dm.runs_per_frame : 0u;
+        runs_x_frame = nbx * dm.band_runs - (nbx ? short_by : 0u);
+        const uint32_t total = runs_x_frame * (uint32_t)fp.n_frames;
+        my_runs = kb < total ? (total - kb + kPerLabel - 1u) / kPerLabel : 0u;
+        by_runs_x_frame.d = runs_x_frame ? runs_x_frame : 1u;
+        by_runs_x_frame.m = runs_x_frame > 1u ? (uint32_t)(0x100000000ull / runs_x_frame) : 0xffffffffu;
+    }
     const uint32_t n = (my_runs << dm.run_shift) * 64u;  // (the last run of the image may be short: checked per entry)
     if (threadIdx.x == 0) {
         s_cursor = 0;
@@ -419,8 +440,17 @@ __global__ __launch_bounds__(kBlock, JPT_PRIMARY_WAVES) void wf2_primary(WideSce
                 const uint32_t idx = start + lanes_below(idle, lane);
                 if (idx < n) {
                     const uint32_t j = idx >> 6;  // local chunk number: run j >> run_shift, position j & run_mask
-                    const uint32_t chunk = ((seg + (j >> dm.run_shift) * kSegments) << dm.run_shift) + (j & run_mask);
-                    const uint32_t f = fdiv(chunk, dm.by_tiles_per_frame), tile = chunk - f * dm.tiles_per_frame;
+                    uint32_t chunk = ((seg + (j >> dm.run_shift) * kSegments) << dm.run_shift) + (j & run_mask);
+                    uint32_t f = fdiv(chunk, dm.by_tiles_per_frame), tile = chunk - f * dm.tiles_per_frame;
+                    if (dm.band_runs) {
+                        const uint32_t m = (j >> dm.run_shift) * kPerLabel + kb;          // run m of label x
+                        f = fdiv(m, by_runs_x_frame);
+                        const uint32_t mf = m - f * runs_x_frame;
+                        const uint32_t jb = fdiv(mf, dm.by_band_runs), ib = mf - jb * dm.band_runs;
+                        const uint32_t rf = (jb * 8u + xb) * dm.band_runs + ib;               // run of the frame
+                        tile = (rf << dm.run_shift) + (j & run_mask);
+                        chunk = (tile < dm.tiles_per_frame && f < (uint32_t)fp.n_frames) ? f * dm.tiles_per_frame + tile : dm.n_chunks;
+                    }
                     const uint32_t slot = tile * 64u + (idx & 63u);
                     int px, ly;
                     slot_to_pixel(slot, dm, px, ly);
@@ -1422,6 +1452,24 @@ Wf2Dims make_dims(int width, int local_rows, int n_frames, const TileWindow& win
     dm.run_shift = run_shift;
     const uint32_t n_runs = (dm.n_chunks + (1u << run_shift) - 1u) >> run_shift;
     dm.seg_cap = (((n_runs + kSegments - 1u) / kSegments) << run_shift) * 64u;
+    dm.band_runs = dm.runs_per_frame = dm.bands_per_frame = 0;
+    dm.by_band_runs = make_fastdiv(1u);
+    if (tuning().xcd_band_rows > 0 && dm.tiles_per_frame > 0) {
+        const uint32_t run_len = 1u << run_shift;
+        const uint32_t runs_per_row = ((uint32_t)dm.tiles_x + run_len - 1u) >> run_shift;
+        dm.runs_per_frame = (dm.tiles_per_frame + run_len - 1u) >> run_shift;
+        dm.band_runs = std::max(1u, runs_per_row * (uint32_t)tuning().xcd_band_rows);
+        dm.bands_per_frame = (dm.runs_per_frame + dm.band_runs - 1u) / dm.band_runs;
+        dm.by_band_runs = make_fastdiv(dm.band_runs);
+        // the fullest label decides the queue capacity
+        uint32_t most = 0;
+        for (uint32_t x = 0; x < 8u; x++) {
+            const uint32_t nbx = dm.bands_per_frame > x ? (dm.bands_per_frame - x + 7u) >> 3 : 0u;
+            const uint32_t short_by = ((dm.bands_per_frame - 1u) & 7u) == x ? dm.bands_per_frame * dm.band_runs - dm.runs_per_frame : 0u;
+            most = std::max(most, (nbx * dm.band_runs - (nbx ? short_by : 0u)) * (uint32_t)n_frames);
+        }
+        dm.seg_cap = (((most + kSegments / 8u - 1u) / (kSegments / 8u)) << run_shift) * 64u;
+    }
     dm.by_tiles_x = make_fastdiv((uint32_t)dm.tiles_x);
     dm.by_tiles_per_frame = make_fastdiv(dm.tiles_per_frame);
     dm.by_slots_per_frame = make_fastdiv(dm.slots_per_frame);

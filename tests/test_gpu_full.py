@@ -210,6 +210,22 @@ def test_c3_full_size_equals_the_oracle(oracle, hiplib):
     assert np.array_equal(up.read_ldr(), want_ldr) and np.array_equal(up.read_depth(), want_depth)
     assert up.stats()["rays"] == cnt["rays"]
     up.close()
+    # ... and the BENCHMARKED configuration itself, named here against the oracle directly (it was only
+    # checked GPU against GPU and by bench.py's parity object): jpt_scene_commit(JPT_BUILD_SAH), blocking and queued renders
+    for asynchronous in (False, True):
+        sah = make_ctx(sc, W, H, B, wire.ACCUM_REF_LDR8, capi.BUILD_SAH)
+        assert sah.tree_kind() == capi.TREE_NATIVE_REACH and sah.ties_exact() == (True, "")
+        if asynchronous:
+            for _ in range(3):                       # the timed region's shape: resets and queued renders back to back
+                sah.accum_reset()
+                sah.render(SPP, 1, asynchronous=True)
+            sah.sync()
+        else:
+            sah.render(SPP, 1)
+        got = sah.read_accum()
+        assert np.array_equal(got, want), int((got != want).any(axis=-1).sum())
+        assert np.array_equal(sah.read_ldr(), want_ldr) and np.array_equal(sah.read_depth(), want_depth)
+        sah.close()
 
 
 @pytest.mark.parametrize("config", ["C2", "C4"])
@@ -874,12 +890,14 @@ def test_bench_self_launch_two_ranks_on_one_gpu(hiplib, launcher):
         assert d["multi_gpu"]["gather_plan"] == {"peer_copies": 1, "distinct_streams": 1, "own_piece_copies": 0}
 
 
-@pytest.mark.parametrize("switch", ["JPT_COOP=1 JPT_COOP_ROUNDS=2", "JPT_TRACE_REGROUP=1", "JPT_TRACE_REGROUP=1 JPT_COOP=1 JPT_COOP_ROUNDS=2"])
+@pytest.mark.parametrize("switch", ["JPT_COOP=1 JPT_COOP_ROUNDS=2", "JPT_TRACE_REGROUP=1", "JPT_TRACE_REGROUP=1 JPT_COOP=1 JPT_COOP_ROUNDS=2",
+                                    "JPT_XCD_BAND_ROWS=2"])
 def test_alternative_tracing_launches_are_bit_identical(hiplib, switch):
     """The tuning switches are read once per process, so the alternative launches run the parity tests in a child process:
     JPT_COOP=1 with an eager hand-over (most tail rays of every launch are walked by wf2_long / coop_walk, which large
-    scenes get by default for their few very long rays) and JPT_TRACE_REGROUP=1 (wf2_trace_rg: ray state in LDS, compacted
-    lists per step kind -- kept as a measured, rejected variant).  Same images bit for bit as the default launches: a subset
+    scenes get by default for their few very long rays), JPT_TRACE_REGROUP=1 (wf2_trace_rg: ray state in LDS, compacted
+    lists per step kind) and JPT_XCD_BAND_ROWS=2 (the primary launch's tiles dealt in bands to the blocks that share an XCD) --
+    the last two kept as measured, rejected variants.  Same images bit for bit as the default launches: a subset
     of the parity suite, against the oracle."""
     import subprocess
     import sys
