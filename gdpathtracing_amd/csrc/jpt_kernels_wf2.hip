@@ -39,6 +39,11 @@ namespace {
 
 constexpr int kBlock = kTraceBlock;
 constexpr uint32_t kSegments = 256u * JPT_WAVES_PER_SIMD;  // persistent grid: one 256-thread block per CU per wave/SIMD
+#ifdef JPT_NO_XCD_BANDS   // (A/B only: the primary launch without the dormant band-dealing code)
+constexpr bool kXcdBands = false;
+#else
+constexpr bool kXcdBands = true;
+#endif
 #ifndef JPT_LEAF_INNER
 #define JPT_LEAF_INNER 0
 #endif
@@ -377,7 +382,7 @@ __global__ __launch_bounds__(kBlock, JPT_PRIMARY_WAVES) void wf2_primary(WideSce
     constexpr uint32_t kPerLabel = kSegments / 8u;
     uint32_t runs_x_frame = 0;   // runs of label x in one frame
     FastDiv by_runs_x_frame = {1u, 0u};
-    if (dm.band_runs) {
+    if (kXcdBands && dm.band_runs) {
         const uint32_t nbx = dm.bands_per_frame > xb ? (dm.bands_per_frame - xb + 7u) >> 3 : 0u;
         const uint32_t short_by = ((dm.bands_per_frame - 1u) & 7u) == xb ? dm.bands_per_frame * dm.band_runs - dm.runs_per_frame : 0u;
         runs_x_frame = nbx * dm.band_runs - (nbx ? short_by : 0u);
@@ -442,7 +447,7 @@ __global__ __launch_bounds__(kBlock, JPT_PRIMARY_WAVES) void wf2_primary(WideSce
                     const uint32_t j = idx >> 6;  // local chunk number: run j >> run_shift, position j & run_mask
                     uint32_t chunk = ((seg + (j >> dm.run_shift) * kSegments) << dm.run_shift) + (j & run_mask);
                     uint32_t f = fdiv(chunk, dm.by_tiles_per_frame), tile = chunk - f * dm.tiles_per_frame;
-                    if (dm.band_runs) {
+                    if (kXcdBands && dm.band_runs) {
                         const uint32_t m = (j >> dm.run_shift) * kPerLabel + kb;          // run m of label x
                         f = fdiv(m, by_runs_x_frame);
                         const uint32_t mf = m - f * runs_x_frame;
@@ -1454,7 +1459,7 @@ Wf2Dims make_dims(int width, int local_rows, int n_frames, const TileWindow& win
     dm.seg_cap = (((n_runs + kSegments - 1u) / kSegments) << run_shift) * 64u;
     dm.band_runs = dm.runs_per_frame = dm.bands_per_frame = 0;
     dm.by_band_runs = make_fastdiv(1u);
-    if (tuning().xcd_band_rows > 0 && dm.tiles_per_frame > 0) {
+    if (kXcdBands && tuning().xcd_band_rows > 0 && dm.tiles_per_frame > 0) {
         const uint32_t run_len = 1u << run_shift;
         const uint32_t runs_per_row = ((uint32_t)dm.tiles_x + run_len - 1u) >> run_shift;
         dm.runs_per_frame = (dm.tiles_per_frame + run_len - 1u) >> run_shift;
