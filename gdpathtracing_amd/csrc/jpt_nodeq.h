@@ -65,8 +65,21 @@ JPT_HD float pow2_at_least(float x)
     return v.f;
 }
 
-JPT_HD double qfloor_(double x) { const double t = (double)(long long)x; return t > x ? t - 1.0 : t; }   // |x| < 2^52 here
-JPT_HD double qceil_(double x) { const double t = (double)(long long)x; return t < x ? t + 1.0 : t; }
+// floor / ceil of a plane number.  The callers clamp the result to [0, 255]; values outside [-4, 300] (huge or infinite boxes
+// of degenerate or hostile records) are clamped BEFORE the integer conversion, which is undefined for them, and a NaN is
+// passed through (the callers give a NaN box the whole range).  In range: exactly what the plain conversion gave.
+JPT_HD double qfloor_(double x)
+{
+    if (!(x >= -4.0 && x <= 300.0)) return x != x ? x : (x < 0.0 ? -4.0 : 300.0);
+    const double t = (double)(long long)x;
+    return t > x ? t - 1.0 : t;
+}
+JPT_HD double qceil_(double x)
+{
+    if (!(x >= -4.0 && x <= 300.0)) return x != x ? x : (x < 0.0 ? -4.0 : 300.0);
+    const double t = (double)(long long)x;
+    return t < x ? t + 1.0 : t;
+}
 
 JPT_HD void quantize_node4(const WideNode4& n, WideNodeQ& q)
 {

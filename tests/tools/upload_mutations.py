@@ -173,6 +173,34 @@ def _commit_child(rng):
     os._exit(0)
 
 
+def _debug_child(rng):
+    """the audit entry points take raw records too: jpt_debug_quantize_nodes4 / jpt_debug_node_step4 (host restatement) on
+    random bit patterns -- NaNs, infinities, denormals, huge and inverted boxes, child words of any value"""
+    import ctypes as C
+    from gdpathtracing_amd import capi
+    L = capi.lib()
+    n = int(rng.integers(1, 40))
+    nodes = rng.integers(0, 1 << 32, size=(n, 32), dtype=np.uint64).astype(np.uint32)
+    special = np.array([0x7fc00000, 0x7f800000, 0xff800000, 0x00000001, 0x80000000, 0x7f7fffff, 0xff7fffff, 0x3f800000, 0], dtype=np.uint32)
+    mask = rng.uniform(size=nodes.shape) < 0.5
+    nodes[mask] = special[rng.integers(0, len(special), size=int(mask.sum()))]
+    if rng.integers(0, 2):       # half the time plausible boxes, so the step itself runs on sane planes with hostile rays
+        f = nodes.view(np.float32)
+        f[:, 0:12] = rng.uniform(-10, 0, size=(n, 12)).astype(np.float32)
+        f[:, 16:28] = rng.uniform(0, 10, size=(n, 12)).astype(np.float32)
+    out = np.zeros((n, 16), dtype=np.uint32)
+    rc = L.jpt_debug_quantize_nodes4(nodes.ctypes.data_as(C.c_void_p), n, out.ctypes.data_as(C.c_void_p))
+    m = int(rng.integers(1, 200))
+    cases = rng.integers(0, 1 << 32, size=(m, 8), dtype=np.uint64).astype(np.uint32)
+    cmask = rng.uniform(size=cases.shape) < 0.3
+    cases[cmask] = special[rng.integers(0, len(special), size=int(cmask.sum()))]
+    cases[:, 7] = rng.integers(0, n + (2 if rng.integers(0, 4) == 0 else 0), size=m)
+    taken = np.zeros(m, dtype=np.uint8)
+    rc2 = L.jpt_debug_node_step4(-1, nodes.ctypes.data_as(C.c_void_p), n, cases.ctypes.data_as(C.c_void_p), m, int(rng.integers(-3, 4)),
+                                 taken.ctypes.data_as(C.c_void_p))
+    os._exit(0 if (rc == 0 and rc2 == 0) else 1)
+
+
 COMMIT_SCENES = []
 
 
@@ -182,6 +210,8 @@ def _child(case_rng_seed, base, as_given, update_route):
     rng = np.random.default_rng(case_rng_seed)
     if update_route == 2:
         _commit_child(rng)
+    if update_route == 3:
+        _debug_child(rng)
     a = {k: v.copy() for k, v in base.items()}
     ctx = host.Context(-1)
     if update_route:
@@ -220,7 +250,7 @@ def run(n_cases=2000, seed=1, timeout_s=5.0, verbose=False):
         case_seed = int(master.integers(0, 1 << 62))
         bi = case % len(bases)
         as_given = bool((case // len(bases)) & 1)
-        update_route = 1 if (case % 7) == 6 else (2 if (case % 7) == 5 else 0)   # 0 upload, 1 TLAS update, 2 commit route
+        update_route = {6: 1, 5: 2, 4: 3 if (case % 21) == 4 else 0}.get(case % 7, 0)   # 0 upload, 1 TLAS update, 2 commit route, 3 audit entries
         pid = os.fork()
         if pid == 0:
             try:
@@ -244,7 +274,7 @@ def run(n_cases=2000, seed=1, timeout_s=5.0, verbose=False):
         tally["cases"] += 1
         what = {"case": case, "seed": case_seed, "base": bi, "as_given": as_given, "update_route": update_route}
         if status is None:
-            what["mutation"] = describe(case_seed, bi, bases) if update_route != 2 else "commit route"
+            what["mutation"] = describe(case_seed, bi, bases) if update_route < 2 else "commit / audit route"
             tally["hung"].append(what)
         elif os.WIFEXITED(status) and os.WEXITSTATUS(status) == 0:
             tally["accepted"] += 1
@@ -252,7 +282,7 @@ def run(n_cases=2000, seed=1, timeout_s=5.0, verbose=False):
             tally["refused"] += 1
         else:
             what["status"] = ("signal %d" % os.WTERMSIG(status)) if os.WIFSIGNALED(status) else ("exit %d" % os.WEXITSTATUS(status))
-            what["mutation"] = describe(case_seed, bi, bases) if update_route != 2 else "commit route"
+            what["mutation"] = describe(case_seed, bi, bases) if update_route < 2 else "commit / audit route"
             tally["crashed"].append(what)
         if verbose and (case + 1) % 500 == 0:
             print("  %d cases, %.1f s" % (case + 1, time.time() - t0), file=sys.stderr)
