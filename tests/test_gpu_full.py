@@ -911,3 +911,25 @@ def test_alternative_tracing_launches_are_bit_identical(hiplib, switch):
                        env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=1500)
     assert p.returncode == 0, p.stdout[-3000:]
     assert " passed" in p.stdout and "failed" not in p.stdout
+
+
+def test_walk_length_statistics_of_a_counting_render(hiplib):
+    """jpt_stats.walk_steps_max / walk_steps_hist (ABI 4): the record steps every traced ray took, from a counting render.  Every
+    ray a kernel walks is in exactly one bucket (rays - sky_culled of them), the longest walk lies in the last non-empty
+    bucket, and the same render with the long-walk hand-over made eager (another process: the switch is read once) leaves the
+    image alone -- covered by test_alternative_tracing_launches_are_bit_identical -- while this one pins the counters."""
+    sc = scenes.demo_scene(5000)
+    ctx = make_ctx(sc, 320, 180, 3, wire.ACCUM_REF_LDR8, capi.BUILD_SAH)
+    ctx.render(2, 1, counted=True)
+    st = ctx.stats()
+    hist = st["walk_steps_hist"]
+    walked = st["rays"] - st["sky_culled"]
+    # (the later segments of a set-aside path are traced by wf2_finish, which keeps no walk statistics: a handful at most)
+    assert walked - 8 * (st["set_aside"] + 1) <= sum(hist) <= walked
+    last = max(k for k, v in enumerate(hist) if v)
+    lo = 0 if last == 0 else 16 * 4 ** (last - 1)
+    assert lo <= st["walk_steps_max"] < 16 * 4 ** last
+    assert st["walk_steps_max"] >= 1
+    # every record step is counted once: internal records + leaf turns + instance entries (a leaf turn tests one or two triangles)
+    assert st["walk_steps_max"] <= st["blas_expand"] + st["tlas_expand"] + st["tri_tests"] + st["inst_visits"]
+    ctx.close()
