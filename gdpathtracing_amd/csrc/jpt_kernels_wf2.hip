@@ -954,7 +954,9 @@ __global__ __launch_bounds__(64) void wf2_trace_rg(WideSceneDev sc, Wf2Buffers w
 // reference gives the instance, or the local ray fails the box of the triangle's reference leaf (jpt_types.h) -- is
 // not shaded: the vertex is set aside (redo_rec; its state parked in the path's thr / rad words), `unreachable` comes back
 // true, and the path leaves the wavefront to be finished by wf2_finish.
-template <bool COUNT>
+// LAST: the vertex is known to be the path's last (bounce == max_bounces): emission or sky is added and the path ends -- no BRDF
+// sample, no next ray -- so the instantiation carries none of that code (wf2_shade's final launch).
+template <bool COUNT, bool LAST = false, bool TEX = true>
 __device__ __forceinline__ bool shade_entry(const SceneShading& sh, const Wf2Buffers& wb, const Wf2Dims& dm, const FrameParams& fp, float cam_far,
                                             int bounce, const float4 ro, const float4 rd, const float4 tin, const float4 ha, const uint32_t hb,
                                             bool check_reach, bool& unreachable, float4& no, float4& nd, float4& nt, DevCounters& cnt)
@@ -1048,10 +1050,10 @@ __device__ __forceinline__ bool shade_entry(const SceneShading& sh, const Wf2Buf
         if (bounce == 0 && (int)f == fp.depth_frame) wb.first_depth[slot] = cam_far;  // (only a redone primary hit can turn into a miss here)
     } else {
         if (COUNT) cnt.shaded_hits++;
-        const Shading s = get_shading_data(sh, h, (hb >> 31) != 0u, stri);
+        const Shading s = get_shading_data<TEX>(sh, h, (hb >> 31) != 0u, stri);
         radiance = radiance + throughput * s.emission;
         if (bounce == 0 && (int)f == fp.depth_frame) wb.first_depth[slot] = length3(s.position - ray.o);
-        if (bounce < fp.max_bounces) alive = bounce_step(s, sx, sy, ray, throughput);
+        if (!LAST && bounce < fp.max_bounces) alive = bounce_step(s, sx, sy, ray, throughput);
     }
     if (alive) {
         // (radiance starts as +0 and +0 + x is x or +0, never -0: "unchanged and never written" means exactly +0)
@@ -1066,8 +1068,8 @@ __device__ __forceinline__ bool shade_entry(const SceneShading& sh, const Wf2Buf
     return alive;
 }
 
-template <bool COUNT>
-__global__ __launch_bounds__(kBlock, JPT_SHADE_WAVES) void wf2_shade(SceneShading sh, Wf2Buffers wb, Wf2Dims dm, FrameParams fp, float cam_far, int bounce,
+template <bool COUNT, bool LAST = false, bool TEX = true>
+__global__ __launch_bounds__(kBlock, LAST ? 8 : JPT_SHADE_WAVES) void wf2_shade(SceneShading sh, Wf2Buffers wb, Wf2Dims dm, FrameParams fp, float cam_far, int bounce,
                                                     DevCounters* __restrict__ counters)
 {
     // grid = (chunks per segment, segments): every 256-entry chunk of every segment is its own block, so the
@@ -1089,7 +1091,11 @@ __global__ __launch_bounds__(kBlock, JPT_SHADE_WAVES) void wf2_shade(SceneShadin
         const float4 ha = wb.hit_a[seg_base + i];
         const uint32_t hb = wb.hit_b[seg_base + i];
         bool unreachable;   // (set aside inside shade_entry: nothing more to do here)
-        alive = shade_entry<COUNT>(sh, wb, dm, fp, cam_far, bounce, ro, rd, tin, ha, hb, true, unreachable, no, nd, nt, cnt);
+        alive = shade_entry<COUNT, LAST, TEX>(sh, wb, dm, fp, cam_far, bounce, ro, rd, tin, ha, hb, true, unreachable, no, nd, nt, cnt);
+    }
+    if (LAST) {   // (no path goes on: nothing to pack)
+        if (COUNT) flush_counters(cnt, counters);
+        return;
     }
     // active-ray packing: wave ballot + prefix popcount, one atomic per wave on the SEGMENT's counter (1792
     // different words: no hot address); the order inside the next queue is irrelevant
@@ -1693,8 +1699,27 @@ void launch_wf2_render(hipStream_t stream, const DeviceScene& ds, const FramePar
         }
         if (ev) (void)hipEventRecord(ev[1], st);
         for (int b = 0; b <= gp.max_bounces; b++) {
-            if (counters) hipLaunchKernelGGL(wf2_shade<true>, sgrid, block, 0, st, sh, wb, dm, gp, cam.far_, b, counters);
-            else hipLaunchKernelGGL(wf2_shade<false>, sgrid, block, 0, st, sh, wb, dm, gp, cam.far_, b, counters);
+            {
+                // instantiations: the paths' last vertices without the BRDF code, scenes without a texture array without
+                // the sampler code
+#ifdef JPT_SHADE_GENERAL_ONLY   // (A/B builds: the one general kernel for every launch)
+                const bool last = false, tex = true;
+#else
+                const bool last = b == gp.max_bounces && tuning().shade_last;
+                const bool tex = sh.tex != nullptr && sh.n_layers > 0 && sh.tex_res > 0;
+#endif
+                const int which = (counters ? 4 : 0) | (last ? 2 : 0) | (tex ? 1 : 0);
+                switch (which) {
+                    case 0: hipLaunchKernelGGL((wf2_shade<false, false, false>), sgrid, block, 0, st, sh, wb, dm, gp, cam.far_, b, counters); break;
+                    case 1: hipLaunchKernelGGL((wf2_shade<false, false, true>), sgrid, block, 0, st, sh, wb, dm, gp, cam.far_, b, counters); break;
+                    case 2: hipLaunchKernelGGL((wf2_shade<false, true, false>), sgrid, block, 0, st, sh, wb, dm, gp, cam.far_, b, counters); break;
+                    case 3: hipLaunchKernelGGL((wf2_shade<false, true, true>), sgrid, block, 0, st, sh, wb, dm, gp, cam.far_, b, counters); break;
+                    case 4: hipLaunchKernelGGL((wf2_shade<true, false, false>), sgrid, block, 0, st, sh, wb, dm, gp, cam.far_, b, counters); break;
+                    case 5: hipLaunchKernelGGL((wf2_shade<true, false, true>), sgrid, block, 0, st, sh, wb, dm, gp, cam.far_, b, counters); break;
+                    case 6: hipLaunchKernelGGL((wf2_shade<true, true, false>), sgrid, block, 0, st, sh, wb, dm, gp, cam.far_, b, counters); break;
+                    default: hipLaunchKernelGGL((wf2_shade<true, true, true>), sgrid, block, 0, st, sh, wb, dm, gp, cam.far_, b, counters); break;
+                }
+            }
             if (b == gp.max_bounces) break;
             if (ev) (void)hipEventRecord(ev[2 * (b + 1)], st);
             if (regroup) {

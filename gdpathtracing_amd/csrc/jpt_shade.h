@@ -184,6 +184,9 @@ __device__ __forceinline__ ShadeTriRegs load_shade_tri(const SceneShading& sc, u
 }
 
 // (the record is passed in so that a caller can ask for it early, together with its other gathers)
+// TEX = false: the scene has no texture array, so texture() returns zero for every material that names a layer (what
+// sample_texture answers then, without carrying its four sampler modes in the kernel)
+template <bool TEX = true>
 __device__ __forceinline__ Shading get_shading_data(const SceneShading& sc, const Hit& h, bool front, const ShadeTriRegs& tr)
 {
     Shading s;
@@ -213,7 +216,7 @@ __device__ __forceinline__ Shading get_shading_data(const SceneShading& sc, cons
     const float em = fmax_(0.0f, material.emission.w);
     s.emission = mk3(material.emission.x * em, material.emission.y * em, material.emission.z * em);
     f3 albedo = mk3(material.albedo.x, material.albedo.y, material.albedo.z);
-    if (material.albedo_texture_index >= 0) albedo = albedo * sample_texture(sc, uvx, uvy, material.albedo_texture_index);
+    if (material.albedo_texture_index >= 0) albedo = albedo * (TEX ? sample_texture(sc, uvx, uvy, material.albedo_texture_index) : mk3(0.0f, 0.0f, 0.0f));
 
     const float metalicity = material.metallic;
     s.fresnel_0 = mk3(mix_(0.02f, albedo.x, metalicity), mix_(0.02f, albedo.y, metalicity), mix_(0.02f, albedo.z, metalicity));

@@ -30,6 +30,7 @@ struct Tuning {
                                    // finished on the native tree with the reach tests inside the walk; exact ties not re-traced)
     long set_aside_cap = -1;       // JPT_SET_ASIDE_CAP: records of the set-aside buffer (-1: the library's rule; tests force 0)
     int reach = 2;                 // JPT_REACH=0: ignore the reach records; 1: check but never redo (timing experiments only)
+    bool shade_last = true;        // JPT_SHADE_LAST=0: the final shading launch uses the general kernel (A/B)
     int xcd_band_rows = 0;         // JPT_XCD_BAND_ROWS=n: the primary launch deals bands of n tile rows to the blocks that share an XCD (0: off)
     int coop = -1;                 // JPT_COOP=0/1: long walks handed over to a whole wave (coop_walk) never / always (-1: scenes of >= 200 000 triangles)
     int coop_rounds = 128;         // JPT_COOP_ROUNDS: ... a ray still walking this many rounds after its block's queue ran dry
@@ -63,6 +64,7 @@ inline const Tuning& tuning()
         v.trace_chain = geti("JPT_TRACE_CHAIN", 0);
         v.max_leaf = geti("JPT_MAX_LEAF", 2);
         v.reach = geti("JPT_REACH", 2);
+        v.shade_last = geti("JPT_SHADE_LAST", 1) != 0;
         v.xcd_band_rows = geti("JPT_XCD_BAND_ROWS", 0);
         v.coop = geti("JPT_COOP", -1);
         v.coop_rounds = geti("JPT_COOP_ROUNDS", 128);
