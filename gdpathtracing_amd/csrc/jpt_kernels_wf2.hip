@@ -956,7 +956,7 @@ __global__ __launch_bounds__(64) void wf2_trace_rg(WideSceneDev sc, Wf2Buffers w
 // true, and the path leaves the wavefront to be finished by wf2_finish.
 // LAST: the vertex is known to be the path's last (bounce == max_bounces): emission or sky is added and the path ends -- no BRDF
 // sample, no next ray -- so the instantiation carries none of that code (wf2_shade's final launch).
-template <bool COUNT, bool LAST = false, bool TEX = true>
+template <bool COUNT, bool LAST = false, int TEX = 3>
 __device__ __forceinline__ bool shade_entry(const SceneShading& sh, const Wf2Buffers& wb, const Wf2Dims& dm, const FrameParams& fp, float cam_far,
                                             int bounce, const float4 ro, const float4 rd, const float4 tin, const float4 ha, const uint32_t hb,
                                             bool check_reach, bool& unreachable, float4& no, float4& nd, float4& nt, DevCounters& cnt)
@@ -1068,8 +1068,11 @@ __device__ __forceinline__ bool shade_entry(const SceneShading& sh, const Wf2Buf
     return alive;
 }
 
-template <bool COUNT, bool LAST = false, bool TEX = true>
-__global__ __launch_bounds__(kBlock, LAST ? 8 : JPT_SHADE_WAVES) void wf2_shade(SceneShading sh, Wf2Buffers wb, Wf2Dims dm, FrameParams fp, float cam_far, int bounce,
+#ifndef JPT_SHADE_NOTEX_WAVES
+#define JPT_SHADE_NOTEX_WAVES 7   // without the sampler code the body takes 67 VGPRs by itself
+#endif
+template <bool COUNT, bool LAST = false, int TEX = 3>
+__global__ __launch_bounds__(kBlock, LAST ? 8 : (TEX == 0 ? JPT_SHADE_NOTEX_WAVES : JPT_SHADE_WAVES)) void wf2_shade(SceneShading sh, Wf2Buffers wb, Wf2Dims dm, FrameParams fp, float cam_far, int bounce,
                                                     DevCounters* __restrict__ counters)
 {
     // grid = (chunks per segment, segments): every 256-entry chunk of every segment is its own block, so the
@@ -1702,23 +1705,23 @@ void launch_wf2_render(hipStream_t stream, const DeviceScene& ds, const FramePar
             {
                 // instantiations: the paths' last vertices without the BRDF code, scenes without a texture array without
                 // the sampler code
-#ifdef JPT_SHADE_GENERAL_ONLY   // (A/B builds: the one general kernel for every launch)
+#ifdef JPT_SHADE_GENERAL_ONLY   // (A/B builds: no last-vertex instantiation, the sampler code always there)
                 const bool last = false, tex = true;
 #else
                 const bool last = b == gp.max_bounces && tuning().shade_last;
                 const bool tex = sh.tex != nullptr && sh.n_layers > 0 && sh.tex_res > 0;
 #endif
-                const int which = (counters ? 4 : 0) | (last ? 2 : 0) | (tex ? 1 : 0);
-                switch (which) {
-                    case 0: hipLaunchKernelGGL((wf2_shade<false, false, false>), sgrid, block, 0, st, sh, wb, dm, gp, cam.far_, b, counters); break;
-                    case 1: hipLaunchKernelGGL((wf2_shade<false, false, true>), sgrid, block, 0, st, sh, wb, dm, gp, cam.far_, b, counters); break;
-                    case 2: hipLaunchKernelGGL((wf2_shade<false, true, false>), sgrid, block, 0, st, sh, wb, dm, gp, cam.far_, b, counters); break;
-                    case 3: hipLaunchKernelGGL((wf2_shade<false, true, true>), sgrid, block, 0, st, sh, wb, dm, gp, cam.far_, b, counters); break;
-                    case 4: hipLaunchKernelGGL((wf2_shade<true, false, false>), sgrid, block, 0, st, sh, wb, dm, gp, cam.far_, b, counters); break;
-                    case 5: hipLaunchKernelGGL((wf2_shade<true, false, true>), sgrid, block, 0, st, sh, wb, dm, gp, cam.far_, b, counters); break;
-                    case 6: hipLaunchKernelGGL((wf2_shade<true, true, false>), sgrid, block, 0, st, sh, wb, dm, gp, cam.far_, b, counters); break;
-                    default: hipLaunchKernelGGL((wf2_shade<true, true, true>), sgrid, block, 0, st, sh, wb, dm, gp, cam.far_, b, counters); break;
+                // 0 no texture array, 1 nearest filter, 2 linear filter (jpt.h: bit 1 of the sampler mode)
+                const int texmode = !tex ? 0 : ((sh.sampler_mode & 2) ? 2 : 1);
+#define JPT_LAUNCH_SHADE(C, L, T) hipLaunchKernelGGL((wf2_shade<C, L, T>), sgrid, block, 0, st, sh, wb, dm, gp, cam.far_, b, counters)
+                if (counters) {
+                    if (last) { if (texmode == 0) JPT_LAUNCH_SHADE(true, true, 0); else if (texmode == 1) JPT_LAUNCH_SHADE(true, true, 1); else JPT_LAUNCH_SHADE(true, true, 2); }
+                    else      { if (texmode == 0) JPT_LAUNCH_SHADE(true, false, 0); else if (texmode == 1) JPT_LAUNCH_SHADE(true, false, 1); else JPT_LAUNCH_SHADE(true, false, 2); }
+                } else {
+                    if (last) { if (texmode == 0) JPT_LAUNCH_SHADE(false, true, 0); else if (texmode == 1) JPT_LAUNCH_SHADE(false, true, 1); else JPT_LAUNCH_SHADE(false, true, 2); }
+                    else      { if (texmode == 0) JPT_LAUNCH_SHADE(false, false, 0); else if (texmode == 1) JPT_LAUNCH_SHADE(false, false, 1); else JPT_LAUNCH_SHADE(false, false, 2); }
                 }
+#undef JPT_LAUNCH_SHADE
             }
             if (b == gp.max_bounces) break;
             if (ev) (void)hipEventRecord(ev[2 * (b + 1)], st);

@@ -149,12 +149,15 @@ __device__ __forceinline__ f3 texel(const SceneShading& sc, int layer, int ix, i
     const uint32_t p = reinterpret_cast<const uint32_t*>(sc.tex)[((size_t)layer * sc.tex_res + iy) * sc.tex_res + ix];
     return mk3(from_unorm8(p & 255u), from_unorm8((p >> 8) & 255u), from_unorm8((p >> 16) & 255u));
 }
+// FILTER: 0 the sampler mode's own bit decides at run time, 1 nearest only, 2 linear only (the shading kernel is instantiated
+// per filter: the bilinear path's four texels and weights cost it a wave per SIMD)
+template <int FILTER = 0>
 __device__ __forceinline__ f3 sample_texture(const SceneShading& sc, float u, float v, int layer)
 {
     if (!sc.tex || sc.n_layers <= 0 || sc.tex_res <= 0) return mk3(0.0f, 0.0f, 0.0f);
     if (layer >= sc.n_layers) layer = sc.n_layers - 1;
     const int res = sc.tex_res;
-    const bool repeat = (sc.sampler_mode & 1) != 0, linear = (sc.sampler_mode & 2) != 0;
+    const bool repeat = (sc.sampler_mode & 1) != 0, linear = FILTER == 0 ? (sc.sampler_mode & 2) != 0 : FILTER == 2;
     const float x = u * (float)res, y = v * (float)res;
     if (!linear) return texel(sc, layer, tex_index(__builtin_floorf(x), res, repeat), tex_index(__builtin_floorf(y), res, repeat));
     const float xs = x - 0.5f, ys = y - 0.5f;
@@ -184,9 +187,10 @@ __device__ __forceinline__ ShadeTriRegs load_shade_tri(const SceneShading& sc, u
 }
 
 // (the record is passed in so that a caller can ask for it early, together with its other gathers)
-// TEX = false: the scene has no texture array, so texture() returns zero for every material that names a layer (what
-// sample_texture answers then, without carrying its four sampler modes in the kernel)
-template <bool TEX = true>
+// TEX = 0: the scene has no texture array, so texture() returns zero for every material that names a layer (what
+// sample_texture answers then, without carrying the sampler code in the kernel)
+// (TEX: 0 no texture array, 1 nearest filter, 2 linear filter, 3 either, decided by the sampler mode at run time)
+template <int TEX = 3>
 __device__ __forceinline__ Shading get_shading_data(const SceneShading& sc, const Hit& h, bool front, const ShadeTriRegs& tr)
 {
     Shading s;
@@ -201,13 +205,19 @@ __device__ __forceinline__ Shading get_shading_data(const SceneShading& sc, cons
     if (mat_id >= sc.n_materials) mat_id = 0;
     const RefMaterial& material = sc.materials[mat_id];
 
+    const float u = h.u, v = h.v;
+    const float w0 = 1.0f - u - v;
+    // (the texture first, while little else is live: the sampler's four texels and weights are the kernel's register peak;
+    // the operations and their order per value are those of main.glsl:200-218 wherever they stand)
+    f3 albedo = mk3(material.albedo.x, material.albedo.y, material.albedo.z);
+    if (material.albedo_texture_index >= 0) {
+        const float uvx = q2.y * w0 + q2.w * u + q3.y * v;
+        const float uvy = q2.z * w0 + q3.x * u + q3.z * v;
+        albedo = albedo * (TEX == 0 ? mk3(0.0f, 0.0f, 0.0f) : sample_texture<(TEX == 3 ? 0 : TEX)>(sc, uvx, uvy, material.albedo_texture_index));
+    }
     const f3 lpos = h.lo + h.ld * h.t;  // hitInfo.position = ray.o + t * ray.d (main.glsl:249)
     s.position = xform_point(b.transform, lpos);
     s.out_dir = normalize3(xform_dir(b.transform, -h.ld));
-    const float u = h.u, v = h.v;
-    const float w0 = 1.0f - u - v;
-    const float uvx = q2.y * w0 + q2.w * u + q3.y * v;
-    const float uvy = q2.z * w0 + q3.x * u + q3.z * v;
     f3 n = mk3(q0.x, q0.y, q0.z) * w0 + mk3(q0.w, q1.x, q1.y) * u + mk3(q1.z, q1.w, q2.x) * v;
     n = normalize3(xform_dir(b.transform, n));
     s.normal = front ? n : -n;
@@ -215,8 +225,6 @@ __device__ __forceinline__ Shading get_shading_data(const SceneShading& sc, cons
     s.lambert_out = dot3(s.normal, s.out_dir);
     const float em = fmax_(0.0f, material.emission.w);
     s.emission = mk3(material.emission.x * em, material.emission.y * em, material.emission.z * em);
-    f3 albedo = mk3(material.albedo.x, material.albedo.y, material.albedo.z);
-    if (material.albedo_texture_index >= 0) albedo = albedo * (TEX ? sample_texture(sc, uvx, uvy, material.albedo_texture_index) : mk3(0.0f, 0.0f, 0.0f));
 
     const float metalicity = material.metallic;
     s.fresnel_0 = mk3(mix_(0.02f, albedo.x, metalicity), mix_(0.02f, albedo.y, metalicity), mix_(0.02f, albedo.z, metalicity));
