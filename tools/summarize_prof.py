@@ -40,9 +40,12 @@ def main(src, dst, tag):
             if r["Counter_Name"] == ctr:
                 per[kname(r["Kernel_Name"])][ctr].append(float(r["Counter_Value"]))
     times = {}
-    for r in csv.DictReader(open(stats)):
-        times[kname(r["Name"])] = dict(calls=int(r["Calls"]), avg_us=float(r["AverageNs"]) / 1e3,
-                                       total_ms=float(r["TotalDurationNs"]) / 1e6, pct=float(r["Percentage"]))
+    for r in csv.DictReader(open(stats)):   # (instantiations of one kernel -- wf2_shade<.., LAST, TEX> -- are one row here)
+        t = times.setdefault(kname(r["Name"]), dict(calls=0, avg_us=0.0, total_ms=0.0, pct=0.0))
+        t["calls"] += int(r["Calls"])
+        t["total_ms"] += float(r["TotalDurationNs"]) / 1e6
+        t["pct"] += float(r["Percentage"])
+        t["avg_us"] = t["total_ms"] * 1e3 / max(t["calls"], 1)
     out = {}
     for k, d in per.items():
         fe = d.get("FETCH_SIZE", [0.0])
