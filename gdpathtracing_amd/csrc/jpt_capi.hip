@@ -112,7 +112,7 @@ struct jpt_ctx {
     // render pipelining (jpt_render_async): consecutive asynchronous renders run their path kernels on two helper
     // streams with two workspaces, so one render's launch tails overlap the next render's kernels; the accumulation
     // kernels stay on the context's stream, in order
-    static constexpr int kPipeSlots = 4;
+    static constexpr int kPipeSlots = 8;
     DevBuf<char> d_workspace_more[kPipeSlots - 1];  // slot 0 is d_workspace
     hipStream_t pipe_stream[kPipeSlots] = {};
     uint64_t async_seq = 0;
@@ -160,7 +160,7 @@ struct jpt_ctx {
     hipStream_t refit_stream = nullptr;
     hipEvent_t ev_set_retired[kInstanceSets] = {}, ev_refit_done = nullptr;
     bool set_retired_valid[kInstanceSets] = {};
-    uint64_t refit_wait_seq = 0, slot_refit_seen[4] = {};
+    uint64_t refit_wait_seq = 0, slot_refit_seen[kPipeSlots] = {};
     DevBuf<uint32_t> d_tlas4_order, d_tlas4_levels;
     uint32_t n_tlas4_levels = 0;
     bool refit_active = false;         // the device's instance level is ahead of the host mirrors (and of the other kernels' arrays)

@@ -55,6 +55,8 @@ struct WfTune {
     int inst_min_lanes;  // other lanes of the wave can make progress meanwhile
     int phase_frac16;    // ... and never more than this many sixteenths of the wave's active rays
     int coop_rounds;     // COOP launches: a ray still walking this many rounds after its block's queue ran dry is handed to wf2_long
+    int tail_rounds;     // COOP == 2: a wave enters its tail phase this many rounds after the queue ran dry ...
+    int tail_lanes;      // ... once it holds at most this many rays
 };
 
 // One round of the walk for every active lane of the wave, "while-while" style so that lanes in different
@@ -253,12 +255,15 @@ __device__ __forceinline__ float wave_min_f(float v)
     return v;
 }
 
+// (`pool`: 2 * kCoopPool words of LDS, word w at pool[(w >> 6) * pool_stride + (w & 63)] -- a flat array with pool_stride = 64,
+// or two rows of the block's stack array, see the tail phase of the tracing kernels)
 template <bool COUNT>
 __device__ __forceinline__ TraceHit coop_walk(const WideSceneDev& sc, const typename Traversal<COUNT, true>::Stack st, int32_t* __restrict__ pool,
-                                           f3 ro, f3 rd, DevCounters& cnt)
+                                           f3 ro, f3 rd, DevCounters& cnt, const uint32_t pool_stride = 64u)
 {
     using Walk = Traversal<COUNT, true>;
     const int lane = threadIdx.x & 63;
+    auto pw = [&](uint32_t w) -> int32_t& { return pool[(w >> 6) * pool_stride + (w & 63u)]; };
     constexpr uint32_t kNone = 0xffffffffu;   // hit.tri of a lane that holds no triangle of its own at hit.t
     Walk tr;
     tr.begin(sc, ro, rd);
@@ -275,8 +280,8 @@ __device__ __forceinline__ TraceHit coop_walk(const WideSceneDev& sc, const type
             if (take) {
                 const uint32_t r = lanes_below(idle, lane);
                 if (!active && r < take) {
-                    const int32_t ref = pool[2u * (n_pool - 1u - r)];
-                    const uint32_t ctx = (uint32_t)pool[2u * (n_pool - 1u - r) + 1u];
+                    const int32_t ref = pw(2u * (n_pool - 1u - r));
+                    const uint32_t ctx = (uint32_t)pw(2u * (n_pool - 1u - r) + 1u);
                     tr.sp = 0;
                     tr.cur = ref;
                     tr.have = true;
@@ -329,8 +334,8 @@ __device__ __forceinline__ TraceHit coop_walk(const WideSceneDev& sc, const type
                 const uint32_t lim = want < room ? want : room;
                 if (give && r < lim) {
                     tr.sp--;
-                    pool[2u * (n_pool + r)] = top;
-                    pool[2u * (n_pool + r) + 1u] = (int32_t)((tr.in_blas ? 1u : 0u) | (tr.cur_inst << 1));
+                    pw(2u * (n_pool + r)) = top;
+                    pw(2u * (n_pool + r) + 1u) = (int32_t)((tr.in_blas ? 1u : 0u) | (tr.cur_inst << 1));
                 }
                 const uint32_t given = (uint32_t)__popcll(gm);
                 n_pool += given < lim ? given : lim;
@@ -362,9 +367,27 @@ __device__ __forceinline__ TraceHit coop_walk(const WideSceneDev& sc, const type
     return out;
 }
 
+// The same walk as the TAIL of a tracing launch (COOP == 2), without a second launch: a wave whose block's queue has been dry for
+// `tail_rounds` rounds and that is down to `tail_lanes` rays stops walking them lane by lane -- a lone ray advances one dependent
+// step per microsecond, and a small render's launches each last as long as their longest walk (tools/step_latency.py: 64 x 64
+// pixels, longest walk 42 steps, launch 48 us; 1920 x 1080 x 1: 102 steps, 110 us) -- and walks them one after the other with
+// all its lanes, again from the root.  The call is OUT OF LINE so that the walk's registers are not the hot loop's (inlined
+// there it cost the loop spills and every launch 10-20 %, round 4); its pool is the top two rows of the wave's own columns of
+// the block's stack array, its private stacks the rows below.
+template <bool COUNT>
+__device__ __attribute__((noinline)) void coop_walk_call(const WideSceneDev* __restrict__ scp, int32_t* lds_col, int32_t* pool, float ox, float oy,
+                                                         float oz, float dx, float dy, float dz, DevCounters* cntp, TraceHit* out)
+{
+    int32_t spill[kStackSpill + 2];   // (the two LDS rows the pool takes are made up for here)
+    const typename Traversal<COUNT, true>::Stack st{lds_col, spill, kTraceBlock, kStackLds - 2, kStackSpill + 2};
+    const WideSceneDev sc = *scp;
+    DevCounters none = {};
+    *out = coop_walk<COUNT>(sc, st, pool, mk3(ox, oy, oz), mk3(dx, dy, dz), COUNT ? *cntp : none, (uint32_t)kTraceBlock);
+}
+
 // ---- bounce 0: generate + trace ------------------------------------------------------------------------
 
-template <bool COUNT, bool W4, bool COOP = false>
+template <bool COUNT, bool W4, int COOP = 0>   // COOP: 0 no, 1 long walks handed over to wf2_long, 2 finished by the wave itself (tail phase)
 __global__ __launch_bounds__(kBlock, JPT_PRIMARY_WAVES) void wf2_primary(WideSceneDev sc, Wf2Buffers wb, Wf2Dims dm, FrameParams fp, RefCamera cam,
                                                       WfTune tune, SkyCull cull, DevCounters* __restrict__ counters)
 {
@@ -492,7 +515,7 @@ __global__ __launch_bounds__(kBlock, JPT_PRIMARY_WAVES) void wf2_primary(WideSce
                 unsaved = true;
                 if (COUNT) count_walk(cnt, walk_steps);
             }
-            if constexpr (COOP && W4) {
+            if constexpr (COOP == 1 && W4) {
                 // the block's queue has been exhausted for kCoopRounds rounds and this ray is still walking: hand it over to
                 // wf2_long (see coop_walk).  (A wave-uniform count of rounds since the queue ran dry, not a per-lane one.)
                 if (exhausted && ++dry_rounds >= (uint32_t)tune.coop_rounds && active) {
@@ -501,6 +524,31 @@ __global__ __launch_bounds__(kBlock, JPT_PRIMARY_WAVES) void wf2_primary(WideSce
                         wb.long_list[k] = make_uint2(path, seg);
                         active = false;
                     }
+                }
+            }
+            if constexpr (COOP == 2 && W4) {
+                if (exhausted && ++dry_rounds >= (uint32_t)tune.tail_rounds && __popcll(__ballot(active)) <= tune.tail_lanes) break;
+            }
+        }
+    }
+    if constexpr (COOP == 2 && W4) {
+        // tail phase (coop_walk_call): the few rays this wave still holds, each walked by the whole wave
+        unsigned long long left = __ballot(active);
+        if (left) {
+            if (__any(unsaved)) save_results();   // (the finished lanes' hits leave the registers the call is free to use)
+            const int wave_col = (int)(threadIdx.x & ~63u);
+            while (left) {
+                const int src = __ffsll((long long)left) - 1;
+                left &= left - 1ull;
+                TraceHit h;
+                const WideSceneDev sc_tail = sc;   // (a copy of its own: `sc` itself must not have its address taken, or the hot loop reads it from scratch)
+                coop_walk_call<COUNT>(&sc_tail, &stack[threadIdx.x], &stack[(kStackLds - 2) * kTraceBlock + wave_col], __shfl(tr.wo.x, src),
+                                      __shfl(tr.wo.y, src), __shfl(tr.wo.z, src), __shfl(tr.wd.x, src), __shfl(tr.wd.y, src), __shfl(tr.wd.z, src),
+                                      COUNT ? &cnt : nullptr, &h);
+                if (lane == src) {
+                    tr.hit = h;
+                    active = false;
+                    unsaved = true;
                 }
             }
         }
@@ -521,7 +569,7 @@ __global__ __launch_bounds__(kBlock, JPT_PRIMARY_WAVES) void wf2_primary(WideSce
 #define JPT_MAX_CHAIN 4
 #endif
 constexpr int kMaxChain = JPT_MAX_CHAIN;
-template <bool COUNT, bool W4, bool COOP = false>
+template <bool COUNT, bool W4, int COOP = 0>
 __global__ __launch_bounds__(kBlock, JPT_WAVES_PER_SIMD) void wf2_trace(WideSceneDev sc, Wf2Buffers wb, Wf2Dims dm, int bounce, WfTune tune,
                                                     int chain, DevCounters* __restrict__ counters)
 {
@@ -603,13 +651,41 @@ __global__ __launch_bounds__(kBlock, JPT_WAVES_PER_SIMD) void wf2_trace(WideScen
                 else save_hit();
                 if (COUNT) count_walk(cnt, walk_steps);
             }
-            if constexpr (COOP && W4) {
+            if constexpr (COOP == 1 && W4) {
                 if (exhausted && ++dry_rounds >= (uint32_t)tune.coop_rounds && active) {
                     const uint32_t k = atomicAdd(&wb.long_count[bounce], 1u);
                     if (k < wb.long_cap) {
                         wb.long_list[k] = make_uint2((uint32_t)my_loc, 0u);
                         active = false;
                     }
+                }
+            }
+            if constexpr (COOP == 2 && W4) {
+                if (exhausted && ++dry_rounds >= (uint32_t)tune.tail_rounds && __popcll(__ballot(active)) <= tune.tail_lanes) break;
+            }
+        }
+    }
+    if constexpr (COOP == 2 && W4) {
+        // tail phase (see wf2_primary)
+        unsigned long long left = __ballot(active);
+        if (left) {
+            if (JPT_LATE_HIT_STORE && unsaved) {
+                save_hit();
+                unsaved = false;
+            }
+            const int wave_col = (int)(threadIdx.x & ~63u);
+            while (left) {
+                const int src = __ffsll((long long)left) - 1;
+                left &= left - 1ull;
+                TraceHit h;
+                const WideSceneDev sc_tail = sc;   // (a copy of its own: `sc` itself must not have its address taken, or the hot loop reads it from scratch)
+                coop_walk_call<COUNT>(&sc_tail, &stack[threadIdx.x], &stack[(kStackLds - 2) * kTraceBlock + wave_col], __shfl(tr.wo.x, src),
+                                      __shfl(tr.wo.y, src), __shfl(tr.wo.z, src), __shfl(tr.wd.x, src), __shfl(tr.wd.y, src), __shfl(tr.wd.z, src),
+                                      COUNT ? &cnt : nullptr, &h);
+                if (lane == src) {
+                    tr.hit = h;
+                    active = false;
+                    save_hit();
                 }
             }
         }
@@ -1652,7 +1728,7 @@ void launch_wf2_render(hipStream_t stream, const DeviceScene& ds, const FramePar
     SceneShading sh = ds.shading();
     if (tuning().reach == 0) sh.reach_tri = nullptr;
     const dim3 block(kBlock);
-    const WfTune tune{tuning().refill_idle, tuning().node_min_lanes, tuning().leaf_min_lanes, tuning().inst_min_lanes, tuning().phase_frac16, tuning().coop_rounds};
+    const WfTune tune{tuning().refill_idle, tuning().node_min_lanes, tuning().leaf_min_lanes, tuning().inst_min_lanes, tuning().phase_frac16, tuning().coop_rounds, tuning().tail_rounds, tuning().tail_lanes};
 
     const int chain = [&] {  // JPT_TRACE_CHAIN overrides (tuning runs); two frame groups share the chip: half-width launches
         const int c = tuning().trace_chain > 0 ? tuning().trace_chain : (groups == 2 ? 2 : async.trace_chain);
@@ -1665,7 +1741,12 @@ void launch_wf2_render(hipStream_t stream, const DeviceScene& ds, const FramePar
     // kRgPool rays in 15 KB of LDS, so ten waves fit a CU: a launch that has the chip to itself wants ~2 560 waves, a queued
     // render (four in flight) a quarter of that.
     // long walks handed over to a whole wave (coop_walk): scenes large enough to have them (JPT_COOP overrides)
-    const bool coop = w4 && (tuning().coop < 0 ? ds.n_tris >= 200000u : tuning().coop != 0);
+    const bool coop_wanted = tuning().coop < 0 ? ds.n_tris >= 200000u : tuning().coop != 0;
+    // ... inside the launch, by the wave that holds them (the tail phase: COOP == 2; default where the rule above asks for the
+    // walk), or by the follow-up launch wf2_long (COOP == 1: JPT_TAIL=0, or a forced JPT_COOP=1)
+    const int tail_cfg = tuning().tail;
+    const bool tail = w4 && (tail_cfg == 2 || (tail_cfg == 1 && !coop_wanted) || (tail_cfg < 0 && tuning().coop < 0 && coop_wanted));
+    const bool coop = w4 && coop_wanted && !tail;
     const bool regroup = tuning().trace_regroup && w4 && ds.stack_need4 <= wf2_rg_stack_capacity() && gb[0].rg_spill != nullptr;
     const int rg_waves = [&] {
         const uint32_t queues = tgrid.x;
@@ -1687,8 +1768,11 @@ void launch_wf2_render(hipStream_t stream, const DeviceScene& ds, const FramePar
         const dim3 sgrid(((dm.seg_cap + kBlock - 1) / kBlock) | 1u, kSegments);
         if (ev) (void)hipEventRecord(ev[0], st);
         if (coop) {
-            if (counters) hipLaunchKernelGGL((wf2_primary<true, true, true>), pgrid, block, 0, st, sc, wb, dm, gp, cam, tune, async.cull, counters);
-            else hipLaunchKernelGGL((wf2_primary<false, true, true>), pgrid, block, 0, st, sc, wb, dm, gp, cam, tune, async.cull, counters);
+            if (counters) hipLaunchKernelGGL((wf2_primary<true, true, 1>), pgrid, block, 0, st, sc, wb, dm, gp, cam, tune, async.cull, counters);
+            else hipLaunchKernelGGL((wf2_primary<false, true, 1>), pgrid, block, 0, st, sc, wb, dm, gp, cam, tune, async.cull, counters);
+        } else if (tail) {
+            if (counters) hipLaunchKernelGGL((wf2_primary<true, true, 2>), pgrid, block, 0, st, sc, wb, dm, gp, cam, tune, async.cull, counters);
+            else hipLaunchKernelGGL((wf2_primary<false, true, 2>), pgrid, block, 0, st, sc, wb, dm, gp, cam, tune, async.cull, counters);
         } else if (counters) {
             if (w4) hipLaunchKernelGGL((wf2_primary<true, true>), pgrid, block, 0, st, sc, wb, dm, gp, cam, tune, async.cull, counters);
             else hipLaunchKernelGGL((wf2_primary<true, false>), pgrid, block, 0, st, sc, wb, dm, gp, cam, tune, async.cull, counters);
@@ -1729,8 +1813,11 @@ void launch_wf2_render(hipStream_t stream, const DeviceScene& ds, const FramePar
                 if (counters) hipLaunchKernelGGL(wf2_trace_rg<true>, dim3(rg_blocks), dim3(64), 0, st, sc, wb, dm, b + 1, chain, rg_waves, counters);
                 else hipLaunchKernelGGL(wf2_trace_rg<false>, dim3(rg_blocks), dim3(64), 0, st, sc, wb, dm, b + 1, chain, rg_waves, counters);
             } else if (coop) {
-                if (counters) hipLaunchKernelGGL((wf2_trace<true, true, true>), tgrid, block, 0, st, sc, wb, dm, b + 1, tune, chain, counters);
-                else hipLaunchKernelGGL((wf2_trace<false, true, true>), tgrid, block, 0, st, sc, wb, dm, b + 1, tune, chain, counters);
+                if (counters) hipLaunchKernelGGL((wf2_trace<true, true, 1>), tgrid, block, 0, st, sc, wb, dm, b + 1, tune, chain, counters);
+                else hipLaunchKernelGGL((wf2_trace<false, true, 1>), tgrid, block, 0, st, sc, wb, dm, b + 1, tune, chain, counters);
+            } else if (tail) {
+                if (counters) hipLaunchKernelGGL((wf2_trace<true, true, 2>), tgrid, block, 0, st, sc, wb, dm, b + 1, tune, chain, counters);
+                else hipLaunchKernelGGL((wf2_trace<false, true, 2>), tgrid, block, 0, st, sc, wb, dm, b + 1, tune, chain, counters);
             } else if (counters) {
                 if (w4) hipLaunchKernelGGL((wf2_trace<true, true>), tgrid, block, 0, st, sc, wb, dm, b + 1, tune, chain, counters);
                 else hipLaunchKernelGGL((wf2_trace<true, false>), tgrid, block, 0, st, sc, wb, dm, b + 1, tune, chain, counters);

@@ -890,12 +890,13 @@ def test_bench_self_launch_two_ranks_on_one_gpu(hiplib, launcher):
         assert d["multi_gpu"]["gather_plan"] == {"peer_copies": 1, "distinct_streams": 1, "own_piece_copies": 0}
 
 
-@pytest.mark.parametrize("switch", ["JPT_COOP=1 JPT_COOP_ROUNDS=2", "JPT_TRACE_REGROUP=1", "JPT_TRACE_REGROUP=1 JPT_COOP=1 JPT_COOP_ROUNDS=2",
-                                    "JPT_XCD_BAND_ROWS=2"])
+@pytest.mark.parametrize("switch", ["JPT_COOP=1 JPT_COOP_ROUNDS=2", "JPT_TAIL=2 JPT_TAIL_ROUNDS=2 JPT_TAIL_LANES=8", "JPT_TRACE_REGROUP=1",
+                                    "JPT_TRACE_REGROUP=1 JPT_COOP=1 JPT_COOP_ROUNDS=2", "JPT_XCD_BAND_ROWS=2"])
 def test_alternative_tracing_launches_are_bit_identical(hiplib, switch):
     """The tuning switches are read once per process, so the alternative launches run the parity tests in a child process:
-    JPT_COOP=1 with an eager hand-over (most tail rays of every launch are walked by wf2_long / coop_walk, which large
-    scenes get by default for their few very long rays), JPT_TRACE_REGROUP=1 (wf2_trace_rg: ray state in LDS, compacted
+    JPT_COOP=1 with an eager hand-over (most tail rays of every launch are walked by wf2_long / coop_walk), JPT_TAIL=2 with eager
+    thresholds (the same walk inside the launch, by the wave that holds the ray: what large scenes get by default for their
+    few very long rays), JPT_TRACE_REGROUP=1 (wf2_trace_rg: ray state in LDS, compacted
     lists per step kind) and JPT_XCD_BAND_ROWS=2 (the primary launch's tiles dealt in bands to the blocks that share an XCD) --
     the last two kept as measured, rejected variants.  Same images bit for bit as the default launches: a subset
     of the parity suite, against the oracle."""

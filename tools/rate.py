@@ -5,7 +5,7 @@ from gdpathtracing_amd import capi, host, scenes
 w, h, spp = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
 n = int(sys.argv[4]) if len(sys.argv) > 4 else 200
 world = int(sys.argv[5]) if len(sys.argv) > 5 else 1   # render rank 0's share of `world` ranks
-sc = scenes.demo_scene(51200)
+sc = {'instanced': lambda: scenes.instanced_scene(), 'unique': lambda: scenes.unique_scene(int(os.environ.get('RATE_TRIS', '1000000')))}.get(os.environ.get('RATE_SCENE', ''), lambda: scenes.demo_scene(51200))()
 if os.environ.get('RATE_CLOSEUP'): sc.camera = scenes.CameraDesc(scenes.transform12(None, (0.0, 0.0, 4.2)), fov_deg=75.0)   # every pixel hits
 if os.environ.get('RATE_TORCH_INIT'): torch.cuda.set_device(0); _z = torch.zeros(4, device='cuda'); torch.cuda.synchronize()
 ctx = host.Context(0); ctx.build_scene(sc, capi.BUILD_SAH); ctx.set_partition(0, world); ctx.set_params(w, h, 4, 0); ctx.set_camera(scenes.camera_block(sc.camera, w, h))
