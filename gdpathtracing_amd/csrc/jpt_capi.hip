@@ -112,7 +112,7 @@ struct jpt_ctx {
     // render pipelining (jpt_render_async): consecutive asynchronous renders run their path kernels on two helper
     // streams with two workspaces, so one render's launch tails overlap the next render's kernels; the accumulation
     // kernels stay on the context's stream, in order
-    static constexpr int kPipeSlots = 8;
+    static constexpr int kPipeSlots = 4;   // (more lose: the hardware runs four queues side by side, profiles/r04/r04ad_blocking_groups_slots_resweep.txt)
     DevBuf<char> d_workspace_more[kPipeSlots - 1];  // slot 0 is d_workspace
     hipStream_t pipe_stream[kPipeSlots] = {};
     uint64_t async_seq = 0;

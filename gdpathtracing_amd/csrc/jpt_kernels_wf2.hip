@@ -146,8 +146,8 @@ struct Wf2Buffers {
     float4* thr;        // per path: where a set-aside path parks that float4 until wf2_finish (otherwise untouched)
     float4* rad;        // per path: radiance.xyz -- touched only by vertices that ADD radiance (emitters) and by paths that
                         // carry some (kHasRadiance in the queue entry): most vertices neither read nor write it
-                        // ([frame][slot]; HDR_F32 mode: also the finished paths' output; w = seed.y of a set-aside path)
-    uint32_t* fin8;     // REF_LDR8 mode: [frame][slot] the finished path's radiance as the rgba8 main.glsl:434 stores (4 bytes, not 16)
+                        // (indexed by path; HDR_F32 mode: also the finished paths' output; w = seed.y of a set-aside path)
+    uint32_t* fin8;     // REF_LDR8 mode: by path, the finished path's radiance as the rgba8 main.glsl:434 stores (4 bytes, not 16)
     float* first_depth; // per slot of the LAST frame: distance of the first hit (or far)
     uint32_t* qcount;   // [max_bounces + 2][kSegments] queue sizes; row b = rays traced in bounce b (b >= 1)
     uint32_t* redo_count;  // [0]: paths set aside because the reference cannot reach their hit (wf2_finish) ...
@@ -186,8 +186,10 @@ struct Wf2Dims {
     uint32_t n_chunks;         // tiles_per_frame * n_frames
     uint32_t seg_cap;          // entries per segment
     uint32_t run_shift;        // a segment is dealt runs of 2^run_shift consecutive chunks (neighbouring tiles of one frame)
-    FastDiv by_tiles_x, by_tiles_per_frame, by_slots_per_frame, by_full_tiles_x;
-    FastDiv by_frames;         // (wf2_accumulate: item -> (pixel, frame))
+    FastDiv by_tiles_x, by_tiles_per_frame, by_full_tiles_x;
+    FastDiv by_frames;         // path -> (slot, frame), path_slot_frame; wf2_accumulate: item -> (pixel, frame)
+    int32_t acc_groups = 1;    // (wf2_accumulate: the frame groups whose blocks of rad / fin8 it reads, group_frames)
+    int32_t samples_together = 0;   // wf2_primary: a wave takes every frame's sample of 64 / n_frames pixels (consecutive path ids)
     // XCD bands (JPT_XCD_BAND_ROWS > 0): blocks b and b + 8 share an XCD and its 4 MB L2 (dispatch is round-robin); the runs of a
     // frame are cut into bands of band_runs consecutive runs (a few tile rows) and band q of every frame belongs to the
     // blocks with seg % 8 == q % 8, so an XCD's rays start in its own stripes of the screen.  0: runs dealt round-robin to
@@ -202,6 +204,16 @@ __device__ __forceinline__ void slot_to_pixel(uint32_t slot, const Wf2Dims& dm, 
     const uint32_t ty = fdiv(tile, dm.by_tiles_x), tx = tile - ty * (uint32_t)dm.tiles_x;
     px = (int)((tx + (uint32_t)dm.tile_x0) * 8u + (lane & 7u));
     ly = (int)((ty + (uint32_t)dm.tile_y0) * 8u + (lane >> 3));
+}
+
+// Path ids count (pixel slot, frame) pairs with the FRAME running fastest: path = slot * n_frames + frame (frames of the
+// launch's group).  The primary launch deals a wave 64 consecutive ids -- every frame's sample of 64 / n_frames neighbouring
+// pixels of one tile row -- so whatever is indexed by path (rad, fin8, thr) is touched in runs, by the primary launch and by
+// the queues' order after it, and wf2_accumulate reads a pixel's frames as one run.
+__device__ __forceinline__ void path_slot_frame(uint32_t path, const Wf2Dims& dm, uint32_t n_frames, uint32_t& slot, uint32_t& f)
+{
+    slot = fdiv(path, dm.by_frames);
+    f = path - slot * n_frames;
 }
 
 // a path is over: its radiance goes where wf2_accumulate reads it -- in REF_LDR8 mode already as the rgba8 value of
@@ -447,10 +459,11 @@ __global__ __launch_bounds__(kBlock, JPT_PRIMARY_WAVES) void wf2_primary(WideSce
             }
         }
         if (unsaved && !is_hit) {   // sky: radiance += 1 * sampleSky(d), path over (main.glsl:380,395-397)
-            const uint32_t f = fdiv(path, dm.by_slots_per_frame);
+            uint32_t pslot, f;
+            path_slot_frame(path, dm, (uint32_t)fp.n_frames, pslot, f);
             const f3 sky = mk3(0.0f, 0.0f, 0.0f) + mk3(1.0f, 1.0f, 1.0f) * sample_sky(tr.wd);
             store_final(wb, fp.accum_mode, path, sky);
-            if ((int)f == fp.depth_frame) wb.first_depth[path - f * dm.slots_per_frame] = cam.far_;
+            if ((int)f == fp.depth_frame) wb.first_depth[pslot] = cam.far_;
         }
         unsaved = false;
     };
@@ -479,12 +492,20 @@ __global__ __launch_bounds__(kBlock, JPT_PRIMARY_WAVES) void wf2_primary(WideSce
                         tile = (rf << dm.run_shift) + (j & run_mask);
                         chunk = (tile < dm.tiles_per_frame && f < (uint32_t)fp.n_frames) ? f * dm.tiles_per_frame + tile : dm.n_chunks;
                     }
-                    const uint32_t slot = tile * 64u + (idx & 63u);
+                    uint32_t slot = tile * 64u + (idx & 63u);
+                    // samples_together: a wave takes 64 consecutive path ids: chunk c is (tile c / F, part c % F), its lanes the samples
+                    // part * 64 + lane of that tile, sample s being frame s % F of the tile's pixel s / F.  Otherwise one frame's sample of
+                    // all 64 pixels of a tile, as rounds 1-3 dealt them (the band dealing keeps that).
+                    if (dm.samples_together && !(kXcdBands && dm.band_runs) && chunk < dm.n_chunks) {
+                        uint32_t unused;
+                        path_slot_frame(chunk * 64u + (idx & 63u), dm, (uint32_t)fp.n_frames, slot, unused);
+                        f = unused;
+                    }
                     int px, ly;
                     slot_to_pixel(slot, dm, px, ly);
                     if (chunk < dm.n_chunks && px < fp.width && ly < fp.local_rows) {
                         const int py = local_to_global_row(ly, fp);
-                        path = f * dm.slots_per_frame + slot;
+                        path = slot * (uint32_t)fp.n_frames + f;
                         if (COUNT) cnt.rays++;
                         // a pixel outside the screen rectangles of all the boxes the TLAS root offers: the walk would
                         // expand the root, fail every box test and end in the sky -- nothing is generated, traced or
@@ -712,9 +733,10 @@ __global__ __launch_bounds__(64) void wf2_long(WideSceneDev sc, Wf2Buffers wb, W
         const uint2 rec = wb.long_list[k];
         if (PRIMARY) {
             const uint32_t path = rec.x, seg = rec.y;
-            const uint32_t f = fdiv(path, dm.by_slots_per_frame);
+            uint32_t pslot, f;
+            path_slot_frame(path, dm, (uint32_t)fp.n_frames, pslot, f);
             int px, ly;
-            slot_to_pixel(path - f * dm.slots_per_frame, dm, px, ly);
+            slot_to_pixel(pslot, dm, px, ly);
             uint32_t sx, sy;
             const Ray ray = primary_ray(cam, fp.width, fp.height, px, local_to_global_row(ly, fp), fp.frame_index + f, sx, sy);
             const TraceHit h = coop_walk<COUNT>(sc, my_stack, s_pool, ray.o, ray.d, cnt);
@@ -728,7 +750,7 @@ __global__ __launch_bounds__(64) void wf2_long(WideSceneDev sc, Wf2Buffers wb, W
                 } else {            // sky (main.glsl:380,395-397)
                     const f3 sky = mk3(0.0f, 0.0f, 0.0f) + mk3(1.0f, 1.0f, 1.0f) * sample_sky(ray.d);
                     store_final(wb, fp.accum_mode, path, sky);
-                    if ((int)f == fp.depth_frame) wb.first_depth[path - f * dm.slots_per_frame] = cam.far_;
+                    if ((int)f == fp.depth_frame) wb.first_depth[pslot] = cam.far_;
                 }
             }
         } else {
@@ -1042,7 +1064,8 @@ __device__ __forceinline__ bool shade_entry(const SceneShading& sh, const Wf2Buf
     const bool had_radiance = (__float_as_uint(rd.w) & kHasRadiance) != 0u;
     f3 throughput, radiance;
     uint32_t sx, sy;
-    const uint32_t f = fdiv(p, dm.by_slots_per_frame), slot = p - f * dm.slots_per_frame;
+    uint32_t slot, f;
+    path_slot_frame(p, dm, (uint32_t)fp.n_frames, slot, f);
     Ray ray;
     ray.o = mk3(ro.x, ro.y, ro.z);
     ray.d = mk3(rd.x, rd.y, rd.z);
@@ -1436,7 +1459,16 @@ __global__ __launch_bounds__(kBlock) void wf2_accumulate(Wf2Buffers wb, Wf2Dims 
         }
     }
     if (!valid) return;
+    // the frames of group g are a block of their own in rad / fin8: [slot][frame of the group] behind the earlier groups' blocks
+    const int g_base = fp.n_frames / dm.acc_groups, g_extra = fp.n_frames % dm.acc_groups;
+    int g = 0, g_f0 = 0, g_nf = g_base + (g_extra > 0 ? 1 : 0);
     for (int f = 0; f < fp.n_frames; f++) {
+        if (f >= g_f0 + g_nf) {
+            g++;
+            g_f0 += g_nf;
+            g_nf = g_base + (g < g_extra ? 1 : 0);
+        }
+        const size_t at = (size_t)g_f0 * dm.slots_per_frame + (size_t)slot * (size_t)g_nf + (size_t)(f - g_f0);
         f3 cur;
         if (sky_constant) {
             cur = sky_value;
@@ -1456,11 +1488,11 @@ __global__ __launch_bounds__(kBlock) void wf2_accumulate(Wf2Buffers wb, Wf2Dims 
                 last = cur;
             }
         } else if (fp.accum_mode == 0) {
-            const uint32_t q = wb.fin8[(size_t)f * dm.slots_per_frame + slot];
+            const uint32_t q = wb.fin8[at];
             cur = mk3(from_unorm8(q & 255u), from_unorm8((q >> 8) & 255u), from_unorm8((q >> 16) & 255u));
             last = cur;   // (display_mode 1 shows the last frame's rgba8 image itself: quantising it again gives the same bytes)
         } else {
-            const float4 r = wb.rad[(size_t)f * dm.slots_per_frame + slot];
+            const float4 r = wb.rad[at];
             cur = mk3(r.x, r.y, r.z);
             last = cur;
         }
@@ -1536,9 +1568,16 @@ Wf2Dims make_dims(int width, int local_rows, int n_frames, const TileWindow& win
     // the window: the chunks counted here are now the window's, i.e. nearly all of them are walked, and the thresholds
     // are lower (C3's window: 24 chunks per segment, runs of 1 / 2 / 4 / 8: 1.125 / 1.120 / 1.114 / 1.116 ms; C2's: 5 per
     // segment, 0.363 / 0.362 / 0.373).  JPT_RUN_SHIFT overrides.
+    dm.samples_together = tuning().primary_samples < 0 ? 1 : (tuning().primary_samples != 0);
     const int forced_shift = tuning().run_shift;
     const uint32_t per_segment = dm.n_chunks / kSegments;
-    const uint32_t run_shift = forced_shift >= 0 ? (uint32_t)forced_shift : (n_frames < 4 || per_segment < 8u ? 0u : (per_segment < 16u ? 1u : 2u));
+    // With samples_together (round 4) a run is consecutive PARTS of one tile, already more alike than neighbouring tiles were, and
+    // what runs add is imbalance: single chunks up to a few hundred per segment (C3, 24 per segment, runs of 1 / 2 / 4 chunks: 843 /
+    // 842 / 858 us queued; close-up and C4, 144: 4.34 / 4.33 / 4.44 and 2.76 / 2.77 / 2.78 ms), runs of four only for the largest
+    // renders (3840x2160x16, 1 157 per segment: 6.02 / 5.90 / 5.84 ms) -- profiles/r04/r04ag_samples_together.txt.
+    const uint32_t rule = dm.samples_together ? (per_segment >= 512u ? 2u : (per_segment >= 256u ? 1u : 0u))
+                                              : (n_frames < 4 || per_segment < 8u ? 0u : (per_segment < 16u ? 1u : 2u));
+    const uint32_t run_shift = forced_shift >= 0 ? (uint32_t)forced_shift : rule;
     dm.run_shift = run_shift;
     const uint32_t n_runs = (dm.n_chunks + (1u << run_shift) - 1u) >> run_shift;
     dm.seg_cap = (((n_runs + kSegments - 1u) / kSegments) << run_shift) * 64u;
@@ -1562,7 +1601,6 @@ Wf2Dims make_dims(int width, int local_rows, int n_frames, const TileWindow& win
     }
     dm.by_tiles_x = make_fastdiv((uint32_t)dm.tiles_x);
     dm.by_tiles_per_frame = make_fastdiv(dm.tiles_per_frame);
-    dm.by_slots_per_frame = make_fastdiv(dm.slots_per_frame);
     dm.by_frames = make_fastdiv((uint32_t)(n_frames > 0 ? n_frames : 1));
     return dm;
 }
@@ -1639,7 +1677,7 @@ size_t wf2_workspace_bytes(int width, int local_rows, int n_frames, int max_boun
             b += (size_t)redo_capacity(paths) * 2 * sizeof(float4) + 256;    // set-aside records
         }
         const Wf2Dims all = make_dims(width, local_rows, n_frames, full_window(width, local_rows));
-        b += (size_t)all.slots_per_frame * (size_t)n_frames * sizeof(float4) + 256;  // rad: [frame][slot], shared by the groups
+        b += (size_t)all.slots_per_frame * (size_t)n_frames * sizeof(float4) + 256;  // rad: a block per group, each [slot][frame of the group]
         b += (size_t)all.slots_per_frame * (size_t)n_frames * sizeof(uint32_t) + 256;  // fin8
         b += (size_t)all.slots_per_frame * sizeof(float) + 256;
         worst = b > worst ? b : worst;
@@ -1705,7 +1743,7 @@ void launch_wf2_render(hipStream_t stream, const DeviceScene& ds, const FramePar
         wb.redo_cap = redo_capacity(paths);
         wb.redo_rec = (float4*)carve((size_t)wb.redo_cap * 2 * sizeof(float4));
         wb.thr = (float4*)carve(paths * sizeof(float4));
-        wb.rad = rad_all + (size_t)f0 * dm_all.slots_per_frame;  // this group's frames of the [frame][slot] array
+        wb.rad = rad_all + (size_t)f0 * dm_all.slots_per_frame;  // this group's block ([slot][frame of the group]: path ids) behind the earlier groups'
         wb.fin8 = fin8_all + (size_t)f0 * dm_all.slots_per_frame;
         wb.first_depth = first_depth;
         gfp[g] = fp;
@@ -1866,6 +1904,8 @@ void launch_wf2_render(hipStream_t stream, const DeviceScene& ds, const FramePar
             hipLaunchKernelGGL(add_queue_counts, dim3((nqc + 255) / 256), dim3(256), 0, stream, gb[0].qcount, gb[g].qcount, nqc);
     }
     Wf2Buffers wb_all = gb[0];
+    Wf2Dims dm_acc = dm_all;
+    dm_acc.acc_groups = groups;
     wb_all.rad = rad_all;
     wb_all.fin8 = fin8_all;
     wb_all.first_depth = first_depth;
@@ -1879,7 +1919,7 @@ void launch_wf2_render(hipStream_t stream, const DeviceScene& ds, const FramePar
     }
     if (async.before_acc) (void)hipStreamWaitEvent(acc_stream, async.before_acc, 0);
     const uint32_t ablocks = ((uint32_t)dm_all.full_tiles_x * (uint32_t)dm_all.full_tiles_y * 64u + kBlock - 1) / kBlock;
-    hipLaunchKernelGGL(wf2_accumulate, dim3(ablocks), block, 0, acc_stream, wb_all, dm_all, fp, cam, async.cull, accum, ldr, depth);
+    hipLaunchKernelGGL(wf2_accumulate, dim3(ablocks), block, 0, acc_stream, wb_all, dm_acc, fp, cam, async.cull, accum, ldr, depth);
 }
 
 uint64_t wf2_pixels_outside_window(const SkyCull& cull, const FrameParams& fp)

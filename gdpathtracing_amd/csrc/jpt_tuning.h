@@ -11,7 +11,7 @@ struct Tuning {
     bool sky_cull = true;          // JPT_SKY_CULL=0: trace every primary ray
     long workspace_budget_mb = 24576;  // JPT_WORKSPACE_BUDGET_MB: frames in flight per launch set
     bool pipelining = true;        // JPT_PIPELINE=0: asynchronous renders run one after another
-    int pipe_slots = 0;            // JPT_PIPE_SLOTS=2..8: renders in flight (0: the library's rule)
+    int pipe_slots = 0;            // JPT_PIPE_SLOTS=2..4: renders in flight (0: the library's rule)
     bool acc_on_slot = true;       // JPT_ACC_ON_SLOT=0: accumulation kernels on the context's stream
     int slot_prio = 3;             // JPT_SLOT_PRIO: priority of the pipeline slots' streams -- 0 all normal, 1 dealt over the device's
                                    // priority levels, 2 two high + two low, 3 (default) all high, 4 all low (jpt_capi.hip, ensure_pipe_slot)
@@ -34,6 +34,8 @@ struct Tuning {
     int xcd_band_rows = 0;         // JPT_XCD_BAND_ROWS=n: the primary launch deals bands of n tile rows to the blocks that share an XCD (0: off)
     int coop = -1;                 // JPT_COOP=0/1: long walks handed over to a whole wave (coop_walk) never / always (-1: scenes of >= 200 000 triangles)
     int coop_rounds = 128;         // JPT_COOP_ROUNDS: ... a ray still walking this many rounds after its block's queue ran dry
+    int primary_samples = -1;      // JPT_PRIMARY_SAMPLES=0/1: a wave of the primary launch takes one frame's sample of an 8 x 8 tile / every frame's
+                                   // sample of 64 / n_frames pixels of a tile (-1: the library's rule)
     int tail = -1;                 // JPT_TAIL: the waves of a tracing launch walk their last, long rays themselves, all lanes on one ray
                                    // (coop_walk_call), instead of handing them to wf2_long: -1 where JPT_COOP's own rule (not a forced
                                    // JPT_COOP=1) asks for the cooperative walk, 0 never, 1 also on the scenes JPT_COOP leaves alone, 2 everywhere
@@ -74,6 +76,7 @@ inline const Tuning& tuning()
         v.coop = geti("JPT_COOP", -1);
         v.coop_rounds = geti("JPT_COOP_ROUNDS", 128);
         if (v.coop_rounds < 1) v.coop_rounds = 1;
+        v.primary_samples = geti("JPT_PRIMARY_SAMPLES", -1);
         v.tail = geti("JPT_TAIL", -1);
         v.tail_rounds = geti("JPT_TAIL_ROUNDS", 128);
         v.tail_lanes = geti("JPT_TAIL_LANES", 8);
