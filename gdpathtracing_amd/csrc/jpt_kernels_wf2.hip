@@ -47,6 +47,9 @@ constexpr bool kXcdBands = true;
 #ifndef JPT_LEAF_INNER
 #define JPT_LEAF_INNER 0
 #endif
+#ifndef JPT_PACK_BY_OCTANT
+#define JPT_PACK_BY_OCTANT 0
+#endif
 constexpr int kLeafInner = JPT_LEAF_INNER;
 struct WfTune {
     int refill_idle;     // refill when at least this many lanes of a wave are idle
@@ -1207,7 +1210,19 @@ __global__ __launch_bounds__(kBlock, LAST ? 8 : (TEX == 0 ? JPT_SHADE_NOTEX_WAVE
         if (lane == 0) wbase = atomicAdd(&wb.qcount[(size_t)(bounce + 1) * kSegments + seg], (uint32_t)__popcll(m));
         wbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)wbase);
         if (alive) {
+#if JPT_PACK_BY_OCTANT
+            // (A/B: the wave's rays leave ordered by the octant of their direction)
+            const uint32_t oct = (__float_as_uint(nd.x) >> 31) | ((__float_as_uint(nd.y) >> 31) << 1) | ((__float_as_uint(nd.z) >> 31) << 2);
+            uint32_t rank = 0, before = 0;
+            for (uint32_t k = 0; k < 8u; k++) {
+                const unsigned long long mk = __ballot(oct == k);
+                if (oct == k) rank = before + lanes_below(mk, lane);
+                before += (uint32_t)__popcll(mk);
+            }
+            const size_t j = seg_base + wbase + rank;
+#else
             const size_t j = seg_base + wbase + lanes_below(m, lane);
+#endif
             wb.ray_o[out][j] = no;
             wb.ray_d[out][j] = nd;
             wb.thr_q[out][j] = nt;
