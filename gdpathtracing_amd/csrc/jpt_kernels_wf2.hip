@@ -47,6 +47,9 @@ constexpr bool kXcdBands = true;
 #ifndef JPT_LEAF_INNER
 #define JPT_LEAF_INNER 0
 #endif
+#ifndef JPT_TILE_MORTON
+#define JPT_TILE_MORTON 0   // (measured: 1-2 % fewer rounds of the primary launch, no time: profiles/r04/r04ag_samples_together.txt)
+#endif
 #ifndef JPT_PACK_BY_OCTANT
 #define JPT_PACK_BY_OCTANT 0
 #endif
@@ -205,8 +208,15 @@ __device__ __forceinline__ void slot_to_pixel(uint32_t slot, const Wf2Dims& dm, 
 {
     const uint32_t tile = slot >> 6, lane = slot & 63u;
     const uint32_t ty = fdiv(tile, dm.by_tiles_x), tx = tile - ty * (uint32_t)dm.tiles_x;
-    px = (int)((tx + (uint32_t)dm.tile_x0) * 8u + (lane & 7u));
-    ly = (int)((ty + (uint32_t)dm.tile_y0) * 8u + (lane >> 3));
+#if JPT_TILE_MORTON
+    // the 64 slots of a tile in Z order (x0 y0 x1 y1 x2 y2): consecutive slots -- what a primary wave takes 64 / n_frames of --
+    // are a compact block of pixels (4 x 2 at 8 frames per render) instead of a piece of a row
+    const uint32_t ix = (lane & 1u) | ((lane >> 1) & 2u) | ((lane >> 2) & 4u), iy = ((lane >> 1) & 1u) | ((lane >> 2) & 2u) | ((lane >> 3) & 4u);
+#else
+    const uint32_t ix = lane & 7u, iy = lane >> 3;
+#endif
+    px = (int)((tx + (uint32_t)dm.tile_x0) * 8u + ix);
+    ly = (int)((ty + (uint32_t)dm.tile_y0) * 8u + iy);
 }
 
 // Path ids count (pixel slot, frame) pairs with the FRAME running fastest: path = slot * n_frames + frame (frames of the
@@ -1315,7 +1325,12 @@ __global__ __launch_bounds__(kBlock) void wf2_accumulate(Wf2Buffers wb, Wf2Dims 
     const bool valid = px < fp.width && ly < fp.local_rows;   // (lanes past the image's edge still help with the shared route)
     const int wtx = (int)ftx - dm.tile_x0, wty = (int)fty - dm.tile_y0;
     const bool in_window = wtx >= 0 && wtx < dm.tiles_x && wty >= 0 && wty < dm.tiles_y;
-    const uint32_t slot = in_window ? ((uint32_t)wty * (uint32_t)dm.tiles_x + (uint32_t)wtx) * 64u + flane : 0u;
+#if JPT_TILE_MORTON
+    const uint32_t in_tile = (flane & 1u) | ((flane & 2u) << 1) | ((flane & 4u) << 2) | ((flane & 8u) >> 2) | ((flane & 16u) >> 1) | (flane & 32u);   // slot_to_pixel's Z order
+#else
+    const uint32_t in_tile = flane;
+#endif
+    const uint32_t slot = in_window ? ((uint32_t)wty * (uint32_t)dm.tiles_x + (uint32_t)wtx) * 64u + in_tile : 0u;
     const size_t idx = valid ? (size_t)ly * fp.width + px : 0;
     // fp.frame_count = ProgressiveRendering frame_count of the FIRST frame of this render
     f3 sum = mk3(0.0f, 0.0f, 0.0f);
