@@ -296,6 +296,7 @@ __device__ __forceinline__ TraceHit coop_walk(const WideSceneDev& sc, const type
     bool active = lane == 0 && tr.have;
     if (lane != 0) tr.have = false;
     uint32_t n_pool = 0;
+    uint32_t my_steps = 0;   // (counting builds: record steps of this lane; their sum is the walk's length, jpt_stats.walk_steps_*)
     for (;;) {
         // idle lanes take pool entries (newest first)
         {
@@ -330,6 +331,7 @@ __device__ __forceinline__ TraceHit coop_walk(const WideSceneDev& sc, const type
             }
         }
         if (!__any(active)) break;   // (and the pool is empty: an idle lane would have taken from it)
+        if (COUNT && active && (tr.have || tr.sp > 0)) my_steps++;
         if (active && !tr.step(sc, st, cnt)) active = false;
         // every lane culls with the closest distance found anywhere; a lane whose own triangle is farther no longer holds one
         {
@@ -368,6 +370,10 @@ __device__ __forceinline__ TraceHit coop_walk(const WideSceneDev& sc, const type
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
+    }
+    if (COUNT) {
+        for (int off = 32; off > 0; off >>= 1) my_steps += (uint32_t)__shfl_xor((int)my_steps, off);
+        if (lane == 0) count_walk(cnt, my_steps);
     }
     // the closest hit: the lanes that hold a triangle at the final distance
     const float best = wave_min_f(tr.hit.t);

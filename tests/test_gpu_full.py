@@ -911,7 +911,10 @@ def test_alternative_tracing_launches_are_bit_identical(hiplib, switch):
         k, v = kv.split("=")
         env[k] = v
     p = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_parity.py"), os.path.join(root, "tests", "test_fuzz.py"),
-                        "-m", "gpu", "-x", "-q", "-k", "c1_cornell or demo_scene_multi_frame or coincident or tie_between or duplicated or native_tree"],
+                        os.path.abspath(__file__), "-m", "gpu", "-x", "-q", "-k",
+                        "c1_cornell or demo_scene_multi_frame or coincident or tie_between or duplicated or native_tree" +
+                        # (the walk-length counters with the cooperative walks in play; the regrouped launches keep none)
+                        ("" if "REGROUP" in switch else " or walk_length_statistics")],
                        env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=1500)
     assert p.returncode == 0, p.stdout[-3000:]
     assert " passed" in p.stdout and "failed" not in p.stdout
