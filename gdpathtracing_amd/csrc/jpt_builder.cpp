@@ -1479,13 +1479,20 @@ struct Child4 {
     }
 };
 
-// collapse the subtree under two-child record `ni` of `src` into `dst`; returns the new record's index
-int32_t collapse4(const std::vector<WideNode>& src, std::vector<WideNode4>& dst, int32_t ni, std::vector<int32_t>& memo)
+// collapse the subtree under two-child record `ni` of `src` into `dst`; returns the new record's index.
+// Order of the records in `dst` (JPT_NODE_ORDER, tuning().node_order): 0 = depth first (a record, then its first child's whole
+// subtree, ...), 1 = the up-to-four child records of a record next to each other (a 128-byte line holds two siblings), then
+// their subtrees.  `at` >= 0: the place the caller has already reserved for this record (memo[ni] == at).
+int32_t collapse4(const std::vector<WideNode>& src, std::vector<WideNode4>& dst, int32_t ni, std::vector<int32_t>& memo, int32_t at = -1)
 {
-    if (memo[(size_t)ni] >= 0) return memo[(size_t)ni];
-    const int32_t self = (int32_t)dst.size();
-    memo[(size_t)ni] = self;
-    dst.emplace_back();
+    if (at < 0 && memo[(size_t)ni] >= 0) return memo[(size_t)ni];
+    const bool siblings = tuning().node_order == 1;
+    int32_t self = at;
+    if (self < 0) {
+        self = (int32_t)dst.size();
+        memo[(size_t)ni] = self;
+        dst.emplace_back();
+    }
     auto kids_of = [&](int32_t n, Child4* out) {
         const WideNode& w = src[(size_t)n];
         for (int k = 0; k < 3; k++) {
@@ -1519,6 +1526,17 @@ int32_t collapse4(const std::vector<WideNode>& src, std::vector<WideNode4>& dst,
     }
     WideNode4 w;
     std::memset(&w, 0, sizeof w);
+    int32_t reserved[4] = {-1, -1, -1, -1};
+    if (siblings)   // places for the children first, side by side; their subtrees follow
+        for (int i = 0; i < n; i++) {
+            const int32_t r = c[i].ref;
+            if (r < 0) continue;
+            const WideNode& s2 = src[(size_t)r];
+            if ((s2.left == r && s2.right == r) || memo[(size_t)r] >= 0) continue;
+            reserved[i] = (int32_t)dst.size();
+            memo[(size_t)r] = reserved[i];
+            dst.emplace_back();
+        }
     for (int i = 0; i < 4; i++) {
         if (i < n) {
             w.lo_x[i] = c[i].lo[0]; w.lo_y[i] = c[i].lo[1]; w.lo_z[i] = c[i].lo[2];
@@ -1527,7 +1545,7 @@ int32_t collapse4(const std::vector<WideNode>& src, std::vector<WideNode4>& dst,
             if (r >= 0) {
                 const WideNode& s2 = src[(size_t)r];
                 if (s2.left == r && s2.right == r) r = kEmptyChild;  // empty-leaf record: nothing below
-                else r = collapse4(src, dst, r, memo);
+                else r = collapse4(src, dst, r, memo, reserved[i]);
             }
             w.child[i] = r;
         } else {
