@@ -56,6 +56,7 @@ constexpr bool kXcdBands = true;
 constexpr int kLeafInner = JPT_LEAF_INNER;
 struct WfTune {
     int refill_idle;     // refill when at least this many lanes of a wave are idle
+    int primary_refill_idle;   // ... in the primary launch
     int node_min_lanes;  // leave the node loop when fewer lanes than this still descend
     int leaf_min_lanes;  // a leaf / instance phase with fewer takers than this is put off to the next round, as long as
     int inst_min_lanes;  // other lanes of the wave can make progress meanwhile
@@ -490,7 +491,7 @@ __global__ __launch_bounds__(kBlock, JPT_PRIMARY_WAVES) void wf2_primary(WideSce
     for (;;) {
         const unsigned long long idle = __ballot(!active);
         const int n_idle = __popcll(idle);
-        if (!exhausted && n_idle >= tune.refill_idle) {
+        if (!exhausted && n_idle >= tune.primary_refill_idle) {
             if (__any(unsaved)) save_results();
             uint32_t start = 0;
             if (lane == 0) start = atomicAdd(&s_cursor, (uint32_t)n_idle);
@@ -1802,7 +1803,7 @@ void launch_wf2_render(hipStream_t stream, const DeviceScene& ds, const FramePar
     SceneShading sh = ds.shading();
     if (tuning().reach == 0) sh.reach_tri = nullptr;
     const dim3 block(kBlock);
-    const WfTune tune{tuning().refill_idle, tuning().node_min_lanes, tuning().leaf_min_lanes, tuning().inst_min_lanes, tuning().phase_frac16, tuning().coop_rounds, tuning().tail_rounds, tuning().tail_lanes};
+    const WfTune tune{tuning().refill_idle, tuning().primary_refill_idle, tuning().node_min_lanes, tuning().leaf_min_lanes, tuning().inst_min_lanes, tuning().phase_frac16, tuning().coop_rounds, tuning().tail_rounds, tuning().tail_lanes};
 
     const int chain = [&] {  // JPT_TRACE_CHAIN overrides (tuning runs); two frame groups share the chip: half-width launches
         const int c = tuning().trace_chain > 0 ? tuning().trace_chain : (groups == 2 ? 2 : async.trace_chain);

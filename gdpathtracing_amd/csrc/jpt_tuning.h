@@ -19,6 +19,7 @@ struct Tuning {
     int run_shift = -1;            // JPT_RUN_SHIFT: tiles dealt to a segment in runs of 2^n (-1: the library's rule)
     int groups = 0;                // JPT_GROUPS=1..4: frame groups of a blocking render (0: the library's rule)
     int refill_idle = 24;          // JPT_REFILL_IDLE: a wave refills when this many lanes are idle (20..32 x 20..32 swept: a 1 % plateau)
+    int primary_refill_idle = -1;  // JPT_PRIMARY_REFILL_IDLE: ... in the primary launch (-1: as refill_idle)
     int node_min_lanes = 24;       // JPT_NODE_MIN_LANES: leave the record loop below this many descending lanes
     int leaf_min_lanes = 16;       // JPT_LEAF_MIN_LANES / JPT_INST_MIN_LANES: a leaf / instance phase with fewer takers waits a round
     int inst_min_lanes = 12;       // (while the wave has other work); 1 = every round, as before
@@ -65,6 +66,8 @@ inline const Tuning& tuning()
         if (v.run_shift > 8) v.run_shift = 8;
         v.groups = geti("JPT_GROUPS", 0);
         v.refill_idle = geti("JPT_REFILL_IDLE", 24);
+        v.primary_refill_idle = geti("JPT_PRIMARY_REFILL_IDLE", -1);
+        if (v.primary_refill_idle < 0) v.primary_refill_idle = v.refill_idle;
         v.node_min_lanes = geti("JPT_NODE_MIN_LANES", 24);
         v.leaf_min_lanes = geti("JPT_LEAF_MIN_LANES", 16);
         v.inst_min_lanes = geti("JPT_INST_MIN_LANES", 12);
