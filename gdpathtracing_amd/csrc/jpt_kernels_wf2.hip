@@ -516,11 +516,8 @@ __global__ __launch_bounds__(kBlock, JPT_PRIMARY_WAVES) void wf2_primary(WideSce
                     // samples_together: a wave takes 64 consecutive path ids: chunk c is (tile c / F, part c % F), its lanes the samples
                     // part * 64 + lane of that tile, sample s being frame s % F of the tile's pixel s / F.  Otherwise one frame's sample of
                     // all 64 pixels of a tile, as rounds 1-3 dealt them (the band dealing keeps that).
-                    if (dm.samples_together && !(kXcdBands && dm.band_runs) && chunk < dm.n_chunks) {
-                        uint32_t unused;
-                        path_slot_frame(chunk * 64u + (idx & 63u), dm, (uint32_t)fp.n_frames, slot, unused);
-                        f = unused;
-                    }
+                    if (dm.samples_together && !(kXcdBands && dm.band_runs) && chunk < dm.n_chunks)
+                        path_slot_frame(chunk * 64u + (idx & 63u), dm, (uint32_t)fp.n_frames, slot, f);
                     int px, ly;
                     slot_to_pixel(slot, dm, px, ly);
                     if (chunk < dm.n_chunks && px < fp.width && ly < fp.local_rows) {
@@ -1434,7 +1431,8 @@ __global__ __launch_bounds__(kBlock) void wf2_accumulate(Wf2Buffers wb, Wf2Dims 
             }
         }
     }
-    // ... then, in the tiles that straddle a cell boundary, pixel by pixel
+    // ... then, in the tiles that straddle a cell boundary, pixel by pixel.  (Sharing the tile's 9 x 9 corners through LDS -- two
+    // passes of the set-up instead of four -- left the kernel at 49.5 us and cost queued renders 1-5 %: profiles/r04/r04ak_acc_corners.txt)
     if (culled && want_cells && !tile_constant) {
         float lo[3] = {1e30f, 1e30f, 1e30f}, hi[3] = {-1e30f, -1e30f, -1e30f};
         bool sane = true;
