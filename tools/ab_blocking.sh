@@ -1,3 +1,5 @@
+#!/bin/bash
+# one blocking render (C3, close-up), three repetitions, for the current build and JPT_LIB alternatives: tools/ab_blocking.sh <label>:<lib.so or -> ...
 cd "$GRAFT_REPO_ROOT"
 for rep in 1 2 3; do
 for spec in "$@"; do

@@ -1,3 +1,5 @@
+#!/bin/bash
+# queued rates (C3, close-up), four repetitions, for the current build and JPT_LIB alternatives: tools/ab_rates.sh <label>:<lib.so or -> ...
 cd "$GRAFT_REPO_ROOT"
 for rep in 1 2 3 4; do
 for spec in "$@"; do

@@ -1,3 +1,5 @@
+#!/bin/bash
+# frame groups of a blocking render (JPT_GROUPS 0..4) and pipeline slots x chained segments of queued renders: the pipeline rules re-checked
 cd "$GRAFT_REPO_ROOT"
 for g in 0 1 2 3 4; do
   export JPT_GROUPS=$g

@@ -1,3 +1,5 @@
+#!/bin/bash
+# the hand-over of long walks to wf2_long forced on the small scenes (JPT_COOP=1, JPT_COOP_ROUNDS=4..64): why it is off there
 cd "$GRAFT_REPO_ROOT"
 for r in 0 4 8 16 32 64; do
   if [ $r = 0 ]; then export JPT_COOP=0; else export JPT_COOP=1 JPT_COOP_ROUNDS=$r; fi

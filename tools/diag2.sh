@@ -1,4 +1,5 @@
 #!/bin/bash
+# a second set of SQ counter passes (instruction fetch, branches, SALU / VMEM cycles, LDS waits and conflicts) for the bench's kernels
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 export JPT_PIPELINE=0 JPT_GROUPS=1   # counters per kernel: launches one after another

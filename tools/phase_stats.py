@@ -1,3 +1,4 @@
+# event counters and wave phase statistics of C3 renders with 0 / 1 / 4 bounces (counting renders)
 import sys; sys.path.insert(0,'.')
 from gdpathtracing_amd import capi, host, scenes
 sc=scenes.demo_scene(51200); W,H=1920,1080

@@ -1,3 +1,5 @@
+#!/bin/bash
+# tracing kernels built for eight waves per SIMD (19 LDS stack entries) against the default seven: builds on the box, rates
 cd "$GRAFT_REPO_ROOT"
 make -s -C gdpathtracing_amd/csrc -j8 OUT=/tmp/libjpt_w8.so OBJDIR=/tmp/obj_w8 EXTRA="-DJPT_WAVES_PER_SIMD=8 -DJPT_STACK_LDS=19 -DJPT_PRIMARY_WAVES=8" > /tmp/build_w8.log 2>&1 || tail -3 /tmp/build_w8.log
 make -s -C gdpathtracing_amd/csrc -j8 OUT=/tmp/libjpt_w8b.so OBJDIR=/tmp/obj_w8b EXTRA="-DJPT_WAVES_PER_SIMD=8 -DJPT_STACK_LDS=19" > /tmp/build_w8b.log 2>&1 || tail -3 /tmp/build_w8b.log

@@ -1,3 +1,5 @@
+#!/bin/bash
+# (round 2) the render window: GPU tests, A/B against a previous library, run lengths at three sizes
 cd "$GRAFT_REPO_ROOT"
 timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -3
 bash tools/ab.sh new:- prev:$PWD/gdpathtracing_amd/libjpt_prev.so 2>&1 | tail -10
