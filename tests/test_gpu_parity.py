@@ -76,6 +76,33 @@ def test_demo_scene_multi_frame(oracle, hiplib, builder, kernel):
         assert np.array_equal(got_ldr, want_ldr)
 
 
+@pytest.mark.parametrize("mode", [wire.ACCUM_REF_LDR8, wire.ACCUM_HDR_F32])
+@pytest.mark.parametrize("frames", [19, 33])
+def test_many_frames_of_an_odd_count(oracle, hiplib, frames, mode):
+    """Frame counts that divide nothing: more frames than a wave has room for whole pixels (a primary wave takes 64 consecutive
+    path ids = slot * n_frames + frame, so a pixel's samples straddle waves), more than wf2_accumulate's shared sky route holds
+    (16), and a continuation render whose first frame is not 1.  Against the oracle, blocking and queued."""
+    sc = scenes.demo_scene(1500)
+    w, h, bounces = 88, 56, 2
+    cam = scenes.camera_block(sc.camera, w, h)
+    ref = oracle.build_scene(sc)
+    want, want_ldr, want_depth, _, _ = oracle.render(ref, cam, w, h, bounces, frames, 1, mode)
+    for asynchronous in (False, True):
+        ctx = host.Context(0)
+        ctx.upload_reference_layout(ref.tri_geom, ref.tri_data, ref.materials, ref.bvh_nodes, ref.instances, ref.tlas_nodes, ref.textures,
+                                    as_given=True)          # (the reference's own trees: bit-identical walks)
+        ctx.set_params(w, h, bounces, mode)
+        ctx.set_camera(cam)
+        first = frames // 3
+        ctx.render(first, 1, asynchronous=asynchronous)
+        ctx.render(frames - first, 1 + first, asynchronous=asynchronous)
+        ctx.sync()
+        assert np.array_equal(ctx.read_accum(), want)
+        assert np.array_equal(ctx.read_ldr(), want_ldr)
+        assert np.array_equal(ctx.read_depth(), want_depth)
+        ctx.close()
+
+
 # ---- moving instances: TLAS update without a rebuild (SURVEY.md 8(f)-3) -------------------------------------
 
 def _moved(scene, moves):
