@@ -1,0 +1,58 @@
+"""Register budgets of the hot kernels (CPU: hipcc cross-compiles to ISA without a GPU).  A queued render shares every SIMD's 512
+vector registers between the launches of four renders, and round 4's two largest steps were register steps -- wf2_shade from 90 to
+67 / 72 registers (seven waves per SIMD instead of five: -8 % on C3), an inlined cooperative walk that cost the tracing loop spills
+(+10-20 %) -- so the budgets DESIGN.md section 4 quotes are pinned here: a change that silently costs a kernel a wave per SIMD, or
+puts scratch traffic into the record loop, fails on the CPU before it is measured on the GPU."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "gdpathtracing_amd", "csrc", "jpt_kernels_wf2.hip")
+
+# kernel (mangled-name fragment) -> (most VGPRs, most bytes of scratch per lane, most scratch instructions in the body)
+BUDGETS = {
+    "9wf2_traceILb0ELb1ELi0E": (72, 320, 12),       # seven waves per SIMD; scratch = the stack entries past the LDS part, rarely touched
+    "9wf2_traceILb0ELb1ELi2E": (72, 1024, 80),      # ... with the tail phase's out-of-line call behind the loop
+    "11wf2_primaryILb0ELb1ELi0E": (72, 320, 12),
+    "11wf2_primaryILb0ELb1ELi2E": (72, 1100, 90),
+    "9wf2_shadeILb0ELb0ELi0E": (72, 0, 0),          # no texture array: 67
+    "9wf2_shadeILb0ELb0ELi1E": (72, 0, 0),          # nearest filter
+    "9wf2_shadeILb0ELb0ELi2E": (72, 0, 0),          # linear filter
+    "9wf2_shadeILb0ELb1ELi0E": (64, 0, 0),          # the paths' last vertices: eight waves
+}
+
+
+@pytest.fixture(scope="module")
+def isa(tmp_path_factory):
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc in this environment")
+    out = str(tmp_path_factory.mktemp("isa") / "wf2.s")
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize"]   # csrc/Makefile's
+    r = subprocess.run([hipcc] + flags + ["-S", "--cuda-device-only", "-o", out, SRC], stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                       text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:]
+    return open(out).read()
+
+
+@pytest.mark.parametrize("kernel", sorted(BUDGETS))
+def test_hot_kernels_keep_their_register_budgets(isa, kernel):
+    vgprs, scratch, scratch_ops = BUDGETS[kernel]
+    m = re.search(r"\.name:\s+_ZN3jpt12_GLOBAL__N_1" + kernel + r"\S*\n\s+\.private_segment_fixed_size: (\d+).*?\.vgpr_count:\s+(\d+)", isa, re.S)
+    assert m, "kernel not found in the ISA: " + kernel
+    body = re.search(r"\n_ZN3jpt12_GLOBAL__N_1" + kernel + r"\S*:.*?s_endpgm", isa, re.S).group(0)
+    got = (int(m.group(2)), int(m.group(1)), len(re.findall(r"\bscratch_(?:load|store)", body)))
+    print(kernel, "vgprs %d scratch %d B scratch instructions %d" % got)
+    assert got[0] <= vgprs, "%s: %d VGPRs, budget %d (a wave per SIMD less)" % (kernel, got[0], vgprs)
+    assert got[1] <= scratch and got[2] <= scratch_ops, "%s: scratch %d B / %d instructions, budget %d / %d (spills?)" % (
+        kernel, got[1], got[2], scratch, scratch_ops)
+
+
+def test_the_makefile_builds_with_the_flags_priced_here():
+    mk = open(os.path.join(ROOT, "gdpathtracing_amd", "csrc", "Makefile")).read()
+    for f in ("-O3", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize"):
+        assert f in mk
