@@ -161,6 +161,7 @@ struct jpt_ctx {
     hipEvent_t ev_set_retired[kInstanceSets] = {}, ev_refit_done = nullptr;
     bool set_retired_valid[kInstanceSets] = {};
     uint64_t refit_wait_seq = 0, slot_refit_seen[kPipeSlots] = {};
+    int idle_streak = 0;   // queued renders in a row that found nothing in flight (do_render_batch)
     DevBuf<uint32_t> d_tlas4_order, d_tlas4_levels;
     uint32_t n_tlas4_levels = 0;
     bool refit_active = false;         // the device's instance level is ahead of the host mirrors (and of the other kernels' arrays)
@@ -789,7 +790,21 @@ int do_render_batch(jpt_ctx* c, int32_t n_frames, uint32_t first_frame_index, bo
             const bool huge = one_workspace > ((size_t)24 << 30);  // 4 x 24 GiB of workspaces is where this stops
             const int pipe_slots = forced_slots ? forced_slots : (huge ? 2 : 4);
             const int slot = (int)(c->async_seq % (uint64_t)pipe_slots);
-            if (wf2 && pipelining && !blocking && !counted && !need_ev && ensure_pipe_slot(c, slot)) {
+            // A host that queues ONE render at a time (jpt_render_async, its own work, jpt_sync or the split read-back, again)
+            // never has a second render in flight: the pipelined form's quarter-width launches then run alone, and a render takes
+            // half as long again as a blocking one (C3 1.93 against 1.26 ms, 3840 x 2160 x 4 spp 3.33 against 2.11:
+            // tools/lone_async_probe.py).  The third queued render in a row that finds nothing in flight -- the event every render
+            // leaves on the context's stream has completed -- is launched like a blocking one instead (frame groups, full-width
+            // launches; nobody waits for it here), and so on until a render finds work in flight.  A queue of renders is not
+            // affected: only its first render finds the pipeline empty.  (JPT_LONE_ASYNC=0: never.)
+            bool lone_async = false;
+            if (wf2 && pipelining && !blocking && !counted && !need_ev) {
+                const bool idle = hipEventQuery(c->ev1) == hipSuccess;
+                (void)hipGetLastError();   // (hipErrorNotReady is an answer, not an error)
+                c->idle_streak = idle ? c->idle_streak + 1 : 0;
+                lone_async = tuning().lone_async && c->idle_streak >= 3;
+            }
+            if (wf2 && pipelining && !blocking && !counted && !need_ev && !lone_async && ensure_pipe_slot(c, slot)) {
                 // asynchronous render: path kernels on a helper stream + the other workspace; the accumulation on `s`
                 hipStream_t ps = c->pipe_stream[slot];
                 DevBuf<char>& ws = slot ? c->d_workspace_more[slot - 1] : c->d_workspace;

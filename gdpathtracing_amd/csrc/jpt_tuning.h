@@ -35,6 +35,7 @@ struct Tuning {
     int xcd_band_rows = 0;         // JPT_XCD_BAND_ROWS=n: the primary launch deals bands of n tile rows to the blocks that share an XCD (0: off)
     int coop = -1;                 // JPT_COOP=0/1: long walks handed over to a whole wave (coop_walk) never / always (-1: scenes of >= 200 000 triangles)
     int coop_rounds = 128;         // JPT_COOP_ROUNDS: ... a ray still walking this many rounds after its block's queue ran dry
+    int lone_async = 1;            // JPT_LONE_ASYNC=0: queued renders that find the pipeline empty are never launched like blocking ones
     int node_order = 0;            // JPT_NODE_ORDER=1: the four-child records of siblings next to each other (0: depth first)
     int primary_samples = -1;      // JPT_PRIMARY_SAMPLES=0/1: a wave of the primary launch takes one frame's sample of an 8 x 8 tile / every frame's
                                    // sample of 64 / n_frames pixels of a tile (-1: the library's rule)
@@ -80,6 +81,7 @@ inline const Tuning& tuning()
         v.coop = geti("JPT_COOP", -1);
         v.coop_rounds = geti("JPT_COOP_ROUNDS", 128);
         if (v.coop_rounds < 1) v.coop_rounds = 1;
+        v.lone_async = geti("JPT_LONE_ASYNC", 1);
         v.node_order = geti("JPT_NODE_ORDER", 0);
         v.primary_samples = geti("JPT_PRIMARY_SAMPLES", -1);
         v.tail = geti("JPT_TAIL", -1);

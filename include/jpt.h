@@ -334,7 +334,9 @@ int jpt_render_counted(jpt_ctx *ctx, int32_t n_frames, uint32_t first_frame_inde
  * tails overlap the next render's kernels), the accumulation kernels run in call order (chained by events through
  * the ctx stream, which waits for each of them: work queued on the ctx stream afterwards sees the result), so the
  * framebuffers hold exactly what serial execution would leave (C3: 1.78 -> 1.28 ms per render when queued; up to four
- * renders are in flight, each with its own workspace). */
+ * renders are in flight, each with its own workspace).  A host that keeps only ONE render in flight (enqueue, own work,
+ * jpt_sync or a read, enqueue ...) is recognised after its third such render and served like jpt_render from then on
+ * (the pipelined launches are narrow: alone they take half as long again), still without blocking the caller. */
 int jpt_render_async(jpt_ctx *ctx, int32_t n_frames, uint32_t first_frame_index);
 int jpt_sync(jpt_ctx *ctx);
 
