@@ -2,7 +2,8 @@
 //
 // All `n_frames` frames of a render are in flight at once as independent paths (pixel x frame); per-pixel
 // RNG streams (main.glsl:409, :386) are carried with the path, so the schedule cannot change results.
-// The grid is G persistent blocks.  Block s owns SEGMENT s of every queue: the screen's 8x8 tiles (x frames)
+// The grid is G persistent blocks.  Block s owns SEGMENT s of every queue: chunks of 64 consecutive path ids
+// (path = pixel slot * n_frames + frame: every frame's sample of a few neighbouring pixels of an 8x8 tile)
 // are dealt round-robin to segments, so each segment is a uniform sample of the image and all hand-offs
 // between kernels stay inside a segment -- no global atomics anywhere on the path.
 //
@@ -11,7 +12,10 @@
 //   wf2_shade    one path vertex per queue entry (main.glsl:378-397 + brdfs.glsl); survivors' next rays are
 //                packed to the front of the segment's next queue (wave ballot + prefix popcount + LDS base).
 //   wf2_trace    bounces >= 1: closest hit of every queued ray.
+//   wf2_finish   the few paths wf2_shade set aside (hits the reference's traversal cannot reach, exact distance ties).
 //   wf2_accumulate  frames IN ORDER per pixel (progressive_rendering.glsl:33-37), display image, depth.
+//   (large scenes: the tracing kernels' COOP == 2 instantiations finish their few very long walks with a whole wave per
+//   ray, coop_walk_call; COOP == 1 hands them to the follow-up launch wf2_long instead)
 //
 // Tracing kernels keep every lane busy: a lane whose ray is finished takes the next ray of the block's
 // segment (cursor in LDS) while its neighbours keep walking -- the wave never waits for its slowest ray.

@@ -736,6 +736,44 @@ def test_asynchronous_renders_pipeline_in_order(oracle, hiplib):
     assert np.array_equal(a[1][0], want) and np.array_equal(a[1][1], want_ldr)
 
 
+def test_one_render_in_flight_at_a_time_then_a_burst(oracle, hiplib):
+    """A host that queues one render, waits, queues the next: from the third such render on the library launches them like
+    blocking renders (frame groups, full-width launches: jpt_capi.hip, `lone_async`), and goes back to the pipelined form as soon
+    as a render finds work in flight.  Eight renders continuing one accumulation -- five one at a time (sync, read-back or the
+    split read-back in between), then a burst of three -- leave what the same frames leave through jpt_render, and that is the
+    oracle's image."""
+    sc = scenes.demo_scene(2500)
+    w, h, bounces = 200, 120, 3
+    cam = scenes.camera_block(sc.camera, w, h)
+    calls = [(2, 1), (1, 3), (2, 4), (3, 6), (1, 9), (2, 10), (2, 12), (1, 14)]
+
+    def run(asynchronous):
+        ctx = make_ctx(sc, w, h, bounces, wire.ACCUM_REF_LDR8, capi.BUILD_REFERENCE_EXACT)
+        mid = None
+        for k, (n, first) in enumerate(calls):
+            ctx.render(n, first, asynchronous=asynchronous)
+            if k < 5:                                   # one at a time
+                if k == 1:
+                    ctx.read_ldr()
+                elif k == 3:
+                    ctx.readback_ldr_begin()
+                    ctx.readback_ldr_end()
+                else:
+                    ctx.sync()
+            if k == 4:
+                mid = ctx.read_accum()
+        out = (mid, ctx.read_accum(), ctx.read_ldr(), ctx.read_depth())
+        ctx.close()
+        return out
+
+    a, b = run(True), run(False)
+    for u, v in zip(a, b):
+        assert np.array_equal(u, v)
+    ref = oracle.build_scene(sc)
+    want, want_ldr, _, _, _ = oracle.render(ref, cam, w, h, bounces, 14, 1, wire.ACCUM_REF_LDR8)
+    assert np.array_equal(a[1], want) and np.array_equal(a[2], want_ldr)
+
+
 def test_memory_policy_caps_the_workspaces_and_keeps_the_image(hiplib):
     """jpt_set_memory_policy: queued renders with four, two and one workspace in flight, and with a budget per workspace
     that forces batches of frames, leave the same accumulation buffer; jpt_get_workspace_bytes shows the cap taking
