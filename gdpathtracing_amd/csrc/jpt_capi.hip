@@ -972,7 +972,7 @@ int do_render_batch(jpt_ctx* c, int32_t n_frames, uint32_t first_frame_index, bo
 
 // local strip-major rows -> full image rows, on the host
 template <typename T>
-void scatter_rows(const std::vector<T>& local, T* out, int32_t width, int32_t height, int32_t rank, int32_t world, int comps)
+void scatter_rows(const T* local, T* out, int32_t width, int32_t height, int32_t rank, int32_t world, int comps)
 {
     const int32_t n_strips = (height + kStripRows - 1) / kStripRows;
     int32_t ly = 0;
@@ -980,10 +980,28 @@ void scatter_rows(const std::vector<T>& local, T* out, int32_t width, int32_t he
         for (int32_t r = 0; r < kStripRows; r++) {
             const int32_t y = s * kStripRows + r;
             if (y >= height) break;
-            std::memcpy(out + (size_t)y * width * comps, local.data() + (size_t)ly * width * comps, (size_t)width * comps * sizeof(T));
+            std::memcpy(out + (size_t)y * width * comps, local + (size_t)ly * width * comps, (size_t)width * comps * sizeof(T));
             ly++;
         }
     }
+}
+template <typename T>
+void scatter_rows(const std::vector<T>& local, T* out, int32_t width, int32_t height, int32_t rank, int32_t world, int comps)
+{
+    scatter_rows(local.data(), out, width, height, rank, world, comps);
+}
+
+// the pinned staging buffer of the display image's read-backs (one full image)
+int ensure_ldr_pinned(jpt_ctx* c)
+{
+    if (c->h_ldr_pinned_px < (size_t)c->width * c->height) {
+        if (c->h_ldr_pinned) (void)hipHostFree(c->h_ldr_pinned);
+        c->h_ldr_pinned = nullptr;
+        c->h_ldr_pinned_px = 0;
+        HIP_TRY(c, hipHostMalloc((void**)&c->h_ldr_pinned, (size_t)c->width * c->height * sizeof(uint32_t), hipHostMallocDefault));
+        c->h_ldr_pinned_px = (size_t)c->width * c->height;
+    }
+    return JPT_OK;
 }
 
 }  // namespace
@@ -1807,17 +1825,33 @@ int jpt_read_ldr_rgba8(jpt_ctx* c, uint8_t* out)
 {
     int rc = read_common(c, out);
     if (rc) return rc;
+    // What the reference does every frame (get_image_uniform_buffer, path_tracing_camera.cpp:228-229).  The image goes through
+    // the context's PINNED staging buffer (the split read-back's) and one host copy into the caller's memory: a device-to-host
+    // copy straight into pageable memory runs at ~3 GB/s (1920 x 1080: 2.7 ms, and another millisecond for a zero-filled
+    // temporary on the way), through pinned memory the 8 MB take ~0.2 ms + the host copy.
     const size_t full = (size_t)c->width * c->height;
-    if (c->assembled || c->assembled_ldr) {
-        HIP_TRY(c, hipMemcpy(out, c->d_full_ldr.p, full * 4, hipMemcpyDeviceToHost));
+    const bool whole = c->assembled || c->assembled_ldr;
+    const size_t px = whole ? full : (size_t)c->local_rows * c->width;
+    if (c->readback_pending) {   // (the staging buffer holds a split read-back in flight: the plain way)
+        std::vector<uint32_t> local(px);
+        if (px) HIP_TRY(c, hipMemcpy(local.data(), whole ? c->d_full_ldr.p : c->d_ldr.p, px * 4, hipMemcpyDeviceToHost));
+        if (whole || c->world == 1) std::memcpy(out, local.data(), px * 4);
+        else {
+            std::memset(out, 0, full * 4);
+            scatter_rows(local, reinterpret_cast<uint32_t*>(out), c->width, c->height, c->rank, c->world, 1);
+        }
         return JPT_OK;
     }
-    std::vector<uint32_t> local((size_t)c->local_rows * c->width);
-    if (!local.empty()) HIP_TRY(c, hipMemcpy(local.data(), c->d_ldr.p, local.size() * 4, hipMemcpyDeviceToHost));
-    if (c->world == 1) std::memcpy(out, local.data(), local.size() * 4);
+    rc = ensure_ldr_pinned(c);
+    if (rc) return rc;
+    if (px) {
+        HIP_TRY(c, hipMemcpyAsync(c->h_ldr_pinned, whole ? c->d_full_ldr.p : c->d_ldr.p, px * 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    if (whole || c->world == 1) std::memcpy(out, c->h_ldr_pinned, px * 4);
     else {
         std::memset(out, 0, full * 4);
-        scatter_rows(local, reinterpret_cast<uint32_t*>(out), c->width, c->height, c->rank, c->world, 1);
+        scatter_rows(c->h_ldr_pinned, reinterpret_cast<uint32_t*>(out), c->width, c->height, c->rank, c->world, 1);
     }
     return JPT_OK;
 }
@@ -1831,11 +1865,9 @@ int jpt_readback_ldr_begin(jpt_ctx* c)
     HIP_TRY(c, hipSetDevice(c->device));
     c->readback_full = c->assembled || c->assembled_ldr;
     const size_t px = c->readback_full ? (size_t)c->width * c->height : (size_t)c->local_rows * c->width;
-    if (c->h_ldr_pinned_px < (size_t)c->width * c->height) {
-        if (c->h_ldr_pinned) (void)hipHostFree(c->h_ldr_pinned);
-        c->h_ldr_pinned = nullptr;
-        HIP_TRY(c, hipHostMalloc((void**)&c->h_ldr_pinned, (size_t)c->width * c->height * sizeof(uint32_t), hipHostMallocDefault));
-        c->h_ldr_pinned_px = (size_t)c->width * c->height;
+    {
+        const int rc = ensure_ldr_pinned(c);
+        if (rc) return rc;
     }
     if (!c->ev_readback) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_readback, hipEventDisableTiming));
     if (px)
@@ -1857,9 +1889,8 @@ int jpt_readback_ldr_end(jpt_ctx* c, uint8_t* out)
     if (c->readback_full || c->world == 1) {
         std::memcpy(out, c->h_ldr_pinned, full * 4);
     } else {
-        std::vector<uint32_t> local(c->h_ldr_pinned, c->h_ldr_pinned + (size_t)c->local_rows * c->width);
         std::memset(out, 0, full * 4);
-        scatter_rows(local, reinterpret_cast<uint32_t*>(out), c->width, c->height, c->rank, c->world, 1);
+        scatter_rows(c->h_ldr_pinned, reinterpret_cast<uint32_t*>(out), c->width, c->height, c->rank, c->world, 1);
     }
     return JPT_OK;
 }

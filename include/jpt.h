@@ -372,7 +372,9 @@ int jpt_set_temporal_params(jpt_ctx *ctx, const void *render_parameters88);
 /* ---- outputs ---------------------------------------------------------------------------------- */
 
 /* replaces: cs->get_image_uniform_buffer(output_texture_rid) (path_tracing_camera.cpp:228-229):
- * W*H*4 bytes, the screen image after ACES(sum / frame_count) (progressive_rendering.glsl:39-45). */
+ * W*H*4 bytes, the screen image after ACES(sum / frame_count) (progressive_rendering.glsl:39-45).  Waits for the work
+ * queued on the context; the bytes travel through the context's pinned staging buffer and one host copy, so `out` may be
+ * ordinary (pageable) memory without the copy running at pageable speed. */
 int jpt_read_ldr_rgba8(jpt_ctx *ctx, uint8_t *out);
 /* Split form of jpt_read_ldr_rgba8 for double-buffered display (the reference stalls on
  * the read-back every frame, path_tracing_camera.cpp:228-230): `begin` enqueues the device->host copy of the
