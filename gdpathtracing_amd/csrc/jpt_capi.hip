@@ -169,6 +169,8 @@ struct jpt_ctx {
     std::vector<uint32_t> tlas4_order_h, tlas4_levels_h;   // the refit schedule, host copy
     uint32_t* h_ldr_pinned = nullptr;
     size_t h_ldr_pinned_px = 0;
+    void* h_read_pinned = nullptr;   // blocking read-backs (staged_read)
+    size_t h_read_bytes = 0;
     hipEvent_t ev_readback = nullptr;
     bool readback_pending = false;
     bool readback_full = false;  // the read-back in flight copies the assembled image (else: this context's rows)
@@ -991,7 +993,27 @@ void scatter_rows(const std::vector<T>& local, T* out, int32_t width, int32_t he
     scatter_rows(local.data(), out, width, height, rank, world, comps);
 }
 
-// the pinned staging buffer of the display image's read-backs (one full image)
+// Blocking read-backs (jpt_read_ldr_rgba8 / accum_f32 / depth_f32): device -> the context's pinned read buffer -> the caller's
+// memory.  A device-to-host copy straight into pageable memory runs at ~3 GB/s (8 MB of display image: 2.7 ms; 33 MB of float4
+// sums: 11 ms); through pinned memory the copy runs at the link's rate and the host copy at memory speed.  (A buffer of its
+// own: the split read-back's staging buffer may hold an image in flight.)
+int staged_read(jpt_ctx* c, const void* src, size_t bytes)
+{
+    if (c->h_read_bytes < bytes) {
+        if (c->h_read_pinned) (void)hipHostFree(c->h_read_pinned);
+        c->h_read_pinned = nullptr;
+        c->h_read_bytes = 0;
+        HIP_TRY(c, hipHostMalloc(&c->h_read_pinned, bytes, hipHostMallocDefault));
+        c->h_read_bytes = bytes;
+    }
+    if (bytes) {
+        HIP_TRY(c, hipMemcpyAsync(c->h_read_pinned, src, bytes, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    return JPT_OK;
+}
+
+// the pinned staging buffer of the display image's split read-backs (one full image)
 int ensure_ldr_pinned(jpt_ctx* c)
 {
     if (c->h_ldr_pinned_px < (size_t)c->width * c->height) {
@@ -1064,6 +1086,7 @@ void jpt_destroy(jpt_ctx* c)
     for (hipEvent_t e : c->trace_events) (void)hipEventDestroy(e);
     if (c->ev_readback) (void)hipEventDestroy(c->ev_readback);
     if (c->h_ldr_pinned) (void)hipHostFree(c->h_ldr_pinned);
+    if (c->h_read_pinned) (void)hipHostFree(c->h_read_pinned);
     if (c->refit_stream) { (void)hipStreamSynchronize(c->refit_stream); (void)hipStreamDestroy(c->refit_stream); }
     for (int k = 0; k < jpt_ctx::kInstanceSets; k++) if (c->ev_set_retired[k]) (void)hipEventDestroy(c->ev_set_retired[k]);
     if (c->ev_refit_done) (void)hipEventDestroy(c->ev_refit_done);
@@ -1825,33 +1848,16 @@ int jpt_read_ldr_rgba8(jpt_ctx* c, uint8_t* out)
 {
     int rc = read_common(c, out);
     if (rc) return rc;
-    // What the reference does every frame (get_image_uniform_buffer, path_tracing_camera.cpp:228-229).  The image goes through
-    // the context's PINNED staging buffer (the split read-back's) and one host copy into the caller's memory: a device-to-host
-    // copy straight into pageable memory runs at ~3 GB/s (1920 x 1080: 2.7 ms, and another millisecond for a zero-filled
-    // temporary on the way), through pinned memory the 8 MB take ~0.2 ms + the host copy.
+    // What the reference does every frame (get_image_uniform_buffer, path_tracing_camera.cpp:228-229): through staged_read.
     const size_t full = (size_t)c->width * c->height;
     const bool whole = c->assembled || c->assembled_ldr;
     const size_t px = whole ? full : (size_t)c->local_rows * c->width;
-    if (c->readback_pending) {   // (the staging buffer holds a split read-back in flight: the plain way)
-        std::vector<uint32_t> local(px);
-        if (px) HIP_TRY(c, hipMemcpy(local.data(), whole ? c->d_full_ldr.p : c->d_ldr.p, px * 4, hipMemcpyDeviceToHost));
-        if (whole || c->world == 1) std::memcpy(out, local.data(), px * 4);
-        else {
-            std::memset(out, 0, full * 4);
-            scatter_rows(local, reinterpret_cast<uint32_t*>(out), c->width, c->height, c->rank, c->world, 1);
-        }
-        return JPT_OK;
-    }
-    rc = ensure_ldr_pinned(c);
+    rc = staged_read(c, whole ? c->d_full_ldr.p : c->d_ldr.p, px * 4);
     if (rc) return rc;
-    if (px) {
-        HIP_TRY(c, hipMemcpyAsync(c->h_ldr_pinned, whole ? c->d_full_ldr.p : c->d_ldr.p, px * 4, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
-    }
-    if (whole || c->world == 1) std::memcpy(out, c->h_ldr_pinned, px * 4);
+    if (whole || c->world == 1) std::memcpy(out, c->h_read_pinned, px * 4);
     else {
         std::memset(out, 0, full * 4);
-        scatter_rows(c->h_ldr_pinned, reinterpret_cast<uint32_t*>(out), c->width, c->height, c->rank, c->world, 1);
+        scatter_rows(static_cast<const uint32_t*>(c->h_read_pinned), reinterpret_cast<uint32_t*>(out), c->width, c->height, c->rank, c->world, 1);
     }
     return JPT_OK;
 }
@@ -1903,19 +1909,18 @@ int jpt_read_accum_f32(jpt_ctx* c, float* out)
     if (c->denoise == JPT_DENOISE_TEMPORAL) {
         // the rgba32f image of this mode is the history image the last pass wrote
         if (!c->hist_written) return fail(c, JPT_E_STATE, "no temporal pass has run since the last reset");
-        HIP_TRY(c, hipMemcpy(out, c->hist_written, full * sizeof(float4), hipMemcpyDeviceToHost));
+        rc = staged_read(c, c->hist_written, full * sizeof(float4));
+        if (rc) return rc;
+        std::memcpy(out, c->h_read_pinned, full * sizeof(float4));
         return JPT_OK;
     }
-    if (c->assembled) {
-        HIP_TRY(c, hipMemcpy(out, c->d_full_accum.p, full * sizeof(float4), hipMemcpyDeviceToHost));
-        return JPT_OK;
-    }
-    std::vector<float> local((size_t)c->local_rows * c->width * 4);
-    if (!local.empty()) HIP_TRY(c, hipMemcpy(local.data(), c->d_accum.p, local.size() * 4, hipMemcpyDeviceToHost));
-    if (c->world == 1) std::memcpy(out, local.data(), local.size() * 4);
+    const size_t n = c->assembled ? full * 4 : (size_t)c->local_rows * c->width * 4;   // floats
+    rc = staged_read(c, c->assembled ? (const void*)c->d_full_accum.p : (const void*)c->d_accum.p, n * sizeof(float));
+    if (rc) return rc;
+    if (c->assembled || c->world == 1) std::memcpy(out, c->h_read_pinned, n * sizeof(float));
     else {
         std::memset(out, 0, full * 16);
-        scatter_rows(local, out, c->width, c->height, c->rank, c->world, 4);
+        scatter_rows(static_cast<const float*>(c->h_read_pinned), out, c->width, c->height, c->rank, c->world, 4);
     }
     return JPT_OK;
 }
@@ -1925,12 +1930,13 @@ int jpt_read_depth_f32(jpt_ctx* c, float* out)
     int rc = read_common(c, out);
     if (rc) return rc;
     const size_t full = (size_t)c->width * c->height;
-    std::vector<float> local((size_t)c->local_rows * c->width);
-    if (!local.empty()) HIP_TRY(c, hipMemcpy(local.data(), c->d_depth.p, local.size() * 4, hipMemcpyDeviceToHost));
-    if (c->world == 1) std::memcpy(out, local.data(), local.size() * 4);
+    const size_t n = (size_t)c->local_rows * c->width;
+    rc = staged_read(c, c->d_depth.p, n * sizeof(float));
+    if (rc) return rc;
+    if (c->world == 1) std::memcpy(out, c->h_read_pinned, n * sizeof(float));
     else {
         std::memset(out, 0, full * 4);
-        scatter_rows(local, out, c->width, c->height, c->rank, c->world, 1);
+        scatter_rows(static_cast<const float*>(c->h_read_pinned), out, c->width, c->height, c->rank, c->world, 1);
     }
     return JPT_OK;
 }
