@@ -383,7 +383,7 @@ int jpt_read_ldr_rgba8(jpt_ctx *ctx, uint8_t *out);
  * the bytes out.  One read-back may be in flight per context. */
 int jpt_readback_ldr_begin(jpt_ctx *ctx);
 int jpt_readback_ldr_end(jpt_ctx *ctx, uint8_t *out);
-/* the rgba32f frameBuffer (progressive_rendering.glsl:10,37): W*H*4 floats */
+/* the rgba32f frameBuffer (progressive_rendering.glsl:10,37): W*H*4 floats (like every jpt_read_*: through pinned staging) */
 int jpt_read_accum_f32(jpt_ctx *ctx, float *out);
 /* the r32f depthBuffer (main.glsl:99,435), last frame: W*H floats */
 int jpt_read_depth_f32(jpt_ctx *ctx, float *out);
