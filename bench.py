@@ -59,14 +59,11 @@ def rel_l2(a, b):
 
 
 def self_launch(n):
-    """python -m torch.distributed.run --nnodes=1 --nproc-per-node n ... bench.py <the same arguments>, as a child process"""
-    import socket
+    """python -m torch.distributed.run --nnodes=1 --nproc-per-node n ... bench.py <the same arguments>, as a child process.
+    --standalone: the launcher's own rendezvous picks its port (a port probed here and closed again could be taken in between)"""
     import subprocess
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1", "--nproc-per-node", str(n),
+           os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL between processes needs it on this driver
     p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
@@ -110,6 +107,8 @@ def main_multi(args):
     t0 = time.time()
     m.build_scene(sc, builder)
     build_s = time.time() - t0
+    for r in range(n):
+        m.ctx(r).set_outputs(depth=args.depth)
     m.set_gather(args.gather == "ldr")
 
     def sync_all():
@@ -217,6 +216,12 @@ def main():
                     help="N > 1: torchrun = one process per GPU under torch.distributed (RCCL gather; started as a child process "
                          "when WORLD_SIZE is not set) -- the driver's mode; multi = ONE process, one context per device through "
                          "jpt_multi_* (what the addon's C++ host uses): every peer pushes its rows to device 0 on its own copy stream")
+    ap.add_argument("--project-ranks", type=int, default=8,
+                    help="N = 1 only: time every rank's share of C3 and of C5 under jpt_set_partition(r, n) for n = 2, 4, .. up to this "
+                         "on the ONE device, add the modelled link time of the gather (piece bytes / 153 GB/s per xGMI link, every peer "
+                         "on its own link) and the measured assembly, and report it as `projected_scaling` (measured: false) -- what "
+                         "the line can say about 2/4/8 GPUs without a multi-GPU node; 0 or 1: skip")
+    ap.add_argument("--depth", action="store_true", help="also produce the r32f depth image every render (only the temporal mode reads it)")
     ap.add_argument("--cpu-sample", default="auto")
     ap.add_argument("--pmc-json", default=os.path.join(ROOT, "profiles", "current_pmc.json"),
                     help="per-launch HBM bytes of each kernel from the committed rocprofv3 --pmc passes (tools/pmc.sh)")
@@ -238,8 +243,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if "WORLD_SIZE" in os.environ and args.launcher == "multi":
+        raise SystemExit("bench.py: --launcher multi is ONE process over all devices; it cannot run under torch.distributed.run (WORLD_SIZE is set)")
     if world != args.gpus:
-        args.gpus = world          # (under torch.distributed.run the launcher's world size is the truth)
+        # a run asked for N GPUs must not report an n_gpus = 1 line with status 0: the launcher's world size and
+        # --gpus have to agree (the driver passes both)
+        raise SystemExit("bench.py: --gpus %d but the launcher's WORLD_SIZE is %d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     # JPT_BENCH_BACKEND=gloo is a functional rehearsal of the N > 1 flow on a box with fewer GPUs than ranks
@@ -295,6 +304,9 @@ def main():
         ctx.upload_reference_layout(*arrs, textures=sc.textures, as_given=args.route == "upload-given")
         build_s = time.time() - t0
     ctx.set_partition(rank, world)
+    # the r32f depth image (main.glsl:435) has one reader, TemporalReprojection; the benchmarked mode is progressive rendering,
+    # where nothing ever reads it: not produced (jpt_set_outputs; --depth keeps it)
+    ctx.set_outputs(depth=args.depth)
     ctx.set_params(W, H, bounces, accum_mode)
     ctx.set_camera(cam)
     ctx.set_kernel({"wavefront": capi.KERNEL_WAVEFRONT, "ref": capi.KERNEL_REFERENCE_LAYOUT}[args.kernel])
@@ -500,6 +512,99 @@ def main():
         ctx.set_camera(cam)
         setup_gather()
 
+    # ---- what 2 / 4 / 8 GPUs would do, projected from ONE: each rank's share timed here, the link modelled (VERDICT r04 task 2) ----
+    projected = None
+    if world == 1 and args.project_ranks > 1 and args.kernel == "wavefront":
+        XGMI_LINK_GBS = 153.0     # ~153 GB/s per xGMI link, one link per peer pair
+        LINK_LATENCY_MS = 0.01    # one peer copy's fixed cost (order of magnitude of a hipMemcpyPeerAsync on an idle link)
+
+        def project_config(w, h, n_spp, n_bounces, n_steps, whole_ms, whole_rays):
+            pcam = scenes.camera_block(sc.camera, w, h)
+            res = {}
+            n = 2
+            while n <= args.project_ranks:
+                per_rank, rays_rank = [], []
+                for r in range(n):
+                    ctx.set_partition(r, n)
+                    ctx.set_params(w, h, n_bounces, accum_mode)
+                    ctx.set_camera(pcam)
+                    ctx.accum_reset()
+                    ctx.render(n_spp, 1)
+                    rays_rank.append(ctx.stats()["rays"])
+                    for _ in range(3):
+                        ctx.accum_reset()
+                        ctx.render(n_spp, 1, asynchronous=True)
+                    barrier()
+                    t0 = time.perf_counter()
+                    for _ in range(n_steps):
+                        ctx.accum_reset()
+                        ctx.render(n_spp, 1, asynchronous=True)
+                    barrier()
+                    per_rank.append((time.perf_counter() - t0) / n_steps * 1e3)
+                # rank 0's assembly of the gathered float4 rows, measured (the other ranks' pieces: whatever the buffer holds)
+                ctx.set_partition(0, n)
+                ctx.set_params(w, h, n_bounces, accum_mode)
+                ctx.set_camera(pcam)
+                ctx.accum_reset()
+                ctx.render(n_spp, 1)
+                piece_rows = partition.max_local_rows(h, n)
+                gathered = torch.zeros((n, piece_rows * w * 4), dtype=torch.float32, device="cuda")
+                ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+                ctx.assemble_from_ranks(gathered.data_ptr(), n)
+                barrier()
+                ev[0].record(stream)
+                for _ in range(5):
+                    ctx.assemble_from_ranks(gathered.data_ptr(), n)
+                ev[1].record(stream)
+                barrier()
+                assemble_ms = ev[0].elapsed_time(ev[1]) / 5
+                del gathered
+                piece_bytes = piece_rows * w * 16
+                gather_ms = piece_bytes / (XGMI_LINK_GBS * 1e9) * 1e3 + LINK_LATENCY_MS    # n - 1 peers, each on its own link, side by side
+                serial = max(per_rank) + gather_ms + assemble_ms
+                overlapped = max(max(per_rank), gather_ms + assemble_ms)   # gather + assembly of render k behind render k + 1 (queued steps)
+                res[str(n)] = dict(rank_ms=[round(x, 4) for x in per_rank], rank_ms_max=round(max(per_rank), 4), rank_ms_mean=round(float(np.mean(per_rank)), 4),
+                                   rays_per_rank=rays_rank, rays_sum_equals_whole=bool(sum(rays_rank) == whole_rays),
+                                   piece_bytes=int(piece_bytes), gather_ms_modelled=round(gather_ms, 4), assemble_ms_measured=round(assemble_ms, 4),
+                                   step_ms_serial=round(serial, 4), step_ms_overlapped=round(overlapped, 4),
+                                   speedup_serial=round(whole_ms / serial, 3), speedup_overlapped=round(whole_ms / overlapped, 3),
+                                   mrays_overlapped=round(whole_rays / overlapped / 1e3, 1))
+                n *= 2
+            return res
+
+        c3_ms = elapsed / args.steps * 1e3
+        projected = {"measured": False,
+                     "method": "every rank's share (jpt_set_partition(r, n): 8-row strips dealt round-robin) rendered on THIS device, queued like the headline; "
+                               "gather = piece bytes / %.0f GB/s (one xGMI link per peer, all peers at once) + %.0f us; assembly measured on this device; "
+                               "speedup = one GPU's ms_per_step / (slowest rank + gather + assembly [serial], or their maximum [overlapped: queued steps])"
+                               % (XGMI_LINK_GBS, LINK_LATENCY_MS * 1e3),
+                     "c3": dict(one_gpu_ms=round(c3_ms, 4), ranks=project_config(W, H, spp, bounces, max(10, args.steps // 2), c3_ms, rays))}
+        # C5 (3840x2160, 16 spp, 6 bounces): one GPU's own rate first
+        W5, H5, SPP5, B5 = 3840, 2160, 16, 6
+        ctx.set_partition(0, 1)
+        ctx.set_params(W5, H5, B5, accum_mode)
+        ctx.set_camera(scenes.camera_block(sc.camera, W5, H5))
+        ctx.accum_reset()
+        ctx.render(SPP5, 1)
+        rays5 = ctx.stats()["rays"]
+        for _ in range(2):
+            ctx.accum_reset()
+            ctx.render(SPP5, 1, asynchronous=True)
+        barrier()
+        steps5 = max(5, args.steps // 5)
+        t0 = time.perf_counter()
+        for _ in range(steps5):
+            ctx.accum_reset()
+            ctx.render(SPP5, 1, asynchronous=True)
+        barrier()
+        c5_ms = (time.perf_counter() - t0) / steps5 * 1e3
+        projected["c5"] = dict(one_gpu_ms=round(c5_ms, 4), rays_per_step=rays5, one_gpu_mrays=round(rays5 / c5_ms / 1e3, 1),
+                               ranks=project_config(W5, H5, SPP5, B5, steps5, c5_ms, rays5))
+        ctx.set_partition(0, 1)
+        ctx.set_params(W, H, bounces, accum_mode)
+        ctx.set_camera(cam)
+        ctx.accum_reset()
+
     # the close-up camera on the same context: every pixel sees geometry, so rays/s here is the traversal rate proper
     closeup = None
     if world == 1 and args.camera == "demo" and args.scene == "demo" and not args.no_closeup:
@@ -526,6 +631,7 @@ def main():
         dctx.upload_reference_layout(*arrs, textures=sc.textures)
         upload_s = time.perf_counter() - t0
         kind = dctx.tree_kind()
+        dctx.set_outputs(depth=args.depth)
         dctx.set_params(W, H, bounces, accum_mode)
         dctx.set_camera(cam)
         main_ctx, ctx = ctx, dctx      # step() / timed() drive `ctx`
@@ -639,13 +745,16 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": "C3: S-demo (open Cornell cube + light + 2 instances of a %d-tri procedural mesh), %dx%d, %d spp, "
-                            "%d bounces, accum=%s, builder=%s, kernel=%s" % (args.tris, W, H, spp, bounces, args.accum, args.builder if args.route == "commit" else args.route, args.kernel)
-                if (args.scene == "demo" and args.camera == "demo") else "%s (camera %s) %dx%d %d spp %d bounces" % (sc.name, args.camera, W, H, spp, bounces),
+                "workload": ("C3: S-demo (open Cornell cube + light + 2 instances of a %d-tri procedural mesh), %dx%d, %d spp, "
+                             "%d bounces, accum=%s, builder=%s, kernel=%s" % (args.tris, W, H, spp, bounces, args.accum, args.builder if args.route == "commit" else args.route, args.kernel)
+                             if (args.scene == "demo" and args.camera == "demo") else "%s (camera %s) %dx%d %d spp %d bounces" % (sc.name, args.camera, W, H, spp, bounces))
+                            + " -- `value` counts %.2f M ray segments per step (every ray_trace() call the reference makes), %.2f M of them sky-culled "
+                              "primaries that NO kernel walks; `value_traced` counts the %.2f M a kernel does walk" % (rays / 1e6, sky / 1e6, traced / 1e6),
                 "unique_tris": sc.n_unique_tris, "instances": len(sc.instances),
                 "rays_per_step": rays, "nominal_rays_per_step": n_pixels * spp * (bounces + 1),
                 "parallelism": "screen strips x%d" % world + ("" if world == 1 else ", gather of %s rows to rank 0" % ("rgba8 display" if args.gather == "ldr" else "float4 accumulation")),
                 "scene_build_s": round(build_s, 4),
+                "outputs": "float4 accumulation + rgba8 display" + (" + r32f depth" if args.depth else " (depth image off: only temporal reprojection reads it)"),
             },
             "roofline": {
                 "bound": "hbm", "kernel": "%s (%d launches per render, serial launches)" % (dom, n_dom),
@@ -689,6 +798,8 @@ def main():
                               "kernel walks (rays - sky_culled); value_blocking = rays_per_step / roofline.blocking_render_ms (the device "
                               "time of one render with nothing queued behind it, as the library runs it; roofline.render_ms is the same "
                               "render with its launches serialised for per-kernel timing)")
+        if projected is not None:
+            out["projected_scaling"] = projected
         if closeup is not None:
             out["value_closeup"] = closeup["value"]
             out["closeup"] = closeup

@@ -19,6 +19,7 @@ BUILD_REFERENCE_EXACT, BUILD_SAH, BUILD_SAH_WATERTIGHT = 0, 1, 2
 KERNEL_WAVEFRONT, KERNEL_REFERENCE_LAYOUT = 0, 1
 SAMPLER_NEAREST_CLAMP, SAMPLER_NEAREST_REPEAT, SAMPLER_LINEAR_CLAMP, SAMPLER_LINEAR_REPEAT = 0, 1, 2, 3
 DENOISE_PROGRESSIVE, DENOISE_TEMPORAL, DENOISE_NONE = 0, 1, 2
+OUTPUT_DEPTH = 1
 UPLOAD_NATIVE_TREE, UPLOAD_WALK_AS_GIVEN = 0, 1
 STREAM_PRIORITY_DEFAULT, STREAM_PRIORITY_NORMAL, STREAM_PRIORITY_HIGH, STREAM_PRIORITY_LOW = 0, 1, 2, 3
 TREE_NONE, TREE_AS_GIVEN, TREE_REFERENCE_EXACT, TREE_NATIVE_REACH, TREE_NATIVE_WATERTIGHT = range(5)
@@ -31,7 +32,7 @@ SYMBOLS = [
     "jpt_scene_set_materials", "jpt_scene_set_textures", "jpt_scene_commit", "jpt_scene_get_reference_buffer",
     "jpt_scene_set_instance_transform", "jpt_scene_update_tlas", "jpt_scene_refit_tlas", "jpt_scene_update_reference_tlas",
     "jpt_set_params", "jpt_set_kernel", "jpt_set_debug_steps", "jpt_set_kernel_timing", "jpt_set_partition", "jpt_set_camera", "jpt_render", "jpt_render_counted", "jpt_render_async",
-    "jpt_sync", "jpt_accum_reset", "jpt_set_progressive_frame_count", "jpt_set_denoising_mode", "jpt_set_temporal_params", "jpt_read_ldr_rgba8", "jpt_readback_ldr_begin", "jpt_readback_ldr_end", "jpt_read_accum_f32", "jpt_read_depth_f32",
+    "jpt_sync", "jpt_accum_reset", "jpt_set_progressive_frame_count", "jpt_set_denoising_mode", "jpt_set_temporal_params", "jpt_set_outputs", "jpt_read_ldr_rgba8", "jpt_readback_ldr_begin", "jpt_readback_ldr_end", "jpt_read_accum_f32", "jpt_read_depth_f32",
     "jpt_device_accum", "jpt_assemble_from_ranks", "jpt_device_ldr", "jpt_assemble_ldr_from_ranks", "jpt_local_rows", "jpt_get_stats",
     "jpt_scene_share", "jpt_multi_create", "jpt_multi_destroy", "jpt_multi_last_error", "jpt_multi_world", "jpt_multi_ctx",
     "jpt_multi_share_scene", "jpt_multi_set_instance_transform", "jpt_multi_update_tlas", "jpt_multi_refit_tlas",
@@ -56,7 +57,7 @@ class Stats(C.Structure):
                 ("last_render_ms", C.c_double), ("last_trace_ms", C.c_double), ("last_build_ms", C.c_double),
                 ("phase", C.c_uint64 * 8), ("sky_culled", C.c_uint64), ("last_primary_ms", C.c_double),
                 ("set_aside", C.c_uint64), ("set_aside_dropped", C.c_uint64),
-                ("walk_steps_max", C.c_uint64), ("walk_steps_hist", C.c_uint64 * 8)]
+                ("walk_steps_max", C.c_uint64), ("walk_steps_hist", C.c_uint64 * 8), ("zero_throughput", C.c_uint64)]
 
     def as_dict(self):
         d = {n: getattr(self, n) for n, _ in self._fields_}
@@ -139,6 +140,8 @@ def lib():
     L.jpt_set_progressive_frame_count.argtypes = [vp, u32]
     L.jpt_set_denoising_mode.argtypes = [vp, i32]
     L.jpt_set_temporal_params.argtypes = [vp, vp]
+    if hasattr(L, "jpt_set_outputs") or "JPT_LIB" not in os.environ:   # (JPT_LIB: an A/B build of an earlier ABI may lack it)
+        L.jpt_set_outputs.argtypes = [vp, C.c_uint32]
     L.jpt_read_ldr_rgba8.argtypes = [vp, vp]
     L.jpt_read_accum_f32.argtypes = [vp, vp]
     L.jpt_readback_ldr_begin.argtypes = [vp]

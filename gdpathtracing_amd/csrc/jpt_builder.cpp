@@ -1152,6 +1152,7 @@ struct Flattener {
     enum : uint8_t { kUnseen = 0, kOpen = 1, kDone = 2 };
     static constexpr uint32_t kMaxDepth = 512u;
     std::vector<uint8_t> blas_state, tlas_state;
+    std::vector<uint8_t> blas_parented, tlas_parented;   // the node has been met as somebody's child
     std::vector<int32_t> blas_memo, tlas_memo;
 
     Flattener(const RefScene& r, WideScene& o) : ref(r), out(o) {}
@@ -1169,6 +1170,25 @@ struct Flattener {
         if (blas_state.empty()) {
             blas_state.assign(ref.bvh_nodes.size(), kUnseen);
             blas_memo.assign(ref.bvh_nodes.size(), 0);
+            blas_parented.assign(ref.bvh_nodes.size(), 0);
+        }
+        // The memo bounds THIS flatten; the walk on the device has no visited set and follows every path (main.glsl:270-303), so a
+        // node WITH CHILDREN under two parents -- a DAG -- costs the walk its number of root-to-leaf paths: 2^60 box visits for a
+        // chain of 60 nodes whose two children are the same next node, i.e. a render that never ends.  Refused.  What
+        // stays legal is sharing that cannot multiply paths: several instances naming one BLAS root (depth 1: not a parent), and
+        // leaves under several parents.
+        if (blas_state[ni] == kOpen) {
+            err = "BVH has a cycle";
+            return ~0;
+        }
+        if (depth > 1) {
+            const RefBvhNode& n = ref.bvh_nodes[ni];
+            const bool interior = !(n.tri_count > 0 || (n.left_child == 0 && n.right_child == 0));
+            if (interior && blas_parented[ni]) {
+                err = "a BVH node with children is reachable from two parents (the traversal follows every path: a shared subtree is walked once per path)";
+                return ~0;
+            }
+            blas_parented[ni] = 1;
         }
         if (blas_state[ni] == kDone) return blas_memo[ni];
         if (blas_state[ni] == kOpen) {
@@ -1272,6 +1292,18 @@ struct Flattener {
         if (tlas_state.empty()) {
             tlas_state.assign(ref.tlas_nodes.size(), kUnseen);
             tlas_memo.assign(ref.tlas_nodes.size(), 0);
+            tlas_parented.assign(ref.tlas_nodes.size(), 0);
+        }
+        if (tlas_state[ni] == kOpen) {
+            err = "TLAS has a cycle";
+            return ~0;
+        }
+        if (depth > 1) {   // (as for the BVH: a TLAS node with children under two parents multiplies the walk's paths)
+            if (ref.tlas_nodes[ni].leftRight != 0u && tlas_parented[ni]) {
+                err = "a TLAS node with children is reachable from two parents (the traversal follows every path: a shared subtree is walked once per path)";
+                return ~0;
+            }
+            tlas_parented[ni] = 1;
         }
         if (tlas_state[ni] == kDone) return tlas_memo[ni];
         if (tlas_state[ni] == kOpen) {

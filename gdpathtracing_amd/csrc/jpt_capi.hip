@@ -108,6 +108,8 @@ struct jpt_ctx {
     uint32_t frame_count = 0;  // frames accumulated since reset
     int32_t kernel_variant = JPT_KERNEL_WAVEFRONT;
     bool debug_steps = false;  // jpt_set_debug_steps: the shader's DEBUG_STEPS build, on the audit kernel
+    uint32_t outputs = JPT_OUTPUT_DEPTH;   // jpt_set_outputs: which of main.glsl's images the renders produce beside the colour
+    bool depth_valid = false;              // d_depth holds the last render's depth image
     DevBuf<char> d_workspace;
     // render pipelining (jpt_render_async): consecutive asynchronous renders run their path kernels on two helper
     // streams with two workspaces, so one render's launch tails overlap the next render's kernels; the accumulation
@@ -215,8 +217,19 @@ int32_t max_rows_of_any_rank(int32_t height, int32_t world)
     return m;
 }
 
+// The blocking read-backs' pinned staging buffer grows to the largest read-back ever made (133 MB after one jpt_read_accum_f32 of a
+// 3840 x 2160 image) and would otherwise be held until jpt_destroy: given back whenever the framebuffers are re-made (another
+// resolution or partition) and by jpt_set_memory_policy; the next read-back allocates what it needs.
+void release_read_staging(jpt_ctx* c)
+{
+    if (c->h_read_pinned) (void)hipHostFree(c->h_read_pinned);
+    c->h_read_pinned = nullptr;
+    c->h_read_bytes = 0;
+}
+
 int alloc_framebuffers(jpt_ctx* c)
 {
+    if ((size_t)max_rows_of_any_rank(c->height, c->world) * c->width != c->d_accum.n) release_read_staging(c);
     c->local_rows = rows_of_rank(c->height, c->rank, c->world);
     // every rank allocates the same (maximum) size so a gather sees equal-sized pieces
     const size_t npx = (size_t)max_rows_of_any_rank(c->height, c->world) * c->width;
@@ -763,11 +776,15 @@ int do_render_batch(jpt_ctx* c, int32_t n_frames, uint32_t first_frame_index, bo
         fp.accum_mode = c->accum_mode;
         fp.display_mode = c->denoise == JPT_DENOISE_PROGRESSIVE ? 0 : 1;
         fp.debug_steps = c->debug_steps ? 1 : 0;
+        // the depth image (main.glsl:432,435) has one reader, the temporal pass: off when the host said so (jpt_set_outputs)
+        const bool want_depth = (c->outputs & JPT_OUTPUT_DEPTH) != 0u || c->denoise == JPT_DENOISE_TEMPORAL;
+        float* const depth_img = want_depth ? c->d_depth.p : nullptr;
+        c->depth_valid = want_depth;
         if (wavefront) {
             fp.frame_index = first_frame_index;
             fp.frame_count = c->frame_count + 1;
             fp.n_frames = n_frames;
-            fp.depth_frame = n_frames - 1;
+            fp.depth_frame = want_depth ? n_frames - 1 : -1;
             const size_t need_ev = c->kernel_timing ? 2 * (size_t)(c->max_bounces + 1) : 0;
             while (c->trace_events.size() < need_ev) {
                 hipEvent_t e;
@@ -852,11 +869,11 @@ int do_render_batch(jpt_ctx* c, int32_t n_frames, uint32_t first_frame_index, bo
                     // side, and four slots plus a busy `s` were five (C3 1.287 -> 1.265 ms, a GPU's eighth of C3 329 -> 306 us)
                     HIP_TRY(c, hipEventRecord(c->ev_paths_done[slot], s));
                     one_group.before_acc = c->ev_paths_done[slot];
-                    launch_wf2_render(ps, c->ds, fp, c->camera, ws.p, c->d_accum.p, c->d_ldr.p, c->d_depth.p, nullptr, nullptr, one_group);
+                    launch_wf2_render(ps, c->ds, fp, c->camera, ws.p, c->d_accum.p, c->d_ldr.p, depth_img, nullptr, nullptr, one_group);
                     HIP_TRY(c, hipEventRecord(c->ev_acc_done[slot], ps));
                     HIP_TRY(c, hipStreamWaitEvent(s, c->ev_acc_done[slot], 0));
                 } else {
-                    launch_wf2_render(ps, c->ds, fp, c->camera, ws.p, c->d_accum.p, c->d_ldr.p, c->d_depth.p, nullptr, nullptr, one_group, s,
+                    launch_wf2_render(ps, c->ds, fp, c->camera, ws.p, c->d_accum.p, c->d_ldr.p, depth_img, nullptr, nullptr, one_group, s,
                                       c->ev_paths_done[slot]);
                     HIP_TRY(c, hipEventRecord(c->ev_acc_done[slot], s));
                 }
@@ -887,7 +904,7 @@ int do_render_batch(jpt_ctx* c, int32_t n_frames, uint32_t first_frame_index, bo
                     const bool small = window_paths <= 1500000u && walked_bytes <= ((size_t)32 << 20);
                     lone.trace_chain = (c->native_tree && !c->ref_is_exact && small) ? 2 : 1;
                 }
-                launch_wf2_render(s, c->ds, fp, c->camera, c->d_workspace.p, c->d_accum.p, c->d_ldr.p, c->d_depth.p, cnt,
+                launch_wf2_render(s, c->ds, fp, c->camera, c->d_workspace.p, c->d_accum.p, c->d_ldr.p, depth_img, cnt,
                                   need_ev ? c->trace_events.data() : nullptr, lone);
             }
         } else {
@@ -896,7 +913,7 @@ int do_render_batch(jpt_ctx* c, int32_t n_frames, uint32_t first_frame_index, bo
                 fp.frame_count = c->frame_count + (uint32_t)f + 1;
                 fp.n_frames = 1;
                 fp.depth_frame = 0;
-                launch_ref_frame(s, c->ds, fp, c->camera, c->d_accum.p, c->d_ldr.p, c->d_depth.p, cnt);
+                launch_ref_frame(s, c->ds, fp, c->camera, c->d_accum.p, c->d_ldr.p, depth_img, cnt);
             }
         }
         if (c->denoise == JPT_DENOISE_TEMPORAL) {
@@ -967,6 +984,7 @@ int do_render_batch(jpt_ctx* c, int32_t n_frames, uint32_t first_frame_index, bo
             c->stats.sky_culled = h.phase[7];
             c->stats.walk_steps_max = h.walk_max;
             for (int k = 0; k < 8; k++) c->stats.walk_steps_hist[k] = h.walk_hist[k];
+            c->stats.zero_throughput = h.zero_thr;
         }
     }
     return JPT_OK;
@@ -1174,6 +1192,7 @@ int jpt_set_memory_policy(jpt_ctx* c, int32_t renders_in_flight, uint64_t worksp
         }
     }
     c->async_seq = 0;   // the next queued render starts at slot 0 again
+    release_read_staging(c);   // (the pinned staging of the blocking read-backs: re-made by the next one)
     return JPT_OK;
 }
 
@@ -1721,6 +1740,7 @@ int jpt_set_params(jpt_ctx* c, int32_t width, int32_t height, int32_t max_bounce
     c->sampler_mode = sampler_mode;
     c->ds.sampler_mode = sampler_mode;
     c->params_set = true;
+    c->depth_valid = false;
     return alloc_framebuffers(c);
 }
 
@@ -1823,6 +1843,14 @@ int jpt_set_denoising_mode(jpt_ctx* c, int32_t mode)
         c->assembled = c->assembled_ldr = false;
     }
     c->denoise = mode;
+    return JPT_OK;
+}
+
+int jpt_set_outputs(jpt_ctx* c, uint32_t outputs)
+{
+    if (!c) return JPT_E_INVALID;
+    if (outputs & ~(uint32_t)JPT_OUTPUT_DEPTH) return fail(c, JPT_E_INVALID, "jpt_set_outputs: unknown output bit");
+    c->outputs = outputs;   // (takes effect with the next render; a depth image already written stays readable until then)
     return JPT_OK;
 }
 
@@ -1929,6 +1957,9 @@ int jpt_read_depth_f32(jpt_ctx* c, float* out)
 {
     int rc = read_common(c, out);
     if (rc) return rc;
+    if (!c->depth_valid)
+        return fail(c, JPT_E_STATE, (c->outputs & JPT_OUTPUT_DEPTH) ? "no render has written the depth image yet"
+                                                                     : "the depth image is switched off (jpt_set_outputs): no render writes it");
     const size_t full = (size_t)c->width * c->height;
     const size_t n = (size_t)c->local_rows * c->width;
     rc = staged_read(c, c->d_depth.p, n * sizeof(float));

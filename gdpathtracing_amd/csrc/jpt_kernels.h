@@ -22,6 +22,8 @@ struct DevCounters {  // SURVEY.md 8(d) event counters
     // how many rays took < 16, < 64, < 256, < 1024, < 4096, < 16384, < 65536, more (a launch cannot end before its longest ray)
     unsigned long long walk_max;
     unsigned long long walk_hist[8];
+    // path vertices that go on with a throughput of exactly (0, 0, 0) (jpt_stats.zero_throughput)
+    unsigned long long zero_thr;
 };
 
 struct FrameParams {
@@ -155,6 +157,7 @@ __device__ __forceinline__ void flush_counters(const DevCounters& c, DevCounters
     if (c.walk_max) atomicMax(&out->walk_max, c.walk_max);
     for (int k = 0; k < 8; k++)
         if (c.walk_hist[k]) atomicAdd(&out->walk_hist[k], c.walk_hist[k]);
+    if (c.zero_thr) atomicAdd(&out->zero_thr, c.zero_thr);
 }
 __device__ __forceinline__ void count_walk(DevCounters& c, uint32_t steps)
 {

@@ -389,7 +389,27 @@ __device__ __forceinline__ TraceHit coop_walk(const WideSceneDev& sc, const type
     out.tri = out.inst = 0u;
     out.front = false;
     if (win && best < 1e9f) {
-        const int w = __ffsll((long long)win) - 1;
+        // Several lanes holding a triangle at the final distance: WHICH lanes walked which subtrees depends on the pool's timing, so
+        // the winner must not be "the lowest lane" -- without the reference's trees to re-decide the tie (watertight scenes,
+        // uploads that are not in pre-order) the flagged winner is shaded as it is, and the image would depend on the schedule
+        // (ADVICE r04).  The winner is a function of the ray alone: the largest triangle index, then the largest instance.
+        unsigned long long pick = win;
+        if (__popcll(win) > 1) {
+            const bool mine = ((win >> lane) & 1ull) != 0ull;
+            uint32_t kt = mine ? tr.hit.tri : 0u;
+            for (int off = 32; off > 0; off >>= 1) {
+                const uint32_t o = (uint32_t)__shfl_xor((int)kt, off);
+                kt = o > kt ? o : kt;
+            }
+            const bool top = mine && tr.hit.tri == kt;
+            uint32_t ki = top ? ((tr.hit.inst >> kInstBits) & kInstMask) : 0u;
+            for (int off = 32; off > 0; off >>= 1) {
+                const uint32_t o = (uint32_t)__shfl_xor((int)ki, off);
+                ki = o > ki ? o : ki;
+            }
+            pick = __ballot(top && ((tr.hit.inst >> kInstBits) & kInstMask) == ki);
+        }
+        const int w = __ffsll((long long)pick) - 1;
         out.t = best;
         out.u = __shfl(tr.hit.u, w);
         out.v = __shfl(tr.hit.v, w);
@@ -460,6 +480,7 @@ __global__ __launch_bounds__(kBlock, JPT_PRIMARY_WAVES) void wf2_primary(WideSce
     const typename Traversal<COUNT, W4>::Stack my_stack{&stack[threadIdx.x], spill, kTraceBlock, kStackLds};
     const size_t seg_base = (size_t)seg * dm.seg_cap;
     uint32_t dry_rounds = 0;   // (COOP: rounds of this wave since the block's queue ran dry; wave-uniform)
+    bool list_full = false;    // (COOP == 1: this lane's reservation in the hand-over list failed: not tried again)
     DevCounters cnt = {};
     Traversal<COUNT, W4> tr;
     bool active = false, exhausted = false;
@@ -560,11 +581,13 @@ __global__ __launch_bounds__(kBlock, JPT_PRIMARY_WAVES) void wf2_primary(WideSce
             if constexpr (COOP == 1 && W4) {
                 // the block's queue has been exhausted for kCoopRounds rounds and this ray is still walking: hand it over to
                 // wf2_long (see coop_walk).  (A wave-uniform count of rounds since the queue ran dry, not a per-lane one.)
-                if (exhausted && ++dry_rounds >= (uint32_t)tune.coop_rounds && active) {
+                if (exhausted && ++dry_rounds >= (uint32_t)tune.coop_rounds && active && !list_full) {
                     const uint32_t k = atomicAdd(&wb.long_count[0], 1u);
                     if (k < wb.long_cap) {
                         wb.long_list[k] = make_uint2(path, seg);
                         active = false;
+                    } else {
+                        list_full = true;   // (the ray keeps walking on its lane; one failed reservation, not one per round: ADVICE r04)
                     }
                 }
             }
@@ -632,6 +655,7 @@ __global__ __launch_bounds__(kBlock, JPT_WAVES_PER_SIMD) void wf2_trace(WideScen
     int32_t spill[kStackSpill];
     const typename Traversal<COUNT, W4>::Stack my_stack{&stack[threadIdx.x], spill, kTraceBlock, kStackLds};
     uint32_t dry_rounds = 0;   // (COOP: rounds of this wave since the block's queue ran dry; wave-uniform)
+    bool list_full = false;    // (COOP == 1: this lane's reservation in the hand-over list failed: not tried again)
     const float4* __restrict__ qo = wb.ray_o[bounce & 1];
     const float4* __restrict__ qd = wb.ray_d[bounce & 1];
     DevCounters cnt = {};
@@ -694,11 +718,13 @@ __global__ __launch_bounds__(kBlock, JPT_WAVES_PER_SIMD) void wf2_trace(WideScen
                 if (COUNT) count_walk(cnt, walk_steps);
             }
             if constexpr (COOP == 1 && W4) {
-                if (exhausted && ++dry_rounds >= (uint32_t)tune.coop_rounds && active) {
+                if (exhausted && ++dry_rounds >= (uint32_t)tune.coop_rounds && active && !list_full) {
                     const uint32_t k = atomicAdd(&wb.long_count[bounce], 1u);
                     if (k < wb.long_cap) {
                         wb.long_list[k] = make_uint2((uint32_t)my_loc, 0u);
                         active = false;
+                    } else {
+                        list_full = true;
                     }
                 }
             }
@@ -787,280 +813,8 @@ __global__ __launch_bounds__(64) void wf2_long(WideSceneDev sc, Wf2Buffers wb, W
     if (COUNT) flush_counters(cnt, counters);
 }
 
-// ---- bounces >= 1, REGROUPED (JPT_TRACE_REGROUP=1; VERDICT r03 task 1) -------------------------------------------------
-//
-// wf2_trace binds a ray to a lane for its whole walk: a record step runs with the 28-39 of 64 lanes whose ray happens to want
-// one, a leaf turn with 16-29.  Here a ray is bound to nothing.  A wave (= a block) keeps kRgPool rays'
-// walk state in LDS -- level ray, closest hit, current record, a short stack: 56 + 4 * kRgStack bytes per ray -- and four byte
-// lists of pool slots: rays that want a record step (NODE), a triangle leaf (LEAF), the world ray (TOP: an instance entry, or
-// a TLAS record after an instance was left) and slots without a ray (FREE).  Each turn the wave takes up to 64 slots off ONE
-// list, pulls their state into registers, runs that one kind of step with every lane occupied, writes the state back and
-// files each slot under what its ray wants next (ballot + prefix popcount per list; everything is wave-synchronous: no
-// barrier, no atomic but the queue cursor).  Per ray the sequence of steps -- the functions of jpt_trace_core.h, the same
-// stack discipline -- is exactly wf2_trace's, so the hits are bit-identical; only which rays share a wave-level step changes.
-// A finished ray's hit stays in its slot until the slot is refilled (written 64 at a time, like wf2_trace's late store).
-#ifndef JPT_RG_POOL
-#define JPT_RG_POOL 160
-#endif
-#ifndef JPT_RG_STACK
-#define JPT_RG_STACK 8
-#endif
-constexpr int kRgPool = JPT_RG_POOL;      // rays in flight per wave (slot ids are bytes)
-constexpr int kRgStack = JPT_RG_STACK;    // stack entries per ray in LDS ...
-constexpr int kRgSpill = 64 - JPT_RG_STACK;   // ... and past them in global memory: 64 in all (the reference's own stack size, main.glsl:272,307)
-static_assert(kRgPool >= 64 && kRgPool <= 256 && kRgPool % 4 == 0, "pool slots are addressed by bytes; a refill takes 64");
-constexpr uint32_t kRgPending = 1u << 25;  // meta word: the slot holds a finished ray's hit that is not written yet
-enum { kRgNode = 0, kRgLeaf = 1, kRgTop = 2, kRgFree = 3 };
-
-struct RgPoolLds {
-    float4 a[kRgPool];                 // level ray origin.xyz, hit.t
-    float4 b[kRgPool];                 // level ray direction.xyz, current record (bits)
-    float4 c[kRgPool];                 // hit.u, hit.v, hit.tri (bits), hit.inst | front << 31 (bits)
-    uint32_t m[kRgPool];               // sp (0..7) | in_blas (8) | cur_inst (9..23) | kRgPending
-    uint32_t loc[kRgPool];             // the ray's queue entry (world ray in, hit out)
-    int32_t stack[kRgStack * kRgPool]; // [entry][slot]
-    uint8_t list[4][256];              // rings of slot ids
-};
-
-constexpr uint32_t kRgMaxBlocks = 2u * kSegments;   // grid cap of a regrouped launch (the spill area is sized for it)
-size_t wf2_rg_spill_bytes(uint32_t blocks) { return (size_t)blocks * kRgPool * kRgSpill * sizeof(int32_t); }
-
-template <bool COUNT>
-__global__ __launch_bounds__(64) void wf2_trace_rg(WideSceneDev sc, Wf2Buffers wb, Wf2Dims dm, int bounce, int chain, int waves_per_queue,
-                                                   DevCounters* __restrict__ counters)
-{
-    __shared__ RgPoolLds P;
-    using Walk = Traversal<COUNT, true>;
-    const int lane = threadIdx.x;
-    const uint32_t seg0 = (blockIdx.x / (uint32_t)waves_per_queue) * (uint32_t)chain;
-    uint32_t end[kMaxChain];
-    uint32_t n = 0;
-    for (int k = 0; k < kMaxChain; k++) {
-        if (k < chain && seg0 + (uint32_t)k < kSegments) n += wb.qcount[(size_t)bounce * kSegments + seg0 + (uint32_t)k];
-        end[k] = n;
-    }
-    if (n == 0) return;
-    uint32_t* __restrict__ cursor = wb.rg_cursor + (size_t)bounce * kSegments + seg0;
-    const float4* __restrict__ qo = wb.ray_o[bounce & 1];
-    const float4* __restrict__ qd = wb.ray_d[bounce & 1];
-    int32_t* __restrict__ spill_base = wb.rg_spill + (size_t)blockIdx.x * kRgPool * kRgSpill;
-    DevCounters cnt = {};
-    // all slots free, nothing pending
-    for (int s = lane; s < kRgPool; s += 64) {
-        P.m[s] = 0u;
-        P.list[kRgFree][s] = (uint8_t)s;
-    }
-    uint32_t hn = 0, hl = 0, ht = 0, hf = 0;            // list heads (free-running; the rings hold 256)
-    uint32_t cn = 0, cl = 0, ct = 0, cf = kRgPool;      // list sizes
-    // 64 queue entries are reserved one refill ahead: the atomic's round trip is over when its result is needed
-    uint32_t next_start = 0;
-    if (lane == 0) next_start = atomicAdd(cursor, 64u);
-    bool exhausted = false;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-
-    auto append = [&](int kind, bool pred, uint32_t id, uint32_t head, uint32_t& count) {
-        const unsigned long long mk = __ballot(pred);
-        if (mk) {
-            if (pred) P.list[kind][(head + count + lanes_below(mk, lane)) & 255u] = (uint8_t)id;
-            count += (uint32_t)__popcll(mk);
-        }
-    };
-    auto stack_of = [&](uint32_t id) {
-        return typename Walk::Stack{&P.stack[id], spill_base + (size_t)id * kRgSpill, kRgPool, kRgStack, kRgSpill};
-    };
-    auto write_hit = [&](uint32_t id) {
-        const float4 a = P.a[id], c = P.c[id];
-        const size_t loc = P.loc[id];
-        wb.hit_a[loc] = make_float4(a.w, c.x, c.y, c.z);
-        wb.hit_b[loc] = __float_as_uint(c.w);
-    };
-    // after a step: the next record off the ray's stack if the step left none, then the slot goes to the list of what the ray
-    // wants next (pop_next of jpt_trace_core.h; a ray that left an instance wants the world ray back: TOP)
-    auto file_slot = [&](bool on, uint32_t id, Walk& tr, const typename Walk::Stack& st) {
-        bool fin = false, left_instance = false;
-        if (on && !tr.have) {
-            if (tr.sp == 0) {
-                fin = true;
-            } else {
-                tr.cur = tr.pop(st);
-                if (tr.cur == kSentinel) {
-                    tr.in_blas = false;
-                    left_instance = true;
-                    if (tr.sp == 0) fin = true;
-                    else tr.cur = tr.pop(st);
-                }
-            }
-        }
-        if (on) {
-            P.b[id].w = __int_as_float(tr.cur);
-            P.m[id] = (uint32_t)tr.sp | (tr.in_blas ? 256u : 0u) | (tr.cur_inst << 9) | (fin ? kRgPending : 0u);
-        }
-        const bool go = on && !fin;
-        const bool to_top = go && !tr.in_blas && (tr.cur < 0 || left_instance);
-        const bool to_node = go && tr.cur >= 0 && !to_top;
-        const bool to_leaf = go && tr.cur < 0 && tr.in_blas;
-        append(kRgNode, to_node, id, hn, cn);
-        append(kRgLeaf, to_leaf, id, hl, cl);
-        append(kRgTop, to_top, id, ht, ct);
-        append(kRgFree, on && fin, id, hf, cf);
-    };
-
-    for (;;) {
-        int kind;
-        uint32_t take;
-        if (!exhausted && cf >= 64u) {
-            kind = kRgFree;
-            take = 64u;
-        } else {
-            // a full chunk if any list has one, else the longest list
-            const uint32_t best = cn >= cl ? (cn >= ct ? cn : ct) : (cl >= ct ? cl : ct);
-            if (best == 0u) break;   // (nothing in flight, and no refill: the queue is exhausted)
-            kind = cn >= 64u ? kRgNode : (cl >= 64u ? kRgLeaf : (ct >= 64u ? kRgTop : (best == cn ? kRgNode : (best == cl ? kRgLeaf : kRgTop))));
-            const uint32_t have_n = kind == kRgNode ? cn : (kind == kRgLeaf ? cl : ct);
-            take = have_n < 64u ? have_n : 64u;
-        }
-        const bool on = (uint32_t)lane < take;
-        if (kind == kRgFree) {
-            // refill: the reserved queue entries go into free slots (whose previous rays' hits are written out first)
-            const uint32_t start = (uint32_t)__builtin_amdgcn_readfirstlane((int)next_start);
-            const uint32_t avail = start < n ? (n - start < 64u ? n - start : 64u) : 0u;
-            if (start + 64u >= n) exhausted = true;
-            else if (lane == 0) next_start = atomicAdd(cursor, 64u);
-            const bool mine = (uint32_t)lane < avail;
-            uint32_t id = 0;
-            bool trivial = false;
-            if (mine) {
-                id = P.list[kRgFree][(hf + (uint32_t)lane) & 255u];
-                if (P.m[id] & kRgPending) write_hit(id);
-                const uint32_t idx = start + (uint32_t)lane;
-                uint32_t k = 0, first = 0;
-                for (int j = 0; j < kMaxChain - 1; j++)
-                    if (idx >= end[j]) {
-                        k = (uint32_t)j + 1u;
-                        first = end[j];
-                    }
-                const size_t loc = (size_t)(seg0 + k) * dm.seg_cap + (idx - first);
-                const float4 ro = qo[loc], rd = qd[loc];
-                // Traversal::begin: the walk starts at the TLAS root with the world ray; hit.t = 1e9 (main.glsl:354)
-                trivial = sc.n_instances == 0u;
-                P.a[id] = make_float4(ro.x, ro.y, ro.z, 1e9f);
-                P.b[id] = make_float4(rd.x, rd.y, rd.z, __int_as_float(sc.tlas_root));
-                P.c[id] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                P.m[id] = trivial ? kRgPending : 0u;
-                P.loc[id] = (uint32_t)loc;
-            }
-            hf += avail;
-            cf -= avail;
-            append(kRgNode, mine && !trivial && sc.tlas_root >= 0, id, hn, cn);
-            append(kRgTop, mine && !trivial && sc.tlas_root < 0, id, ht, ct);
-            append(kRgFree, mine && trivial, id, hf, cf);
-        } else if (kind == kRgNode) {
-            uint32_t id = 0;
-            Walk tr;
-            if (on) id = P.list[kRgNode][(hn + (uint32_t)lane) & 255u];
-            hn += take;
-            cn -= take;
-            const typename Walk::Stack st = stack_of(id);
-            tr.have = true;
-            if (on) {
-                const float4 a = P.a[id], b = P.b[id];
-                const uint32_t m = P.m[id];
-                tr.o = mk3(a.x, a.y, a.z);
-                tr.d = mk3(b.x, b.y, b.z);
-                tr.hit.t = a.w;
-                tr.cur = __float_as_int(b.w);
-                tr.sp = (int)(m & 255u);
-                tr.in_blas = (m & 256u) != 0u;
-                tr.cur_inst = (m >> 9) & kInstMask;
-                tr.set_level();
-                tr.node_step4(sc, st, cnt);
-            }
-            if (COUNT && lane == 0) {
-                cnt.phase[0]++;
-                cnt.phase[1]++;
-                cnt.phase[2] += take;
-            }
-            file_slot(on, id, tr, st);
-        } else if (kind == kRgLeaf) {
-            uint32_t id = 0;
-            Walk tr;
-            if (on) id = P.list[kRgLeaf][(hl + (uint32_t)lane) & 255u];
-            hl += take;
-            cl -= take;
-            const typename Walk::Stack st = stack_of(id);
-            tr.have = true;
-            if (on) {
-                const float4 a = P.a[id], b = P.b[id], c = P.c[id];
-                const uint32_t m = P.m[id];
-                tr.o = mk3(a.x, a.y, a.z);
-                tr.d = mk3(b.x, b.y, b.z);
-                tr.hit.t = a.w;
-                tr.hit.u = c.x;
-                tr.hit.v = c.y;
-                tr.hit.tri = __float_as_uint(c.z);
-                tr.hit.inst = __float_as_uint(c.w) & 0x7fffffffu;
-                tr.hit.front = (__float_as_uint(c.w) >> 31) != 0u;
-                tr.cur = __float_as_int(b.w);
-                tr.sp = (int)(m & 255u);
-                tr.in_blas = true;
-                tr.cur_inst = (m >> 9) & kInstMask;
-                tr.leaf_step(sc, cnt);
-                P.a[id].w = tr.hit.t;
-                P.c[id] = make_float4(tr.hit.u, tr.hit.v, __uint_as_float(tr.hit.tri), __uint_as_float(tr.hit.inst | (tr.hit.front ? 0x80000000u : 0u)));
-            }
-            if (COUNT && lane == 0) {
-                cnt.phase[0]++;
-                cnt.phase[3]++;
-                cnt.phase[4] += take;
-            }
-            file_slot(on, id, tr, st);
-        } else {
-            uint32_t id = 0;
-            Walk tr;
-            if (on) id = P.list[kRgTop][(ht + (uint32_t)lane) & 255u];
-            ht += take;
-            ct -= take;
-            const typename Walk::Stack st = stack_of(id);
-            tr.have = true;
-            if (on) {
-                const uint32_t m = P.m[id];
-                const size_t loc = P.loc[id];
-                const float4 ro = qo[loc], rd = qd[loc];
-                tr.wo = mk3(ro.x, ro.y, ro.z);
-                tr.wd = mk3(rd.x, rd.y, rd.z);
-                tr.cur = __float_as_int(P.b[id].w);
-                tr.sp = (int)(m & 255u);
-                tr.in_blas = false;
-                tr.cur_inst = (m >> 9) & kInstMask;
-                if (tr.cur < 0) {
-                    tr.instance_step(sc, st, cnt);   // the instance's local ray, a sentinel on the stack, the BLAS root
-                } else {
-                    tr.o = tr.wo;                    // a TLAS record after an instance: its box tests read the world ray
-                    tr.d = tr.wd;
-                }
-                P.a[id].x = tr.o.x;
-                P.a[id].y = tr.o.y;
-                P.a[id].z = tr.o.z;
-                P.b[id].x = tr.d.x;
-                P.b[id].y = tr.d.y;
-                P.b[id].z = tr.d.z;
-            }
-            if (COUNT && lane == 0) {
-                cnt.phase[0]++;
-                cnt.phase[5]++;
-                cnt.phase[6] += take;
-            }
-            file_slot(on, id, tr, st);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-    }
-    // the hits still waiting in their slots
-    for (int s = lane; s < kRgPool; s += 64)
-        if (P.m[s] & kRgPending) write_hit((uint32_t)s);
-    if (COUNT) flush_counters(cnt, counters);
-}
+#include "jpt_kernels_wf2_variants.h"   // wf2_trace_rg (JPT_TRACE_REGROUP=1: measured, not kept)
+#include "jpt_kernels_wf2_pool.h"       // wf2_trace_pool (JPT_TRACE_REGROUP=2)
 
 // ---- shading: one path vertex per queue entry (main.glsl:378-397) -------------------------------------------
 
@@ -1174,6 +928,7 @@ __device__ __forceinline__ bool shade_entry(const SceneShading& sh, const Wf2Buf
         radiance = radiance + throughput * s.emission;
         if (bounce == 0 && (int)f == fp.depth_frame) wb.first_depth[slot] = length3(s.position - ray.o);
         if (!LAST && bounce < fp.max_bounces) alive = bounce_step(s, sx, sy, ray, throughput);
+        if (COUNT && alive && throughput.x == 0.0f && throughput.y == 0.0f && throughput.z == 0.0f) cnt.zero_thr++;
     }
     if (alive) {
         // (radiance starts as +0 and +0 + x is x or +0, never -0: "unchanged and never written" means exactly +0)
@@ -1372,8 +1127,12 @@ __global__ __launch_bounds__(kBlock) void wf2_accumulate(Wf2Buffers wb, Wf2Dims 
     f3 sky_value = mk3(0.0f, 0.0f, 0.0f);
     // values * 255 + 0.5 of the sky along the ray through a raster position, per channel; false: the camera block does not
     // behave there (the clip-space w changes sign against `w_ref`, or a NaN)
+    // (raster_direction_approx: reciprocal estimates instead of six divisions and a square root -- a few ulp of d.y, i.e. 1e-5 of a
+    // cell against kCellMargin = 1e-2; a corner cost 90 VALU instructions, four of them per pixel of every tile that straddles a
+    // cell boundary)
+    const float two_over_w = 2.0f / (float)fp.width, two_over_h = 2.0f / (float)fp.height;
     auto sky_cells_at = [&](float fx, float fy, float w_ref, float& w_out, float v[3], f3& d) -> bool {
-        d = raster_direction(cam, fp.width, fp.height, fx, fy, w_out);
+        d = raster_direction_approx(cam, two_over_w, two_over_h, fx, fy, w_out);
         const f3 c = mk3(0.0f, 0.0f, 0.0f) + mk3(1.0f, 1.0f, 1.0f) * sample_sky(d);
         v[0] = clamp_(c.x, 0.0f, 1.0f) * 255.0f + 0.5f;
         v[1] = clamp_(c.y, 0.0f, 1.0f) * 255.0f + 0.5f;
@@ -1712,7 +1471,7 @@ size_t wf2_workspace_bytes(int width, int local_rows, int n_frames, int max_boun
             b += paths * sizeof(float4) + 256;        // thr
             b += ((size_t)(max_bounces + 2) * kSegments * 2 + 192) * sizeof(uint32_t) + 256;   // queue sizes + the set-aside count + the regrouped launches' cursors + the hand-over counts
             b += (size_t)kCoopListCap * sizeof(uint2) + 256;                                     // rays handed over to wf2_long
-            if (tuning().trace_regroup) b += wf2_rg_spill_bytes(kRgMaxBlocks) + 256;
+            if (tuning().trace_regroup) b += std::max(wf2_rg_spill_bytes(kRgMaxBlocks), wf2_pool_spill_bytes(kPoolMaxBlocks)) + 256;
             b += (size_t)redo_capacity(paths) * 2 * sizeof(float4) + 256;    // set-aside records
         }
         const Wf2Dims all = make_dims(width, local_rows, n_frames, full_window(width, local_rows));
@@ -1759,7 +1518,7 @@ void launch_wf2_render(hipStream_t stream, const DeviceScene& ds, const FramePar
         gb[g].long_count = gb[g].rg_cursor + (size_t)nq * kSegments;   // (128 words: one count per launch, max_bounces <= 64)
         gb[g].long_list = (uint2*)carve((size_t)kCoopListCap * sizeof(uint2));
         gb[g].long_cap = kCoopListCap;
-        gb[g].rg_spill = tuning().trace_regroup ? (int32_t*)carve(wf2_rg_spill_bytes(kRgMaxBlocks)) : nullptr;
+        gb[g].rg_spill = tuning().trace_regroup ? (int32_t*)carve(std::max(wf2_rg_spill_bytes(kRgMaxBlocks), wf2_pool_spill_bytes(kPoolMaxBlocks))) : nullptr;
     }
     float4* rad_all = (float4*)carve((size_t)dm_all.slots_per_frame * (size_t)fp.n_frames * sizeof(float4));
     uint32_t* fin8_all = (uint32_t*)carve((size_t)dm_all.slots_per_frame * (size_t)fp.n_frames * sizeof(uint32_t));
@@ -1788,7 +1547,7 @@ void launch_wf2_render(hipStream_t stream, const DeviceScene& ds, const FramePar
         gfp[g] = fp;
         gfp[g].frame_index = fp.frame_index + (uint32_t)f0;
         gfp[g].n_frames = nf;
-        gfp[g].depth_frame = (f0 + nf == fp.n_frames) ? nf - 1 : -1;  // the render's last frame writes the depth image
+        gfp[g].depth_frame = (fp.depth_frame >= 0 && f0 + nf == fp.n_frames) ? nf - 1 : -1;  // the render's last frame writes the depth image (when there is one: jpt_set_outputs)
     }
 
     const bool w4 = tuning().bvh_width == 4 && ds.use4;
@@ -1824,7 +1583,20 @@ void launch_wf2_render(hipStream_t stream, const DeviceScene& ds, const FramePar
     const int tail_cfg = tuning().tail;
     const bool tail = w4 && (tail_cfg == 2 || (tail_cfg == 1 && !coop_wanted) || (tail_cfg < 0 && tuning().coop < 0 && coop_wanted));
     const bool coop = w4 && coop_wanted && !tail;
-    const bool regroup = tuning().trace_regroup && w4 && ds.stack_need4 <= wf2_rg_stack_capacity() && gb[0].rg_spill != nullptr;
+    const bool regroup = tuning().trace_regroup == 1 && w4 && ds.stack_need4 <= wf2_rg_stack_capacity() && gb[0].rg_spill != nullptr;
+    // JPT_TRACE_REGROUP=2: the pooled launches (wf2_trace_pool): a wave per pool of kPoolRays rays, turns prepared one ahead.  The
+    // grid is generous -- a wave that finds its queue too short for it (1 024 rays per wave) exits at once -- and capped by the
+    // spill area; not with the cooperative tail (scenes of >= 200 000 triangles keep wf2_trace)
+    const bool pool = tuning().trace_regroup == 2 && w4 && !coop && !tail && ds.stack_need4 <= (uint32_t)(kPoolStack + kPoolSpill) && gb[0].rg_spill != nullptr;
+    const int pool_waves = [&] {
+        const uint32_t queues = tgrid.x;
+        const uint32_t target = tuning().rg_waves > 0 ? (uint32_t)tuning().rg_waves * queues : 3072u;
+        uint32_t wv = (target + queues - 1u) / queues;
+        if (wv < 1u) wv = 1u;
+        while (wv > 1u && wv * queues > kPoolMaxBlocks) wv--;
+        return (int)wv;
+    }();
+    const uint32_t pool_blocks = tgrid.x * (uint32_t)pool_waves;
     const int rg_waves = [&] {
         const uint32_t queues = tgrid.x;
         const uint32_t target = async.trace_chain >= 4 ? 640u : (groups == 2 ? 1280u : 2560u);
@@ -1886,7 +1658,10 @@ void launch_wf2_render(hipStream_t stream, const DeviceScene& ds, const FramePar
             }
             if (b == gp.max_bounces) break;
             if (ev) (void)hipEventRecord(ev[2 * (b + 1)], st);
-            if (regroup) {
+            if (pool) {
+                if (counters) hipLaunchKernelGGL(wf2_trace_pool<true>, dim3(pool_blocks), dim3(64), 0, st, sc, wb, dm, b + 1, chain, pool_waves, tuning().pool_min_prefetch, counters);
+                else hipLaunchKernelGGL(wf2_trace_pool<false>, dim3(pool_blocks), dim3(64), 0, st, sc, wb, dm, b + 1, chain, pool_waves, tuning().pool_min_prefetch, counters);
+            } else if (regroup) {
                 if (counters) hipLaunchKernelGGL(wf2_trace_rg<true>, dim3(rg_blocks), dim3(64), 0, st, sc, wb, dm, b + 1, chain, rg_waves, counters);
                 else hipLaunchKernelGGL(wf2_trace_rg<false>, dim3(rg_blocks), dim3(64), 0, st, sc, wb, dm, b + 1, chain, rg_waves, counters);
             } else if (coop) {

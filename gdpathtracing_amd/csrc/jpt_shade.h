@@ -123,6 +123,24 @@ __device__ __forceinline__ f3 raster_direction(const RefCamera& cam, int width, 
     return normalize3(mk3(wx, wy, wz) - mk3(cam.position.x, cam.position.y, cam.position.z));
 }
 
+// The same direction to a few ulp, for callers that only BOUND what a pixel's rays can see (wf2_accumulate's sky cells, which
+// keep a margin a thousand times the rounding of this arithmetic): the six divisions and the square root of raster_direction as
+// reciprocal estimates (v_rcp_f32 / v_rsq_f32, 1 ulp each), 30 instructions instead of 90.  Never used for a value that is stored.
+__device__ __forceinline__ f3 raster_direction_approx(const RefCamera& cam, float two_over_w, float two_over_h, float fx, float fy, float& ww_out)
+{
+    const float nx = fx * two_over_w - 1.0f, ny = -(fy * two_over_h - 1.0f);
+    const float* m = cam.ivp;
+    const float wx = m[0] * nx + m[4] * ny + m[8] + m[12];
+    const float wy = m[1] * nx + m[5] * ny + m[9] + m[13];
+    const float wz = m[2] * nx + m[6] * ny + m[10] + m[14];
+    const float ww = m[3] * nx + m[7] * ny + m[11] + m[15];
+    ww_out = ww;
+    const float iw = __builtin_amdgcn_rcpf(ww);
+    const f3 v = mk3(wx * iw - cam.position.x, wy * iw - cam.position.y, wz * iw - cam.position.z);
+    const float il = __builtin_amdgcn_rsqf(v.x * v.x + v.y * v.y + v.z * v.z);
+    return mk3(v.x * il, v.y * il, v.z * il);
+}
+
 __device__ __forceinline__ f3 sample_sky(f3 d)  // main.glsl:189-192
 {
     const float t = 0.5f * (d.y + 1.0f);

@@ -179,6 +179,12 @@ struct Traversal {
         const float4 h1 = ld4(base + (rec + 16u));   // scale.y, scale.z, lo_x, lo_y
         const float4 h2 = ld4(base + (rec + 32u));   // lo_z, hi_x, hi_y, hi_z
         const float4 cf = ld4(base + (rec + 48u));   // child references
+        node_step4_rec(h0, h1, h2, cf, st, cnt);
+    }
+    // ... the step itself, on a record that is already in registers (the pooled launches ask for the records of their NEXT turn
+    // before they compute the current one: wf2_trace_pool)
+    __device__ __forceinline__ void node_step4_rec(const float4 h0, const float4 h1, const float4 h2, const float4 cf, const Stack& st, DevCounters& cnt)
+    {
         if (COUNT) {
             if (in_blas) cnt.blas_expand++;
             else cnt.tlas_expand++;

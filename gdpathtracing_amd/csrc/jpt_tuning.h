@@ -44,7 +44,9 @@ struct Tuning {
                                    // JPT_COOP=1) asks for the cooperative walk, 0 never, 1 also on the scenes JPT_COOP leaves alone, 2 everywhere
     int tail_rounds = 128;         // JPT_TAIL_ROUNDS: ... from this many rounds after the block's queue ran dry
     int tail_lanes = 8;            // JPT_TAIL_LANES: ... once a wave is down to this many rays
-    bool trace_regroup = false;    // JPT_TRACE_REGROUP=1: bounce launches by wf2_trace_rg (ray state in LDS, compacted lists of rays per step kind)
+    int trace_regroup = 0;         // JPT_TRACE_REGROUP=1: bounce launches by wf2_trace_rg (ray state in LDS, compacted lists of rays per step kind: round 4,
+                                   // measured, not kept); 2: by wf2_trace_pool (the same with turns prepared one ahead and a lean state: round 5)
+    int pool_min_prefetch = 40;    // JPT_POOL_MIN_PREFETCH: wf2_trace_pool prepares its next turn ahead only when a list holds this many rays
     int rg_waves = 0;              // JPT_RG_WAVES: waves (= blocks) per queue of the regrouped launches (0: the library's rule)
 };
 
@@ -87,7 +89,8 @@ inline const Tuning& tuning()
         v.tail = geti("JPT_TAIL", -1);
         v.tail_rounds = geti("JPT_TAIL_ROUNDS", 128);
         v.tail_lanes = geti("JPT_TAIL_LANES", 8);
-        v.trace_regroup = geti("JPT_TRACE_REGROUP", 0) != 0;
+        v.trace_regroup = geti("JPT_TRACE_REGROUP", 0);
+        v.pool_min_prefetch = geti("JPT_POOL_MIN_PREFETCH", 40);
         v.rg_waves = geti("JPT_RG_WAVES", 0);
         v.exact_shadow = geti("JPT_EXACT_SHADOW", 1) != 0;
         if (const char* e = std::getenv("JPT_SET_ASIDE_CAP")) v.set_aside_cap = std::atol(e);

@@ -225,6 +225,10 @@ class Context:
         p = np.ascontiguousarray(params, dtype=wire.TEMPORAL_PARAMS).reshape(1)
         self._ck(self._lib.jpt_set_temporal_params(self.h, _ptr(p)), "jpt_set_temporal_params")
 
+    def set_outputs(self, depth: bool = True):
+        """jpt_set_outputs: the r32f depth image (main.glsl:435) has one reader, TemporalReprojection; off saves its passes"""
+        self._ck(self._lib.jpt_set_outputs(self.h, capi.OUTPUT_DEPTH if depth else 0), "jpt_set_outputs")
+
     # ---- outputs
     def read_ldr(self) -> np.ndarray:
         out = np.zeros((self.height, self.width, 4), dtype=np.uint8)

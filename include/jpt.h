@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define JPT_ABI_VERSION 4
+#define JPT_ABI_VERSION 5
 
 typedef struct jpt_ctx jpt_ctx;
 
@@ -131,6 +131,10 @@ typedef struct {
      * ray does, one dependent fetch after another (launch tails). */
     uint64_t walk_steps_max;    /* most record steps (internal records + leaf turns + instance entries) one ray took */
     uint64_t walk_steps_hist[8];/* rays that took < 16, < 64, < 256, < 1024, < 4096, < 16384, < 65536, more steps */
+    /* ABI 5 -- counting renders: path vertices that go on although their throughput has become exactly (0, 0, 0) (brdf()
+     * returns 0 when n.v < 0, brdfs.glsl:14): every later vertex of such a path adds 0 * emission (main.glsl:380), SURVEY.md
+     * section 7 lists ending them as a result-preserving freedom; DESIGN.md section 8 says what share of the rays they are */
+    uint64_t zero_throughput;   /* ... such vertices (each is the start of one more ray segment) */
 } jpt_stats;
 
 /* ---- lifetime --------------------------------------------------------------------------------- */
@@ -181,7 +185,10 @@ int jpt_set_stream_priority(jpt_ctx *ctx, int32_t priority);
  *                      render calls return JPT_E_LIMIT and allocate nothing (the audit kernel needs no workspace).
  * Takes effect with the next render; workspaces no longer allowed are freed at once (the call waits for renders in
  * flight).  jpt_get_workspace_bytes reports what is allocated now.  No reference counterpart (the reference's
- * workspace is the two images of one frame). */
+ * workspace is the two images of one frame).
+ * Host side: the blocking read-backs (jpt_read_*) go through one PINNED staging buffer per context, as large as the
+ * largest read-back made so far (133 MB after a jpt_read_accum_f32 of a 3840x2160 image); this call and every change of
+ * resolution or partition give it back, the next read-back allocates what it needs.  It is not part of the bytes reported. */
 int jpt_set_memory_policy(jpt_ctx *ctx, int32_t renders_in_flight, uint64_t workspace_budget_bytes);
 int jpt_get_workspace_bytes(jpt_ctx *ctx, uint64_t *bytes_out);
 
@@ -368,6 +375,15 @@ int jpt_set_denoising_mode(jpt_ctx *ctx, int32_t mode);
  * the history image to read (even: frameBuffer1) and to write; blendFactor is not read by the shader
  * (temporal_reprojection.glsl:64 uses the literal 0.75) and is not read here. */
 int jpt_set_temporal_params(jpt_ctx *ctx, const void *render_parameters88);
+
+/* Which of main.glsl's two images a render produces (ABI 5).  The reference stores both every frame (main.glsl:434-435), but its
+ * r32f depth image has one reader, TemporalReprojection (temporal_reprojection.glsl:45-58; add_existing_buffer at
+ * temporal_reprojection.cpp:33): in the progressive and "none" modes nothing ever looks at it ("result-
+ * preserving freedoms").  JPT_OUTPUT_DEPTH off: the kernels neither keep the first-hit distances nor write the depth image
+ * (8.3 MB per 1080p render), and jpt_read_depth_f32 answers JPT_E_STATE.  Default: on, as the reference; JPT_DENOISE_TEMPORAL
+ * renders produce it whatever this says.  The colour image, the accumulation and the display image are not affected. */
+enum { JPT_OUTPUT_DEPTH = 1 };
+int jpt_set_outputs(jpt_ctx *ctx, uint32_t outputs);
 
 /* ---- outputs ---------------------------------------------------------------------------------- */
 

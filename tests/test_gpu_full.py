@@ -929,6 +929,7 @@ def test_bench_self_launch_two_ranks_on_one_gpu(hiplib, launcher):
 
 
 @pytest.mark.parametrize("switch", ["JPT_COOP=1 JPT_COOP_ROUNDS=2", "JPT_TAIL=2 JPT_TAIL_ROUNDS=2 JPT_TAIL_LANES=8", "JPT_TRACE_REGROUP=1",
+                                    "JPT_TRACE_REGROUP=2", "JPT_TRACE_REGROUP=2 JPT_POOL_MIN_PREFETCH=1", "JPT_TRACE_REGROUP=2 JPT_POOL_MIN_PREFETCH=65",
                                     "JPT_TRACE_REGROUP=1 JPT_COOP=1 JPT_COOP_ROUNDS=2", "JPT_XCD_BAND_ROWS=2", "JPT_PRIMARY_SAMPLES=0",
                                     "JPT_GROUPS=3", "JPT_GROUPS=2 JPT_PRIMARY_SAMPLES=0"])
 def test_alternative_tracing_launches_are_bit_identical(hiplib, switch):
@@ -978,3 +979,75 @@ def test_walk_length_statistics_of_a_counting_render(hiplib):
     # every record step is counted once: internal records + leaf turns + instance entries (a leaf turn tests one or two triangles)
     assert st["walk_steps_max"] <= st["blas_expand"] + st["tlas_expand"] + st["tri_tests"] + st["inst_visits"]
     ctx.close()
+
+
+def test_depth_image_is_optional(hiplib):
+    """jpt_set_outputs (ABI 5; SURVEY.md section 7: the r32f depth image has one reader, temporal reprojection).  With the depth
+    output off the kernels keep no first-hit distances and write no depth image: the accumulation and the display image are the
+    same bytes, jpt_read_depth_f32 says JPT_E_STATE; switched on again the next render writes it; the temporal mode produces it
+    whatever the switch says.  Blocking, queued and audit-kernel renders."""
+    sc = scenes.demo_scene(5000)
+    w, h = 320, 184
+    for kernel in KERNELS:
+        ctx = make_ctx(sc, w, h, 3, wire.ACCUM_REF_LDR8, capi.BUILD_SAH, kernel)
+        ctx.render(3, 1)
+        want, want_ldr, want_depth = ctx.read_accum(), ctx.read_ldr(), ctx.read_depth()
+        ctx.set_outputs(depth=False)
+        for asynchronous in (False, True):
+            ctx.accum_reset()
+            ctx.render(3, 1, asynchronous=asynchronous)
+            assert np.array_equal(ctx.read_accum(), want) and np.array_equal(ctx.read_ldr(), want_ldr)
+            with pytest.raises(capi.JptError) as e:
+                ctx.read_depth()
+            assert "(-4)" in str(e.value) and "switched off" in str(e.value)      # JPT_E_STATE
+        ctx.set_outputs(depth=True)
+        with pytest.raises(capi.JptError):
+            ctx.read_depth()                      # on again, but no render has written it yet
+        ctx.accum_reset()
+        ctx.render(3, 1)
+        assert np.array_equal(ctx.read_depth(), want_depth) and np.array_equal(ctx.read_accum(), want)
+        ctx.close()
+
+
+def test_rank_shares_add_up_to_the_whole_image(hiplib):
+    """bench.py's `projected_scaling` times every rank's share of a render on one device (VERDICT r04 task 2): the eight shares of an
+    8-way partition are the whole image's work -- their ray segments sum to the whole render's, every counter does, and their rows
+    are the whole image's rows."""
+    sc = scenes.demo_scene(5000)
+    w, h, spp, bounces = 480, 270, 2, 3
+    whole = make_ctx(sc, w, h, bounces, wire.ACCUM_REF_LDR8)
+    whole.render(spp, 1, counted=True)
+    want, st = whole.read_accum(), whole.stats()
+    whole.close()
+    keys = ("rays", "blas_expand", "tri_tests", "tlas_expand", "inst_visits", "shaded_hits", "sky_culled", "zero_throughput")
+    for world in (2, 8):
+        tot = dict.fromkeys(keys, 0)
+        got = np.zeros_like(want)
+        ctx = make_ctx(sc, w, h, bounces, wire.ACCUM_REF_LDR8)
+        for r in range(world):
+            ctx.set_partition(r, world)
+            ctx.set_params(w, h, bounces, wire.ACCUM_REF_LDR8)
+            ctx.set_camera(scenes.camera_block(sc.camera, w, h))
+            ctx.render(spp, 1, counted=True)
+            s = ctx.stats()
+            for k in keys:
+                tot[k] += s[k]
+            rows = partition.rows_of_rank(h, r, world)
+            got[rows] = ctx.read_accum()[rows]
+        ctx.close()
+        assert tot == {k: st[k] for k in keys}
+        assert np.array_equal(got, want)
+
+
+def test_zero_throughput_vertices_are_counted(hiplib):
+    """jpt_stats.zero_throughput (ABI 5): path vertices that go on with a throughput of exactly (0, 0, 0) -- brdf() returned 0 because
+    n.v < 0 at a hit whose interpolated normal faces away from the viewer (brdfs.glsl:14) -- counted by a counting render."""
+    sc = scenes.demo_scene(5000)
+    w, h, spp, bounces = 320, 180, 2, 4
+    ctx = make_ctx(sc, w, h, bounces, wire.ACCUM_REF_LDR8)
+    ctx.render(spp, 1, counted=True)
+    st = ctx.stats()
+    ctx.close()
+    assert 0 <= st["zero_throughput"] <= st["shaded_hits"]
+    # such vertices exist on a smooth-shaded mesh seen at grazing angles, and they are few
+    assert st["zero_throughput"] < 0.05 * st["rays"]

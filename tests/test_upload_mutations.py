@@ -48,8 +48,11 @@ def test_tlas_cycle_is_an_error_not_a_crash():
         ctx.close()
 
 
-def test_shared_subtrees_cost_their_size_not_two_to_the_depth():
-    """a DAG (both children of every node the same next node) is walked as given; the flatten expands each node once"""
+def test_shared_subtrees_are_refused_not_walked_two_to_the_depth_times():
+    """a DAG (both children of every node the same next node) is refused: the flatten would expand each node once (its memo), but
+    the traversal on the device has no visited set and follows every path -- 2^60 box visits per ray that enters the box, a render
+    that never ends.  Sharing that cannot multiply paths stays legal: several instances on one BLAS root, and a LEAF
+    under two parents"""
     from gdpathtracing_amd import capi, host, scenes, wire
     from oracle import binding as ob
     ref = ob.build_scene(scenes.cornell_scene())
@@ -68,14 +71,37 @@ def test_shared_subtrees_cost_their_size_not_two_to_the_depth():
     tlas["leftRight"][0] = 0
     tlas["blas"][0] = 0
     ctx = host.Context(-1)
-    ctx.upload_reference_layout(ref.tri_geom, ref.tri_data, ref.materials, bvh, inst, tlas)   # 2^60 calls before the memo
+    for as_given in (False, True):
+        with pytest.raises(capi.JptError) as e:
+            ctx.upload_reference_layout(ref.tri_geom, ref.tri_data, ref.materials, bvh, inst, tlas, as_given=as_given)   # (2^60 calls before the memo)
+        assert "(-1)" in str(e.value) and "two parents" in str(e.value)      # JPT_E_INVALID
+    # a LEAF under two parents multiplies nothing: walked as given (the reach rule does not cover it)
+    leafy = np.zeros(2, dtype=wire.BVH_NODE)
+    leafy["aabbMin"][:, :3] = -1.0
+    leafy["aabbMax"][:, :3] = 1.0
+    leafy["left_child"][0] = leafy["right_child"][0] = 1
+    leafy["tri_count"][1] = 1
+    ctx.upload_reference_layout(ref.tri_geom, ref.tri_data, ref.materials, leafy, inst, tlas)
     assert ctx.tree_kind() == capi.TREE_AS_GIVEN and "reachable twice" in ctx.upload_note()
+    # two instances on one BLAS root: legal, and still the native tree
+    two = np.concatenate([inst, inst])
+    tl2 = np.zeros(4, dtype=wire.TLAS_NODE)
+    tl2["aabbMin"], tl2["aabbMax"] = -10.0, 10.0
+    tl2["leftRight"][0] = 1 | (2 << 16)
+    tl2["blas"][1], tl2["blas"][2] = 0, 1
+    good = np.zeros(1, dtype=wire.BVH_NODE)
+    good["aabbMin"][:, :3] = -1.0
+    good["aabbMax"][:, :3] = 1.0
+    good["tri_count"][0] = 1
+    ctx.upload_reference_layout(ref.tri_geom, ref.tri_data, ref.materials, good, two, tl2)
     # ... and a BVH cycle is refused
+    bvh["right_child"][:depth] = 0
     bvh["left_child"][depth - 1] = 3
-    bvh["tri_count"][depth] = 1
+    for i in range(depth - 1):
+        bvh["right_child"][i] = depth      # (a leaf under many parents: fine)
     with pytest.raises(capi.JptError) as e:
         ctx.upload_reference_layout(ref.tri_geom, ref.tri_data, ref.materials, bvh, inst, tlas)
-    assert "cycle" in str(e.value)
+    assert "cycle" in str(e.value) or "two parents" in str(e.value)
     ctx.close()
 
 

@@ -116,10 +116,23 @@ def test_arrays_the_reach_rule_does_not_cover_are_walked_as_given(hiplib, oracle
     bad["first_tri_index"][a] = bad["first_tri_index"][b]
     bad["tri_count"][a] = 1
     _falls_back(ref, "two leaves", bvh_nodes=bad)
-    # a subtree reachable twice
+    # a LEAF reachable twice (both children of a node): outside the reach rule, walked as given ...
+    leafset = set(int(x) for x in leaves)
+    par = next(int(i) for i in deep if int(nodes["left_child"][i]) in leafset)
     bad = nodes.copy()
-    bad["right_child"][deep[0]] = bad["left_child"][deep[0]]
+    bad["right_child"][par] = bad["left_child"][par]
     _falls_back(ref, "reachable twice", bvh_nodes=bad)
+    # ... but a node WITH CHILDREN under two parents is refused: the device's walk has no visited set and would walk the shared
+    # subtree once per path (2^depth for a chain of such nodes: ADVICE r04)
+    par = next(int(i) for i in deep if int(nodes["left_child"][i]) not in leafset)
+    bad = nodes.copy()
+    bad["right_child"][par] = bad["left_child"][par]
+    for as_given in (False, True):
+        ctx = host.Context(-1)
+        with pytest.raises(capi.JptError) as e:
+            ctx.upload_reference_layout(ref.tri_geom, ref.tri_data, ref.materials, bad, ref.instances, ref.tlas_nodes, ref.textures, as_given=as_given)
+        assert "two parents" in str(e.value)
+        ctx.close()
     # an instance whose matrices do not belong together
     bad = ref.instances.copy()
     bad["inverse_transform"][1][12] += 3.0

@@ -18,7 +18,7 @@ for cam_name in ("demo", "closeup"):
     ctx.render(8, 1, counted=True)
     st = ctx.stats()
     ph = st["phase"]
-    print(label, cam_name, {k: st[k] for k in ("rays", "blas_expand", "tri_tests", "tlas_expand", "inst_visits", "shaded_hits", "sky_culled")},
+    print(label, cam_name, {k: st[k] for k in ("rays", "blas_expand", "tri_tests", "tlas_expand", "inst_visits", "shaded_hits", "sky_culled", "zero_throughput") if k in st},
           "rounds %d node_iters %d lanes/iter %.1f leaf_phases %d lanes %.1f inst_phases %d lanes %.1f" % (
               ph[0], ph[1], ph[2] / max(ph[1], 1), ph[3], ph[4] / max(ph[3], 1), ph[5], ph[6] / max(ph[5], 1)))
     ctx.close()
