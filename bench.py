@@ -700,7 +700,8 @@ def main():
                 if pj.get("_meta", {}).get("csrc_sha") != kernels_sha:
                     raise LookupError("profiled on other kernels")
                 traffic = int(pj[dom]["hbm_bytes_per_launch"])
-                traffic_src = os.path.relpath(args.pmc_json, ROOT) + ": (2*FETCH_SIZE + WRITE_SIZE) KiB per launch of %s, separate --pmc passes" % dom
+                traffic_src = os.path.relpath(args.pmc_json, ROOT) + ": read bytes [%s] + WRITE_SIZE KiB per launch of %s, separate --pmc passes" % (
+                    pj[dom].get("fetch_method", "2 * FETCH_SIZE"), dom)
             except LookupError:
                 traffic, stale = None, "profiles/current_pmc.json was collected on other kernel sources than the ones running (csrc hash %s): re-run tools/round_profiles.sh" % kernels_sha
             except Exception:

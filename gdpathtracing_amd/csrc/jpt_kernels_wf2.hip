@@ -51,6 +51,9 @@ constexpr bool kXcdBands = true;
 #ifndef JPT_LEAF_INNER
 #define JPT_LEAF_INNER 0
 #endif
+#ifndef JPT_TRACE_FINISH_MISSES
+#define JPT_TRACE_FINISH_MISSES 0   // (1 / 2: wf2_trace finishes the walks that missed; measured, not kept -- see save_hit)
+#endif
 #ifndef JPT_TILE_MORTON
 #define JPT_TILE_MORTON 0   // (measured: 1-2 % fewer rounds of the primary launch, no time: profiles/r04/r04ag_samples_together.txt)
 #endif
@@ -168,6 +171,7 @@ struct Wf2Buffers {
     uint32_t long_cap;     //     wf2_long launch that follows, so one list serves all launches of a render
     uint32_t* rg_cursor;   // regrouped tracing launches (wf2_trace_rg): [max_bounces + 2][kSegments] queue cursors, shared by the waves of a queue
     int32_t* rg_spill;     // ... and the stack entries past the LDS part: [block][pool slot][entry]
+    int32_t accum_mode;    // JPT_ACCUM_* (store_final outside the kernels that get FrameParams)
     uint32_t redo_cap;     // records redo_rec holds (a few paths in 10^7 are set aside: not one record per path).  A hit
                            // that finds the buffer full is shaded as found -- the native tree's closest hit, without the
                            // reference's crack -- and counted in redo_count[1] (jpt_stats.set_aside_dropped)
@@ -634,31 +638,20 @@ __global__ __launch_bounds__(kBlock, JPT_PRIMARY_WAVES) void wf2_primary(WideSce
 #define JPT_MAX_CHAIN 4
 #endif
 constexpr int kMaxChain = JPT_MAX_CHAIN;
-template <bool COUNT, bool W4, int COOP = 0>
-__global__ __launch_bounds__(kBlock, JPT_WAVES_PER_SIMD) void wf2_trace(WideSceneDev sc, Wf2Buffers wb, Wf2Dims dm, int bounce, WfTune tune,
-                                                    int chain, DevCounters* __restrict__ counters)
+// The walk of one block's ray queue -- `n` entries in the consecutive segments seg0, seg0 + 1, .. (end[k] = entries in the first k + 1
+// of them) -- with the block's stack columns and queue cursor in LDS: the body of wf2_trace, and the second phase of wf2_bounce.
+template <bool COUNT, bool W4, int COOP>
+__device__ __forceinline__ void trace_queue(const WideSceneDev& sc, const Wf2Buffers& wb, const Wf2Dims& dm, const int bounce, const WfTune& tune,
+                                            const uint32_t seg0, const uint32_t (&end)[kMaxChain], const uint32_t n, int32_t* __restrict__ stack,
+                                            uint32_t* __restrict__ s_cursor, DevCounters& cnt)
 {
-    __shared__ int32_t stack[kStackLds * kBlock];
-    __shared__ uint32_t s_cursor;
     const int lane = threadIdx.x & 63;
-    const uint32_t seg0 = blockIdx.x * (uint32_t)chain;
-    // end[k] = entries in segments seg0 .. seg0 + k (wave-uniform, kept in scalars)
-    uint32_t end[kMaxChain];
-    uint32_t n = 0;
-    for (int k = 0; k < kMaxChain; k++) {
-        if (k < chain && seg0 + (uint32_t)k < kSegments) n += wb.qcount[(size_t)bounce * kSegments + seg0 + (uint32_t)k];
-        end[k] = n;
-    }
-    if (n == 0) return;
-    if (threadIdx.x == 0) s_cursor = 0;
-    __syncthreads();
     int32_t spill[kStackSpill];
     const typename Traversal<COUNT, W4>::Stack my_stack{&stack[threadIdx.x], spill, kTraceBlock, kStackLds};
     uint32_t dry_rounds = 0;   // (COOP: rounds of this wave since the block's queue ran dry; wave-uniform)
     bool list_full = false;    // (COOP == 1: this lane's reservation in the hand-over list failed: not tried again)
     const float4* __restrict__ qo = wb.ray_o[bounce & 1];
     const float4* __restrict__ qd = wb.ray_d[bounce & 1];
-    DevCounters cnt = {};
     Traversal<COUNT, W4> tr;
     bool active = false, exhausted = false;
 #ifndef JPT_LATE_HIT_STORE
@@ -671,6 +664,27 @@ __global__ __launch_bounds__(kBlock, JPT_WAVES_PER_SIMD) void wf2_trace(WideScen
     // wave refills (two dozen lanes at once) instead of in the round each walk happens to end in (some lane does in
     // nearly every round: a dozen instructions per round for one or two lanes' stores).
     auto save_hit = [&]() {
+#if JPT_TRACE_FINISH_MISSES
+        // (-DJPT_TRACE_FINISH_MISSES=1 / 2, VERDICT r04 task 6: a walk that MISSED is finished where it ends -- the `!is_hit` branch
+        // of shade_entry, same operations in the same order: radiance so far + throughput * sampleSky(d), main.glsl:366-368,380 --
+        // and its hit record says "done" (t = -1), so that wf2_shade drops the entry.  The walk's registers are dead here.
+        // Measured, not kept: profiles/r05/)
+        if (!(tr.hit.t < 1e9f)) {
+            const float4 tq = wb.thr_q[bounce & 1][my_loc];
+            const uint32_t pw = __float_as_uint(qd[my_loc].w);
+            const uint32_t p = pw & kPathMask;
+            f3 radiance = mk3(0.0f, 0.0f, 0.0f);
+            if (pw & kHasRadiance) {
+                const float4 r4 = wb.rad[p];
+                radiance = mk3(r4.x, r4.y, r4.z);
+            }
+            radiance = radiance + mk3(tq.x, tq.y, tq.z) * sample_sky(tr.wd);
+            store_final(wb, wb.accum_mode, p, radiance);
+            if (COUNT) cnt.rays++;
+            wb.hit_a[my_loc] = make_float4(-1.0f, 0.0f, 0.0f, 0.0f);
+            return;
+        }
+#endif
         wb.hit_a[my_loc] = make_float4(tr.hit.t, tr.hit.u, tr.hit.v, __uint_as_float(tr.hit.tri));
         wb.hit_b[my_loc] = tr.hit.inst | (tr.hit.front ? 0x80000000u : 0u);
     };
@@ -684,7 +698,7 @@ __global__ __launch_bounds__(kBlock, JPT_WAVES_PER_SIMD) void wf2_trace(WideScen
                 unsaved = false;
             }
             uint32_t start = 0;
-            if (lane == 0) start = atomicAdd(&s_cursor, (uint32_t)n_idle);
+            if (lane == 0) start = atomicAdd(s_cursor, (uint32_t)n_idle);
             start = (uint32_t)__builtin_amdgcn_readfirstlane((int)start);
             if (start + (uint32_t)n_idle >= n) exhausted = true;
             if (start < n && !active) {
@@ -759,6 +773,27 @@ __global__ __launch_bounds__(kBlock, JPT_WAVES_PER_SIMD) void wf2_trace(WideScen
         }
     }
     if (JPT_LATE_HIT_STORE && unsaved) save_hit();
+}
+
+template <bool COUNT, bool W4, int COOP = 0>
+__global__ __launch_bounds__(kBlock, JPT_WAVES_PER_SIMD) void wf2_trace(WideSceneDev sc, Wf2Buffers wb, Wf2Dims dm, int bounce, WfTune tune,
+                                                    int chain, DevCounters* __restrict__ counters)
+{
+    __shared__ int32_t stack[kStackLds * kBlock];
+    __shared__ uint32_t s_cursor;
+    const uint32_t seg0 = blockIdx.x * (uint32_t)chain;
+    // end[k] = entries in segments seg0 .. seg0 + k (wave-uniform, kept in scalars)
+    uint32_t end[kMaxChain];
+    uint32_t n = 0;
+    for (int k = 0; k < kMaxChain; k++) {
+        if (k < chain && seg0 + (uint32_t)k < kSegments) n += wb.qcount[(size_t)bounce * kSegments + seg0 + (uint32_t)k];
+        end[k] = n;
+    }
+    if (n == 0) return;
+    if (threadIdx.x == 0) s_cursor = 0;
+    __syncthreads();
+    DevCounters cnt = {};
+    trace_queue<COUNT, W4, COOP>(sc, wb, dm, bounce, tune, seg0, end, n, stack, &s_cursor, cnt);
     if (COUNT) flush_counters(cnt, counters);
 }
 
@@ -964,12 +999,26 @@ __global__ __launch_bounds__(kBlock, LAST ? 8 : (TEX == 0 ? JPT_SHADE_NOTEX_WAVE
     bool alive = false;
     float4 no, nd, nt;
     if (i < n) {
+#if JPT_TRACE_FINISH_MISSES == 2
+        // (the hit record FIRST, the rest of the entry only if its path goes on: a dependent round trip for every entry, 52 bytes
+        // less for the entries wf2_trace finished)
+        const float4 ha = wb.hit_a[seg_base + i];
+        if (!(bounce > 0 && ha.x < 0.0f)) {
+            const float4 ro = wb.ray_o[in][seg_base + i], rd = wb.ray_d[in][seg_base + i];
+            const float4 tin = bounce > 0 ? wb.thr_q[in][seg_base + i] : make_float4(1.0f, 1.0f, 1.0f, 0.0f);
+            const uint32_t hb = wb.hit_b[seg_base + i];
+            bool unreachable;
+            alive = shade_entry<COUNT, LAST, TEX>(sh, wb, dm, fp, cam_far, bounce, ro, rd, tin, ha, hb, true, unreachable, no, nd, nt, cnt);
+        }
+#else
         const float4 ro = wb.ray_o[in][seg_base + i], rd = wb.ray_d[in][seg_base + i];
         const float4 tin = bounce > 0 ? wb.thr_q[in][seg_base + i] : make_float4(1.0f, 1.0f, 1.0f, 0.0f);
         const float4 ha = wb.hit_a[seg_base + i];
         const uint32_t hb = wb.hit_b[seg_base + i];
         bool unreachable;   // (set aside inside shade_entry: nothing more to do here)
-        alive = shade_entry<COUNT, LAST, TEX>(sh, wb, dm, fp, cam_far, bounce, ro, rd, tin, ha, hb, true, unreachable, no, nd, nt, cnt);
+        if (!(JPT_TRACE_FINISH_MISSES && bounce > 0 && ha.x < 0.0f))   // (an entry wf2_trace has finished: nothing left to do)
+            alive = shade_entry<COUNT, LAST, TEX>(sh, wb, dm, fp, cam_far, bounce, ro, rd, tin, ha, hb, true, unreachable, no, nd, nt, cnt);
+#endif
     }
     if (LAST) {   // (no path goes on: nothing to pack)
         if (COUNT) flush_counters(cnt, counters);
@@ -1000,6 +1049,68 @@ __global__ __launch_bounds__(kBlock, LAST ? 8 : (TEX == 0 ? JPT_SHADE_NOTEX_WAVE
             wb.ray_d[out][j] = nd;
             wb.thr_q[out][j] = nt;
         }
+    }
+    if (COUNT) flush_counters(cnt, counters);
+}
+
+// ---- SMALL renders: one launch per bounce -- shade(b), then trace(b + 1), segment by segment (VERDICT r04 task 2) ----------
+//
+// A render is eleven dependent launches however little work it holds, each at least as long as its longest walk (DESIGN.md
+// section 4: a GPU's eighth of C3 is 0.31 ms of launches for 0.11 ms of work).  The hand-off from wf2_shade(b) to
+// wf2_trace(b + 1) never leaves a segment -- block s of the tracing launch reads what the blocks of the shading launch wrote
+// into segment s's queue -- so for small renders one block does both: it shades its segment's entries (grid-stride; the next
+// queue's size is counted in LDS instead of with global atomics), and after a block barrier (workgroup-scope release / acquire:
+// the queue entries went through this CU's L1) it walks the queue it has just written.  Six launches instead of eleven; same
+// operations on the same entries, so the same image.  Blocks now differ in what they are doing at any moment -- a shading
+// phase waits on gathers, a tracing phase issues VALU work -- which is what renders in flight otherwise provide.
+template <bool COUNT, int TEX>
+__global__ __launch_bounds__(kBlock, JPT_WAVES_PER_SIMD) void wf2_bounce(WideSceneDev sc, SceneShading sh, Wf2Buffers wb, Wf2Dims dm, FrameParams fp, float cam_far,
+                                                                         int bounce, WfTune tune, DevCounters* __restrict__ counters)
+{
+    __shared__ int32_t stack[kStackLds * kBlock];
+    __shared__ uint32_t s_cursor, s_next;
+    const int lane = threadIdx.x & 63;
+    const uint32_t seg = blockIdx.x;
+    const uint32_t n = wb.qcount[(size_t)bounce * kSegments + seg];
+    if (threadIdx.x == 0) {
+        s_cursor = 0;
+        s_next = 0;
+    }
+    __syncthreads();
+    DevCounters cnt = {};
+    const size_t seg_base = (size_t)seg * dm.seg_cap;
+    const int in = bounce & 1, out = (bounce + 1) & 1;
+    for (uint32_t base = 0; base < n; base += kBlock) {
+        const uint32_t i = base + threadIdx.x;
+        bool alive = false;
+        float4 no, nd, nt;
+        if (i < n) {
+            const float4 ro = wb.ray_o[in][seg_base + i], rd = wb.ray_d[in][seg_base + i];
+            const float4 tin = bounce > 0 ? wb.thr_q[in][seg_base + i] : make_float4(1.0f, 1.0f, 1.0f, 0.0f);
+            const float4 ha = wb.hit_a[seg_base + i];
+            const uint32_t hb = wb.hit_b[seg_base + i];
+            bool unreachable;
+            alive = shade_entry<COUNT, false, TEX>(sh, wb, dm, fp, cam_far, bounce, ro, rd, tin, ha, hb, true, unreachable, no, nd, nt, cnt);
+        }
+        const unsigned long long m = __ballot(alive);
+        if (m) {
+            uint32_t wbase = 0;
+            if (lane == 0) wbase = atomicAdd(&s_next, (uint32_t)__popcll(m));
+            wbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)wbase);
+            if (alive) {
+                const size_t j = seg_base + wbase + lanes_below(m, lane);
+                wb.ray_o[out][j] = no;
+                wb.ray_d[out][j] = nd;
+                wb.thr_q[out][j] = nt;
+            }
+        }
+    }
+    __syncthreads();   // the segment's next queue is complete and visible to the whole block
+    const uint32_t n_next = s_next;
+    if (threadIdx.x == 0) wb.qcount[(size_t)(bounce + 1) * kSegments + seg] = n_next;   // (the host's ray count, the next launch's size)
+    if (n_next != 0u) {
+        const uint32_t end[kMaxChain] = {n_next, n_next, n_next, n_next};
+        trace_queue<COUNT, true, 0>(sc, wb, dm, bounce + 1, tune, seg, end, n_next, stack, &s_cursor, cnt);
     }
     if (COUNT) flush_counters(cnt, counters);
 }
@@ -1539,6 +1650,7 @@ void launch_wf2_render(hipStream_t stream, const DeviceScene& ds, const FramePar
         wb.hit_a = (float4*)carve(q * sizeof(float4));
         wb.hit_b = (uint32_t*)carve(q * sizeof(uint32_t));
         wb.redo_cap = redo_capacity(paths);
+        wb.accum_mode = fp.accum_mode;
         wb.redo_rec = (float4*)carve((size_t)wb.redo_cap * 2 * sizeof(float4));
         wb.thr = (float4*)carve(paths * sizeof(float4));
         wb.rad = rad_all + (size_t)f0 * dm_all.slots_per_frame;  // this group's block ([slot][frame of the group]: path ids) behind the earlier groups'
@@ -1597,6 +1709,12 @@ void launch_wf2_render(hipStream_t stream, const DeviceScene& ds, const FramePar
         return (int)wv;
     }();
     const uint32_t pool_blocks = tgrid.x * (uint32_t)pool_waves;
+    // One launch per bounce (wf2_bounce) for renders of few paths: JPT_FUSE_BOUNCE=0 never, 1 whenever the launches allow it, -1
+    // (default) the library's rule: windows of at most `fuse_max_paths` paths.  Not with per-launch events (kernel timing wants the
+    // tracing launches on their own), nor with the cooperative or regrouped launches.
+    const size_t window_paths = (size_t)dm_all.slots_per_frame * (size_t)fp.n_frames;
+    const bool fuse = w4 && !coop && !tail && !regroup && !pool && trace_events == nullptr &&
+                      (tuning().fuse_bounce > 0 || (tuning().fuse_bounce < 0 && window_paths <= (size_t)tuning().fuse_max_paths));
     const int rg_waves = [&] {
         const uint32_t queues = tgrid.x;
         const uint32_t target = async.trace_chain >= 4 ? 640u : (groups == 2 ? 1280u : 2560u);
@@ -1635,6 +1753,15 @@ void launch_wf2_render(hipStream_t stream, const DeviceScene& ds, const FramePar
         }
         if (ev) (void)hipEventRecord(ev[1], st);
         for (int b = 0; b <= gp.max_bounces; b++) {
+            if (fuse && b < gp.max_bounces) {   // shade(b) + trace(b + 1) as one launch (small renders: wf2_bounce)
+                const bool tex = sh.tex != nullptr && sh.n_layers > 0 && sh.tex_res > 0;
+                const int texmode = !tex ? 0 : ((sh.sampler_mode & 2) ? 2 : 1);
+#define JPT_LAUNCH_BOUNCE(C, T) hipLaunchKernelGGL((wf2_bounce<C, T>), pgrid, block, 0, st, sc, sh, wb, dm, gp, cam.far_, b, tune, counters)
+                if (counters) { if (texmode == 0) JPT_LAUNCH_BOUNCE(true, 0); else if (texmode == 1) JPT_LAUNCH_BOUNCE(true, 1); else JPT_LAUNCH_BOUNCE(true, 2); }
+                else          { if (texmode == 0) JPT_LAUNCH_BOUNCE(false, 0); else if (texmode == 1) JPT_LAUNCH_BOUNCE(false, 1); else JPT_LAUNCH_BOUNCE(false, 2); }
+#undef JPT_LAUNCH_BOUNCE
+                continue;
+            }
             {
                 // instantiations: the paths' last vertices without the BRDF code, scenes without a texture array without
                 // the sampler code

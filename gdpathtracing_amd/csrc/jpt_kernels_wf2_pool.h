@@ -140,8 +140,12 @@ struct PoolWave {
         if (!exhausted && cf >= 64u) {
             const uint32_t start = (uint32_t)__builtin_amdgcn_readfirstlane((int)next_start);
             const uint32_t avail = start < n ? (n - start < 64u ? n - start : 64u) : 0u;
-            if (start + 64u >= n) exhausted = true;
-            else if (lane == 0) next_start = atomicAdd(cursor, 64u);
+            // (`exhausted` set BEFORE the one-lane branch: as `if (..) exhausted = true; else if (lane == 0) ..` it became a value
+            // merged at the join of a divergent branch, i.e. divergent to the compiler, and with it every list head and count: VGPRs,
+            // exec-mask branches)
+            const bool last = start + 64u >= n;
+            exhausted = last;
+            if (!last && lane == 0) next_start = atomicAdd(cursor, 64u);
             if (avail != 0u) {   // (0: the queue ended exactly at the last refill -- on to the lists)
                 t.kind = kPoolFree;
                 t.take = avail;
@@ -156,9 +160,10 @@ struct PoolWave {
                 if (idx >= end1) k = 2u, first = end1;
                 if (idx >= end2) k = 3u, first = end2;
                 t.loc = (seg0 + k) * seg_cap + (idx - first);
-                t.r4 = qo[t.loc];
-                t.r5 = qd[t.loc];
-                t.a = t.b = t.r0 = t.r1 = t.r2 = t.r3 = nobody_reads4();
+                t.r0 = qo[t.loc];
+                t.r1 = qd[t.loc];
+                t.r2 = ld4(nodes), t.r3 = ld4(nodes + 16);   // (every turn asks for FOUR 16-byte words: see take())
+                t.a = t.b = t.r4 = t.r5 = nobody_reads4();
                 t.cm = nobody_reads2();
                 hf += avail;
                 cf -= avail;
@@ -167,6 +172,9 @@ struct PoolWave {
         }
         const uint32_t best = cn >= cl ? (cn >= ct ? cn : ct) : (cl >= ct ? cl : ct);
         if (best == 0u || best < at_least) {
+            // (no turn, no loads: the wait makes this path agree with the others about what is outstanding afterwards -- nothing that
+            // a later turn could be kept waiting for; the wave has nothing else to do here anyway)
+            __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
             t.kind = kPoolNone;
             t.take = 0u;
             t.id = t.loc = nobody_reads();
@@ -197,6 +205,11 @@ struct PoolWave {
         t.b = P->b[t.id];
         t.cm = P->cm[t.id];
         const int32_t cur = (int32_t)t.cm.x;
+        // EXACTLY FOUR 16-byte global loads, whatever the kind.  The memory counter of this chip is in order: the wait at the start
+        // of a turn can leave the NEXT turn's loads in flight only if the compiler knows how many of them there are -- on every
+        // path alike; with 2 / 4 / 6 loads depending on the kind it waited for everything (vmcnt(0)) and the prefetch bought
+        // nothing (profiles/r05/r05b_*: no difference between preparing ahead and not).  What does not fit in four is asked for at
+        // the start of the turn itself: the second triangle's edges, the instance's third row and root.
         if (KIND == kPoolNode) {
             const char* p = nodes + ((size_t)(uint32_t)cur << 6);
             t.r0 = ld4(p), t.r1 = ld4(p + 16), t.r2 = ld4(p + 32), t.r3 = ld4(p + 48);
@@ -208,7 +221,8 @@ struct PoolWave {
             const char* p = tris + (size_t)first * sizeof(WideTri);
             const char* q = tris + (size_t)second * sizeof(WideTri);   // (a leaf of one triangle asks for it twice: no read past the array)
             t.r0 = ld4(p), t.r1 = ld4(p + 16), t.r2 = ld4(p + 32);
-            t.r3 = ld4(q), t.r4 = ld4(q + 16), t.r5 = ld4(q + 32);
+            t.r3 = ld4(q);
+            t.r4 = t.r5 = nobody_reads4();
             t.loc = P->loc[t.id];
         } else {
             t.loc = P->loc[t.id];
@@ -216,7 +230,8 @@ struct PoolWave {
             t.r5 = qd[t.loc];
             // (a TLAS record after an instance was left reads no instance: record 0 stands in)
             const char* p = insts + (size_t)(cur < 0 ? (uint32_t)~cur : 0u) * sizeof(WideInstance);
-            t.r0 = ld4(p), t.r1 = ld4(p + 16), t.r2 = ld4(p + 32), t.r3 = ld4(p + 48);
+            t.r0 = ld4(p), t.r1 = ld4(p + 16);
+            t.r2 = t.r3 = nobody_reads4();
         }
     }
 
@@ -263,8 +278,8 @@ struct PoolWave {
             // refill: the reserved queue entries start their walk at the TLAS root with the world ray; closest distance 1e9 (main.glsl:354)
             const bool trivial = n_instances == 0u;
             if (on) {
-                P->a[id] = make_float4(t.r4.x, t.r4.y, t.r4.z, 1e9f);
-                P->b[id] = make_float4(t.r5.x, t.r5.y, t.r5.z, 0.0f);
+                P->a[id] = make_float4(t.r0.x, t.r0.y, t.r0.z, 1e9f);
+                P->b[id] = make_float4(t.r1.x, t.r1.y, t.r1.z, 0.0f);
                 P->cm[id] = make_uint2((uint32_t)tlas_root, 0u);
                 P->loc[id] = t.loc;
                 if (trivial) hit_a[t.loc] = make_float4(1e9f, 0.0f, 0.0f, 0.0f);
@@ -272,6 +287,7 @@ struct PoolWave {
             append(kPoolNode, on && !trivial && tlas_root >= 0, id, hn, cn);
             append(kPoolTop, on && !trivial && tlas_root < 0, id, ht, ct);
             append(kPoolFree, on && trivial, id, hf, cf);
+            asm volatile("" ::"v"(t.r2.x), "v"(t.r3.x));   // (the two stand-in loads are part of the count: not to be optimised away)
             return;
         }
         const uint32_t m = t.cm.y;
@@ -341,8 +357,11 @@ struct PoolWave {
                         accepted = true;
                     }
                 };
+                // (the second triangle's two edges: asked for now, used after the first triangle's test)
+                const char* q = tris + (size_t)(first + (count > 1u ? 1u : 0u)) * sizeof(WideTri);
+                const float4 s1 = ld4(q + 16), s2 = ld4(q + 32);
                 test(t.r0, t.r1, t.r2, first);
-                if (count > 1u) test(t.r3, t.r4, t.r5, first + 1u);
+                if (count > 1u) test(t.r3, s1, s2, first + 1u);
                 for (uint32_t i = 2; i < count; i++) {   // (leaves of more than two triangles: JPT_MAX_LEAF > 2)
                     const char* p = tris + (size_t)(first + i) * sizeof(WideTri);
                     test(ld4(p), ld4(p + 16), ld4(p + 32), first + i);
@@ -369,7 +388,9 @@ struct PoolWave {
                     // Traversal::instance_step on the prefetched instance record: the instance's local ray (main.glsl:319-320), a
                     // sentinel on the stack, the BLAS root
                     tr.cur_inst = (uint32_t)~tr.cur;
-                    const float4 m0 = t.r0, m1 = t.r1, m2 = t.r2;
+                    const char* ip = insts + (size_t)tr.cur_inst * sizeof(WideInstance);
+                    const float4 m0 = t.r0, m1 = t.r1, m2 = ld4(ip + 32);   // (third row and root: asked for now -- a handful of instances are L1 hits)
+                    const int32_t root = *reinterpret_cast<const int32_t*>(ip + 48);
                     if (COUNT) cnt.inst_visits++;
                     tr.o = mk3(m0.x * tr.wo.x + m0.w * tr.wo.y + m1.z * tr.wo.z + m2.y, m0.y * tr.wo.x + m1.x * tr.wo.y + m1.w * tr.wo.z + m2.z,
                                m0.z * tr.wo.x + m1.y * tr.wo.y + m2.x * tr.wo.z + m2.w);
@@ -377,7 +398,7 @@ struct PoolWave {
                                m0.z * tr.wd.x + m1.y * tr.wd.y + m2.x * tr.wd.z);
                     tr.in_blas = true;
                     tr.push(st, kSentinel);
-                    tr.cur = __float_as_int(t.r3.x);
+                    tr.cur = root;
                 } else {
                     tr.o = tr.wo;   // a TLAS record after an instance: its box tests read the world ray
                     tr.d = tr.wd;

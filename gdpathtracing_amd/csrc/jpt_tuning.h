@@ -47,6 +47,8 @@ struct Tuning {
     int trace_regroup = 0;         // JPT_TRACE_REGROUP=1: bounce launches by wf2_trace_rg (ray state in LDS, compacted lists of rays per step kind: round 4,
                                    // measured, not kept); 2: by wf2_trace_pool (the same with turns prepared one ahead and a lean state: round 5)
     int pool_min_prefetch = 40;    // JPT_POOL_MIN_PREFETCH: wf2_trace_pool prepares its next turn ahead only when a list holds this many rays
+    int fuse_bounce = -1;          // JPT_FUSE_BOUNCE=0/1: wf2_shade(b) + wf2_trace(b + 1) as one launch per bounce (wf2_bounce) never / always (-1: small renders)
+    int fuse_max_paths = 0;        // JPT_FUSE_MAX_PATHS: ... the rule's bound on the render window's paths (0: the rule is off)
     int rg_waves = 0;              // JPT_RG_WAVES: waves (= blocks) per queue of the regrouped launches (0: the library's rule)
 };
 
@@ -92,6 +94,8 @@ inline const Tuning& tuning()
         v.trace_regroup = geti("JPT_TRACE_REGROUP", 0);
         v.pool_min_prefetch = geti("JPT_POOL_MIN_PREFETCH", 40);
         v.rg_waves = geti("JPT_RG_WAVES", 0);
+        v.fuse_bounce = geti("JPT_FUSE_BOUNCE", -1);
+        v.fuse_max_paths = geti("JPT_FUSE_MAX_PATHS", 0);
         v.exact_shadow = geti("JPT_EXACT_SHADOW", 1) != 0;
         if (const char* e = std::getenv("JPT_SET_ASIDE_CAP")) v.set_aside_cap = std::atol(e);
         if (const char* e = std::getenv("JPT_UPLOAD_WALK")) v.upload_as_given = e[0] == 'g' || e[0] == 'G';

@@ -386,6 +386,7 @@ class PathTracingCamera:
 
     def render(self, n_frames: int = 1):                            # path_tracing_camera.cpp:193-232
         self.ctx.set_denoising_mode(self.denoising_mode)            # the switch at :207-225
+        self.ctx.set_outputs(depth=self.denoising_mode == self.TEMPORAL_REPROJECTION)   # (main.glsl:435's image has one reader)
         self.ctx.set_camera(scenes.camera_block(self.camera_desc, self.width, self.height))
         first = self.frame_index + 1                                # camera.frame_index++ before the dispatch
         if self.denoising_mode == self.PROGRESSIVE_RENDERING:

@@ -234,6 +234,9 @@ class ComputeShader {
         }
         if (!dev_->frame_pending) return;
         int rc = jpt_set_denoising_mode(dev_->ctx, temporal_ ? JPT_DENOISE_TEMPORAL : JPT_DENOISE_PROGRESSIVE);
+        // main.glsl's r32f depth image has one reader, temporal_reprojection.glsl (this adapter never hands it to the host:
+        // get_image_uniform_buffer is only asked for the screen, path_tracing_camera.cpp:228-229): not produced in the other modes
+        if (rc == JPT_OK) rc = jpt_set_outputs(dev_->ctx, temporal_ ? JPT_OUTPUT_DEPTH : 0u);
         if (rc == JPT_OK && temporal_) {
             const Slot* p = nullptr;
             for (auto& kv : slots_)
@@ -258,6 +261,7 @@ class ComputeShader {
         Traits::resize(out, (size_t)dev_->width * dev_->height * 4);
         if (dev_->frame_pending) {  // no post-processing pass ran (denoising_mode == NONE): main.glsl's own rgba8 image
             int rc = jpt_set_denoising_mode(dev_->ctx, JPT_DENOISE_NONE);
+            if (rc == JPT_OK) rc = jpt_set_outputs(dev_->ctx, 0u);   // (nobody reads the depth image in this mode)
             if (rc == JPT_OK) rc = jpt_render(dev_->ctx, 1, dev_->camera_frame_index);
             if (rc != JPT_OK) error_ = jpt_last_error(dev_->ctx);
             dev_->frame_pending = false;

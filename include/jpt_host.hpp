@@ -719,6 +719,8 @@ class PathTracingCamera {
         camera.set_camera_transform(global_transform, projection_matrix);           // :198
         camera.frame_index++;                                                       // :199
         check(ctx, jpt_set_camera(ctx, &camera), "jpt_set_camera");                 // :200
+        // (the r32f depth image of main.glsl:435 is read by the temporal pass only: not produced in the other two modes)
+        check(ctx, jpt_set_outputs(ctx, denoising_mode == TEMPORAL_REPROJECTION ? JPT_OUTPUT_DEPTH : 0u), "jpt_set_outputs");
         switch (denoising_mode) {                                                   // :207-225
             case PROGRESSIVE_RENDERING:
                 check(ctx, jpt_set_denoising_mode(ctx, JPT_DENOISE_PROGRESSIVE), "jpt_set_denoising_mode");

@@ -23,6 +23,7 @@ BUDGETS = {
     "9wf2_shadeILb0ELb0ELi1E": (72, 0, 0),          # nearest filter
     "9wf2_shadeILb0ELb0ELi2E": (72, 0, 0),          # linear filter
     "9wf2_shadeILb0ELb1ELi0E": (64, 0, 0),          # the paths' last vertices: eight waves
+    "10wf2_bounceILb0ELi0E": (72, 420, 40),         # shade(b) + trace(b + 1) of small renders: seven waves; a dozen spills in the shading phase
 }
 
 

@@ -10,7 +10,7 @@ BIN=tools/micro/fetch_calib
 timeout 120 $BIN > $OUT/plain.txt 2>&1
 rocprofv3 -L 2>/dev/null | grep -o 'TCC_EA0_RDREQ[A-Za-z0-9_]*\|TCC_EA0_RD_UNCACHED[A-Za-z0-9_]*\|TCC_BUBBLE[A-Za-z0-9_]*' | sort -u > $OUT/counters_available.txt
 i=0
-for set in "FETCH_SIZE" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" "TCP_TCC_READ_REQ_sum TCC_READ_sum"; do
+for set in "FETCH_SIZE" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" "TCP_TCC_READ_REQ_sum TCC_READ_sum" "TCC_EA0_RDREQ_DRAM_sum TCC_EA0_RDREQ_sum"; do
   i=$((i+1))
   timeout 180 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT/p$i -- $BIN > $OUT/p$i.log 2>&1
 done

@@ -35,12 +35,19 @@ def main(src):
             row["known_bytes_per_rdreq"] = round(KNOWN[k] / rd, 2)
             if "TCC_EA0_RDREQ_32B_sum" in d:
                 row["rdreq_32B_share"] = round(d["TCC_EA0_RDREQ_32B_sum"] / rd, 4)
+            if "TCC_EA0_RDREQ_128B_sum" in d:
+                r128, r32 = d["TCC_EA0_RDREQ_128B_sum"], d.get("TCC_EA0_RDREQ_32B_sum", 0.0)
+                r64 = d.get("TCC_EA0_RDREQ_64B_sum", rd - r128 - r32)
+                row["rdreq_128B_share"] = round(r128 / rd, 4)
+                row["bytes_by_request_size"] = 32 * r32 + 64 * r64 + 128 * r128
+                row["known_over_bytes_by_request_size"] = round(KNOWN[k] / max(row["bytes_by_request_size"], 1), 4)
         out[k] = row
     json.dump(out, open(os.path.join(src, "summary.json"), "w"), indent=1, sort_keys=True)
-    print("%-16s %12s %14s %10s %12s %10s" % ("shape", "known MiB", "FETCH_SIZE MiB", "known/FS", "B per RDREQ", "32B share"))
+    print("%-16s %10s %14s %9s %11s %9s %10s %22s" % ("shape", "known MiB", "FETCH_SIZE MiB", "known/FS", "B per RDREQ", "32B share", "128B share", "known / (32,64,128)-sum"))
     for k, r in out.items():
-        print("%-16s %12.1f %14s %10s %12s %10s" % (k, r["known_bytes"] / 2**20, "%.1f" % (r["fetch_size_bytes"] / 2**20) if "fetch_size_bytes" in r else "-",
-                                                   r.get("known_over_fetch_size", "-"), r.get("known_bytes_per_rdreq", "-"), r.get("rdreq_32B_share", "-")))
+        print("%-16s %10.1f %14s %9s %11s %9s %10s %22s" % (k, r["known_bytes"] / 2**20, "%.1f" % (r["fetch_size_bytes"] / 2**20) if "fetch_size_bytes" in r else "-",
+                                                          r.get("known_over_fetch_size", "-"), r.get("known_bytes_per_rdreq", "-"), r.get("rdreq_32B_share", "-"),
+                                                          r.get("rdreq_128B_share", "-"), r.get("known_over_bytes_by_request_size", "-")))
 
 
 if __name__ == "__main__":

@@ -3,10 +3,14 @@
 under profiles/<round>/: per-kernel time stats, and per-launch HBM traffic of each kernel from the
 FETCH_SIZE / WRITE_SIZE passes.
 
-HBM bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: the counters are in KiB and, on gfx950,
-FETCH_SIZE reports half the bytes of wide coalesced reads (MI355X_MICROARCH.md, HBM section).  The
-factor 2 is exact for the queue / framebuffer streams; for the scattered 16-byte BVH fetches it is an
-upper bound (uncalibrated access width), so the figure is conservative (never low).
+Read bytes per launch.  FETCH_SIZE (KiB) tallies every memory-side read request of the L2s at 64 bytes, whatever it asked for
+(tools/micro/fetch_calib.hip, profiles/r05/r05a_fetch_calib.txt: a coalesced stream is 128-byte requests -- FETCH_SIZE reads half
+the bytes, the guide's factor 2; a lane's gather of one 64-byte record is a 64-byte request -- FETCH_SIZE is EXACT, and a miss
+does not fill the other half of the 128-byte line; a 16-byte read costs a 64-byte request).  The tracing kernels mix both, so
+the bytes come from the request counters themselves when the fourth pass of tools/pmc.sh is there:
+    read bytes = 32 * TCC_EA0_RDREQ_32B + 64 * TCC_EA0_RDREQ_64B + 128 * TCC_EA0_RDREQ_128B
+and `fetch_method` says so; without that pass the old 2 * FETCH_SIZE is reported and labelled an upper bound (it is one: exact
+for streams, twice the truth for record gathers).  WRITE_SIZE (KiB) reads the bytes exactly.
 
     python tools/summarize_prof.py gpurun_out/prof profiles/r01 <tag>
 """
@@ -32,13 +36,14 @@ def main(src, dst, tag):
     stats = glob.glob(os.path.join(src, "trace", "*", "*kernel_stats.csv"))[0]
     shutil.copy(stats, os.path.join(dst, tag + "_kernel_stats.csv"))
     per = collections.defaultdict(lambda: collections.defaultdict(list))
-    for which, ctr in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
+    rd_ctrs = ("TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_32B_sum", "TCC_EA0_RDREQ_64B_sum", "TCC_EA0_RDREQ_128B_sum")
+    for which, ctrs in (("pmc_fetch", ("FETCH_SIZE",)), ("pmc_write", ("WRITE_SIZE",)), ("pmc_rdreq", rd_ctrs)):
         f = glob.glob(os.path.join(src, which, "*", "*counter_collection.csv"))
         if not f:
             continue
         for r in csv.DictReader(open(f[0])):
-            if r["Counter_Name"] == ctr:
-                per[kname(r["Kernel_Name"])][ctr].append(float(r["Counter_Value"]))
+            if r["Counter_Name"] in ctrs:
+                per[kname(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
     times = {}
     for r in csv.DictReader(open(stats)):   # (instantiations of one kernel -- wf2_shade<.., LAST, TEX> -- are one row here)
         t = times.setdefault(kname(r["Name"]), dict(calls=0, avg_us=0.0, total_ms=0.0, pct=0.0))
@@ -52,8 +57,18 @@ def main(src, dst, tag):
         wr = d.get("WRITE_SIZE", [0.0])
         fetch = sum(fe) / max(len(fe), 1)
         write = sum(wr) / max(len(wr), 1)
+        avg = lambda c: (sum(d[c]) / len(d[c])) if d.get(c) else None
+        rd, r32, r64, r128 = (avg(c) for c in rd_ctrs)
+        if rd and r128 is not None:
+            r32 = r32 or 0.0
+            r64 = r64 if r64 is not None else rd - r128 - r32
+            read_bytes, method = 32 * r32 + 64 * r64 + 128 * r128, "request sizes: 32 r32 + 64 r64 + 128 r128 (TCC_EA0_RDREQ_*)"
+        else:
+            read_bytes, method = 2 * fetch * 1024, "2 * FETCH_SIZE: an upper bound (exact for coalesced streams, twice the bytes of 64-byte record gathers)"
         out[k] = dict(launches=len(fe), fetch_kib_per_launch=round(fetch, 1), write_kib_per_launch=round(write, 1),
-                      hbm_bytes_per_launch=int((2 * fetch + write) * 1024), time=times.get(k))
+                      read_bytes_per_launch=int(read_bytes), fetch_method=method,
+                      rdreq_per_launch=rd, rdreq_128B_share=(round(r128 / rd, 4) if rd and r128 is not None else None),
+                      hbm_bytes_per_launch=int(read_bytes + write * 1024), time=times.get(k))
     bench = os.path.join(src, "bench.json")
     if os.path.exists(bench):
         shutil.copy(bench, os.path.join(dst, tag + "_bench.json"))
