@@ -43,24 +43,6 @@ namespace {
 
 constexpr int kBlock = kTraceBlock;
 constexpr uint32_t kSegments = 256u * JPT_WAVES_PER_SIMD;  // persistent grid: one 256-thread block per CU per wave/SIMD
-#ifdef JPT_NO_XCD_BANDS   // (A/B only: the primary launch without the dormant band-dealing code)
-constexpr bool kXcdBands = false;
-#else
-constexpr bool kXcdBands = true;
-#endif
-#ifndef JPT_LEAF_INNER
-#define JPT_LEAF_INNER 0
-#endif
-#ifndef JPT_TRACE_FINISH_MISSES
-#define JPT_TRACE_FINISH_MISSES 0   // (1 / 2: wf2_trace finishes the walks that missed; measured, not kept -- see save_hit)
-#endif
-#ifndef JPT_TILE_MORTON
-#define JPT_TILE_MORTON 0   // (measured: 1-2 % fewer rounds of the primary launch, no time: profiles/r04/r04ag_samples_together.txt)
-#endif
-#ifndef JPT_PACK_BY_OCTANT
-#define JPT_PACK_BY_OCTANT 0
-#endif
-constexpr int kLeafInner = JPT_LEAF_INNER;
 struct WfTune {
     int refill_idle;     // refill when at least this many lanes of a wave are idle
     int primary_refill_idle;   // ... in the primary launch
@@ -104,22 +86,6 @@ __device__ __forceinline__ bool walk_round(Traversal<COUNT, W4>& tr, bool active
         }
         if (want) tr.node_step(sc, st, cnt);
         if (COUNT && want) steps++;
-        // -DJPT_LEAF_INNER=n (VERDICT r03 task 1, "leaves inside the record loop"; a build-time constant: as a run-time knob the
-        // dormant code alone cost the loop two registers and a spill): when at least n lanes have arrived at a leaf, the
-        // leaves are tested here, inside the loop, and those lanes rejoin the descent at once instead of waiting for the loop
-        // to run down to node_min_lanes.  0 (default): off -- measured, profiles/r04/r04n_leaf_inner.txt.
-        if (W4 && kLeafInner > 0) {
-            const bool wl_in = active && tr.wants_leaf();
-            const unsigned long long lm = __ballot(wl_in);
-            if (__popcll(lm) >= kLeafInner) {
-                if (COUNT && lane0) {
-                    cnt.phase[3]++;
-                    cnt.phase[4] += (unsigned long long)__popcll(lm);
-                }
-                if (wl_in) tr.leaf_step(sc, cnt);
-                if (COUNT && wl_in) steps++;
-            }
-        }
     }
     bool wl = active && tr.wants_leaf();
     bool wi = active && tr.wants_instance();
@@ -171,7 +137,6 @@ struct Wf2Buffers {
     uint32_t long_cap;     //     wf2_long launch that follows, so one list serves all launches of a render
     uint32_t* rg_cursor;   // regrouped tracing launches (wf2_trace_rg): [max_bounces + 2][kSegments] queue cursors, shared by the waves of a queue
     int32_t* rg_spill;     // ... and the stack entries past the LDS part: [block][pool slot][entry]
-    int32_t accum_mode;    // JPT_ACCUM_* (store_final outside the kernels that get FrameParams)
     uint32_t redo_cap;     // records redo_rec holds (a few paths in 10^7 are set aside: not one record per path).  A hit
                            // that finds the buffer full is shaded as found -- the native tree's closest hit, without the
                            // reference's crack -- and counted in redo_count[1] (jpt_stats.set_aside_dropped)
@@ -205,25 +170,13 @@ struct Wf2Dims {
     FastDiv by_frames;         // path -> (slot, frame), path_slot_frame; wf2_accumulate: item -> (pixel, frame)
     int32_t acc_groups = 1;    // (wf2_accumulate: the frame groups whose blocks of rad / fin8 it reads, group_frames)
     int32_t samples_together = 0;   // wf2_primary: a wave takes every frame's sample of 64 / n_frames pixels (consecutive path ids)
-    // XCD bands (JPT_XCD_BAND_ROWS > 0): blocks b and b + 8 share an XCD and its 4 MB L2 (dispatch is round-robin); the runs of a
-    // frame are cut into bands of band_runs consecutive runs (a few tile rows) and band q of every frame belongs to the
-    // blocks with seg % 8 == q % 8, so an XCD's rays start in its own stripes of the screen.  0: runs dealt round-robin to
-    // all segments (every XCD sees every part of the screen).
-    uint32_t band_runs, runs_per_frame, bands_per_frame;
-    FastDiv by_band_runs;
 };
 
 __device__ __forceinline__ void slot_to_pixel(uint32_t slot, const Wf2Dims& dm, int& px, int& ly)
 {
     const uint32_t tile = slot >> 6, lane = slot & 63u;
     const uint32_t ty = fdiv(tile, dm.by_tiles_x), tx = tile - ty * (uint32_t)dm.tiles_x;
-#if JPT_TILE_MORTON
-    // the 64 slots of a tile in Z order (x0 y0 x1 y1 x2 y2): consecutive slots -- what a primary wave takes 64 / n_frames of --
-    // are a compact block of pixels (4 x 2 at 8 frames per render) instead of a piece of a row
-    const uint32_t ix = (lane & 1u) | ((lane >> 1) & 2u) | ((lane >> 2) & 4u), iy = ((lane >> 1) & 1u) | ((lane >> 2) & 2u) | ((lane >> 3) & 4u);
-#else
     const uint32_t ix = lane & 7u, iy = lane >> 3;
-#endif
     px = (int)((tx + (uint32_t)dm.tile_x0) * 8u + ix);
     ly = (int)((ty + (uint32_t)dm.tile_y0) * 8u + iy);
 }
@@ -458,22 +411,7 @@ __global__ __launch_bounds__(kBlock, JPT_PRIMARY_WAVES) void wf2_primary(WideSce
     // runs seg, seg + G, seg + 2G, ... of 2^run_shift consecutive chunks belong to this block
     const uint32_t run_mask = (1u << dm.run_shift) - 1u;
     const uint32_t n_runs = (dm.n_chunks + run_mask) >> dm.run_shift;
-    uint32_t my_runs = seg < n_runs ? (n_runs - seg + kSegments - 1u) / kSegments : 0u;
-    // XCD bands: this block is member k of the 224 blocks with label x = seg % 8; they share the runs of the bands q = x, x + 8, ...
-    // of every frame, run m of them (frame-major) going to member m % 224
-    const uint32_t xb = seg & 7u, kb = seg >> 3;
-    constexpr uint32_t kPerLabel = kSegments / 8u;
-    uint32_t runs_x_frame = 0;   // runs of label x in one frame
-    FastDiv by_runs_x_frame = {1u, 0u};
-    if (kXcdBands && dm.band_runs) {
-        const uint32_t nbx = dm.bands_per_frame > xb ? (dm.bands_per_frame - xb + 7u) >> 3 : 0u;
-        const uint32_t short_by = ((dm.bands_per_frame - 1u) & 7u) == xb ? dm.bands_per_frame * dm.band_runs - dm.runs_per_frame : 0u;
-        runs_x_frame = nbx * dm.band_runs - (nbx ? short_by : 0u);
-        const uint32_t total = runs_x_frame * (uint32_t)fp.n_frames;
-        my_runs = kb < total ? (total - kb + kPerLabel - 1u) / kPerLabel : 0u;
-        by_runs_x_frame.d = runs_x_frame ? runs_x_frame : 1u;
-        by_runs_x_frame.m = runs_x_frame > 1u ? (uint32_t)(0x100000000ull / runs_x_frame) : 0xffffffffu;
-    }
+    const uint32_t my_runs = seg < n_runs ? (n_runs - seg + kSegments - 1u) / kSegments : 0u;
     const uint32_t n = (my_runs << dm.run_shift) * 64u;  // (the last run of the image may be short: checked per entry)
     if (threadIdx.x == 0) {
         s_cursor = 0;
@@ -530,22 +468,14 @@ __global__ __launch_bounds__(kBlock, JPT_PRIMARY_WAVES) void wf2_primary(WideSce
                 const uint32_t idx = start + lanes_below(idle, lane);
                 if (idx < n) {
                     const uint32_t j = idx >> 6;  // local chunk number: run j >> run_shift, position j & run_mask
-                    uint32_t chunk = ((seg + (j >> dm.run_shift) * kSegments) << dm.run_shift) + (j & run_mask);
-                    uint32_t f = fdiv(chunk, dm.by_tiles_per_frame), tile = chunk - f * dm.tiles_per_frame;
-                    if (kXcdBands && dm.band_runs) {
-                        const uint32_t m = (j >> dm.run_shift) * kPerLabel + kb;          // run m of label x
-                        f = fdiv(m, by_runs_x_frame);
-                        const uint32_t mf = m - f * runs_x_frame;
-                        const uint32_t jb = fdiv(mf, dm.by_band_runs), ib = mf - jb * dm.band_runs;
-                        const uint32_t rf = (jb * 8u + xb) * dm.band_runs + ib;               // run of the frame
-                        tile = (rf << dm.run_shift) + (j & run_mask);
-                        chunk = (tile < dm.tiles_per_frame && f < (uint32_t)fp.n_frames) ? f * dm.tiles_per_frame + tile : dm.n_chunks;
-                    }
+                    const uint32_t chunk = ((seg + (j >> dm.run_shift) * kSegments) << dm.run_shift) + (j & run_mask);
+                    uint32_t f = fdiv(chunk, dm.by_tiles_per_frame);
+                    const uint32_t tile = chunk - f * dm.tiles_per_frame;
                     uint32_t slot = tile * 64u + (idx & 63u);
                     // samples_together: a wave takes 64 consecutive path ids: chunk c is (tile c / F, part c % F), its lanes the samples
                     // part * 64 + lane of that tile, sample s being frame s % F of the tile's pixel s / F.  Otherwise one frame's sample of
-                    // all 64 pixels of a tile, as rounds 1-3 dealt them (the band dealing keeps that).
-                    if (dm.samples_together && !(kXcdBands && dm.band_runs) && chunk < dm.n_chunks)
+                    // all 64 pixels of a tile, as rounds 1-3 dealt them.
+                    if (dm.samples_together && chunk < dm.n_chunks)
                         path_slot_frame(chunk * 64u + (idx & 63u), dm, (uint32_t)fp.n_frames, slot, f);
                     int px, ly;
                     slot_to_pixel(slot, dm, px, ly);
@@ -664,27 +594,6 @@ __device__ __forceinline__ void trace_queue(const WideSceneDev& sc, const Wf2Buf
     // wave refills (two dozen lanes at once) instead of in the round each walk happens to end in (some lane does in
     // nearly every round: a dozen instructions per round for one or two lanes' stores).
     auto save_hit = [&]() {
-#if JPT_TRACE_FINISH_MISSES
-        // (-DJPT_TRACE_FINISH_MISSES=1 / 2, VERDICT r04 task 6: a walk that MISSED is finished where it ends -- the `!is_hit` branch
-        // of shade_entry, same operations in the same order: radiance so far + throughput * sampleSky(d), main.glsl:366-368,380 --
-        // and its hit record says "done" (t = -1), so that wf2_shade drops the entry.  The walk's registers are dead here.
-        // Measured, not kept: profiles/r05/)
-        if (!(tr.hit.t < 1e9f)) {
-            const float4 tq = wb.thr_q[bounce & 1][my_loc];
-            const uint32_t pw = __float_as_uint(qd[my_loc].w);
-            const uint32_t p = pw & kPathMask;
-            f3 radiance = mk3(0.0f, 0.0f, 0.0f);
-            if (pw & kHasRadiance) {
-                const float4 r4 = wb.rad[p];
-                radiance = mk3(r4.x, r4.y, r4.z);
-            }
-            radiance = radiance + mk3(tq.x, tq.y, tq.z) * sample_sky(tr.wd);
-            store_final(wb, wb.accum_mode, p, radiance);
-            if (COUNT) cnt.rays++;
-            wb.hit_a[my_loc] = make_float4(-1.0f, 0.0f, 0.0f, 0.0f);
-            return;
-        }
-#endif
         wb.hit_a[my_loc] = make_float4(tr.hit.t, tr.hit.u, tr.hit.v, __uint_as_float(tr.hit.tri));
         wb.hit_b[my_loc] = tr.hit.inst | (tr.hit.front ? 0x80000000u : 0u);
     };
@@ -999,26 +908,12 @@ __global__ __launch_bounds__(kBlock, LAST ? 8 : (TEX == 0 ? JPT_SHADE_NOTEX_WAVE
     bool alive = false;
     float4 no, nd, nt;
     if (i < n) {
-#if JPT_TRACE_FINISH_MISSES == 2
-        // (the hit record FIRST, the rest of the entry only if its path goes on: a dependent round trip for every entry, 52 bytes
-        // less for the entries wf2_trace finished)
-        const float4 ha = wb.hit_a[seg_base + i];
-        if (!(bounce > 0 && ha.x < 0.0f)) {
-            const float4 ro = wb.ray_o[in][seg_base + i], rd = wb.ray_d[in][seg_base + i];
-            const float4 tin = bounce > 0 ? wb.thr_q[in][seg_base + i] : make_float4(1.0f, 1.0f, 1.0f, 0.0f);
-            const uint32_t hb = wb.hit_b[seg_base + i];
-            bool unreachable;
-            alive = shade_entry<COUNT, LAST, TEX>(sh, wb, dm, fp, cam_far, bounce, ro, rd, tin, ha, hb, true, unreachable, no, nd, nt, cnt);
-        }
-#else
         const float4 ro = wb.ray_o[in][seg_base + i], rd = wb.ray_d[in][seg_base + i];
         const float4 tin = bounce > 0 ? wb.thr_q[in][seg_base + i] : make_float4(1.0f, 1.0f, 1.0f, 0.0f);
         const float4 ha = wb.hit_a[seg_base + i];
         const uint32_t hb = wb.hit_b[seg_base + i];
         bool unreachable;   // (set aside inside shade_entry: nothing more to do here)
-        if (!(JPT_TRACE_FINISH_MISSES && bounce > 0 && ha.x < 0.0f))   // (an entry wf2_trace has finished: nothing left to do)
-            alive = shade_entry<COUNT, LAST, TEX>(sh, wb, dm, fp, cam_far, bounce, ro, rd, tin, ha, hb, true, unreachable, no, nd, nt, cnt);
-#endif
+        alive = shade_entry<COUNT, LAST, TEX>(sh, wb, dm, fp, cam_far, bounce, ro, rd, tin, ha, hb, true, unreachable, no, nd, nt, cnt);
     }
     if (LAST) {   // (no path goes on: nothing to pack)
         if (COUNT) flush_counters(cnt, counters);
@@ -1032,19 +927,7 @@ __global__ __launch_bounds__(kBlock, LAST ? 8 : (TEX == 0 ? JPT_SHADE_NOTEX_WAVE
         if (lane == 0) wbase = atomicAdd(&wb.qcount[(size_t)(bounce + 1) * kSegments + seg], (uint32_t)__popcll(m));
         wbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)wbase);
         if (alive) {
-#if JPT_PACK_BY_OCTANT
-            // (A/B: the wave's rays leave ordered by the octant of their direction)
-            const uint32_t oct = (__float_as_uint(nd.x) >> 31) | ((__float_as_uint(nd.y) >> 31) << 1) | ((__float_as_uint(nd.z) >> 31) << 2);
-            uint32_t rank = 0, before = 0;
-            for (uint32_t k = 0; k < 8u; k++) {
-                const unsigned long long mk = __ballot(oct == k);
-                if (oct == k) rank = before + lanes_below(mk, lane);
-                before += (uint32_t)__popcll(mk);
-            }
-            const size_t j = seg_base + wbase + rank;
-#else
             const size_t j = seg_base + wbase + lanes_below(m, lane);
-#endif
             wb.ray_o[out][j] = no;
             wb.ray_d[out][j] = nd;
             wb.thr_q[out][j] = nt;
@@ -1199,11 +1082,7 @@ __global__ __launch_bounds__(kBlock) void wf2_accumulate(Wf2Buffers wb, Wf2Dims 
     const bool valid = px < fp.width && ly < fp.local_rows;   // (lanes past the image's edge still help with the shared route)
     const int wtx = (int)ftx - dm.tile_x0, wty = (int)fty - dm.tile_y0;
     const bool in_window = wtx >= 0 && wtx < dm.tiles_x && wty >= 0 && wty < dm.tiles_y;
-#if JPT_TILE_MORTON
-    const uint32_t in_tile = (flane & 1u) | ((flane & 2u) << 1) | ((flane & 4u) << 2) | ((flane & 8u) >> 2) | ((flane & 16u) >> 1) | (flane & 32u);   // slot_to_pixel's Z order
-#else
     const uint32_t in_tile = flane;
-#endif
     const uint32_t slot = in_window ? ((uint32_t)wty * (uint32_t)dm.tiles_x + (uint32_t)wtx) * 64u + in_tile : 0u;
     const size_t idx = valid ? (size_t)ly * fp.width + px : 0;
     // fp.frame_count = ProgressiveRendering frame_count of the FIRST frame of this render
@@ -1490,24 +1369,6 @@ Wf2Dims make_dims(int width, int local_rows, int n_frames, const TileWindow& win
     dm.run_shift = run_shift;
     const uint32_t n_runs = (dm.n_chunks + (1u << run_shift) - 1u) >> run_shift;
     dm.seg_cap = (((n_runs + kSegments - 1u) / kSegments) << run_shift) * 64u;
-    dm.band_runs = dm.runs_per_frame = dm.bands_per_frame = 0;
-    dm.by_band_runs = make_fastdiv(1u);
-    if (kXcdBands && tuning().xcd_band_rows > 0 && dm.tiles_per_frame > 0) {
-        const uint32_t run_len = 1u << run_shift;
-        const uint32_t runs_per_row = ((uint32_t)dm.tiles_x + run_len - 1u) >> run_shift;
-        dm.runs_per_frame = (dm.tiles_per_frame + run_len - 1u) >> run_shift;
-        dm.band_runs = std::max(1u, runs_per_row * (uint32_t)tuning().xcd_band_rows);
-        dm.bands_per_frame = (dm.runs_per_frame + dm.band_runs - 1u) / dm.band_runs;
-        dm.by_band_runs = make_fastdiv(dm.band_runs);
-        // the fullest label decides the queue capacity
-        uint32_t most = 0;
-        for (uint32_t x = 0; x < 8u; x++) {
-            const uint32_t nbx = dm.bands_per_frame > x ? (dm.bands_per_frame - x + 7u) >> 3 : 0u;
-            const uint32_t short_by = ((dm.bands_per_frame - 1u) & 7u) == x ? dm.bands_per_frame * dm.band_runs - dm.runs_per_frame : 0u;
-            most = std::max(most, (nbx * dm.band_runs - (nbx ? short_by : 0u)) * (uint32_t)n_frames);
-        }
-        dm.seg_cap = (((most + kSegments / 8u - 1u) / (kSegments / 8u)) << run_shift) * 64u;
-    }
     dm.by_tiles_x = make_fastdiv((uint32_t)dm.tiles_x);
     dm.by_tiles_per_frame = make_fastdiv(dm.tiles_per_frame);
     dm.by_frames = make_fastdiv((uint32_t)(n_frames > 0 ? n_frames : 1));
@@ -1650,7 +1511,6 @@ void launch_wf2_render(hipStream_t stream, const DeviceScene& ds, const FramePar
         wb.hit_a = (float4*)carve(q * sizeof(float4));
         wb.hit_b = (uint32_t*)carve(q * sizeof(uint32_t));
         wb.redo_cap = redo_capacity(paths);
-        wb.accum_mode = fp.accum_mode;
         wb.redo_rec = (float4*)carve((size_t)wb.redo_cap * 2 * sizeof(float4));
         wb.thr = (float4*)carve(paths * sizeof(float4));
         wb.rad = rad_all + (size_t)f0 * dm_all.slots_per_frame;  // this group's block ([slot][frame of the group]: path ids) behind the earlier groups'

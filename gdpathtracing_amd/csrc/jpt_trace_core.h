@@ -21,9 +21,6 @@ constexpr int kTraceBlock = 256;
 #ifndef JPT_WALK_WIDEN
 #define JPT_WALK_WIDEN 1
 #endif
-#ifndef JPT_SORT_NEAREST_ONLY
-#define JPT_SORT_NEAREST_ONLY 0
-#endif
 constexpr int kStackLds = JPT_STACK_LDS;              // per-lane entries kept in LDS ([entry][lane], conflict-free)
 constexpr int kStackSpill = 76;            // deeper entries go to scratch (rare)
 constexpr int32_t kSentinel = 0x7fffffff;  // "leave the instance" marker on the stack
@@ -227,16 +224,6 @@ struct Traversal {
             return ((t_in <= t_out) & (ch != kEmptyChild)) ? __float_as_uint(t_in) : kInvalid;
         };
         uint32_t k0 = key(0, r0), k1 = key(1, r1), k2 = key(2, r2), k3 = key(3, r3);
-#ifdef JPT_COUNT_BEHIND
-        // (probe, counting builds: record steps a distance kept with the stack entry would have culled -- the record's own box,
-        // planes 0 and 255, entered behind the hit in hand -- and steps that found no usable child; walk_hist[6], [7])
-        if (COUNT) {
-            const float e_in = fmax_(fmax_(fmax_(negx ? __builtin_fmaf(255.0f, ax, nbx) : nbx, negy ? __builtin_fmaf(255.0f, ay, nby) : nby),
-                                           negz ? __builtin_fmaf(255.0f, az, nbz) : nbz), 0.0f);
-            if (e_in > tcur) cnt.walk_hist[6]++;
-            if (fminf(fminf(__uint_as_float(k0), __uint_as_float(k1)), fminf(__uint_as_float(k2), __uint_as_float(k3))) == __uint_as_float(kInvalid)) cnt.walk_hist[7]++;
-        }
-#endif
         // 5-comparator network on (key, child reference) pairs: one compare, min, max and two selects per
         // exchange.  (Looking the references up by slot after a key-only sort compiled to nested branches.)
         auto cswap = [](uint32_t& ka, uint32_t& kb, int32_t& ra, int32_t& rb) {
@@ -248,14 +235,6 @@ struct Traversal {
         cswap(k0, k1, r0, r1);
         cswap(k2, k3, r2, r3);
         cswap(k0, k2, r0, r2);
-#if JPT_SORT_NEAREST_ONLY
-        // (A/B: three comparators put the nearest child first; the others are pushed as they lie)
-        have = k0 < kInvalid;
-        cur = have ? r0 : cur;
-        if (k3 < kInvalid) push(st, r3);
-        if (k1 < kInvalid) push(st, r1);
-        if (k2 < kInvalid) push(st, r2);
-#else
         cswap(k1, k3, r1, r3);
         cswap(k1, k2, r1, r2);
         // usable children are now a prefix: descend into the nearest, push the others farthest first
@@ -268,7 +247,6 @@ struct Traversal {
             }
             push(st, r1);
         }
-#endif
     }
 
     // internal record: both children's boxes in one 64-byte fetch; descends into the nearer valid child

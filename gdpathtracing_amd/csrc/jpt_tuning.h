@@ -32,7 +32,6 @@ struct Tuning {
     long set_aside_cap = -1;       // JPT_SET_ASIDE_CAP: records of the set-aside buffer (-1: the library's rule; tests force 0)
     int reach = 2;                 // JPT_REACH=0: ignore the reach records; 1: check but never redo (timing experiments only)
     bool shade_last = true;        // JPT_SHADE_LAST=0: the final shading launch uses the general kernel (A/B)
-    int xcd_band_rows = 0;         // JPT_XCD_BAND_ROWS=n: the primary launch deals bands of n tile rows to the blocks that share an XCD (0: off)
     int coop = -1;                 // JPT_COOP=0/1: long walks handed over to a whole wave (coop_walk) never / always (-1: scenes of >= 200 000 triangles)
     int coop_rounds = 128;         // JPT_COOP_ROUNDS: ... a ray still walking this many rounds after its block's queue ran dry
     int lone_async = 1;            // JPT_LONE_ASYNC=0: queued renders that find the pipeline empty are never launched like blocking ones
@@ -81,7 +80,6 @@ inline const Tuning& tuning()
         v.max_leaf = geti("JPT_MAX_LEAF", 2);
         v.reach = geti("JPT_REACH", 2);
         v.shade_last = geti("JPT_SHADE_LAST", 1) != 0;
-        v.xcd_band_rows = geti("JPT_XCD_BAND_ROWS", 0);
         v.coop = geti("JPT_COOP", -1);
         v.coop_rounds = geti("JPT_COOP_ROUNDS", 128);
         if (v.coop_rounds < 1) v.coop_rounds = 1;

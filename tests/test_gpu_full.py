@@ -929,9 +929,8 @@ def test_bench_self_launch_two_ranks_on_one_gpu(hiplib, launcher):
 
 
 @pytest.mark.parametrize("switch", ["JPT_COOP=1 JPT_COOP_ROUNDS=2", "JPT_TAIL=2 JPT_TAIL_ROUNDS=2 JPT_TAIL_LANES=8", "JPT_TRACE_REGROUP=1",
-                                    "JPT_TRACE_REGROUP=2", "JPT_TRACE_REGROUP=2 JPT_POOL_MIN_PREFETCH=1", "JPT_TRACE_REGROUP=2 JPT_POOL_MIN_PREFETCH=65",
-                                    "JPT_FUSE_BOUNCE=1", "JPT_FUSE_BOUNCE=0",
-                                    "JPT_TRACE_REGROUP=1 JPT_COOP=1 JPT_COOP_ROUNDS=2", "JPT_XCD_BAND_ROWS=2", "JPT_PRIMARY_SAMPLES=0",
+                                    "JPT_TRACE_REGROUP=2", "JPT_TRACE_REGROUP=2 JPT_POOL_MIN_PREFETCH=1", "JPT_FUSE_BOUNCE=1",
+                                    "JPT_TRACE_REGROUP=1 JPT_COOP=1 JPT_COOP_ROUNDS=2", "JPT_PRIMARY_SAMPLES=0",
                                     "JPT_GROUPS=3", "JPT_GROUPS=2 JPT_PRIMARY_SAMPLES=0"])
 def test_alternative_tracing_launches_are_bit_identical(hiplib, switch):
     """The tuning switches are read once per process, so the alternative launches run the parity tests in a child process:
