@@ -493,7 +493,7 @@ def main():
         for _ in range(2):
             step()
         barrier()
-        steps5 = max(5, args.steps // 5)
+        steps5 = max(8, (2 * args.steps) // 5)
         elapsed5 = timed(steps5)
         got5 = (ctx.read_ldr() if args.gather == "ldr" else ctx.read_accum()) if rank == 0 else None
         multi["c5_phase_ms_per_rank"] = phase_split(2)
@@ -578,7 +578,7 @@ def main():
                                "gather = piece bytes / %.0f GB/s (one xGMI link per peer, all peers at once) + %.0f us; assembly measured on this device; "
                                "speedup = one GPU's ms_per_step / (slowest rank + gather + assembly [serial], or their maximum [overlapped: queued steps])"
                                % (XGMI_LINK_GBS, LINK_LATENCY_MS * 1e3),
-                     "c3": dict(one_gpu_ms=round(c3_ms, 4), ranks=project_config(W, H, spp, bounces, max(10, args.steps // 2), c3_ms, rays))}
+                     "c3": dict(one_gpu_ms=round(c3_ms, 4), ranks=project_config(W, H, spp, bounces, args.steps, c3_ms, rays))}   # (as many queued steps as the headline: a shorter queue reads higher per step)
         # C5 (3840x2160, 16 spp, 6 bounces): one GPU's own rate first
         W5, H5, SPP5, B5 = 3840, 2160, 16, 6
         ctx.set_partition(0, 1)
@@ -591,7 +591,7 @@ def main():
             ctx.accum_reset()
             ctx.render(SPP5, 1, asynchronous=True)
         barrier()
-        steps5 = max(5, args.steps // 5)
+        steps5 = max(8, (2 * args.steps) // 5)   # (20 by default: four renders are in flight, a queue of ten reads 15 % higher per step)
         t0 = time.perf_counter()
         for _ in range(steps5):
             ctx.accum_reset()

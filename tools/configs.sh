@@ -4,7 +4,7 @@ cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out/configs
 n=0
 # (the whole JSON line of every config is kept: gpurun_out/configs/NN.json -> profiles/<round>/configs/)
-run() { label="$1"; shift; n=$((n+1)); python bench.py --steps 40 --warmup 4 --no-cpu-baseline --no-closeup --no-dropin "$@" 2>&1 | grep '^{' | tee gpurun_out/configs/$(printf %02d $n).json | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$label |', d['value'], 'Mrays/s |', d['ms_per_step'], 'ms/step | rays/step', d['config']['rays_per_step'], '| build_s', d['config']['scene_build_s'])"; }
+run() { label="$1"; shift; n=$((n+1)); python bench.py --steps 40 --warmup 4 --no-cpu-baseline --no-closeup --no-dropin --project-ranks 0 "$@" 2>&1 | grep '^{' | tee gpurun_out/configs/$(printf %02d $n).json | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$label |', d['value'], 'Mrays/s |', d['ms_per_step'], 'ms/step | rays/step', d['config']['rays_per_step'], '| build_s', d['config']['scene_build_s'])"; }
 run "C3 (headline)" 
 run "C3 hdr accumulation" --accum hdr
 run "C2 1280x720 4spp 3b" --width 1280 --height 720 --spp 4 --bounces 3

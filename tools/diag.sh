@@ -4,7 +4,7 @@
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 export JPT_PIPELINE=0 JPT_GROUPS=1   # counters per kernel: launches one after another
-ARGS="bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-closeup $*"
+ARGS="bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-closeup --project-ranks 0 $*"
 OUT=${DIAG_OUT:-gpurun_out/diag}
 mkdir -p $OUT
 i=0

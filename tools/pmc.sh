@@ -8,7 +8,7 @@ cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 # per-kernel durations are only meaningful when launches do not overlap: the profiled run serialises them
 export JPT_PIPELINE=0 JPT_GROUPS=1
-ARGS="bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-closeup $*"
+ARGS="bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-closeup --project-ranks 0 $*"
 rm -rf gpurun_out/prof
 mkdir -p gpurun_out/prof
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof/trace -- python3 $ARGS > gpurun_out/prof/trace.log 2>&1

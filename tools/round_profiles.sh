@@ -15,8 +15,9 @@ python bench.py > gpurun_out/round/${tag}_bench_default.json 2> gpurun_out/round
 bash tools/configs.sh > gpurun_out/round/${tag}_configs.txt 2>&1
 mkdir -p gpurun_out/round/configs && cp gpurun_out/configs/*.json gpurun_out/round/configs/
 bash tools/counters.sh $tag:- 2>&1 | grep -v amdgpu.ids > gpurun_out/round/${tag}_counters.txt
-( cd tools/micro && for m in valu_issue node_fetch; do [ -x $m ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 -o $m $m.hip; timeout 300 ./$m; done ) > /dev/null 2>&1
+( cd tools/micro && for m in valu_issue node_fetch fetch_calib; do [ -x $m ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 -o $m $m.hip; timeout 300 ./$m; done ) > /dev/null 2>&1
 ( cd tools/micro && timeout 300 ./valu_issue ) > gpurun_out/round/valu_issue.txt 2>&1
 ( cd tools/micro && timeout 300 ./node_fetch ) > gpurun_out/round/node_fetch.txt 2>&1
 python tools/hwq_probe.py > gpurun_out/round/hwq_probe.txt 2>&1
+rm -rf gpurun_out/prof gpurun_out/diag/p*/ gpurun_out/configs   # (raw CSVs: the call's output may not exceed 64 MiB)
 ls -la gpurun_out/round

@@ -19,7 +19,7 @@ for wl in ${@:-c4 unique unique4m closeup}; do
   cp gpurun_out/diag_$wl/sq.json gpurun_out/round/${tag}_${wl}_sq.json
   cp gpurun_out/round/${tag}_${wl}_pmc.json profiles/current_pmc_$wl.json 2>/dev/null
   cp gpurun_out/round/${tag}_${wl}_sq.json profiles/current_sq_$wl.json 2>/dev/null
-  python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-closeup $a > gpurun_out/round/${tag}_${wl}_bench_line.json 2> gpurun_out/round/bench_$wl.err
+  python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-closeup --project-ranks 0 $a > gpurun_out/round/${tag}_${wl}_bench_line.json 2> gpurun_out/round/bench_$wl.err
   rm -rf gpurun_out/diag_$wl/p*/   # (raw CSVs: tens of MB)
 done
 rm -rf gpurun_out/prof
