@@ -992,7 +992,8 @@ __global__ __launch_bounds__(kBlock, JPT_WAVES_PER_SIMD) void wf2_bounce(WideSce
     const uint32_t n_next = s_next;
     if (threadIdx.x == 0) wb.qcount[(size_t)(bounce + 1) * kSegments + seg] = n_next;   // (the host's ray count, the next launch's size)
     if (n_next != 0u) {
-        const uint32_t end[kMaxChain] = {n_next, n_next, n_next, n_next};
+        uint32_t end[kMaxChain];
+        for (int k = 0; k < kMaxChain; k++) end[k] = n_next;
         trace_queue<COUNT, true, 0>(sc, wb, dm, bounce + 1, tune, seg, end, n_next, stack, &s_cursor, cnt);
     }
     if (COUNT) flush_counters(cnt, counters);
@@ -1062,11 +1063,83 @@ __global__ __launch_bounds__(64) void wf2_finish(WideSceneDev sc, TieShadowDev s
     if (COUNT) flush_counters(cnt, counters);
 }
 
+// ---- the sky cells of culled pixels (wf2_accumulate; the argument is there) -------------------------------------------------
+constexpr float kCellMargin = 0.01f;
+// values * 255 + 0.5 of the sky along the ray through a raster position, per channel; false: the camera block does not behave
+// there (the clip-space w changes sign against `w_ref`, or a NaN).  (raster_direction_approx: reciprocal estimates instead of six
+// divisions and a square root -- a few ulp of d.y, i.e. 1e-5 of a cell against kCellMargin = 1e-2.)
+__device__ __forceinline__ bool sky_cells_at(const RefCamera& cam, float two_over_w, float two_over_h, float fx, float fy, float w_ref, float& w_out,
+                                             float v[3], f3& d)
+{
+    d = raster_direction_approx(cam, two_over_w, two_over_h, fx, fy, w_out);
+    const f3 c = mk3(0.0f, 0.0f, 0.0f) + mk3(1.0f, 1.0f, 1.0f) * sample_sky(d);
+    v[0] = clamp_(c.x, 0.0f, 1.0f) * 255.0f + 0.5f;
+    v[1] = clamp_(c.y, 0.0f, 1.0f) * 255.0f + 0.5f;
+    v[2] = clamp_(c.z, 0.0f, 1.0f) * 255.0f + 0.5f;
+    return (w_out * w_ref > 0.0f) && (d.y == d.y);   // (callers that compare the signs themselves pass w_ref = 1)
+}
+// how far d.y can leave the range of the four corner values inside the quadrilateral, in cells; 1e30 when it is too wide to bound
+__device__ __forceinline__ float sky_interior_excess(const f3 c[4])
+{
+#ifdef JPT_SKY_CELL_NO_EXCESS   // (round 3's rule, for showing that test_sky_cells_of_culled_pixels_... catches it)
+    return 0.0f;
+#endif
+    float chord2 = 0.0f, ay = 0.0f;
+    for (int i = 0; i < 4; i++) {
+        ay = fmax_(ay, __builtin_fabsf(c[i].y));
+        for (int j = i + 1; j < 4; j++) {
+            const f3 e = c[i] - c[j];
+            chord2 = fmax_(chord2, e.x * e.x + e.y * e.y + e.z * e.z);
+        }
+    }
+    if (!(chord2 < 0.2f)) return 1e30f;                        // (also a NaN)
+    const float theta2 = 1.1f * chord2;                        // theta <= 0.5: theta^2 < 1.03 chord^2
+    const float m = fmin_(1.0f, ay + __builtin_sqrtf(theta2));  // max |d.y| inside: a corner's, plus at most theta
+    return 6.4f * 0.25f * theta2 * m;
+}
+
+// The TILE-level test of wf2_accumulate as a pass of its own, one LANE per 8 x 8 tile instead of one wave (round 5): do the four
+// corner rays of the tile agree on one rgba8 sky cell per channel, with the margins of the argument in wf2_accumulate?  Then every
+// culled pixel of the tile has that value for all its frames: tile_cell = 0x80000000 | r | g << 8 | b << 16; else 0 (the tile's
+// culled pixels are decided one by one, or take the exact route).  Depends on the camera and the image size only, so the launch goes
+// out with the render's first kernels and costs the accumulation nothing: 32 400 lanes instead of 32 400 waves x ~300 instructions.
+__global__ __launch_bounds__(kBlock) void wf2_sky_tiles(Wf2Dims dm, FrameParams fp, RefCamera cam, uint32_t* __restrict__ tile_cell)
+{
+    const uint32_t t = blockIdx.x * kBlock + threadIdx.x;
+    if (t >= (uint32_t)dm.full_tiles_x * (uint32_t)dm.full_tiles_y) return;
+    const uint32_t fty = fdiv(t, dm.by_full_tiles_x), ftx = t - fty * (uint32_t)dm.full_tiles_x;
+    const int tx0 = (int)ftx * 8, ty0 = local_to_global_row((int)fty * 8, fp);
+    const float two_over_w = 2.0f / (float)fp.width, two_over_h = 2.0f / (float)fp.height;
+    float lo[3] = {1e30f, 1e30f, 1e30f}, hi[3] = {-1e30f, -1e30f, -1e30f};
+    f3 cd[4];
+    float w0 = 1.0f;
+    bool ok = true;
+    for (int corner = 0; corner < 4; corner++) {
+        float ww, v[3];
+        (void)sky_cells_at(cam, two_over_w, two_over_h, (float)(tx0 + 8 * (corner & 1)), (float)(ty0 + 8 * (corner >> 1)), 1.0f, ww, v, cd[corner]);
+        if (corner == 0) w0 = ww;
+        ok = ok && (ww == ww) && (v[0] == v[0]) && (ww * w0 > 0.0f);   // no NaN, and the four w of one sign
+        for (int k = 0; k < 3; k++) {
+            lo[k] = fmin_(lo[k], v[k]);
+            hi[k] = fmax_(hi[k], v[k]);
+        }
+    }
+    const float excess = sky_interior_excess(cd);
+    uint32_t cell = 0x80000000u;
+    for (int k = 0; k < 3; k++) {
+        const float l = lo[k] - excess, h = hi[k] + excess;
+        const float c = __builtin_floorf(l);
+        ok = ok && (l - c >= kCellMargin) && (h - c <= 1.0f - kCellMargin) && (h - l < 0.5f);
+        cell |= ((uint32_t)c & 255u) << (8 * k);
+    }
+    tile_cell[t] = ok ? cell : 0u;
+}
+
 // ---- per pixel: frames in order -> accumulation buffer, display image, depth ----------------------------------
 
 __global__ __launch_bounds__(kBlock) void wf2_accumulate(Wf2Buffers wb, Wf2Dims dm, FrameParams fp, RefCamera cam, SkyCull cull,
                                                          float4* __restrict__ accum, uint32_t* __restrict__ ldr,
-                                                         float* __restrict__ depth_out)
+                                                         float* __restrict__ depth_out, const uint32_t* __restrict__ tile_cell)
 {
     // one thread per pixel of the context's share of the image, tile by tile (a wave = one 8 x 8 tile); `slot` is the
     // pixel's place in the window
@@ -1112,75 +1185,22 @@ __global__ __launch_bounds__(kBlock) void wf2_accumulate(Wf2Buffers wb, Wf2Dims 
     // tried.  When that holds every frame quantises to that cell and the eight primary rays -- seed, sincos, 4 x 4
     // transform, three divisions, a normalisation each -- need not be made.  Pixels near a cell boundary (a few per cent:
     // horizontal bands) and cameras whose clip-space w changes sign inside the pixel take the exact per-frame route below.
-    constexpr float kCellMargin = 0.01f;
     bool sky_constant = false;
     f3 sky_value = mk3(0.0f, 0.0f, 0.0f);
-    // values * 255 + 0.5 of the sky along the ray through a raster position, per channel; false: the camera block does not
-    // behave there (the clip-space w changes sign against `w_ref`, or a NaN)
-    // (raster_direction_approx: reciprocal estimates instead of six divisions and a square root -- a few ulp of d.y, i.e. 1e-5 of a
-    // cell against kCellMargin = 1e-2; a corner cost 90 VALU instructions, four of them per pixel of every tile that straddles a
-    // cell boundary)
     const float two_over_w = 2.0f / (float)fp.width, two_over_h = 2.0f / (float)fp.height;
-    auto sky_cells_at = [&](float fx, float fy, float w_ref, float& w_out, float v[3], f3& d) -> bool {
-        d = raster_direction_approx(cam, two_over_w, two_over_h, fx, fy, w_out);
-        const f3 c = mk3(0.0f, 0.0f, 0.0f) + mk3(1.0f, 1.0f, 1.0f) * sample_sky(d);
-        v[0] = clamp_(c.x, 0.0f, 1.0f) * 255.0f + 0.5f;
-        v[1] = clamp_(c.y, 0.0f, 1.0f) * 255.0f + 0.5f;
-        v[2] = clamp_(c.z, 0.0f, 1.0f) * 255.0f + 0.5f;
-        return (w_out * w_ref > 0.0f) && (d.y == d.y);   // (callers that compare the signs themselves pass w_ref = 1)
-    };
-    // the bound above from the four corner directions, in cells; 1e30 when the quadrilateral is too wide to bound this way
-    auto interior_excess = [&](const f3 c[4]) -> float {
-#ifdef JPT_SKY_CELL_NO_EXCESS   // (round 3's rule, for showing that test_sky_cells_of_culled_pixels_... catches it)
-        return 0.0f;
-#endif
-        float chord2 = 0.0f, ay = 0.0f;
-        for (int i = 0; i < 4; i++) {
-            ay = fmax_(ay, __builtin_fabsf(c[i].y));
-            for (int j = i + 1; j < 4; j++) {
-                const f3 e = c[i] - c[j];
-                chord2 = fmax_(chord2, e.x * e.x + e.y * e.y + e.z * e.z);
-            }
-        }
-        if (!(chord2 < 0.2f)) return 1e30f;                        // (also a NaN)
-        const float theta2 = 1.1f * chord2;                        // theta <= 0.5: theta^2 < 1.03 chord^2
-        const float m = fmin_(1.0f, ay + __builtin_sqrtf(theta2));  // max |d.y| inside: a corner's, plus at most theta
-        return 6.4f * 0.25f * theta2 * m;
-    };
     const bool want_cells = fp.accum_mode == 0 && fp.n_frames > 1;
-    // First for the whole TILE at once (a wave is one 8 x 8 tile, eight consecutive image rows): its four corner rays, one
-    // per lane group; when they agree on the cells, every culled pixel of the tile has that value.  (The same argument over
-    // eight pixels instead of one; theta is eight times larger, so wide lenses fail here and pass pixel by pixel.)
+    // First for the whole TILE at once (a wave is one 8 x 8 tile, eight consecutive image rows): do its four corner rays agree on the
+    // cells?  Then every culled pixel of the tile has that value.  (The same argument over eight pixels instead of one; theta is
+    // eight times larger, so wide lenses fail here and pass pixel by pixel.)  Decided by wf2_sky_tiles, one lane per tile, while
+    // the render's paths were traced: here one word per wave.
     bool tile_constant = false;
-    if (want_cells && __any(culled)) {
-        const int tx0 = (int)ftx * 8, ty0 = local_to_global_row((int)fty * 8, fp);
-        float ww, v[3];
-        {   // (every lane evaluates one of the four corners: lanes 0..3 hold the four)
-            const int corner = lane & 3;
-            f3 dc;
-            bool ok = sky_cells_at((float)(tx0 + 8 * (corner & 1)), (float)(ty0 + 8 * (corner >> 1)), 1.0f, ww, v, dc);
-            ok = (ww == ww) && (v[0] == v[0]) && (ww * __shfl(ww, 0) > 0.0f);   // no NaN, and the four w of one sign
-            f3 cd[4];
-            for (int i = 0; i < 4; i++) cd[i] = mk3(__shfl(dc.x, i), __shfl(dc.y, i), __shfl(dc.z, i));
-            const float excess = interior_excess(cd);
-            bool same = true;
-            f3 val;
-            float cellv[3];
-            for (int k = 0; k < 3; k++) {
-                const float a = __shfl(v[k], 0), b = __shfl(v[k], 1), c2 = __shfl(v[k], 2), d2 = __shfl(v[k], 3);
-                const float lo = fmin_(fmin_(a, b), fmin_(c2, d2)) - excess, hi = fmax_(fmax_(a, b), fmax_(c2, d2)) + excess;
-                cellv[k] = __builtin_floorf(lo);
-                same = same && (lo - cellv[k] >= kCellMargin) && (hi - cellv[k] <= 1.0f - kCellMargin) && (hi - lo < 0.5f);
-            }
-            const unsigned long long okm = __ballot(ok);
-            same = same && ((okm & 0xfull) == 0xfull);
-            if (same) {
-                tile_constant = true;
-                val = mk3(from_unorm8((uint32_t)cellv[0]), from_unorm8((uint32_t)cellv[1]), from_unorm8((uint32_t)cellv[2]));
-                if (culled) {
-                    sky_constant = true;
-                    sky_value = val;
-                }
+    if (want_cells && tile_cell != nullptr && __any(culled)) {
+        const uint32_t tc = tile_cell[__builtin_amdgcn_readfirstlane((int)ftile)];
+        if (tc & 0x80000000u) {
+            tile_constant = true;
+            if (culled) {
+                sky_constant = true;
+                sky_value = mk3(from_unorm8(tc & 255u), from_unorm8((tc >> 8) & 255u), from_unorm8((tc >> 16) & 255u));
             }
         }
     }
@@ -1193,7 +1213,7 @@ __global__ __launch_bounds__(kBlock) void wf2_accumulate(Wf2Buffers wb, Wf2Dims 
         f3 cd[4];
         for (int corner = 0; corner < 4; corner++) {
             float ww, v[3];
-            const bool ok = sky_cells_at((float)(px + (corner & 1)), (float)(py + (corner >> 1)), w_first, ww, v, cd[corner]);
+            const bool ok = sky_cells_at(cam, two_over_w, two_over_h, (float)(px + (corner & 1)), (float)(py + (corner >> 1)), w_first, ww, v, cd[corner]);
             if (corner == 0) w_first = ww;
             sane = sane && (corner == 0 ? (ww == ww) : ok);
             for (int k = 0; k < 3; k++) {
@@ -1201,7 +1221,7 @@ __global__ __launch_bounds__(kBlock) void wf2_accumulate(Wf2Buffers wb, Wf2Dims 
                 hi[k] = fmax_(hi[k], v[k]);
             }
         }
-        const float excess = interior_excess(cd);
+        const float excess = sky_interior_excess(cd);
         bool same = sane;
         float cell[3];
         for (int k = 0; k < 3; k++) {
@@ -1450,6 +1470,7 @@ size_t wf2_workspace_bytes(int width, int local_rows, int n_frames, int max_boun
         b += (size_t)all.slots_per_frame * (size_t)n_frames * sizeof(float4) + 256;  // rad: a block per group, each [slot][frame of the group]
         b += (size_t)all.slots_per_frame * (size_t)n_frames * sizeof(uint32_t) + 256;  // fin8
         b += (size_t)all.slots_per_frame * sizeof(float) + 256;
+        b += (size_t)all.full_tiles_x * (size_t)all.full_tiles_y * sizeof(uint32_t) + 256;   // the tiles' sky cells (wf2_sky_tiles)
         worst = b > worst ? b : worst;
     }
     return worst + 17 * 256;
@@ -1495,6 +1516,7 @@ void launch_wf2_render(hipStream_t stream, const DeviceScene& ds, const FramePar
     float4* rad_all = (float4*)carve((size_t)dm_all.slots_per_frame * (size_t)fp.n_frames * sizeof(float4));
     uint32_t* fin8_all = (uint32_t*)carve((size_t)dm_all.slots_per_frame * (size_t)fp.n_frames * sizeof(uint32_t));
     float* first_depth = (float*)carve((size_t)dm_all.slots_per_frame * sizeof(float));
+    uint32_t* sky_tiles = (uint32_t*)carve((size_t)dm_all.full_tiles_x * (size_t)dm_all.full_tiles_y * sizeof(uint32_t));
     for (int g = 0; g < groups; g++) {
         int f0, nf;
         group_frames(fp.n_frames, groups, g, f0, nf);
@@ -1686,6 +1708,12 @@ void launch_wf2_render(hipStream_t stream, const DeviceScene& ds, const FramePar
         }
     };
 
+    // the sky cells of whole tiles (REF_LDR8 accumulation of several frames: wf2_accumulate), ahead of the path kernels
+    const bool want_cells = fp.accum_mode == 0 && fp.n_frames > 1;
+    if (want_cells) {
+        const uint32_t n_tiles = (uint32_t)dm_all.full_tiles_x * (uint32_t)dm_all.full_tiles_y;
+        hipLaunchKernelGGL(wf2_sky_tiles, dim3((n_tiles + kBlock - 1) / kBlock), block, 0, stream, dm_all, fp, cam, sky_tiles);
+    }
     if (groups == 1) {
         run_group(stream, gb[0], gdm[0], gfp[0], trace_events);
     } else {
@@ -1720,7 +1748,7 @@ void launch_wf2_render(hipStream_t stream, const DeviceScene& ds, const FramePar
     }
     if (async.before_acc) (void)hipStreamWaitEvent(acc_stream, async.before_acc, 0);
     const uint32_t ablocks = ((uint32_t)dm_all.full_tiles_x * (uint32_t)dm_all.full_tiles_y * 64u + kBlock - 1) / kBlock;
-    hipLaunchKernelGGL(wf2_accumulate, dim3(ablocks), block, 0, acc_stream, wb_all, dm_acc, fp, cam, async.cull, accum, ldr, depth);
+    hipLaunchKernelGGL(wf2_accumulate, dim3(ablocks), block, 0, acc_stream, wb_all, dm_acc, fp, cam, async.cull, accum, ldr, depth, want_cells ? sky_tiles : nullptr);
 }
 
 uint64_t wf2_pixels_outside_window(const SkyCull& cull, const FrameParams& fp)

@@ -426,13 +426,13 @@ __global__ __launch_bounds__(64) void wf2_trace_pool(WideSceneDev sc, Wf2Buffers
     w.lane = threadIdx.x;
     const uint32_t wave_in_queue = blockIdx.x % (uint32_t)waves_per_queue;
     w.seg0 = (blockIdx.x / (uint32_t)waves_per_queue) * (uint32_t)chain;
-    uint32_t end[kMaxChain];
+    constexpr int kPoolChain = 4;   // (PoolWave::choose finds an entry's segment among four: the launcher chains at most that many)
+    uint32_t end[kPoolChain];
     uint32_t n = 0;
-    for (int k = 0; k < kMaxChain; k++) {
+    for (int k = 0; k < kPoolChain; k++) {
         if (k < chain && w.seg0 + (uint32_t)k < kSegments) n += wb.qcount[(size_t)bounce * kSegments + w.seg0 + (uint32_t)k];
         end[k] = n;
     }
-    static_assert(kMaxChain == 4, "PoolWave::choose finds an entry's segment among four");
     // a queue of n rays is worth n / 1024 waves (at least one): a pool that is not refilled a few times runs mostly half empty
     if (n == 0 || wave_in_queue * 1024u >= n) return;
     w.n = n;

@@ -14,8 +14,8 @@ mkdir -p gpurun_out/prof
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof/trace -- python3 $ARGS > gpurun_out/prof/trace.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/prof/pmc_fetch -- python3 $ARGS > gpurun_out/prof/pmc_fetch.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/prof/pmc_write -- python3 $ARGS > gpurun_out/prof/pmc_write.log 2>&1
-# 4. the read requests by size: FETCH_SIZE tallies every request at 64 bytes, whether it asked for 64 (a lane's record gather) or 128
-#    (a coalesced stream) -- tools/micro/fetch_calib.hip, profiles/r05/r05a_fetch_calib.txt; bytes = 32 r32 + 64 r64 + 128 r128
+# 4. the read requests by size (FETCH_SIZE tallies every request at 64 bytes; on gfx950 every one is a 128-byte line fill:
+#    tools/micro/fetch_calib.hip, profiles/r05/r05a_fetch_calib.txt); bytes = 32 r32 + 64 r64 + 128 r128
 timeout 300 rocprofv3 --kernel-trace --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum --output-format csv -d gpurun_out/prof/pmc_rdreq -- python3 $ARGS > gpurun_out/prof/pmc_rdreq.log 2>&1
 grep '^{' gpurun_out/prof/trace.log | tail -1 > gpurun_out/prof/bench.json
 ls -R gpurun_out/prof | head -40

@@ -3,14 +3,14 @@
 under profiles/<round>/: per-kernel time stats, and per-launch HBM traffic of each kernel from the
 FETCH_SIZE / WRITE_SIZE passes.
 
-Read bytes per launch.  FETCH_SIZE (KiB) tallies every memory-side read request of the L2s at 64 bytes, whatever it asked for
-(tools/micro/fetch_calib.hip, profiles/r05/r05a_fetch_calib.txt: a coalesced stream is 128-byte requests -- FETCH_SIZE reads half
-the bytes, the guide's factor 2; a lane's gather of one 64-byte record is a 64-byte request -- FETCH_SIZE is EXACT, and a miss
-does not fill the other half of the 128-byte line; a 16-byte read costs a 64-byte request).  The tracing kernels mix both, so
-the bytes come from the request counters themselves when the fourth pass of tools/pmc.sh is there:
+Read bytes per launch.  FETCH_SIZE (KiB) tallies every memory-side read request of the L2s at 64 bytes, and on gfx950 every such
+request is a 128-byte line fill -- tools/micro/fetch_calib.hip (profiles/r05/r05a_fetch_calib.txt, r05b_pool_fm_calib_stdout.txt): a
+coalesced stream, a lane's gather of one 64-byte record, of both halves of a line, of 16 bytes, of a 48-byte triangle all show
+TCC_EA0_RDREQ_128B = TCC_EA0_RDREQ (the 32- and 64-byte request counters read zero) and move 6-7 TB/s of lines.  So the guide's
+factor 2 holds for every access shape (a 64-byte record gather fetches its neighbour too: half of the line is not asked for).  The
+bytes are taken from the request counters themselves when the fourth pass of tools/pmc.sh is there,
     read bytes = 32 * TCC_EA0_RDREQ_32B + 64 * TCC_EA0_RDREQ_64B + 128 * TCC_EA0_RDREQ_128B
-and `fetch_method` says so; without that pass the old 2 * FETCH_SIZE is reported and labelled an upper bound (it is one: exact
-for streams, twice the truth for record gathers).  WRITE_SIZE (KiB) reads the bytes exactly.
+(`fetch_method` says so), else from 2 * FETCH_SIZE -- the same number on this chip.  WRITE_SIZE (KiB) reads the bytes exactly.
 
     python tools/summarize_prof.py gpurun_out/prof profiles/r01 <tag>
 """
@@ -64,7 +64,7 @@ def main(src, dst, tag):
             r64 = r64 if r64 is not None else rd - r128 - r32
             read_bytes, method = 32 * r32 + 64 * r64 + 128 * r128, "request sizes: 32 r32 + 64 r64 + 128 r128 (TCC_EA0_RDREQ_*)"
         else:
-            read_bytes, method = 2 * fetch * 1024, "2 * FETCH_SIZE: an upper bound (exact for coalesced streams, twice the bytes of 64-byte record gathers)"
+            read_bytes, method = 2 * fetch * 1024, "2 * FETCH_SIZE (every request is a 128-byte line fill tallied at 64: tools/micro/fetch_calib.hip)"
         out[k] = dict(launches=len(fe), fetch_kib_per_launch=round(fetch, 1), write_kib_per_launch=round(write, 1),
                       read_bytes_per_launch=int(read_bytes), fetch_method=method,
                       rdreq_per_launch=rd, rdreq_128B_share=(round(r128 / rd, 4) if rd and r128 is not None else None),
