@@ -130,6 +130,12 @@ struct jpt_ctx {
     DevBuf<uint32_t> d_ldr;
     DevBuf<float> d_depth;
     DevBuf<DevCounters> d_counters;
+    // the tiles' sky cells (launch_sky_tiles): a function of the camera, the image size and the partition -- made when one of them
+    // changes, read by every accumulation until then
+    DevBuf<uint32_t> d_sky_tiles;
+    RefCamera sky_tiles_camera;
+    int32_t sky_tiles_key[5] = {0, 0, 0, 0, 0};   // width, height, local_rows, rank, world
+    bool sky_tiles_valid = false;
     // assembled full image on the gathering rank
     DevBuf<float4> d_full_accum;
     DevBuf<uint32_t> d_full_ldr;
@@ -793,6 +799,29 @@ int do_render_batch(jpt_ctx* c, int32_t n_frames, uint32_t first_frame_index, bo
             }
             c->trace_events_used = (int32_t)need_ev;
             if (wf2) compute_sky_cull(c, c->async.cull);
+            // the sky cells of whole tiles, for wf2_accumulate (REF_LDR8 sums of several frames): on the context's stream, which every
+            // accumulation is ordered behind; again only when the camera (its frame index aside), the image size or the partition changed
+            c->async.sky_tiles = nullptr;
+            if (wf2 && c->accum_mode == JPT_ACCUM_REF_LDR8 && n_frames > 1) {
+                const int32_t key[5] = {c->width, c->height, c->local_rows, c->rank, c->world};
+                RefCamera cam_key = c->camera;
+                cam_key.frame_index = 0;
+                const size_t n_tiles = wf2_sky_tile_count(c->width, c->local_rows);
+                if (!c->sky_tiles_valid || c->d_sky_tiles.n < n_tiles || std::memcmp(key, c->sky_tiles_key, sizeof key) != 0 ||
+                    std::memcmp(&cam_key, &c->sky_tiles_camera, sizeof cam_key) != 0) {
+                    if (c->d_sky_tiles.n < n_tiles) {
+                        HIP_TRY(c, hipStreamSynchronize(s));   // (renders in flight may read the old buffer)
+                        for (int k = 0; k < jpt_ctx::kPipeSlots; k++)
+                            if (c->pipe_stream[k]) HIP_TRY(c, hipStreamSynchronize(c->pipe_stream[k]));
+                        HIP_TRY(c, c->d_sky_tiles.resize(n_tiles));
+                    }
+                    launch_sky_tiles(s, fp, c->camera, c->d_sky_tiles.p);
+                    std::memcpy(c->sky_tiles_key, key, sizeof key);
+                    c->sky_tiles_camera = cam_key;
+                    c->sky_tiles_valid = true;
+                }
+                c->async.sky_tiles = c->d_sky_tiles.p;
+            }
             const bool pipelining = tuning().pipelining;
             // renders in flight (JPT_PIPE_SLOTS overrides): a render is eleven dependent launches of >= 25-30 us each
             // however little work it holds, so several of them are needed to fill the chip

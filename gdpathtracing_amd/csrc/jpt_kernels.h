@@ -176,6 +176,11 @@ void launch_ref_frame(hipStream_t stream, const DeviceScene& ds, const FramePara
 // fp.frame_index / fp.frame_count are those of the FIRST frame.  The first (max_bounces + 2) *
 // wf2_segments() u32 of `workspace` are per-bounce, per-segment queue sizes afterwards; rows 1..max_bounces
 // sum to the secondary ray segments traced.  trace_events: pairs around wf2_primary and each wf2_trace.
+// The sky cell of every 8 x 8 tile of the context's share of the image whose four corner rays agree on one (wf2_sky_tiles: the
+// tile-level test of wf2_accumulate, one lane per tile).  Depends on the camera, the image size and the partition only -- the host
+// runs it when those change, not per render.  wf2_sky_tile_count: words `tile_cell` must hold.
+size_t wf2_sky_tile_count(int width, int local_rows);
+void launch_sky_tiles(hipStream_t stream, const FrameParams& fp, const RefCamera& cam, uint32_t* tile_cell);
 uint32_t wf2_segments();
 uint32_t trace_stack_capacity();  // entries a lane's traversal stack can hold (LDS + scratch)
 size_t wf2_workspace_bytes(int width, int local_rows, int n_frames, int max_bounces);
@@ -194,6 +199,8 @@ struct Wf2Async {
     SkyCull cull;          // for the primary launch of this render
     int trace_chain = 1;   // wf2_trace: consecutive segments per block (1: lowest latency; 4 when renders are queued)
     hipEvent_t before_acc = nullptr;  // the accumulation kernel waits for this event (whatever its stream)
+    const uint32_t* sky_tiles = nullptr;   // per 8 x 8 tile of the context's share of the image: its one rgba8 sky cell, if it has one
+                                           // (launch_sky_tiles; null: wf2_accumulate decides every culled pixel by itself)
 };
 void launch_wf2_render(hipStream_t stream, const DeviceScene& ds, const FrameParams& fp, const RefCamera& cam, void* workspace,
                        float4* accum, uint32_t* ldr, float* depth, DevCounters* counters, hipEvent_t* trace_events,

@@ -1101,8 +1101,9 @@ __device__ __forceinline__ float sky_interior_excess(const f3 c[4])
 // The TILE-level test of wf2_accumulate as a pass of its own, one LANE per 8 x 8 tile instead of one wave (round 5): do the four
 // corner rays of the tile agree on one rgba8 sky cell per channel, with the margins of the argument in wf2_accumulate?  Then every
 // culled pixel of the tile has that value for all its frames: tile_cell = 0x80000000 | r | g << 8 | b << 16; else 0 (the tile's
-// culled pixels are decided one by one, or take the exact route).  Depends on the camera and the image size only, so the launch goes
-// out with the render's first kernels and costs the accumulation nothing: 32 400 lanes instead of 32 400 waves x ~300 instructions.
+// culled pixels are decided one by one, or take the exact route).  Depends on the camera, the image size and the partition only:
+// the host runs it when one of those changes (jpt_capi.hip), not per render -- 32 400 lanes once per camera instead of 32 400 waves
+// x ~300 instructions in every accumulation.
 __global__ __launch_bounds__(kBlock) void wf2_sky_tiles(Wf2Dims dm, FrameParams fp, RefCamera cam, uint32_t* __restrict__ tile_cell)
 {
     const uint32_t t = blockIdx.x * kBlock + threadIdx.x;
@@ -1397,6 +1398,13 @@ Wf2Dims make_dims(int width, int local_rows, int n_frames, const TileWindow& win
 
 }  // namespace
 
+size_t wf2_sky_tile_count(int width, int local_rows) { return (size_t)((width + 7) / 8) * (size_t)((local_rows + 7) / 8); }
+void launch_sky_tiles(hipStream_t stream, const FrameParams& fp, const RefCamera& cam, uint32_t* tile_cell)
+{
+    const Wf2Dims dm = make_dims(fp.width, fp.local_rows, 1, full_window(fp.width, fp.local_rows));
+    const uint32_t n_tiles = (uint32_t)dm.full_tiles_x * (uint32_t)dm.full_tiles_y;
+    if (n_tiles) hipLaunchKernelGGL(wf2_sky_tiles, dim3((n_tiles + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, dm, fp, cam, tile_cell);
+}
 uint32_t wf2_segments() { return kSegments; }
 uint32_t trace_stack_capacity() { return (uint32_t)(kStackLds + kStackSpill); }
 uint32_t wf2_rg_stack_capacity() { return (uint32_t)(kRgStack + kRgSpill); }
@@ -1470,7 +1478,6 @@ size_t wf2_workspace_bytes(int width, int local_rows, int n_frames, int max_boun
         b += (size_t)all.slots_per_frame * (size_t)n_frames * sizeof(float4) + 256;  // rad: a block per group, each [slot][frame of the group]
         b += (size_t)all.slots_per_frame * (size_t)n_frames * sizeof(uint32_t) + 256;  // fin8
         b += (size_t)all.slots_per_frame * sizeof(float) + 256;
-        b += (size_t)all.full_tiles_x * (size_t)all.full_tiles_y * sizeof(uint32_t) + 256;   // the tiles' sky cells (wf2_sky_tiles)
         worst = b > worst ? b : worst;
     }
     return worst + 17 * 256;
@@ -1516,7 +1523,6 @@ void launch_wf2_render(hipStream_t stream, const DeviceScene& ds, const FramePar
     float4* rad_all = (float4*)carve((size_t)dm_all.slots_per_frame * (size_t)fp.n_frames * sizeof(float4));
     uint32_t* fin8_all = (uint32_t*)carve((size_t)dm_all.slots_per_frame * (size_t)fp.n_frames * sizeof(uint32_t));
     float* first_depth = (float*)carve((size_t)dm_all.slots_per_frame * sizeof(float));
-    uint32_t* sky_tiles = (uint32_t*)carve((size_t)dm_all.full_tiles_x * (size_t)dm_all.full_tiles_y * sizeof(uint32_t));
     for (int g = 0; g < groups; g++) {
         int f0, nf;
         group_frames(fp.n_frames, groups, g, f0, nf);
@@ -1708,12 +1714,6 @@ void launch_wf2_render(hipStream_t stream, const DeviceScene& ds, const FramePar
         }
     };
 
-    // the sky cells of whole tiles (REF_LDR8 accumulation of several frames: wf2_accumulate), ahead of the path kernels
-    const bool want_cells = fp.accum_mode == 0 && fp.n_frames > 1;
-    if (want_cells) {
-        const uint32_t n_tiles = (uint32_t)dm_all.full_tiles_x * (uint32_t)dm_all.full_tiles_y;
-        hipLaunchKernelGGL(wf2_sky_tiles, dim3((n_tiles + kBlock - 1) / kBlock), block, 0, stream, dm_all, fp, cam, sky_tiles);
-    }
     if (groups == 1) {
         run_group(stream, gb[0], gdm[0], gfp[0], trace_events);
     } else {
@@ -1748,7 +1748,7 @@ void launch_wf2_render(hipStream_t stream, const DeviceScene& ds, const FramePar
     }
     if (async.before_acc) (void)hipStreamWaitEvent(acc_stream, async.before_acc, 0);
     const uint32_t ablocks = ((uint32_t)dm_all.full_tiles_x * (uint32_t)dm_all.full_tiles_y * 64u + kBlock - 1) / kBlock;
-    hipLaunchKernelGGL(wf2_accumulate, dim3(ablocks), block, 0, acc_stream, wb_all, dm_acc, fp, cam, async.cull, accum, ldr, depth, want_cells ? sky_tiles : nullptr);
+    hipLaunchKernelGGL(wf2_accumulate, dim3(ablocks), block, 0, acc_stream, wb_all, dm_acc, fp, cam, async.cull, accum, ldr, depth, async.sky_tiles);
 }
 
 uint64_t wf2_pixels_outside_window(const SkyCull& cull, const FrameParams& fp)

@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 5, call h: the tiles' sky cells decided by a pass of their own (wf2_sky_tiles) -- the whole GPU suite, wf2_accumulate's
+# round 5, call h: the tiles' sky cells decided by a pass of their own (wf2_sky_tiles), once per camera -- the whole GPU suite, wf2_accumulate's
 # duration against the previous commit (kernel trace of serial launches, same box), queued rates, the default bench line
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
