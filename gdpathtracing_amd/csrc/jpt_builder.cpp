@@ -529,6 +529,7 @@ struct TlasSahBuilder {
             cbox.grow(c);
         }
         constexpr int kBins = 16;
+        constexpr int kSweepMax = 4096;
         int best_axis = -1, best_bin = -1;
         float best_cost = FLT_MAX;
         for (int axis = 0; axis < 3; axis++) {
@@ -570,7 +571,51 @@ struct TlasSahBuilder {
             }
         }
         int mid = lo + (hi - lo) / 2;
-        if (best_axis >= 0) {
+        static const bool sweep_on = std::getenv("JPT_TLAS_SWEEP") && std::atoi(std::getenv("JPT_TLAS_SWEEP")) != 0;   // EXPERIMENT
+        if (sweep_on && hi - lo <= kSweepMax) {
+            // every split position of every axis (instances sorted by their boxes' centres), not 15 bin borders per axis
+            const int n = hi - lo;
+            std::vector<float> right_area((size_t)n);
+            float sweep_cost = FLT_MAX;
+            int sweep_axis = -1, sweep_at = -1;
+            auto by_centre = [&](int axis) {
+                std::sort(order.begin() + lo, order.begin() + hi, [&](uint32_t x, uint32_t y) {
+                    float a[3], b[3], c[3], d[3];
+                    box_of(inst[x], a, b);
+                    box_of(inst[y], c, d);
+                    const float cx = a[axis] + b[axis], cy = c[axis] + d[axis];
+                    return cx < cy || (cx == cy && x < y);
+                });
+            };
+            for (int axis = 0; axis < 3; axis++) {
+                by_centre(axis);
+                Box3 acc;
+                for (int i = n - 1; i > 0; i--) {
+                    float a[3], b[3];
+                    box_of(inst[order[(size_t)(lo + i)]], a, b);
+                    acc.grow(a);
+                    acc.grow(b);
+                    right_area[(size_t)i] = acc.half_area();
+                }
+                acc = Box3();
+                for (int i = 0; i < n - 1; i++) {
+                    float a[3], b[3];
+                    box_of(inst[order[(size_t)(lo + i)]], a, b);
+                    acc.grow(a);
+                    acc.grow(b);
+                    const float cost = acc.half_area() * float(i + 1) + right_area[(size_t)(i + 1)] * float(n - i - 1);
+                    if (cost < sweep_cost) {
+                        sweep_cost = cost;
+                        sweep_axis = axis;
+                        sweep_at = i + 1;
+                    }
+                }
+            }
+            if (sweep_axis >= 0) {
+                if (sweep_axis != 2) by_centre(sweep_axis);
+                mid = lo + sweep_at;
+            }
+        } else if (best_axis >= 0) {
             const float c0 = cbox.lo[best_axis], scale = float(kBins) / (cbox.hi[best_axis] - c0);
             auto it = std::partition(order.begin() + lo, order.begin() + hi, [&](uint32_t id) {
                 float a[3], b[3];
@@ -711,6 +756,123 @@ ReachInst reach_instance(const float* t12, const ReachInst& mesh_root)
     return r;
 }
 
+// Native scenes: the world box of an instance from up to `n_boxes` boxes of its mesh's tree instead of the root's alone.  The
+// reference's rule -- the box of the root box's eight transformed corners (bvh.h:90-115) -- grows by up to a factor of two in
+// footprint when the instance is rotated; the native TLAS only has to contain the triangles, so it takes the union of the
+// transformed boxes of a cut through the tree (the largest box opened first), each padded like the root's, and intersects that
+// with the root's (InstanceCuts: the cut depends on the mesh alone, so it is made once per mesh).  What the reference's own box
+// decides stays with the reach records (reach_instance).
+struct InstanceCuts {
+    struct Box {
+        float c[3], e[3];   // centre, half extent
+        float lo[3], hi[3];
+    };
+    const std::vector<RefBvhNode>& nodes;
+    int n_boxes;
+    std::vector<std::pair<uint32_t, std::vector<Box>>> per_root;   // (a scene has few meshes; the boxes side by side, not scattered over the node array)
+
+    // JPT_INSTANCE_BOXES (1 024) boxes per instance while the scene's instances x boxes stay below 2^18 box transforms (a TLAS
+    // update is meant to take milliseconds); never fewer than 16
+    static int boxes_for(size_t n_instances)
+    {
+        const int want = tuning().instance_boxes;
+        if (want <= 1) return want;
+        const size_t share = ((size_t)1 << 18) / std::max<size_t>(n_instances, 1);
+        return (int)std::max<size_t>(std::min<size_t>((size_t)want, share), std::min<size_t>((size_t)want, 16));
+    }
+
+    const std::vector<Box>& cut_of(uint32_t root)
+    {
+        for (const auto& e : per_root)
+            if (e.first == root) return e.second;
+        auto interior = [&](uint32_t n) {
+            const RefBvhNode& b = nodes[n];
+            return b.tri_count == 0 && !(b.left_child == 0 && b.right_child == 0) && b.left_child < nodes.size() && b.right_child < nodes.size();
+        };
+        auto area = [&](uint32_t n) {
+            const RefBvhNode& b = nodes[n];
+            const float dx = b.aabbMax.x - b.aabbMin.x, dy = b.aabbMax.y - b.aabbMin.y, dz = b.aabbMax.z - b.aabbMin.z;
+            return dx * dy + dy * dz + dz * dx;
+        };
+        // the largest box opened first, until n_boxes (leaves and boxes that cannot be opened go straight to the cut)
+        std::vector<uint32_t> cut;
+        std::vector<std::pair<float, uint32_t>> open;   // a max-heap by area
+        auto file = [&](uint32_t n) {
+            if (interior(n)) {
+                open.emplace_back(area(n), n);
+                std::push_heap(open.begin(), open.end());
+            } else {
+                cut.push_back(n);
+            }
+        };
+        file(root);
+        while (!open.empty() && (int)(cut.size() + open.size()) < n_boxes) {
+            std::pop_heap(open.begin(), open.end());
+            const uint32_t n = open.back().second;
+            open.pop_back();
+            file(nodes[n].left_child);
+            file(nodes[n].right_child);
+        }
+        for (const auto& o : open) cut.push_back(o.second);
+        std::vector<Box> boxes;
+        for (uint32_t n : cut) {
+            const RefBvhNode& b = nodes[n];
+            if (!(b.aabbMin.x <= b.aabbMax.x && b.aabbMin.y <= b.aabbMax.y && b.aabbMin.z <= b.aabbMax.z)) continue;   // an empty leaf's box
+            Box x;
+            const float lo[3] = {b.aabbMin.x, b.aabbMin.y, b.aabbMin.z}, hi[3] = {b.aabbMax.x, b.aabbMax.y, b.aabbMax.z};
+            for (int k = 0; k < 3; k++) {
+                x.lo[k] = lo[k];
+                x.hi[k] = hi[k];
+                x.c[k] = 0.5f * (lo[k] + hi[k]);
+                x.e[k] = 0.5f * (hi[k] - lo[k]);
+            }
+            boxes.push_back(x);
+        }
+        per_root.emplace_back(root, std::move(boxes));
+        return per_root.back().second;
+    }
+
+    void tighten(RefInstance& inst)
+    {
+        if (n_boxes <= 1 || inst.blas_index >= nodes.size()) return;
+        const std::vector<Box>& cut = cut_of(inst.blas_index);
+        if (cut.size() < 2) return;
+        float lo[3] = {1e34f, 1e34f, 1e34f}, hi[3] = {-1e34f, -1e34f, -1e34f};
+        const float* m = inst.transform;   // column-major 4 x 4
+        if (m[3] == 0.0f && m[7] == 0.0f && m[11] == 0.0f && m[15] == 1.0f) {
+            // the image of a box under an affine map: centre' -+ |M| half-extent (9 + 9 products instead of eight corners x 16); a
+            // few ulp of the coordinates away from the corner rule's box: twice its padding, on the union
+            float am[9];
+            for (int r = 0; r < 3; r++)
+                for (int k = 0; k < 3; k++) am[k * 3 + r] = std::fabs(m[k * 4 + r]);
+            for (const Box& x : cut)
+                for (int r = 0; r < 3; r++) {
+                    const float wc = m[r] * x.c[0] + m[4 + r] * x.c[1] + m[8 + r] * x.c[2] + m[12 + r];
+                    const float we = am[r] * x.e[0] + am[3 + r] * x.e[1] + am[6 + r] * x.e[2];
+                    lo[r] = std::min(lo[r], wc - we);
+                    hi[r] = std::max(hi[r], wc + we);
+                }
+            float big = 0.0f;
+            for (int r = 0; r < 3; r++) big = std::max(big, std::max(std::fabs(lo[r]), std::fabs(hi[r])));
+            const float pad = big * 4e-6f;
+            for (int r = 0; r < 3; r++) {
+                lo[r] -= pad;
+                hi[r] += pad;
+            }
+        } else {
+            for (const Box& x : cut) {
+                Vec4 l, h;
+                instance_world_box(inst.transform, Vec4{x.lo[0], x.lo[1], x.lo[2], 1.0f}, Vec4{x.hi[0], x.hi[1], x.hi[2], 1.0f}, /*pad_box*/ true, l, h);
+                lo[0] = std::min(lo[0], l.x); lo[1] = std::min(lo[1], l.y); lo[2] = std::min(lo[2], l.z);
+                hi[0] = std::max(hi[0], h.x); hi[1] = std::max(hi[1], h.y); hi[2] = std::max(hi[2], h.z);
+            }
+        }
+        if (!(lo[0] <= hi[0] && lo[1] <= hi[1] && lo[2] <= hi[2])) return;
+        inst.aabbMin = Vec4{std::max(inst.aabbMin.x, lo[0]), std::max(inst.aabbMin.y, lo[1]), std::max(inst.aabbMin.z, lo[2]), inst.aabbMin.w};
+        inst.aabbMax = Vec4{std::min(inst.aabbMax.x, hi[0]), std::min(inst.aabbMax.y, hi[1]), std::min(inst.aabbMax.z, hi[2]), inst.aabbMax.w};
+    }
+};
+
 // instances (geometry_group3d.cpp:322-341) and TLAS::build (bvh.cpp:264-317) over the BLASes already in `out`
 bool SceneBuilder::rebuild_instances(BuildMode mode, RefScene& out, std::string& err)
 {
@@ -720,6 +882,7 @@ bool SceneBuilder::rebuild_instances(BuildMode mode, RefScene& out, std::string&
     }
     out.instances.clear();
     out.tlas_nodes.clear();
+    InstanceCuts cuts{out.bvh_nodes, InstanceCuts::boxes_for(instances_.size()), {}};
     for (const PendingInstance& pi : instances_) {
         RefInstance inst;
         std::memset(&inst, 0, sizeof inst);
@@ -727,6 +890,7 @@ bool SceneBuilder::rebuild_instances(BuildMode mode, RefScene& out, std::string&
         for (int k = 0; k < 3; k++) inst.material[k] = pi.mats[k];
         const RefBvhNode& root = out.bvh_nodes[inst.blas_index];
         instance_record(pi.t12, root.aabbMin, root.aabbMax, is_native(mode), inst);  // jpt_instance_math.h
+        if (is_native(mode)) cuts.tighten(inst);
         out.instances.push_back(inst);
     }
     out.reach_inst.clear();
@@ -947,6 +1111,7 @@ bool native_instances_from_uploaded(const std::vector<RefInstance>& up_inst, con
         }
         instances.resize(ni);
         reach.resize(ni);
+        InstanceCuts cuts{out.bvh_nodes, InstanceCuts::boxes_for(ni), {}};
         for (size_t i = 0; i < ni; i++) {
             if (leaf_of[i] == kNone) {
                 why = "an instance is in no TLAS leaf";
@@ -972,6 +1137,7 @@ bool native_instances_from_uploaded(const std::vector<RefInstance>& up_inst, con
             n.blas_index = out.mesh_roots[mesh];
             const RefBvhNode& root = out.bvh_nodes[n.blas_index];
             instance_world_box(n.transform, root.aabbMin, root.aabbMax, /*pad_box*/ true, n.aabbMin, n.aabbMax);
+            cuts.tighten(n);
             instances[i] = n;
             // the reach record: the box ray_trace_tlas tests before it enters the instance is its TLAS leaf's
             ReachInst r = out.mesh_ref_root[mesh];
@@ -1511,6 +1677,72 @@ struct Child4 {
     }
 };
 
+// JPT_COLLAPSE (bit 0: the TLAS, bit 1: the meshes' trees): WHICH two-child records become four-child records, chosen for the fewest expected record steps instead of
+// greedily.  A ray that enters a kept record pays one step whatever the number of its slots, so the cost of a collapse is the sum
+// of the kept records' surface areas; the leaves are the same either way.  F(n, k) = least such sum below record n when n's
+// subtree may fill at most k slots of the kept record above it:
+//     F(leaf, k) = 0
+//     F(n, 1)    = A(n) + min over a of F(left, a) + F(right, 4 - a)               (n kept: its own four slots dealt to its sides)
+//     F(n, k)    = min(F(n, 1), min over a in 1..k-1 of F(left, a) + F(right, k - a))   (n dissolved into the record above)
+// (the dynamic programme of Ylitie, Karras, Laine 2017, section 3, for width 4 and fixed leaves).  pick[n][k-1] = the a taken, 0 =
+// n is kept.  Evaluated lazily from the roots that collapse_root is asked for; records shared by instances are visited once.
+struct CollapsePlan {
+    const std::vector<WideNode>& src;
+    std::vector<float> f;        // [n][3]: F(n, 1..3)
+    std::vector<uint8_t> pick;   // [n][3]
+    std::vector<uint8_t> done;
+    explicit CollapsePlan(const std::vector<WideNode>& s) : src(s), f(s.size() * 3, 0.0f), pick(s.size() * 3, 0), done(s.size(), 0) {}
+    bool is_leaf(int32_t r) const
+    {
+        if (r < 0) return true;
+        const WideNode& w = src[(size_t)r];
+        return w.left == r && w.right == r;   // empty-leaf record
+    }
+    float F(int32_t r, int k) const { return is_leaf(r) ? 0.0f : f[(size_t)r * 3 + (size_t)(k - 1)]; }
+    void solve(int32_t n)
+    {
+        if (is_leaf(n) || done[(size_t)n]) return;
+        done[(size_t)n] = 1;
+        const WideNode& w = src[(size_t)n];
+        solve(w.left);
+        solve(w.right);
+        float lo[3], hi[3];
+        for (int k = 0; k < 3; k++) {
+            lo[k] = std::min(w.lmin[k], w.rmin[k]);
+            hi[k] = std::max(w.lmax[k], w.rmax[k]);
+        }
+        const float dx = std::max(hi[0] - lo[0], 0.0f), dy = std::max(hi[1] - lo[1], 0.0f), dz = std::max(hi[2] - lo[2], 0.0f);
+        const float area = dx * dy + dy * dz + dz * dx;
+        float best = FLT_MAX;
+        uint8_t best_a = 2;
+        for (int a = 1; a <= 3; a++) {
+            const float v = F(w.left, a) + F(w.right, 4 - a);
+            if (v < best || (v == best && a == 2)) {   // (ties: the even split)
+                best = v;
+                best_a = (uint8_t)a;
+            }
+        }
+        float* fn = &f[(size_t)n * 3];
+        uint8_t* pn = &pick[(size_t)n * 3];
+        fn[0] = area + best;
+        pn[0] = best_a;
+        for (int k = 2; k <= 3; k++) {
+            float bk = fn[0];
+            uint8_t ak = 0;
+            for (int a = 1; a < k; a++) {
+                const float v = F(w.left, a) + F(w.right, k - a);
+                if (v < bk) {
+                    bk = v;
+                    ak = (uint8_t)a;
+                }
+            }
+            fn[k - 1] = bk;
+            pn[k - 1] = ak;
+        }
+    }
+};
+thread_local CollapsePlan* tl_plan = nullptr;
+
 // collapse the subtree under two-child record `ni` of `src` into `dst`; returns the new record's index.
 // Order of the records in `dst` (JPT_NODE_ORDER, tuning().node_order): 0 = depth first (a record, then its first child's whole
 // subtree, ...), 1 = the up-to-four child records of a record next to each other (a 128-byte line holds two siblings), then
@@ -1537,7 +1769,28 @@ int32_t collapse4(const std::vector<WideNode>& src, std::vector<WideNode4>& dst,
     Child4 c[4];
     int n = 2;
     kids_of(ni, c);
-    while (n < 4) {
+    if (tl_plan) {   // the plan's cut: slot budgets dealt down the two sides
+        tl_plan->solve(ni);
+        int budget[4] = {(int)tl_plan->pick[(size_t)ni * 3], 0, 0, 0};
+        budget[1] = 4 - budget[0];
+        for (int i = 0; i < n;) {
+            const int32_t r = c[i].ref;
+            const int a = (budget[i] > 1 && !tl_plan->is_leaf(r)) ? (int)tl_plan->pick[(size_t)r * 3 + (size_t)(budget[i] - 1)] : 0;
+            if (a == 0) {   // a leaf, or kept as a record of its own
+                i++;
+                continue;
+            }
+            Child4 two[2];
+            kids_of(r, two);
+            const int b = budget[i] - a;
+            c[i] = two[0];
+            budget[i] = a;
+            c[n] = two[1];
+            budget[n] = b;
+            n++;   // (slot i is looked at again with its smaller budget)
+        }
+    }
+    while (!tl_plan && n < 4) {
         int best = -1;
         float best_area = -1.0f;
         for (int i = 0; i < n; i++)
@@ -1715,7 +1968,10 @@ bool reflatten_tlas(const RefScene& ref, WideScene& out, bool with4, std::string
     }
     if (with4) {
         std::vector<int32_t> memo_t(out.tlas_nodes.size(), -1);
+        CollapsePlan plan_t(out.tlas_nodes);
+        tl_plan = (tuning().collapse & 1) ? &plan_t : nullptr;
         out.tlas_root4 = collapse_root(out.tlas_nodes, out.tlas_nodes4, out.tlas_root, memo_t);
+        tl_plan = nullptr;
     }
     compute_stack_need(out);
     return true;
@@ -1727,10 +1983,18 @@ void flatten4(WideScene& out)
     out.tlas_nodes4.clear();
     std::vector<int32_t> memo(out.blas_nodes.size(), -1);
     out.instances4 = out.instances;
-    for (size_t i = 0; i < out.instances.size(); i++)
-        out.instances4[i].root = collapse_root(out.blas_nodes, out.blas_nodes4, out.instances[i].root, memo);
+    {
+        CollapsePlan plan(out.blas_nodes);
+        tl_plan = (tuning().collapse & 2) ? &plan : nullptr;
+        for (size_t i = 0; i < out.instances.size(); i++)
+            out.instances4[i].root = collapse_root(out.blas_nodes, out.blas_nodes4, out.instances[i].root, memo);
+        tl_plan = nullptr;
+    }
     std::vector<int32_t> memo_t(out.tlas_nodes.size(), -1);
+    CollapsePlan plan_t(out.tlas_nodes);
+    tl_plan = (tuning().collapse & 1) ? &plan_t : nullptr;
     out.tlas_root4 = collapse_root(out.tlas_nodes, out.tlas_nodes4, out.tlas_root, memo_t);
+    tl_plan = nullptr;
 }
 
 }  // namespace jpt

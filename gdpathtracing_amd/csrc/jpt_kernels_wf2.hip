@@ -1188,6 +1188,7 @@ __global__ __launch_bounds__(kBlock) void wf2_accumulate(Wf2Buffers wb, Wf2Dims 
     // horizontal bands) and cameras whose clip-space w changes sign inside the pixel take the exact per-frame route below.
     bool sky_constant = false;
     f3 sky_value = mk3(0.0f, 0.0f, 0.0f);
+    uint32_t sky_word = 0u;   // ... as the rgba8 word it is converted from
     const float two_over_w = 2.0f / (float)fp.width, two_over_h = 2.0f / (float)fp.height;
     const bool want_cells = fp.accum_mode == 0 && fp.n_frames > 1;
     // First for the whole TILE at once (a wave is one 8 x 8 tile, eight consecutive image rows): do its four corner rays agree on the
@@ -1201,6 +1202,7 @@ __global__ __launch_bounds__(kBlock) void wf2_accumulate(Wf2Buffers wb, Wf2Dims 
             tile_constant = true;
             if (culled) {
                 sky_constant = true;
+                sky_word = tc & 0xffffffu;
                 sky_value = mk3(from_unorm8(tc & 255u), from_unorm8((tc >> 8) & 255u), from_unorm8((tc >> 16) & 255u));
             }
         }
@@ -1233,7 +1235,8 @@ __global__ __launch_bounds__(kBlock) void wf2_accumulate(Wf2Buffers wb, Wf2Dims 
         }
         if (same) {
             sky_constant = true;
-            sky_value = mk3(from_unorm8((uint32_t)cell[0]), from_unorm8((uint32_t)cell[1]), from_unorm8((uint32_t)cell[2]));
+            sky_word = ((uint32_t)cell[0] & 255u) | (((uint32_t)cell[1] & 255u) << 8) | (((uint32_t)cell[2] & 255u) << 16);
+            sky_value = mk3(from_unorm8(sky_word & 255u), from_unorm8((sky_word >> 8) & 255u), from_unorm8((sky_word >> 16) & 255u));
         }
     }
     // The culled pixels that did not pass (near a cell boundary) need their frames' exact values -- eight primary rays
@@ -1271,7 +1274,38 @@ __global__ __launch_bounds__(kBlock) void wf2_accumulate(Wf2Buffers wb, Wf2Dims 
     // the frames of group g are a block of their own in rad / fin8: [slot][frame of the group] behind the earlier groups' blocks
     const int g_base = fp.n_frames / dm.acc_groups, g_extra = fp.n_frames % dm.acc_groups;
     int g = 0, g_f0 = 0, g_nf = g_base + (g_extra > 0 ? 1 : 0);
-    for (int f = 0; f < fp.n_frames; f++) {
+    // The usual case first -- rgba8 samples, one frame group, 4 / 8 / 12 / 16 frames: a pixel's frames are 16 to 64 consecutive bytes of
+    // fin8, fetched as one to four 16-byte loads that are all in flight together.  (The loop below waits for a 4-byte load per frame,
+    // eight trips to the cache one after another: the kernel was bound by that latency, not by its 53 MB -- round 5.)
+    const bool packed_frames = fp.accum_mode == 0 && dm.acc_groups == 1 && fp.n_frames >= 4 && fp.n_frames <= kSharedFrames && (fp.n_frames & 3) == 0;
+    if (packed_frames) {
+        // every lane's frames as rgba8 words first -- the window's pixels from fin8, a culled pixel's from its one sky cell or from
+        // the wave's shared exact values -- then ONE conversion-and-add per frame for all of them
+        uint4 q[kSharedFrames / 4];
+        const uint4* mine = reinterpret_cast<const uint4*>(wb.fin8 + (size_t)slot * (size_t)fp.n_frames);
+        const uint4* shared = reinterpret_cast<const uint4*>(&s_val[wave][my_rank * (uint32_t)fp.n_frames]);
+#pragma unroll
+        for (int c = 0; c < kSharedFrames / 4; c++) {
+            q[c] = make_uint4(sky_word, sky_word, sky_word, sky_word);
+            if (c * 4 < fp.n_frames) {
+                if (!culled) q[c] = mine[c];
+                else if (slow) q[c] = shared[c];
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < kSharedFrames / 4; c++) {
+            if (c * 4 >= fp.n_frames) break;
+            const uint32_t qs[4] = {q[c].x, q[c].y, q[c].z, q[c].w};
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const f3 cur = mk3(from_unorm8(qs[j] & 255u), from_unorm8((qs[j] >> 8) & 255u), from_unorm8((qs[j] >> 16) & 255u));
+                last = cur;
+                sum = have_prev ? cur + sum : cur;  // progressive_rendering.glsl:34-36
+                have_prev = true;
+            }
+        }
+    }
+    for (int f = 0; f < fp.n_frames && !packed_frames; f++) {
         if (f >= g_f0 + g_nf) {
             g++;
             g_f0 += g_nf;

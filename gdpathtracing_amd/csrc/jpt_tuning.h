@@ -48,6 +48,9 @@ struct Tuning {
     int pool_min_prefetch = 40;    // JPT_POOL_MIN_PREFETCH: wf2_trace_pool prepares its next turn ahead only when a list holds this many rays
     int fuse_bounce = -1;          // JPT_FUSE_BOUNCE=0/1: wf2_shade(b) + wf2_trace(b + 1) as one launch per bounce (wf2_bounce) never / always (-1: small renders)
     int fuse_max_paths = 0;        // JPT_FUSE_MAX_PATHS: ... the rule's bound on the render window's paths (0: the rule is off)
+    int collapse = 3;              // JPT_COLLAPSE: two-child records merged into four-child ones by the least-area plan (jpt_builder.cpp, CollapsePlan) -- 0 greedily (the largest box first: rounds 1-4), 1 the TLAS, 2 the meshes' trees, 3 both
+    int instance_boxes = 1024;     // JPT_INSTANCE_BOXES: a native scene's instance boxes bound up to this many boxes of the mesh's tree, transformed one by one
+                                   // (1: the root box's corners, as the reference's rule and rounds 1-4)
     int rg_waves = 0;              // JPT_RG_WAVES: waves (= blocks) per queue of the regrouped launches (0: the library's rule)
 };
 
@@ -92,6 +95,8 @@ inline const Tuning& tuning()
         v.trace_regroup = geti("JPT_TRACE_REGROUP", 0);
         v.pool_min_prefetch = geti("JPT_POOL_MIN_PREFETCH", 40);
         v.rg_waves = geti("JPT_RG_WAVES", 0);
+        v.collapse = geti("JPT_COLLAPSE", 3);
+        v.instance_boxes = geti("JPT_INSTANCE_BOXES", 1024);
         v.fuse_bounce = geti("JPT_FUSE_BOUNCE", -1);
         v.fuse_max_paths = geti("JPT_FUSE_MAX_PATHS", 0);
         v.exact_shadow = geti("JPT_EXACT_SHADOW", 1) != 0;

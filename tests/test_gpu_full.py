@@ -931,16 +931,18 @@ def test_bench_self_launch_two_ranks_on_one_gpu(hiplib, launcher):
 @pytest.mark.parametrize("switch", ["JPT_COOP=1 JPT_COOP_ROUNDS=2", "JPT_TAIL=2 JPT_TAIL_ROUNDS=2 JPT_TAIL_LANES=8", "JPT_TRACE_REGROUP=1",
                                     "JPT_TRACE_REGROUP=2", "JPT_TRACE_REGROUP=2 JPT_POOL_MIN_PREFETCH=1", "JPT_FUSE_BOUNCE=1",
                                     "JPT_TRACE_REGROUP=1 JPT_COOP=1 JPT_COOP_ROUNDS=2", "JPT_PRIMARY_SAMPLES=0",
-                                    "JPT_GROUPS=3", "JPT_GROUPS=2 JPT_PRIMARY_SAMPLES=0"])
+                                    "JPT_GROUPS=3", "JPT_GROUPS=2 JPT_PRIMARY_SAMPLES=0", "JPT_COLLAPSE=0 JPT_INSTANCE_BOXES=1"])
 def test_alternative_tracing_launches_are_bit_identical(hiplib, switch):
     """The tuning switches are read once per process, so the alternative launches run the parity tests in a child process:
     JPT_COOP=1 with an eager hand-over (most tail rays of every launch are walked by wf2_long / coop_walk), JPT_TAIL=2 with eager
     thresholds (the same walk inside the launch, by the wave that holds the ray: what large scenes get by default for their
     few very long rays), JPT_TRACE_REGROUP=1 (wf2_trace_rg: ray state in LDS, compacted
-    lists per step kind) and JPT_XCD_BAND_ROWS=2 (the primary launch's tiles dealt in bands to the blocks that share an XCD) --
-    the last two kept as measured, rejected variants -- JPT_PRIMARY_SAMPLES=0 (a primary wave takes one frame's sample of a tile,
+    lists per step kind), JPT_TRACE_REGROUP=2 (wf2_trace_pool) and JPT_FUSE_BOUNCE=1 (wf2_bounce) -- kept as measured, rejected
+    variants -- JPT_PRIMARY_SAMPLES=0 (a primary wave takes one frame's sample of a tile,
     as rounds 1-3 dealt them, instead of every frame's sample of a few pixels) and JPT_GROUPS=3 / 2 (blocking renders split
-    into frame groups of unequal size: every group's paths live in a block of their own, which wf2_accumulate must find).  Same images bit for bit as the default launches: a subset
+    into frame groups of unequal size: every group's paths live in a block of their own, which wf2_accumulate must find), and
+    JPT_COLLAPSE=0 JPT_INSTANCE_BOXES=1 (the native trees as rounds 1-4 made them: four-child records collapsed greedily, an
+    instance's world box from its root box's corners).  Same images bit for bit as the default launches: a subset
     of the parity suite, against the oracle."""
     import subprocess
     import sys

@@ -120,3 +120,42 @@ def test_call_order_errors(hiplib):
         ctx.set_instance_transform(len(sc.instances), sc.instances[0].transform)
     assert hiplib.jpt_scene_set_instance_transform(ctx.h, 0, None) == -1
     ctx.close()
+
+
+def test_native_instance_boxes_bound_the_triangles_more_tightly_than_the_root_boxes_corners(hiplib):
+    """A native scene's instance boxes (jpt_builder.cpp, tighten_instance_box): inside the reference's rule -- the box of the root
+    box's eight transformed corners, bvh.h:90-115 -- never cutting a triangle of the instance (every world-space vertex inside,
+    no tolerance), and for instances turned about an axis clearly smaller in footprint; an instance moved later gets the same box
+    as a fresh commit (test_update_equals_fresh_commit covers the bytes)."""
+    sc = scenes.instanced_scene(n_side=5, n_unique=3, tris_per_mesh=256)
+    ctx = host.Context(-1)
+    ctx.build_scene(sc, capi.BUILD_SAH)
+    inst = ctx.reference_buffer(capi.BUF_INSTANCES, wire.BLAS_INSTANCE)
+    nodes = ctx.reference_buffer(capi.BUF_BVH_NODES, wire.BVH_NODE)
+    geom = ctx.reference_buffer(capi.BUF_TRI_GEOMETRY, wire.TRI_GEOMETRY)
+    shrunk = 0
+    for k in range(len(inst)):
+        m = np.asarray(inst[k]["transform"], dtype=np.float64).reshape(4, 4).T   # column-major
+        root = nodes[int(inst[k]["blas_index"])]
+        lo, hi = np.asarray(root["aabbMin"][:3], np.float64), np.asarray(root["aabbMax"][:3], np.float64)
+        corners = np.array([[hi[0] if i & 1 else lo[0], hi[1] if i & 2 else lo[1], hi[2] if i & 4 else lo[2], 1.0] for i in range(8)])
+        wc = (m @ corners.T).T[:, :3]
+        rule_lo, rule_hi = wc.min(0), wc.max(0)
+        blo, bhi = np.asarray(inst[k]["aabbMin"][:3], np.float64), np.asarray(inst[k]["aabbMax"][:3], np.float64)
+        pad = 4e-6 * max(np.abs(rule_lo).max(), np.abs(rule_hi).max())
+        assert (blo >= rule_lo - pad).all() and (bhi <= rule_hi + pad).all()
+        # the instance's triangles: the leaves under its root
+        todo, tris = [int(inst[k]["blas_index"])], []
+        while todo:
+            n = nodes[todo.pop()]
+            if n["tri_count"] > 0:
+                tris += list(range(int(n["first_tri_index"]), int(n["first_tri_index"]) + int(n["tri_count"])))
+            elif n["left_child"] or n["right_child"]:
+                todo += [int(n["left_child"]), int(n["right_child"])]
+        assert tris
+        v = np.asarray(geom[tris]["vertices"][:, :, :3], np.float64).reshape(-1, 3)
+        wv = (m @ np.c_[v, np.ones(len(v))].T).T[:, :3]
+        assert (wv >= blo).all() and (wv <= bhi).all()
+        rule_area, area = np.prod((rule_hi - rule_lo)[[0, 2]]), np.prod((bhi - blo)[[0, 2]])
+        shrunk += area < 0.9 * rule_area
+    assert shrunk >= len(inst) // 4, shrunk   # (the blobs are turned about y by random angles)
