@@ -77,20 +77,6 @@ __device__ __forceinline__ bool walk_round(Traversal<COUNT, W4>& tr, bool active
     const int imin = tune.inst_min_lanes < cap ? tune.inst_min_lanes : cap;
     for (int it = 0; it < 64; it++) {
         if (active && !tr.have && tr.sp > 0) tr.pop_next(st);
-#if JPT_SPECULATE
-        // A lane that has reached a leaf puts it aside (one per lane) and goes on with the next record of the same instance, so
-        // that it takes part in this record loop instead of idling until the leaf phase; the triangle tests happen in the next
-        // leaf phase that runs.  Never across an instance's end: the leaf needs the instance's local ray.
-        if (W4 && active && tr.have && tr.cur < 0 && tr.in_blas && tr.pend == 0 && tr.sp > 0) {
-            const int32_t nxt = tr.pop(st);
-            if (nxt == kSentinel) {
-                tr.sp++;   // (not taken: the entry stays where it is)
-            } else {
-                tr.pend = tr.cur;
-                tr.cur = nxt;
-            }
-        }
-#endif
         const bool want = active && tr.wants_node();
         const unsigned long long m = __ballot(want);
         if (m == 0 || (it > 0 && __popcll(m) < kNodeMinLanes)) break;
@@ -101,11 +87,7 @@ __device__ __forceinline__ bool walk_round(Traversal<COUNT, W4>& tr, bool active
         if (want) tr.node_step(sc, st, cnt);
         if (COUNT && want) steps++;
     }
-#if JPT_SPECULATE
-    bool wl = active && (tr.wants_leaf() || tr.pend != 0);
-#else
     bool wl = active && tr.wants_leaf();
-#endif
     bool wi = active && tr.wants_instance();
     if (W4 && (tune.leaf_min_lanes > 1 || tune.inst_min_lanes > 1)) {   // (reference trees, with leaves of up to 64 triangles, lose 5 % by waiting)
         const int nl = __popcll(__ballot(wl)), ni = __popcll(__ballot(wi));
@@ -126,17 +108,7 @@ __device__ __forceinline__ bool walk_round(Traversal<COUNT, W4>& tr, bool active
             cnt.phase[6] += (unsigned long long)ni;
         }
     }
-#if JPT_SPECULATE
-    if (wl) {   // the leaf put aside first; a lane that holds two takes two phases
-        const bool aside = tr.pend != 0;
-        const int32_t ref = aside ? tr.pend : tr.cur;
-        tr.pend = 0;
-        if (!aside) tr.have = false;
-        tr.leaf_step_ref(sc, cnt, ref);
-    }
-#else
     if (wl) tr.leaf_step(sc, cnt);
-#endif
     if (wi) tr.instance_step(sc, st, cnt);
     if (COUNT && (wl || wi)) steps++;
     return active && tr.finished();

@@ -9,10 +9,6 @@
 #include "jpt_kernels.h"
 #include "jpt_shade.h"
 
-#ifndef JPT_SPECULATE
-#define JPT_SPECULATE 0   // 1: a lane that reaches a leaf puts it aside and steps its next record meanwhile (walk_round; experiment)
-#endif
-
 namespace jpt {
 
 constexpr int kTraceBlock = 256;
@@ -100,9 +96,6 @@ struct Traversal {
     int sp;
     uint32_t cur_inst;
     bool in_blas, have;
-#if JPT_SPECULATE
-    int32_t pend;   // a leaf of the current instance put aside while the lane goes on with its next record (0: none; walk_round)
-#endif
 
     // The stack: entries 0..kStackLds-1 in LDS (`lds` = this lane's column), deeper ones in `spill`, a
     // per-lane scratch array owned by the kernel (kept OUT of this struct so the struct stays in registers).
@@ -152,9 +145,6 @@ struct Traversal {
         cur_inst = 0;
         cur = sc.tlas_root;
         have = sc.n_instances != 0;
-#if JPT_SPECULATE
-        pend = 0;
-#endif
     }
 
     // slab constants of the current-level ray (o, d)
@@ -174,11 +164,7 @@ struct Traversal {
     __device__ __forceinline__ bool wants_node() const { return have && cur >= 0; }
     __device__ __forceinline__ bool wants_leaf() const { return have && cur < 0 && in_blas; }
     __device__ __forceinline__ bool wants_instance() const { return have && cur < 0 && !in_blas; }
-#if JPT_SPECULATE
-    __device__ __forceinline__ bool finished() const { return !have && sp == 0 && pend == 0; }
-#else
     __device__ __forceinline__ bool finished() const { return !have && sp == 0; }
-#endif
 
     // four-child record: four box tests on the quantised planes, children visited nearest first.  The order among
     // children is a performance choice only (the closest hit does not depend on it).
@@ -306,15 +292,10 @@ struct Traversal {
     // returns do skip work, and the branching form is 30 % faster.
     __device__ __forceinline__ void leaf_step(const WideSceneDev& sc, DevCounters& cnt)
     {
-        have = false;
-        leaf_step_ref(sc, cnt, cur);
-    }
-    // ... of the leaf `ref` (the current record, or one put aside)
-    __device__ __forceinline__ void leaf_step_ref(const WideSceneDev& sc, DevCounters& cnt, const int32_t ref)
-    {
-        const uint32_t bits = (uint32_t)~ref;
+        const uint32_t bits = (uint32_t)~cur;
         const uint32_t first = bits & kLeafFirstMask;
         const uint32_t count = (bits >> kLeafCountShift) + 1u;
+        have = false;
         for (uint32_t i = 0; i < count; i++) {
             const uint32_t ti = first + i;
             const WideTri* tp = sc.tris + ti;
