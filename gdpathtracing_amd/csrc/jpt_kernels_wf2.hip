@@ -114,6 +114,68 @@ __device__ __forceinline__ bool walk_round(Traversal<COUNT, W4>& tr, bool active
     return active && tr.finished();
 }
 
+// What a render writes once and reads once -- ray and hit queues, finished paths' colours, the framebuffers -- goes past the caches
+// with the non-temporal hint (`nt` on the load / store), so that 200 MB of hand-offs per launch do not push the tree's records out of
+// the 4 MB L2s: C3 -2.5 %, close-up -1.4 %, the 4 M-triangle scene -3 % (round 5, profiles/r05/r05w_nt_streams_rates.txt).
+// -DJPT_NT_STREAMS=0: plain loads and stores; 1: the loads only; 2: the stores only (A/B builds).
+#ifndef JPT_NT_STREAMS
+#define JPT_NT_STREAMS 3
+#endif
+typedef float jpt_v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 stream_ld4(const float4* p)
+{
+#if JPT_NT_STREAMS & 1
+    const jpt_v4f v = __builtin_nontemporal_load(reinterpret_cast<const jpt_v4f*>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+#else
+    return *p;
+#endif
+}
+__device__ __forceinline__ void stream_st4(float4* p, const float4 v)
+{
+#if JPT_NT_STREAMS & 2
+    jpt_v4f w;
+    w.x = v.x; w.y = v.y; w.z = v.z; w.w = v.w;
+    __builtin_nontemporal_store(w, reinterpret_cast<jpt_v4f*>(p));
+#else
+    *p = v;
+#endif
+}
+typedef uint32_t jpt_v4u __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 stream_ldu4(const uint4* p)
+{
+#if JPT_NT_STREAMS & 1
+    const jpt_v4u v = __builtin_nontemporal_load(reinterpret_cast<const jpt_v4u*>(p));
+    return make_uint4(v.x, v.y, v.z, v.w);
+#else
+    return *p;
+#endif
+}
+__device__ __forceinline__ void stream_stf(float* p, const float v)
+{
+#if JPT_NT_STREAMS & 2
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
+__device__ __forceinline__ uint32_t stream_ldu(const uint32_t* p)
+{
+#if JPT_NT_STREAMS & 1
+    return __builtin_nontemporal_load(p);
+#else
+    return *p;
+#endif
+}
+__device__ __forceinline__ void stream_stu(uint32_t* p, const uint32_t v)
+{
+#if JPT_NT_STREAMS & 2
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
+
 constexpr uint32_t kHasRadiance = 0x80000000u;   // queue entry, direction.w: rad[path] holds the path's radiance (else it is 0)
 constexpr uint32_t kPathMask = 0x7fffffffu;
 
@@ -195,8 +257,8 @@ __device__ __forceinline__ void path_slot_frame(uint32_t path, const Wf2Dims& dm
 // main.glsl:434 (the accumulation sums exactly those quantised values, progressive_rendering.glsl:33), 4 bytes per path
 __device__ __forceinline__ void store_final(const Wf2Buffers& wb, int accum_mode, uint32_t p, f3 r)
 {
-    if (accum_mode == 0) wb.fin8[p] = unorm8(r.x) | (unorm8(r.y) << 8) | (unorm8(r.z) << 16);
-    else wb.rad[p] = make_float4(r.x, r.y, r.z, 0.0f);
+    if (accum_mode == 0) stream_stu(&wb.fin8[p], unorm8(r.x) | (unorm8(r.y) << 8) | (unorm8(r.z) << 16));
+    else stream_st4(&wb.rad[p], make_float4(r.x, r.y, r.z, 0.0f));
 }
 
 // Is pixel (px, py) outside the screen rectangles of all the boxes the TLAS root offers (SkyCull, jpt_kernels.h)?  Its
@@ -439,10 +501,10 @@ __global__ __launch_bounds__(kBlock, JPT_PRIMARY_WAVES) void wf2_primary(WideSce
             base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
             if (is_hit) {
                 const uint32_t j = base + lanes_below(hm, lane);
-                wb.ray_o[0][seg_base + j] = make_float4(tr.wo.x, tr.wo.y, tr.wo.z, 0.0f);
-                wb.ray_d[0][seg_base + j] = make_float4(tr.wd.x, tr.wd.y, tr.wd.z, __uint_as_float(path));
-                wb.hit_a[seg_base + j] = make_float4(tr.hit.t, tr.hit.u, tr.hit.v, __uint_as_float(tr.hit.tri));
-                wb.hit_b[seg_base + j] = tr.hit.inst | (tr.hit.front ? 0x80000000u : 0u);
+                stream_st4(&wb.ray_o[0][seg_base + j], make_float4(tr.wo.x, tr.wo.y, tr.wo.z, 0.0f));
+                stream_st4(&wb.ray_d[0][seg_base + j], make_float4(tr.wd.x, tr.wd.y, tr.wd.z, __uint_as_float(path)));
+                stream_st4(&wb.hit_a[seg_base + j], make_float4(tr.hit.t, tr.hit.u, tr.hit.v, __uint_as_float(tr.hit.tri)));
+                stream_stu(&wb.hit_b[seg_base + j], tr.hit.inst | (tr.hit.front ? 0x80000000u : 0u));
             }
         }
         if (unsaved && !is_hit) {   // sky: radiance += 1 * sampleSky(d), path over (main.glsl:380,395-397)
@@ -594,8 +656,8 @@ __device__ __forceinline__ void trace_queue(const WideSceneDev& sc, const Wf2Buf
     // wave refills (two dozen lanes at once) instead of in the round each walk happens to end in (some lane does in
     // nearly every round: a dozen instructions per round for one or two lanes' stores).
     auto save_hit = [&]() {
-        wb.hit_a[my_loc] = make_float4(tr.hit.t, tr.hit.u, tr.hit.v, __uint_as_float(tr.hit.tri));
-        wb.hit_b[my_loc] = tr.hit.inst | (tr.hit.front ? 0x80000000u : 0u);
+        stream_st4(&wb.hit_a[my_loc], make_float4(tr.hit.t, tr.hit.u, tr.hit.v, __uint_as_float(tr.hit.tri)));
+        stream_stu(&wb.hit_b[my_loc], tr.hit.inst | (tr.hit.front ? 0x80000000u : 0u));
     };
 
     for (;;) {
@@ -621,7 +683,7 @@ __device__ __forceinline__ void trace_queue(const WideSceneDev& sc, const Wf2Buf
                             first = end[j];
                         }
                     const size_t loc = (size_t)(seg0 + k) * dm.seg_cap + (idx - first);
-                    const float4 ro = qo[loc], rd = qd[loc];
+                    const float4 ro = stream_ld4(&qo[loc]), rd = stream_ld4(&qd[loc]);
                     tr.begin(sc, mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z));
                     my_loc = loc;
                     active = true;
@@ -908,10 +970,10 @@ __global__ __launch_bounds__(kBlock, LAST ? 8 : (TEX == 0 ? JPT_SHADE_NOTEX_WAVE
     bool alive = false;
     float4 no, nd, nt;
     if (i < n) {
-        const float4 ro = wb.ray_o[in][seg_base + i], rd = wb.ray_d[in][seg_base + i];
-        const float4 tin = bounce > 0 ? wb.thr_q[in][seg_base + i] : make_float4(1.0f, 1.0f, 1.0f, 0.0f);
-        const float4 ha = wb.hit_a[seg_base + i];
-        const uint32_t hb = wb.hit_b[seg_base + i];
+        const float4 ro = stream_ld4(&wb.ray_o[in][seg_base + i]), rd = stream_ld4(&wb.ray_d[in][seg_base + i]);
+        const float4 tin = bounce > 0 ? stream_ld4(&wb.thr_q[in][seg_base + i]) : make_float4(1.0f, 1.0f, 1.0f, 0.0f);
+        const float4 ha = stream_ld4(&wb.hit_a[seg_base + i]);
+        const uint32_t hb = stream_ldu(&wb.hit_b[seg_base + i]);
         bool unreachable;   // (set aside inside shade_entry: nothing more to do here)
         alive = shade_entry<COUNT, LAST, TEX>(sh, wb, dm, fp, cam_far, bounce, ro, rd, tin, ha, hb, true, unreachable, no, nd, nt, cnt);
     }
@@ -928,9 +990,9 @@ __global__ __launch_bounds__(kBlock, LAST ? 8 : (TEX == 0 ? JPT_SHADE_NOTEX_WAVE
         wbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)wbase);
         if (alive) {
             const size_t j = seg_base + wbase + lanes_below(m, lane);
-            wb.ray_o[out][j] = no;
-            wb.ray_d[out][j] = nd;
-            wb.thr_q[out][j] = nt;
+            stream_st4(&wb.ray_o[out][j], no);
+            stream_st4(&wb.ray_d[out][j], nd);
+            stream_st4(&wb.thr_q[out][j], nt);
         }
     }
     if (COUNT) flush_counters(cnt, counters);
@@ -968,10 +1030,10 @@ __global__ __launch_bounds__(kBlock, JPT_WAVES_PER_SIMD) void wf2_bounce(WideSce
         bool alive = false;
         float4 no, nd, nt;
         if (i < n) {
-            const float4 ro = wb.ray_o[in][seg_base + i], rd = wb.ray_d[in][seg_base + i];
-            const float4 tin = bounce > 0 ? wb.thr_q[in][seg_base + i] : make_float4(1.0f, 1.0f, 1.0f, 0.0f);
-            const float4 ha = wb.hit_a[seg_base + i];
-            const uint32_t hb = wb.hit_b[seg_base + i];
+            const float4 ro = stream_ld4(&wb.ray_o[in][seg_base + i]), rd = stream_ld4(&wb.ray_d[in][seg_base + i]);
+            const float4 tin = bounce > 0 ? stream_ld4(&wb.thr_q[in][seg_base + i]) : make_float4(1.0f, 1.0f, 1.0f, 0.0f);
+            const float4 ha = stream_ld4(&wb.hit_a[seg_base + i]);
+            const uint32_t hb = stream_ldu(&wb.hit_b[seg_base + i]);
             bool unreachable;
             alive = shade_entry<COUNT, false, TEX>(sh, wb, dm, fp, cam_far, bounce, ro, rd, tin, ha, hb, true, unreachable, no, nd, nt, cnt);
         }
@@ -982,9 +1044,9 @@ __global__ __launch_bounds__(kBlock, JPT_WAVES_PER_SIMD) void wf2_bounce(WideSce
             wbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)wbase);
             if (alive) {
                 const size_t j = seg_base + wbase + lanes_below(m, lane);
-                wb.ray_o[out][j] = no;
-                wb.ray_d[out][j] = nd;
-                wb.thr_q[out][j] = nt;
+                stream_st4(&wb.ray_o[out][j], no);
+                stream_st4(&wb.ray_d[out][j], nd);
+                stream_st4(&wb.thr_q[out][j], nt);
             }
         }
     }
@@ -1163,7 +1225,7 @@ __global__ __launch_bounds__(kBlock) void wf2_accumulate(Wf2Buffers wb, Wf2Dims 
     f3 sum = mk3(0.0f, 0.0f, 0.0f);
     bool have_prev = fp.frame_count > 1;
     if (have_prev && valid) {
-        const float4 prev = accum[idx];
+        const float4 prev = stream_ld4(&accum[idx]);
         sum = mk3(prev.x, prev.y, prev.z);
     }
     f3 last = mk3(0.0f, 0.0f, 0.0f);
@@ -1288,7 +1350,7 @@ __global__ __launch_bounds__(kBlock) void wf2_accumulate(Wf2Buffers wb, Wf2Dims 
         for (int c = 0; c < kSharedFrames / 4; c++) {
             q[c] = make_uint4(sky_word, sky_word, sky_word, sky_word);
             if (c * 4 < fp.n_frames) {
-                if (!culled) q[c] = mine[c];
+                if (!culled) q[c] = stream_ldu4(&mine[c]);
                 else if (slow) q[c] = shared[c];
             }
         }
@@ -1331,11 +1393,11 @@ __global__ __launch_bounds__(kBlock) void wf2_accumulate(Wf2Buffers wb, Wf2Dims 
                 last = cur;
             }
         } else if (fp.accum_mode == 0) {
-            const uint32_t q = wb.fin8[at];
+            const uint32_t q = stream_ldu(&wb.fin8[at]);
             cur = mk3(from_unorm8(q & 255u), from_unorm8((q >> 8) & 255u), from_unorm8((q >> 16) & 255u));
             last = cur;   // (display_mode 1 shows the last frame's rgba8 image itself: quantising it again gives the same bytes)
         } else {
-            const float4 r = wb.rad[at];
+            const float4 r = stream_ld4(&wb.rad[at]);
             cur = mk3(r.x, r.y, r.z);
             last = cur;
         }
@@ -1343,13 +1405,13 @@ __global__ __launch_bounds__(kBlock) void wf2_accumulate(Wf2Buffers wb, Wf2Dims 
         have_prev = true;
     }
     if (fp.n_frames > 0) {
-        accum[idx] = make_float4(sum.x, sum.y, sum.z, 1.0f);
+        stream_st4(&accum[idx], make_float4(sum.x, sum.y, sum.z, 1.0f));
         const float fc = (float)(fp.frame_count + (uint32_t)fp.n_frames - 1u);
         const f3 col = fp.display_mode == 1 ? last : aces_film(mk3(sum.x / fc, sum.y / fc, sum.z / fc) * 1.0f);
-        ldr[idx] = unorm8(col.x) | (unorm8(col.y) << 8) | (unorm8(col.z) << 16) | 0xFF000000u;
+        stream_stu(&ldr[idx], unorm8(col.x) | (unorm8(col.y) << 8) | (unorm8(col.z) << 16) | 0xFF000000u);
         if (depth_out) {
             const float dist = culled ? cam.far_ : wb.first_depth[slot];
-            depth_out[idx] = cam.far_ / (cam.far_ - cam.near_) * (1.0f - cam.near_ / dist);  // main.glsl:432
+            stream_stf(&depth_out[idx], cam.far_ / (cam.far_ - cam.near_) * (1.0f - cam.near_ / dist));  // main.glsl:432
         }
     }
 }
