@@ -25,6 +25,8 @@ void RefScene::clear()
     reach_tri.clear();
     reach_inst.clear();
     mesh_ref_root.clear();
+    inst_cut_boxes.clear();
+    inst_cut_range.clear();
     up_mesh_root.clear();
     up_blas_index.clear();
     exact.clear();
@@ -833,6 +835,32 @@ struct InstanceCuts {
         return per_root.back().second;
     }
 
+    // the cuts as flat arrays for the device's refit: boxes[6 * k] = centre.xyz, half extent.xyz; range[2 * i] = instance i's first
+    // box and count (0: its box is the root's alone)
+    void export_to(const std::vector<RefInstance>& instances, std::vector<float>& boxes, std::vector<uint32_t>& range)
+    {
+        boxes.clear();
+        range.assign(instances.size() * 2, 0u);
+        if (n_boxes <= 1) return;
+        std::vector<std::pair<uint32_t, uint32_t>> placed(per_root.size(), {0u, 0u});
+        for (size_t r = 0; r < per_root.size(); r++) {
+            const std::vector<Box>& cut = per_root[r].second;
+            placed[r] = {(uint32_t)(boxes.size() / 6), cut.size() < 2 ? 0u : (uint32_t)cut.size()};
+            if (cut.size() < 2) continue;
+            for (const Box& x : cut) {
+                boxes.insert(boxes.end(), x.c, x.c + 3);
+                boxes.insert(boxes.end(), x.e, x.e + 3);
+            }
+        }
+        for (size_t i = 0; i < instances.size(); i++)
+            for (size_t r = 0; r < per_root.size(); r++)
+                if (per_root[r].first == instances[i].blas_index) {
+                    range[2 * i] = placed[r].first;
+                    range[2 * i + 1] = placed[r].second;
+                    break;
+                }
+    }
+
     void tighten(RefInstance& inst)
     {
         if (n_boxes <= 1 || inst.blas_index >= nodes.size()) return;
@@ -894,6 +922,9 @@ bool SceneBuilder::rebuild_instances(BuildMode mode, RefScene& out, std::string&
         if (is_native(mode)) cuts.tighten(inst);
         out.instances.push_back(inst);
     }
+    out.inst_cut_boxes.clear();
+    out.inst_cut_range.clear();
+    if (is_native(mode)) cuts.export_to(out.instances, out.inst_cut_boxes, out.inst_cut_range);
     out.reach_inst.clear();
     if (mode == BuildMode::Sah && out.mesh_ref_root.size() == meshes_.size())
         for (const PendingInstance& pi : instances_) out.reach_inst.push_back(reach_instance(pi.t12, out.mesh_ref_root[pi.mesh]));

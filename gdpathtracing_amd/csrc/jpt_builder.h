@@ -75,6 +75,11 @@ struct RefScene {
     std::vector<ReachTri> reach_tri;
     std::vector<ReachInst> reach_inst;
     std::vector<ReachInst> mesh_ref_root;     // root_lo / root_hi filled; one per unique mesh
+    // native commits: the boxes that bound an instance's world box (jpt_builder.cpp, InstanceCuts) -- per box centre.xyz and half
+    // extent.xyz in the mesh's space, per instance (first box, count) -- so that a device refit (jpt_scene_refit_tlas) gives a moved
+    // instance the box a host update would
+    std::vector<float> inst_cut_boxes;
+    std::vector<uint32_t> inst_cut_range;
     // route (i) on the native tree (native_from_uploaded): per unique BLAS the node index the CALLER's arrays gave its
     // root, and per instance the blas_index the caller uploaded -- what jpt_scene_update_reference_tlas matches new
     // BLASInstance records against

@@ -97,6 +97,8 @@ struct jpt_ctx {
     DevBuf<uint32_t> d_x_tri_native, d_x_native_ref, d_x_tri_leaf, d_x_subtree_end, d_x_tlas_parent, d_x_inst_leaf;
     DevBuf<ReachTri> d_reach_tri;   // reach records (JPT_BUILD_SAH): per triangle / per instance (one per copy of the instance level)
     DevBuf<ReachInst> d_reach_inst;
+    DevBuf<float> d_cut_boxes;         // RefScene::inst_cut_boxes / inst_cut_range (device refits)
+    DevBuf<uint32_t> d_cut_range;
     BuildMode build_mode = BuildMode::ReferenceExact;
     DeviceScene ds;
 
@@ -431,6 +433,8 @@ int upload_scene(jpt_ctx* c)
     HIP_TRY(c, c->d_winst4.upload(c->wide.instances4, s));
     HIP_TRY(c, c->d_reach_tri.upload(c->ref.reach_tri, s));
     HIP_TRY(c, c->d_reach_inst.upload(c->ref.reach_inst, s));
+    HIP_TRY(c, c->d_cut_boxes.upload(c->ref.inst_cut_boxes, s));
+    HIP_TRY(c, c->d_cut_range.upload(c->ref.inst_cut_range, s));
     HIP_TRY(c, hipStreamSynchronize(s));
     {
         const int rc4 = upload_nodes4(c, false);
@@ -1474,6 +1478,8 @@ int upload_tlas_update(jpt_ctx* c)
     HIP_TRY(c, c->d_winst.upload(c->wide.instances, s));
     HIP_TRY(c, c->d_winst4.upload(c->wide.instances4, s));
     HIP_TRY(c, c->d_reach_inst.upload(c->ref.reach_inst, s));
+    HIP_TRY(c, c->d_cut_boxes.upload(c->ref.inst_cut_boxes, s));
+    HIP_TRY(c, c->d_cut_range.upload(c->ref.inst_cut_range, s));
     HIP_TRY(c, hipStreamSynchronize(s));
     {
         const int rc4 = upload_nodes4(c, true);
@@ -1591,7 +1597,9 @@ int jpt_scene_refit_tlas(jpt_ctx* c, const float* transforms12, uint32_t n_insta
     const uint32_t tail_base = (uint32_t)(c->wide.blas_nodes4.size() + (size_t)next * c->tlas4_cap);
     ReachInst* reach_next = c->ds.reach_tri ? (next ? c->d_reach_inst_more[next - 1].p : c->d_reach_inst.p) : nullptr;
     launch_tlas4_refit(rs, dev_view, n_instances, c->d_bvh.p, inst_next, nullptr, winst4_next, c->d_nodes4.p, tail_base,
-                       c->d_tlas4_order.p, c->d_tlas4_levels.p, c->n_tlas4_levels, reach_next, c->d_nodesq.p, (uint32_t)c->wide.tlas_nodes4.size());
+                       c->d_tlas4_order.p, c->d_tlas4_levels.p, c->n_tlas4_levels, reach_next, c->d_nodesq.p, (uint32_t)c->wide.tlas_nodes4.size(),
+                       c->ref.inst_cut_range.size() == 2 * (size_t)n_instances && !c->ref.inst_cut_boxes.empty() ? c->d_cut_boxes.p : nullptr,
+                       c->ref.inst_cut_range.size() == 2 * (size_t)n_instances && !c->ref.inst_cut_boxes.empty() ? c->d_cut_range.p : nullptr);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipEventRecord(c->ev_refit_copied[st], rs));
     HIP_TRY(c, hipEventRecord(c->ev_refit_done, rs));

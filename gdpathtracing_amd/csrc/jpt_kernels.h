@@ -212,7 +212,8 @@ void launch_wf2_render(hipStream_t stream, const DeviceScene& ds, const FramePar
 void launch_tlas4_refit(hipStream_t stream, const float* transforms12, uint32_t n_instances, const RefBvhNode* bvh,
                         RefInstance* ref_instances, WideInstance* wide_instances, WideInstance* wide_instances4, WideNode4* nodes4,
                         uint32_t n_blas_records, const uint32_t* order, const uint32_t* level_start, uint32_t n_levels,
-                        ReachInst* reach_instances /* may be null */, WideNodeQ* nodesq, uint32_t n_tlas_records);
+                        ReachInst* reach_instances /* may be null */, WideNodeQ* nodesq, uint32_t n_tlas_records,
+                        const float* cut_boxes = nullptr, const uint32_t* cut_range = nullptr /* RefScene::inst_cut_*: may be null */);
 
 // one dispatch of temporal_reprojection.glsl over a whole image (jpt_kernels_post.hip): screen rgba8 in/out, depth
 // read-only, hist1 / hist2 the two rgba32f history images

@@ -92,7 +92,8 @@ __global__ __launch_bounds__(256) void temporal_kernel(RefTemporalParams tp, uin
 // traversal records' inverse matrices
 __global__ __launch_bounds__(256) void instance_refit_kernel(const float* __restrict__ t12, uint32_t n, const RefBvhNode* __restrict__ bvh,
                                                              RefInstance* __restrict__ ref_inst, WideInstance* __restrict__ winst,
-                                                             WideInstance* __restrict__ winst4, ReachInst* __restrict__ reach)
+                                                             WideInstance* __restrict__ winst4, ReachInst* __restrict__ reach,
+                                                             const float* __restrict__ cut_boxes, const uint32_t* __restrict__ cut_range)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -110,6 +111,32 @@ __global__ __launch_bounds__(256) void instance_refit_kernel(const float* __rest
         reach[i] = r;
     }
     instance_record(t, root.aabbMin, root.aabbMax, true, inst);
+    // ... bound more tightly by the boxes of the mesh's tree the host chose at the last commit (jpt_builder.cpp, InstanceCuts::tighten:
+    // the same arithmetic -- centre' -+ |M| half extent, the union padded, intersected with the root rule's box); affine transforms
+    // only, which is what a Transform3D is
+    const uint32_t n_cut = cut_range ? cut_range[2 * i + 1] : 0u;
+    if (n_cut >= 2u) {
+        const float* m = inst.transform;   // column-major 4 x 4
+        float am[9];
+        for (int r = 0; r < 3; r++)
+            for (int k = 0; k < 3; k++) am[k * 3 + r] = __builtin_fabsf(m[k * 4 + r]);
+        float lo[3] = {1e34f, 1e34f, 1e34f}, hi[3] = {-1e34f, -1e34f, -1e34f};
+        const float* b = cut_boxes + (size_t)cut_range[2 * i] * 6;
+        for (uint32_t k = 0; k < n_cut; k++, b += 6)
+            for (int r = 0; r < 3; r++) {
+                const float wc = m[r] * b[0] + m[4 + r] * b[1] + m[8 + r] * b[2] + m[12 + r];
+                const float we = am[r] * b[3] + am[3 + r] * b[4] + am[6 + r] * b[5];
+                lo[r] = fminf(lo[r], wc - we);
+                hi[r] = fmaxf(hi[r], wc + we);
+            }
+        float big = 0.0f;
+        for (int r = 0; r < 3; r++) big = fmaxf(big, fmaxf(__builtin_fabsf(lo[r]), __builtin_fabsf(hi[r])));
+        const float pad = big * 4e-6f;
+        if (lo[0] <= hi[0] && lo[1] <= hi[1] && lo[2] <= hi[2]) {
+            inst.aabbMin = Vec4{fmaxf(inst.aabbMin.x, lo[0] - pad), fmaxf(inst.aabbMin.y, lo[1] - pad), fmaxf(inst.aabbMin.z, lo[2] - pad), inst.aabbMin.w};
+            inst.aabbMax = Vec4{fminf(inst.aabbMax.x, hi[0] + pad), fminf(inst.aabbMax.y, hi[1] + pad), fminf(inst.aabbMax.z, hi[2] + pad), inst.aabbMax.w};
+        }
+    }
     ref_inst[i] = inst;
     for (int c = 0; c < 4; c++)
         for (int r = 0; r < 3; r++) {
@@ -174,11 +201,11 @@ __global__ __launch_bounds__(256) void quantize_tail_kernel(const WideNode4* __r
 void launch_tlas4_refit(hipStream_t stream, const float* transforms12, uint32_t n_instances, const RefBvhNode* bvh,
                         RefInstance* ref_instances, WideInstance* wide_instances, WideInstance* wide_instances4, WideNode4* nodes4,
                         uint32_t n_blas_records, const uint32_t* order, const uint32_t* level_start, uint32_t n_levels, ReachInst* reach,
-                        WideNodeQ* nodesq, uint32_t n_tlas_records)
+                        WideNodeQ* nodesq, uint32_t n_tlas_records, const float* cut_boxes, const uint32_t* cut_range)
 {
     if (n_instances == 0) return;
     hipLaunchKernelGGL(instance_refit_kernel, dim3((n_instances + 255) / 256), dim3(256), 0, stream, transforms12, n_instances, bvh,
-                       ref_instances, wide_instances, wide_instances4, reach);
+                       ref_instances, wide_instances, wide_instances4, reach, cut_boxes, cut_range);
     if (n_levels) {
         hipLaunchKernelGGL(tlas4_refit_kernel, dim3(1), dim3(1024), 0, stream, nodes4, n_blas_records, order, level_start, n_levels,
                            ref_instances);
