@@ -32,8 +32,11 @@ import time
 
 import numpy as np
 
-# (No environment is prepared for the library: its pipeline streams take their hardware queues from the highest stream
-# priority level's own pool; round 1 needed GPU_MAX_HW_QUEUES=16 exported before torch started HIP.)
+# Six renders in flight want six hardware queues for their streams, and the runtime makes GPU_MAX_HW_QUEUES per stream priority level
+# -- four unless told otherwise at the process's FIRST HIP call, which in this program is torch's.  So the variable is set here, before
+# torch is imported (never over a value the caller exported); the library measures whether it took and falls back to four renders in
+# flight if not (the line reports both under "config").
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "6")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -432,6 +435,7 @@ def main():
     # through the context's stream.  (A queue of K renders takes K x rate + the latency of the last one, ~3 ms: small
     # K reads lower.)
     elapsed = timed(args.steps)
+    renders_in_flight = ctx.renders_in_flight()   # 6 where six of the library's streams run side by side, else 4
     gpu_image = ctx.read_accum() if (world == 1 and rank == 0) else None   # the image the timed region left behind (parity)
     verified = None
     if (args.verify or world > 1) and rank == 0:   # N > 1: always -- the assembled image of the last timed step against one context's
@@ -755,6 +759,7 @@ def main():
                 "rays_per_step": rays, "nominal_rays_per_step": n_pixels * spp * (bounces + 1),
                 "parallelism": "screen strips x%d" % world + ("" if world == 1 else ", gather of %s rows to rank 0" % ("rgba8 display" if args.gather == "ldr" else "float4 accumulation")),
                 "scene_build_s": round(build_s, 4),
+                "renders_in_flight": renders_in_flight, "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"),
                 "outputs": "float4 accumulation + rgba8 display" + (" + r32f depth" if args.depth else " (depth image off: only temporal reprojection reads it)"),
             },
             "roofline": {

@@ -9,6 +9,11 @@ import ctypes as C
 import os
 import subprocess
 
+# the library keeps six renders in flight where six of its streams get a hardware queue each: GPU_MAX_HW_QUEUES (per stream priority
+# level, four by default) is read by the HIP runtime at the process's first HIP call -- set here, before this module's users can have
+# made one through the library, never over a value the caller exported (jpt.h, jpt_create)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "6")
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("JPT_LIB", os.path.join(_HERE, "libjpt_hip.so"))  # JPT_LIB: A/B builds (tools/ab.sh)
 CSRC = os.path.join(_HERE, "csrc")
@@ -27,7 +32,7 @@ BUF_TRI_GEOMETRY, BUF_TRI_DATA, BUF_MATERIALS, BUF_BVH_NODES, BUF_INSTANCES, BUF
 
 # every symbol include/jpt.h declares
 SYMBOLS = [
-    "jpt_abi_version", "jpt_create", "jpt_destroy", "jpt_last_error", "jpt_set_stream", "jpt_get_stream", "jpt_set_stream_priority", "jpt_set_memory_policy", "jpt_get_workspace_bytes",
+    "jpt_abi_version", "jpt_create", "jpt_destroy", "jpt_last_error", "jpt_set_stream", "jpt_get_stream", "jpt_set_stream_priority", "jpt_renders_in_flight", "jpt_set_memory_policy", "jpt_get_workspace_bytes",
     "jpt_scene_upload_reference_layout", "jpt_set_upload_mode", "jpt_scene_tree_kind", "jpt_scene_upload_note", "jpt_scene_ties_exact", "jpt_scene_begin", "jpt_scene_add_mesh", "jpt_scene_add_instance",
     "jpt_scene_set_materials", "jpt_scene_set_textures", "jpt_scene_commit", "jpt_scene_get_reference_buffer",
     "jpt_scene_set_instance_transform", "jpt_scene_update_tlas", "jpt_scene_refit_tlas", "jpt_scene_update_reference_tlas",
@@ -142,6 +147,9 @@ def lib():
     L.jpt_set_temporal_params.argtypes = [vp, vp]
     if hasattr(L, "jpt_set_outputs") or "JPT_LIB" not in os.environ:   # (JPT_LIB: an A/B build of an earlier ABI may lack it)
         L.jpt_set_outputs.argtypes = [vp, C.c_uint32]
+    if hasattr(L, "jpt_renders_in_flight") or "JPT_LIB" not in os.environ:
+        L.jpt_renders_in_flight.argtypes = [vp]
+        L.jpt_renders_in_flight.restype = C.c_int
     L.jpt_read_ldr_rgba8.argtypes = [vp, vp]
     L.jpt_read_accum_f32.argtypes = [vp, vp]
     L.jpt_readback_ldr_begin.argtypes = [vp]

@@ -116,7 +116,9 @@ struct jpt_ctx {
     // render pipelining (jpt_render_async): consecutive asynchronous renders run their path kernels on two helper
     // streams with two workspaces, so one render's launch tails overlap the next render's kernels; the accumulation
     // kernels stay on the context's stream, in order
-    static constexpr int kPipeSlots = 4;   // (more lose: the hardware runs four queues side by side, profiles/r04/r04ad_blocking_groups_slots_resweep.txt)
+    static constexpr int kPipeSlots = 8;   // the most; the rule is 4, or 6 where six of the slots' streams run side by side (six_queues_probe)
+    int six_queues = -1;                   // -1: not probed yet; 0 / 1
+    int last_pipe_slots = 0;               // jpt_renders_in_flight
     DevBuf<char> d_workspace_more[kPipeSlots - 1];  // slot 0 is d_workspace
     hipStream_t pipe_stream[kPipeSlots] = {};
     uint64_t async_seq = 0;
@@ -160,7 +162,7 @@ struct jpt_ctx {
     uint64_t refit_seq = 0;
     // Several copies of the instance level (RefInstance + WideInstance arrays, TLAS tail of d_nodes4): a refit writes
     // a copy the renders in flight do NOT read, so the renders after a refit overlap with the renders before it.
-    static constexpr int kInstanceSets = 4;   // as many as renders in flight: a queue of animation steps stays pipelined
+    static constexpr int kInstanceSets = 8;   // as many as renders in flight can be: a queue of animation steps stays pipelined
     DevBuf<RefInstance> d_instances_more[kInstanceSets - 1];
     DevBuf<WideInstance> d_winst4_more[kInstanceSets - 1];
     DevBuf<ReachInst> d_reach_inst_more[kInstanceSets - 1];
@@ -667,8 +669,7 @@ int do_render(jpt_ctx* c, int32_t n_frames, uint32_t first_frame_index, bool cou
 // streams that share a queue execute in submission order.  With all of this library's streams at the normal level the
 // rate of queued renders depended on which streams happened to share a queue (round 1, C3: 1.32 ms per render with the
 // most fortunate order, 1.60 and 2.39 with others); the pipeline slots now take their queues from the highest priority
-// level's pool (ensure_pipe_slot below), and the helper streams of frame groups stay at the normal level with the
-// context's stream.
+// level's pool (ensure_pipe_slot below), and so do the helper streams of frame groups (round 5: below).
 // frame groups: `groups - 1` helper streams (launch_wf2_render); false = not available, renders run serially
 bool ensure_group_streams(jpt_ctx* c, int groups)
 {
@@ -678,10 +679,22 @@ bool ensure_group_streams(jpt_ctx* c, int groups)
         return false;
     }
     for (int k = 0; k + 1 < groups && k < 3; k++) {
-        if (!c->async.aux_stream[k] && hipStreamCreateWithFlags(&c->async.aux_stream[k], hipStreamNonBlocking) != hipSuccess) {
-            c->async.aux_stream[k] = nullptr;
-            (void)hipGetLastError();
-            return false;
+        if (!c->async.aux_stream[k]) {
+            // At the pipeline slots' priority level (ensure_pipe_slot: the highest by default), not at the context stream's: the
+            // normal level's queues are dealt in the order of first use among ALL the process's streams, and a helper stream that
+            // lands on the context stream's queue runs its group AFTER group 0 instead of beside it -- 1.24 -> 1.48 ms per blocking
+            // C3 render after a counted render had run first, with six queues per level (round 5, profiles/r05/r05an_…).  At the
+            // slots' level it shares a queue with an idle slot stream at worst.
+            int least = 0, greatest = 0;
+            const bool high = c->slot_priority != JPT_STREAM_PRIORITY_NORMAL && c->slot_priority != JPT_STREAM_PRIORITY_LOW && tuning().slot_prio != 0 &&
+                              hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least > greatest;
+            const hipError_t e = high ? hipStreamCreateWithPriority(&c->async.aux_stream[k], hipStreamNonBlocking, greatest)
+                                      : hipStreamCreateWithFlags(&c->async.aux_stream[k], hipStreamNonBlocking);
+            if (e != hipSuccess) {
+                c->async.aux_stream[k] = nullptr;
+                (void)hipGetLastError();
+                return false;
+            }
         }
         if (!c->async.join[k] && hipEventCreateWithFlags(&c->async.join[k], hipEventDisableTiming) != hipSuccess) {
             c->async.join[k] = nullptr;
@@ -722,6 +735,42 @@ bool ensure_pipe_slot(jpt_ctx* c, int slot)
     if (ok && !c->ev_acc_done[slot]) ok = hipEventCreateWithFlags(&c->ev_acc_done[slot], hipEventDisableTiming) == hipSuccess;
     if (!ok) (void)hipGetLastError();
     return ok;
+}
+
+// Do SIX of the slots' streams run side by side?  A stream runs on one of the hardware queues of its priority level's pool --
+// GPU_MAX_HW_QUEUES per level, four by default, fixed at the process's first HIP call -- and streams that share a queue run one after
+// the other: with the default pool a fifth and sixth render in flight cost 15-20 % (r04ad), with a pool of six or more they are worth
+// 4 % on C3 and 15 % on small renders (profiles/r05/r05aj_slots_hw_queues_chain_sweep.txt).  The environment is the host's to set
+// (bench.py and the Python binding do; jpt_create tries, jpt.h); what the library does is LOOK: one wave per slot stream busy for
+// 0.4 ms, all six launched together -- side by side they are done in about that time, on four queues in about twice that.  Once per
+// context, ~1 ms, before its first queued render.
+bool six_queues_probe(jpt_ctx* c)
+{
+    if (c->six_queues >= 0) return c->six_queues != 0;
+    c->six_queues = 0;
+    constexpr int kProbe = 6;
+    for (int k = 0; k < kProbe; k++)
+        if (!ensure_pipe_slot(c, k)) return false;
+    int khz = 0;
+    if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, c->device) != hipSuccess || khz <= 0) {
+        (void)hipGetLastError();
+        return false;
+    }
+    const long long ticks = (long long)khz * 400 / 1000;   // 0.4 ms
+    for (int k = 0; k < kProbe; k++) launch_queue_spin(c->pipe_stream[k], 1);   // (the module is loaded, the queues exist)
+    for (int k = 0; k < kProbe; k++)
+        if (hipStreamSynchronize(c->pipe_stream[k]) != hipSuccess) return false;
+    double best = 1e9;
+    for (int rep = 0; rep < 2; rep++) {   // the better of two: a host hiccup can only make it look serial
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int k = 0; k < kProbe; k++) launch_queue_spin(c->pipe_stream[k], ticks);
+        for (int k = 0; k < kProbe; k++)
+            if (hipStreamSynchronize(c->pipe_stream[k]) != hipSuccess) return false;
+        best = std::min(best, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    }
+    if (hipGetLastError() != hipSuccess) return false;
+    c->six_queues = best < 0.4 * 1.6 ? 1 : 0;
+    return c->six_queues != 0;
 }
 
 int do_render_batch(jpt_ctx* c, int32_t n_frames, uint32_t first_frame_index, bool counted, bool blocking)
@@ -840,8 +889,11 @@ int do_render_batch(jpt_ctx* c, int32_t n_frames, uint32_t first_frame_index, bo
             // 0.193, 4K x 16 spp 11.1 vs 11.1.  Renders whose workspace exceeds 24 GiB keep two slots and full-width launches.
             const size_t one_workspace = wf2 ? wf2_workspace_bytes(c->width, c->local_rows, n_frames, c->max_bounces) : 0;
             const bool huge = one_workspace > ((size_t)24 << 30);  // 4 x 24 GiB of workspaces is where this stops
-            const int pipe_slots = forced_slots ? forced_slots : (huge ? 2 : 4);
+            // ... six where the slots' streams have six hardware queues to themselves (six_queues_probe), four otherwise
+            const bool may_queue = wf2 && pipelining && !blocking && !counted;
+            const int pipe_slots = forced_slots ? forced_slots : (huge ? 2 : ((tuning().six_slots && may_queue && six_queues_probe(c)) ? 6 : 4));
             const int slot = (int)(c->async_seq % (uint64_t)pipe_slots);
+            if (may_queue) c->last_pipe_slots = pipe_slots;
             // A host that queues ONE render at a time (jpt_render_async, its own work, jpt_sync or the split read-back, again)
             // never has a second render in flight: the pipelined form's quarter-width launches then run alone, and a render takes
             // half as long again as a blocking one (C3 1.93 against 1.26 ms, 3840 x 2160 x 4 spp 3.33 against 2.11:
@@ -1096,6 +1148,15 @@ int jpt_create(int device_id, jpt_ctx** out)
         *out = c;
         return JPT_OK;
     }
+    // Six renders in flight want six hardware queues for their streams; the runtime makes GPU_MAX_HW_QUEUES per priority level (four
+    // by default) and reads the variable at the process's first HIP call.  If that has not happened yet this is it: ask for six (as many as slots: jpt_tuning.h),
+    // unless the host has chosen (never overwritten) or declined (JPT_HW_QUEUES=0).  Whether it took is measured, not assumed
+    // (six_queues_probe).
+    if (tuning().hw_queues > 0) {
+        char v[16];
+        std::snprintf(v, sizeof v, "%d", tuning().hw_queues);
+        (void)setenv("GPU_MAX_HW_QUEUES", v, 0);
+    }
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess || n <= 0) {
@@ -1182,6 +1243,8 @@ int jpt_set_stream(jpt_ctx* c, void* hip_stream)
     return JPT_OK;
 }
 
+int jpt_renders_in_flight(const jpt_ctx* c) { return c ? c->last_pipe_slots : 0; }
+
 int jpt_set_stream_priority(jpt_ctx* c, int32_t priority)
 {
     if (!c) return JPT_E_INVALID;
@@ -1206,7 +1269,7 @@ int jpt_set_stream_priority(jpt_ctx* c, int32_t priority)
 int jpt_set_memory_policy(jpt_ctx* c, int32_t renders_in_flight, uint64_t workspace_budget_bytes)
 {
     if (!c) return JPT_E_INVALID;
-    if (renders_in_flight < 0 || renders_in_flight > jpt_ctx::kPipeSlots) return fail(c, JPT_E_INVALID, "renders_in_flight must be 0 (the library's rule) or 1..4");
+    if (renders_in_flight < 0 || renders_in_flight > jpt_ctx::kPipeSlots) return fail(c, JPT_E_INVALID, "renders_in_flight must be 0 (the library's rule) or 1..8");
     c->max_slots = renders_in_flight;
     c->workspace_budget = workspace_budget_bytes;
     if (c->device < 0) return JPT_OK;

@@ -206,6 +206,9 @@ void launch_wf2_render(hipStream_t stream, const DeviceScene& ds, const FramePar
                        float4* accum, uint32_t* ldr, float* depth, DevCounters* counters, hipEvent_t* trace_events,
                        const Wf2Async& async, hipStream_t acc_stream = nullptr, hipEvent_t paths_done = nullptr);
 
+// one wave busy for `ticks` of the device's wall clock (hipDeviceAttributeWallClockRate), to see which streams run side by side
+void launch_queue_spin(hipStream_t stream, long long ticks);
+
 // Moving instances without the host (jpt_scene_refit_tlas): instance records from new transforms, then the boxes of the
 // four-child TLAS records bottom-up over the unchanged topology.  transforms12: n x 12 floats on the device; bvh: the
 // reference-layout BLAS nodes (root boxes); order / level_start: tlas4_refit_schedule, on the device.

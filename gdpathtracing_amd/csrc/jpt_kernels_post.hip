@@ -86,6 +86,16 @@ __global__ __launch_bounds__(256) void temporal_kernel(RefTemporalParams tp, uin
     screen[i] = unorm8(col.x) | (unorm8(col.y) << 8) | (unorm8(col.z) << 16) | 0xFF000000u;
 }
 
+// ---- how many of the pipeline slots' streams run side by side (jpt_capi.hip, six_queues_probe) ---------------------------------
+
+// one wave that keeps its hardware queue busy for `ticks` of the constant-rate wall clock
+__global__ __launch_bounds__(64) void queue_spin_kernel(long long ticks)
+{
+    const long long t0 = (long long)wall_clock64();
+    while ((long long)wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+void launch_queue_spin(hipStream_t stream, long long ticks) { hipLaunchKernelGGL(queue_spin_kernel, dim3(1), dim3(64), 0, stream, ticks); }
+
 // ---- device-side refit of the instance level (jpt_scene_refit_tlas) -------------------------------------------------
 
 // one thread per instance: the BLASInstance record (jpt_instance_math.h, the host builder's own code) and the hot

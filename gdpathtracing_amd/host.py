@@ -110,6 +110,10 @@ class Context:
         """capi.STREAM_PRIORITY_*: the priority level of the streams queued renders run on (jpt_set_stream_priority)."""
         self._ck(self._lib.jpt_set_stream_priority(self.h, priority), "jpt_set_stream_priority")
 
+    def renders_in_flight(self) -> int:
+        """the pipeline slots the last queued render was dealt among: 4, or 6 where six slot streams run side by side (0 before the first)"""
+        return int(self._lib.jpt_renders_in_flight(self.h)) if hasattr(self._lib, "jpt_renders_in_flight") else 0
+
     def set_debug_steps(self, enable: bool):
         """main.glsl's DEBUG_STEPS build: the image is the primary ray's triangle-test count / 256 (jpt_set_debug_steps)."""
         self._ck(self._lib.jpt_set_debug_steps(self.h, 1 if enable else 0), "jpt_set_debug_steps")

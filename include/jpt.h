@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define JPT_ABI_VERSION 5
+#define JPT_ABI_VERSION 6
 
 typedef struct jpt_ctx jpt_ctx;
 
@@ -158,7 +158,7 @@ int jpt_set_stream(jpt_ctx *ctx, void *hip_stream);
  * framework queue its own work -- a collective on the finished rows -- behind the renders (bench.py wraps it in
  * torch.cuda.ExternalStream).  No reference counterpart. */
 int jpt_get_stream(jpt_ctx *ctx, void **hip_stream);
-/* Queued renders (jpt_render_async) run their path kernels on up to four internal streams ("pipeline slots").  The HIP
+/* Queued renders (jpt_render_async) run their path kernels on four or six internal streams ("pipeline slots").  The HIP
  * runtime deals the streams of a process onto a small pool of hardware queues PER PRIORITY LEVEL, and streams that share
  * a queue run in submission order; so by default the slots are created at the device's HIGHEST stream priority, whose
  * pool they have to themselves as long as the host, torch and RCCL keep their streams at the normal level (DESIGN.md
@@ -169,15 +169,25 @@ int jpt_get_stream(jpt_ctx *ctx, void **hip_stream);
  *   NORMAL   the level everything else uses: no pre-emption of host work; the queued rate then depends on which streams
  *            happen to share a hardware queue
  *   HIGH / LOW   the device's highest / lowest level
+ * The pool has GPU_MAX_HW_QUEUES queues per level -- four unless the environment says otherwise at the process's FIRST HIP call.
+ * Six renders in flight are worth 4 % on a 1920x1080x8-spp render and 15 % on small ones when the slots' six streams get a queue
+ * each, and cost as much when they have to share four: the first jpt_create of a process that has made no HIP call yet asks the
+ * runtime for six (never over a value the host exported; JPT_HW_QUEUES=0 in the environment: leaves it alone), and every
+ * context MEASURES, before its first queued render, whether six of its streams run side by side (~1 ms) -- six slots if they do,
+ * four if not.  A host that initialises HIP itself exports GPU_MAX_HW_QUEUES=6 before it does (six, not more: with
+ * eight a SECOND context's streams pair up on some queues and it renders a third slower).
+ * jpt_renders_in_flight: the slots the last queued render was dealt among (0 before the first).
  * No reference counterpart. */
 enum { JPT_STREAM_PRIORITY_DEFAULT = 0, JPT_STREAM_PRIORITY_NORMAL = 1, JPT_STREAM_PRIORITY_HIGH = 2, JPT_STREAM_PRIORITY_LOW = 3 };
 int jpt_set_stream_priority(jpt_ctx *ctx, int32_t priority);
+int jpt_renders_in_flight(const jpt_ctx *ctx);
 
 /* Device memory a context may spend on renders in flight.  A wavefront render keeps 168 bytes per path (pixel x frame of
- * the render window) in a workspace, and queued renders (jpt_render_async) use up to four workspaces at once -- 11 GB for
+ * the render window) in a workspace, and queued renders (jpt_render_async) use four or six workspaces at once -- 11 GB for
  * four 1920x1080x8-spp renders: fine on a 288 GB device the library has to itself, the first thing an application sharing
  * the GPU with its own renderer will want to cap.
- *   renders_in_flight  1..4 workspaces / pipeline slots; 0: the library's rule (4; 2 when one workspace exceeds 24 GiB).
+ *   renders_in_flight  1..8 workspaces / pipeline slots; 0: the library's rule (4, or 6 where six slot streams run side by side;
+ *                      2 when one workspace exceeds 24 GiB).
  *                      1 serialises queued renders (about 1.5 x the time per render at C3's size).
  *   workspace_budget_bytes  most bytes ONE workspace may take; a render with more frames than fit runs as batches of
  *                      frames in frame order, same image (0: the library's rule, 24 GiB).  One frame is the smallest

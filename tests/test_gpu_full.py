@@ -775,7 +775,7 @@ def test_one_render_in_flight_at_a_time_then_a_burst(oracle, hiplib):
 
 
 def test_memory_policy_caps_the_workspaces_and_keeps_the_image(hiplib):
-    """jpt_set_memory_policy: queued renders with four, two and one workspace in flight, and with a budget per workspace
+    """jpt_set_memory_policy: queued renders with six, four, two and one workspace in flight, and with a budget per workspace
     that forces batches of frames, leave the same accumulation buffer; jpt_get_workspace_bytes shows the cap taking
     effect (workspaces past it are freed by the call)."""
     sc = scenes.demo_scene(2500)
@@ -797,9 +797,13 @@ def test_memory_policy_caps_the_workspaces_and_keeps_the_image(hiplib):
         ctx.close()
         return out, used, after
 
-    full, used4, after4 = run(0, 0)
+    full, used4, after4 = run(4, 0)
     one_ws = used4 // 4
     assert used4 == 4 * one_ws and after4 == one_ws            # four equal workspaces; the cap to one freed three
+    ruled, used_rule, _ = run(0, 0)                             # the library's rule: four, or six where six slot streams run side by side
+    assert used_rule in (4 * one_ws, 6 * one_ws) and np.array_equal(full, ruled)
+    six, used6, _ = run(6, 0)
+    assert used6 == 6 * one_ws and np.array_equal(full, six)
     two, used2, _ = run(2, 0)
     one, used1, _ = run(1, 0)
     assert used2 == 2 * one_ws and used1 == one_ws
@@ -808,7 +812,7 @@ def test_memory_policy_caps_the_workspaces_and_keeps_the_image(hiplib):
     for other in (two, one, batched):
         assert np.array_equal(full, other)
     with pytest.raises(RuntimeError):
-        make_ctx(sc, w, h, bounces, wire.ACCUM_REF_LDR8, capi.BUILD_SAH).set_memory_policy(5, 0)
+        make_ctx(sc, w, h, bounces, wire.ACCUM_REF_LDR8, capi.BUILD_SAH).set_memory_policy(9, 0)
     # a budget below ONE frame's workspace is refused by the render (JPT_E_LIMIT), nothing is allocated past it;
     # the audit kernel, which needs no workspace, still renders
     ctx = make_ctx(sc, w, h, bounces, wire.ACCUM_REF_LDR8, capi.BUILD_SAH)
@@ -1053,3 +1057,39 @@ def test_zero_throughput_vertices_are_counted(hiplib):
     assert 0 <= st["zero_throughput"] <= st["shaded_hits"]
     # such vertices exist on a smooth-shaded mesh seen at grazing angles, and they are few
     assert st["zero_throughput"] < 0.05 * st["rays"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("queues,slots", [("6", 6), ("4", 4)])
+def test_renders_in_flight_follow_the_hardware_queues(hiplib, queues, slots):
+    """Six renders in flight where six of the library's streams get a hardware queue each (GPU_MAX_HW_QUEUES >= 6 at the process's
+    first HIP call), four where they would have to share the default pool of four -- measured by the library before its first queued
+    render (jpt_capi.hip, six_queues_probe), reported by jpt_renders_in_flight.  Either way a queue of renders leaves the image of
+    the same renders made one at a time.  The variable is read once per process: a child process per setting."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import sys, numpy as np
+sys.path.insert(0, %r)
+from gdpathtracing_amd import capi, host, scenes
+sc = scenes.demo_scene(3000)
+w, h = 256, 144
+cam = scenes.camera_block(sc.camera, w, h)
+def ctx_for():
+    c = host.Context(0); c.build_scene(sc, capi.BUILD_SAH); c.set_params(w, h, 3, capi.ACCUM_REF_LDR8); c.set_camera(cam); return c
+a = ctx_for()
+assert a.renders_in_flight() == 0
+for k in range(9): a.render(2, 1 + 2 * k, asynchronous=True)
+a.sync()
+b = ctx_for()
+for k in range(9): b.render(2, 1 + 2 * k)
+assert np.array_equal(a.read_accum(), b.read_accum()) and np.array_equal(a.read_ldr(), b.read_ldr())
+print("slots", a.renders_in_flight())
+''' % root
+    env = dict(os.environ)
+    env["GPU_MAX_HW_QUEUES"] = queues
+    env.pop("JPT_PIPE_SLOTS", None)
+    p = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert ("slots %d" % slots) in p.stdout, p.stdout
