@@ -657,7 +657,7 @@ def main():
             torch.cuda.set_stream(stream)
         dropin = dict(value=round(d_rays * d_steps / d_elapsed / 1e6, 3), ms_per_step=round(d_elapsed / d_steps * 1e3, 4), steps=d_steps,
                       tree={capi.TREE_AS_GIVEN: "as given", capi.TREE_NATIVE_REACH: "native + reach records"}.get(kind, str(kind)),
-                      upload_s=round(upload_s, 4), note=dctx.upload_note() or None,
+                      upload_s=round(upload_s, 4), note=dctx.upload_note() or None, renders_in_flight=dctx.renders_in_flight(),
                       differing_pixels_vs_commit_route=int((d_image != gpu_image).any(axis=-1).sum()),
                       what="jpt_scene_upload_reference_layout of the reference-layout arrays (route i), same workload, queued renders")
         dctx.close()

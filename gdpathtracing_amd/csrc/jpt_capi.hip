@@ -119,6 +119,7 @@ struct jpt_ctx {
     static constexpr int kPipeSlots = 8;   // the most; the rule is 4, or 6 where six of the slots' streams run side by side (six_queues_probe)
     int six_queues = -1;                   // -1: not probed yet; 0 / 1
     int last_pipe_slots = 0;               // jpt_renders_in_flight
+    bool aux_borrowed[3] = {};             // async.aux_stream[k] is pipe_stream[k] (ensure_group_streams): not destroyed on its own
     DevBuf<char> d_workspace_more[kPipeSlots - 1];  // slot 0 is d_workspace
     hipStream_t pipe_stream[kPipeSlots] = {};
     uint64_t async_seq = 0;
@@ -670,6 +671,7 @@ int do_render(jpt_ctx* c, int32_t n_frames, uint32_t first_frame_index, bool cou
 // rate of queued renders depended on which streams happened to share a queue (round 1, C3: 1.32 ms per render with the
 // most fortunate order, 1.60 and 2.39 with others); the pipeline slots now take their queues from the highest priority
 // level's pool (ensure_pipe_slot below), and so do the helper streams of frame groups (round 5: below).
+bool ensure_pipe_slot(jpt_ctx* c, int slot);
 // frame groups: `groups - 1` helper streams (launch_wf2_render); false = not available, renders run serially
 bool ensure_group_streams(jpt_ctx* c, int groups)
 {
@@ -680,17 +682,20 @@ bool ensure_group_streams(jpt_ctx* c, int groups)
     }
     for (int k = 0; k + 1 < groups && k < 3; k++) {
         if (!c->async.aux_stream[k]) {
-            // At the pipeline slots' priority level (ensure_pipe_slot: the highest by default), not at the context stream's: the
-            // normal level's queues are dealt in the order of first use among ALL the process's streams, and a helper stream that
-            // lands on the context stream's queue runs its group AFTER group 0 instead of beside it -- 1.24 -> 1.48 ms per blocking
-            // C3 render after a counted render had run first, with six queues per level (round 5, profiles/r05/r05an_…).  At the
-            // slots' level it shares a queue with an idle slot stream at worst.
-            int least = 0, greatest = 0;
-            const bool high = c->slot_priority != JPT_STREAM_PRIORITY_NORMAL && c->slot_priority != JPT_STREAM_PRIORITY_LOW && tuning().slot_prio != 0 &&
-                              hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least > greatest;
-            const hipError_t e = high ? hipStreamCreateWithPriority(&c->async.aux_stream[k], hipStreamNonBlocking, greatest)
-                                      : hipStreamCreateWithFlags(&c->async.aux_stream[k], hipStreamNonBlocking);
-            if (e != hipSuccess) {
+            // The helper stream of group k + 1 IS pipeline slot k's stream (highest priority level by default, ensure_pipe_slot), not a
+            // stream of its own at the context stream's level: the normal level's queues are dealt in the order of first use among ALL
+            // the process's streams, and a helper that lands on the context stream's queue runs its group AFTER group 0 instead of
+            // beside it -- 1.24 -> 1.48 ms per blocking C3 render after a counted render had run first, with six queues per level
+            // (round 5, profiles/r05/r05an_...).  And not an extra stream at the slots' level either: a seventh stream there takes
+            // one of the six queues the slots are measured to have to themselves (six_queues_probe).  A blocking render runs when
+            // the renders queued before it have been ordered ahead of it on the context's stream; its groups queue behind whatever a
+            // slot still holds.  (Normal / low slot priority chosen by the host: a stream of its own, as before.)
+            const bool borrow = c->slot_priority != JPT_STREAM_PRIORITY_NORMAL && c->slot_priority != JPT_STREAM_PRIORITY_LOW && tuning().slot_prio != 0;
+            if (borrow) {
+                if (!ensure_pipe_slot(c, k)) return false;
+                c->async.aux_stream[k] = c->pipe_stream[k];
+                c->aux_borrowed[k] = true;
+            } else if (hipStreamCreateWithFlags(&c->async.aux_stream[k], hipStreamNonBlocking) != hipSuccess) {
                 c->async.aux_stream[k] = nullptr;
                 (void)hipGetLastError();
                 return false;
@@ -1209,7 +1214,7 @@ void jpt_destroy(jpt_ctx* c)
     for (int k = 0; k < 3; k++) {
         if (c->async.aux_stream[k]) {
             (void)hipStreamSynchronize(c->async.aux_stream[k]);
-            (void)hipStreamDestroy(c->async.aux_stream[k]);
+            if (!c->aux_borrowed[k]) (void)hipStreamDestroy(c->async.aux_stream[k]);   // (a borrowed one goes with the pipeline slots below)
         }
         if (c->async.join[k]) (void)hipEventDestroy(c->async.join[k]);
     }
@@ -1255,6 +1260,15 @@ int jpt_set_stream_priority(jpt_ctx* c, int32_t priority)
     // the pipeline slots' streams are made on first use: drop the ones that exist, the next queued render makes new ones
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    for (int k = 0; k < 3; k++) {   // the frame groups' helper streams follow: borrowed slot streams go with the slots, own ones are re-made
+        if (c->async.aux_stream[k]) {
+            (void)hipStreamSynchronize(c->async.aux_stream[k]);
+            if (!c->aux_borrowed[k]) (void)hipStreamDestroy(c->async.aux_stream[k]);
+            c->async.aux_stream[k] = nullptr;
+            c->aux_borrowed[k] = false;
+        }
+    }
+    c->six_queues = -1;   // (measured again for the new streams)
     for (int k = 0; k < jpt_ctx::kPipeSlots; k++) {
         if (c->pipe_stream[k]) {
             (void)hipStreamSynchronize(c->pipe_stream[k]);
