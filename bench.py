@@ -187,8 +187,8 @@ def main_multi(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=100)   # (six renders are in flight: the timed region includes the queue's fill and drain, ~1 % of 100 steps)
+    ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--spp", type=int, default=8)
@@ -595,7 +595,7 @@ def main():
             ctx.accum_reset()
             ctx.render(SPP5, 1, asynchronous=True)
         barrier()
-        steps5 = max(8, (2 * args.steps) // 5)   # (20 by default: four renders are in flight, a queue of ten reads 15 % higher per step)
+        steps5 = max(8, (2 * args.steps) // 5)   # (40 by default: six renders are in flight, a queue of ten reads 15 % higher per step)
         t0 = time.perf_counter()
         for _ in range(steps5):
             ctx.accum_reset()
