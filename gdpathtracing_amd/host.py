@@ -97,7 +97,7 @@ class Context:
             0 if tex is None else tex.shape[1], 0 if tex is None else tex.shape[0]), "jpt_scene_upload_reference_layout")
 
     def set_memory_policy(self, renders_in_flight: int = 0, workspace_budget_bytes: int = 0):
-        """Cap on the device memory spent on renders in flight: 1..4 workspaces (0: the library's rule) and the most bytes
+        """Cap on the device memory spent on renders in flight: 1..8 workspaces (0: the library's rule -- 4, or 6 where six slot streams run side by side) and the most bytes
         one workspace may take (0: 24 GiB) -- jpt_set_memory_policy."""
         self._ck(self._lib.jpt_set_memory_policy(self.h, renders_in_flight, workspace_budget_bytes), "jpt_set_memory_policy")
 
