@@ -37,6 +37,10 @@ import numpy as np
 # torch is imported (never over a value the caller exported); the library measures whether it took and falls back to four renders in
 # flight if not (the line reports both under "config").
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "6")
+# dmabuf IPC: RCCL between processes (and CUDA-tensor sharing) needs it on this pool's driver -- `hipIpcGetMemHandle: invalid argument`
+# without it.  Set here, at the top of the file, so that the ranks the DRIVER starts with `python -m torch.distributed.run ... bench.py`
+# get it too, not only the ones self_launch() starts (never over a value the caller exported).
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -734,6 +738,65 @@ def main():
                 binding = "valu_issue"
             else:
                 binding = "dependent_fetch_latency"
+        # ---- the line's roofline: the resource that BINDS the dominant kernel (VERDICT r05 task 3).  The tree is cache-resident, so
+        # bytes asked for / duration against the HBM peak is not a bound (the same arithmetic exceeds 1 on the close-up); what the
+        # counters show is VALU issue.  bound = "valu_issue": achieved = wave-level VALU instructions x the ISA's priced cycles per
+        # instruction / launch duration (G issue-cycles/s over the chip's 1024 SIMDs), peak = 1024 SIMDs x the measured clock, frac =
+        # their ratio (valu_issue_frac of the committed SQ passes); lane_frac = frac x the share of the 64 lanes those instructions
+        # have enabled = the share of the chip's lane throughput the launch uses.  The HBM pair stays, under `hbm`: counter traffic
+        # (what reaches the fabric) and the cache-served request rate (today's algorithmic bytes / duration).  Without current
+        # counter passes (sources changed since: profiles_stale) nothing can be said about the binding and frac is null.
+        v = valu or {}
+        lane_util = v.get("lane_utilisation")
+        hbm_block = {
+            "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "achieved": round(traffic / (dom_ms * 1e-3) / 1e9, 2) if traffic else None, "frac": hbm_frac,
+            "traffic": traffic, "traffic_source": traffic_src,
+            "algorithmic_bytes": int(alg),
+            "cache_served_achieved": round(achieved, 2), "cache_served_frac": round(achieved / HBM_PEAK_GBS, 5),
+            "note": "achieved / frac = bytes that reach the fabric per launch (rocprofv3 PMC passes) / launch duration / 8 TB/s; cache_served_* = "
+                    "bytes the kernel ASKS for (records, triangles, instances, rays in, hits out: exact event counts of the bounce launches x "
+                    "record sizes) / duration -- requests the L2s and the Infinity Cache serve (the scene is 6 MB), NOT a bound: it may exceed 1",
+            "compulsory_framebuffer_bytes_per_render": int(n_pixels * (16 + 4 + 4)),
+            "ref_layout_algorithmic_bytes_per_render": int(alg_ref),
+        }
+        if valu_issue_frac is not None and binding in ("valu_issue", "dependent_fetch_latency"):
+            peak_issue = 1024.0 * float(v.get("clock_ghz") or 2.4)                     # G issue-cycles/s: 256 CUs x 4 SIMDs x clock
+            head = {"bound": "valu_issue", "achieved": round(valu_issue_frac * peak_issue, 1), "peak": round(peak_issue, 1),
+                    "unit": "G VALU issue-cycles/s", "frac": valu_issue_frac,
+                    "lane_frac": round(valu_issue_frac * lane_util, 4) if lane_util is not None else None}
+        elif binding == "hbm":
+            head = {"bound": "hbm", "achieved": hbm_block["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_frac, "lane_frac": None}
+        else:
+            head = {"bound": None, "achieved": None, "peak": None, "unit": None, "frac": None, "lane_frac": None}
+        roofline = dict(head)
+        roofline.update({
+            "kernel": "%s (%d launches per render, serial launches)" % (dom, n_dom),
+            "kernel_ms": round(dom_ms, 4),
+            "traffic": traffic,
+            "binding": binding,
+            "hbm": hbm_block,
+            "wait_frac": v.get("wait_frac"), "l2_hit": v.get("l2_hit"),
+            # from the committed SQ-counter passes of this command (profiles/current_sq.json, stamped with the hash of the kernel
+            # sources they ran on; null + `profiles_stale` when the sources have changed since)
+            "valu_issue_frac": valu_issue_frac,
+            "lane_utilisation": lane_util,
+            "valu": valu,
+            "profiles_stale": stale,
+            "kernels_sha": kernels_sha,
+            "note": "frac = share of the chip's VALU issue capacity the dominant kernel's launches use (wave-level VALU instructions x the "
+                    "cycles the ISA prices them at / (1024 SIMDs x launch cycles)); lane_frac = frac x enabled lanes / 64.  binding = "
+                    "\"valu_issue\" at frac >= 0.6, else \"dependent_fetch_latency\" (the waves sit in s_waitcnt on the next record of "
+                    "their rays' chains: wait_frac); \"hbm\" only when counter traffic / duration reaches 0.6 of the 8 TB/s peak.",
+            "primary_kernel_ms": round(float(np.mean(primary_ms)), 4),
+            "render_ms": round(float(np.mean(render_ms)), 4),
+            "render_ms_note": "one render alone, launches serialised (kernel timing on); ms_per_step is the pipelined rate",
+            "blocking_render_ms": round(float(np.mean(blocking_ms)), 4),
+        })
+        for name, f in (("roofline.frac", roofline["frac"]), ("roofline.hbm.frac", hbm_frac), ("roofline.lane_frac", roofline["lane_frac"])):
+            if f is not None and not (0.0 <= f <= 1.0):
+                sys.stderr.write("bench.py: %s = %r is not a fraction of a peak\n" % (name, f))
+                status = 4
         sky = total.get("sky_culled", 0)
         traced = rays - sky
         out = {
@@ -762,37 +825,7 @@ def main():
                 "renders_in_flight": renders_in_flight, "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"),
                 "outputs": "float4 accumulation + rgba8 display" + (" + r32f depth" if args.depth else " (depth image off: only temporal reprojection reads it)"),
             },
-            "roofline": {
-                "bound": "hbm", "kernel": "%s (%d launches per render, serial launches)" % (dom, n_dom),
-                "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                "algorithmic_bytes": int(alg), "kernel_ms": round(dom_ms, 4),
-                "traffic": traffic, "traffic_source": traffic_src,
-                "hbm_frac": hbm_frac,
-                "binding": binding,
-                "wait_frac": (valu or {}).get("wait_frac"), "l2_hit": (valu or {}).get("l2_hit"),
-                # from the committed SQ-counter passes of this command (profiles/current_sq.json, stamped with the hash of the
-                # kernel sources they ran on; null + `profiles_stale` when the sources have changed since): share of the chip's
-                # VALU issue capacity the launch used (wave-level instructions x the ISA's priced cycles / (1024 SIMDs x cycles))
-                # and share of the 64 lanes its VALU instructions have enabled
-                "valu_issue_frac": valu_issue_frac,
-                "lane_utilisation": (valu or {}).get("lane_utilisation"),
-                "valu": valu,
-                "profiles_stale": stale,
-                "kernels_sha": kernels_sha,
-                "note": "achieved = bytes the kernel ASKS for (records, triangles, instances, rays in, hits out: exact event counts "
-                        "of the bounce launches x record sizes) / launch duration; the scene (6 MB) is L2 / Infinity-Cache resident, "
-                        "so these are cache-served requests and hbm_frac (counter traffic / duration / peak) is what reaches HBM. "
-                        "The kernel uses about two thirds of the chip's VALU issue capacity at about a third of its lanes and waits "
-                        "on dependent fetches for the rest (valu: committed SQ counters; DESIGN.md section 4).",
-                "primary_kernel_ms": round(float(np.mean(primary_ms)), 4),
-                "render_ms": round(float(np.mean(render_ms)), 4),
-                "render_ms_note": "one render alone, launches serialised (kernel timing on); ms_per_step is the pipelined rate",
-                "blocking_render_ms": round(float(np.mean(blocking_ms)), 4),
-                # what a render must move through HBM whatever the caches do -- the framebuffers it leaves
-                # behind (float4 sums, rgba8 screen, r32f depth), per render, not per launch
-                "compulsory_framebuffer_bytes_per_render": int(n_pixels * (16 + 4 + 4)),
-                "ref_layout_algorithmic_bytes_per_render": int(alg_ref),
-            },
+            "roofline": roofline,
             "counters": total,
         }
         # (`rays` counts every ray_trace() invocation the reference would make; sky_culled of them are primaries
@@ -800,7 +833,7 @@ def main():
         out["traced_rays_per_step"] = traced
         out["value_traced"] = round(traced * args.steps / elapsed / 1e6, 3)
         out["value_blocking"] = round(rays / (float(np.mean(blocking_ms)) * 1e-3) / 1e6, 3) if np.mean(blocking_ms) > 0 else None
-        out["value_notes"] = ("value = rays_per_step / ms_per_step (queued renders, four in flight); value_traced counts only the rays a "
+        out["value_notes"] = ("value = rays_per_step / ms_per_step (queued renders, config.renders_in_flight of them in flight); value_traced counts only the rays a "
                               "kernel walks (rays - sky_culled); value_blocking = rays_per_step / roofline.blocking_render_ms (the device "
                               "time of one render with nothing queued behind it, as the library runs it; roofline.render_ms is the same "
                               "render with its launches serialised for per-kernel timing)")

@@ -1153,15 +1153,9 @@ int jpt_create(int device_id, jpt_ctx** out)
         *out = c;
         return JPT_OK;
     }
-    // Six renders in flight want six hardware queues for their streams; the runtime makes GPU_MAX_HW_QUEUES per priority level (four
-    // by default) and reads the variable at the process's first HIP call.  If that has not happened yet this is it: ask for six (as many as slots: jpt_tuning.h),
-    // unless the host has chosen (never overwritten) or declined (JPT_HW_QUEUES=0).  Whether it took is measured, not assumed
-    // (six_queues_probe).
-    if (tuning().hw_queues > 0) {
-        char v[16];
-        std::snprintf(v, sizeof v, "%d", tuning().hw_queues);
-        (void)setenv("GPU_MAX_HW_QUEUES", v, 0);
-    }
+    // (Six renders in flight want six hardware queues for their streams; the runtime makes GPU_MAX_HW_QUEUES per priority level, four
+    // by default, and reads the variable at the process's first HIP call.  That is the HOST's to export before it starts threads --
+    // jpt.h "Process environment"; the library never writes the environment, it only measures what it got: six_queues_probe.)
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess || n <= 0) {

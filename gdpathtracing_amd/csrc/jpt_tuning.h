@@ -13,9 +13,6 @@ struct Tuning {
     bool pipelining = true;        // JPT_PIPELINE=0: asynchronous renders run one after another
     int pipe_slots = 0;            // JPT_PIPE_SLOTS=2..8: renders in flight (0: the library's rule -- 4, or 6 where six slot streams run side by side)
     bool six_slots = true;         // JPT_SIX_SLOTS=0: never more than four by rule
-    int hw_queues = 6;             // JPT_HW_QUEUES: what jpt_create asks the runtime for (GPU_MAX_HW_QUEUES, if unset and not too late); 0: nothing
-                                   // (six, not more: a second context's six streams then land on the same six queues as the first's, one each --
-                                   // with eight its streams pair up on some queues and it renders a third slower: profiles/r05/r05am_two_contexts_hw_queues.txt)
     bool acc_on_slot = true;       // JPT_ACC_ON_SLOT=0: accumulation kernels on the context's stream
     int slot_prio = 3;             // JPT_SLOT_PRIO: priority of the pipeline slots' streams -- 0 all normal, 1 dealt over the device's
                                    // priority levels, 2 two high + two low, 3 (default) all high, 4 all low (jpt_capi.hip, ensure_pipe_slot)
@@ -71,7 +68,6 @@ inline const Tuning& tuning()
         v.pipelining = geti("JPT_PIPELINE", 1) != 0;
         v.pipe_slots = geti("JPT_PIPE_SLOTS", 0);
         v.six_slots = geti("JPT_SIX_SLOTS", 1) != 0;
-        v.hw_queues = geti("JPT_HW_QUEUES", 6);
         v.acc_on_slot = geti("JPT_ACC_ON_SLOT", 1) != 0;
         v.slot_prio = geti("JPT_SLOT_PRIO", 3);
         v.bvh_width = geti("JPT_BVH_WIDTH", 4) == 2 ? 2 : 4;

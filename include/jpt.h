@@ -171,11 +171,13 @@ int jpt_get_stream(jpt_ctx *ctx, void **hip_stream);
  *   HIGH / LOW   the device's highest / lowest level
  * The pool has GPU_MAX_HW_QUEUES queues per level -- four unless the environment says otherwise at the process's FIRST HIP call.
  * Six renders in flight are worth 4 % on a 1920x1080x8-spp render and 15 % on small ones when the slots' six streams get a queue
- * each, and cost as much when they have to share four: the first jpt_create of a process that has made no HIP call yet asks the
- * runtime for six (never over a value the host exported; JPT_HW_QUEUES=0 in the environment: leaves it alone), and every
- * context MEASURES, before its first queued render, whether six of its streams run side by side (~1 ms) -- six slots if they do,
- * four if not.  A host that initialises HIP itself exports GPU_MAX_HW_QUEUES=6 before it does (six, not more: with
- * eight a SECOND context's streams pair up on some queues and it renders a third slower).
+ * each, and cost as much when they have to share four.  PROCESS ENVIRONMENT: the library never writes it (a setenv from a
+ * shared library races with every getenv of a multi-threaded host and changes the queue count for all other HIP users of the
+ * process).  A host that wants six renders in flight exports GPU_MAX_HW_QUEUES=6 itself, before its first HIP call and before it
+ * starts threads (bench.py and the Python binding do, with os.environ.setdefault at import; six, not more: with eight a SECOND
+ * context's streams pair up on some queues and it renders a third slower).  Every context MEASURES, before its first queued
+ * render, whether six of its streams run side by side (~1 ms) -- six slots if they do, four if not: a host that exports nothing
+ * gets four, which is also all that one blocking render per displayed frame (the addon's use) can ever use.
  * jpt_renders_in_flight: the slots the last queued render was dealt among (0 before the first).
  * No reference counterpart. */
 enum { JPT_STREAM_PRIORITY_DEFAULT = 0, JPT_STREAM_PRIORITY_NORMAL = 1, JPT_STREAM_PRIORITY_HIGH = 2, JPT_STREAM_PRIORITY_LOW = 3 };
