@@ -224,7 +224,6 @@ void launch_temporal(hipStream_t stream, const RefTemporalParams& tp, uint32_t* 
                      float4* hist2);
 
 int wf2_wanted_groups(int n_frames, size_t paths);
-uint32_t wf2_rg_stack_capacity();   // stack entries of the regrouped bounce launches (JPT_TRACE_REGROUP), LDS + global
 // pixels of this context's share of the image that lie outside the render's window (the tile-aligned bounding rectangle
 // of the sky cull's screen rectangles): the primary launch does not even enumerate them (their rays are sky by the
 // cull's argument; the event counters are completed with their number on the host)

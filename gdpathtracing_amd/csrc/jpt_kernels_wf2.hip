@@ -14,8 +14,8 @@
 //   wf2_trace    bounces >= 1: closest hit of every queued ray.
 //   wf2_finish   the few paths wf2_shade set aside (hits the reference's traversal cannot reach, exact distance ties).
 //   wf2_accumulate  frames IN ORDER per pixel (progressive_rendering.glsl:33-37), display image, depth.
-//   (large scenes: the tracing kernels' COOP == 2 instantiations finish their few very long walks with a whole wave per
-//   ray, coop_walk_call; COOP == 1 hands them to the follow-up launch wf2_long instead)
+//   (large scenes: the tracing kernels' TAIL instantiations finish their few very long walks with a whole wave per ray,
+//   coop_walk_call)
 //
 // Tracing kernels keep every lane busy: a lane whose ray is finished takes the next ray of the block's
 // segment (cursor in LDS) while its neighbours keep walking -- the wave never waits for its slowest ray.
@@ -50,8 +50,7 @@ struct WfTune {
     int leaf_min_lanes;  // a leaf / instance phase with fewer takers than this is put off to the next round, as long as
     int inst_min_lanes;  // other lanes of the wave can make progress meanwhile
     int phase_frac16;    // ... and never more than this many sixteenths of the wave's active rays
-    int coop_rounds;     // COOP launches: a ray still walking this many rounds after its block's queue ran dry is handed to wf2_long
-    int tail_rounds;     // COOP == 2: a wave enters its tail phase this many rounds after the queue ran dry ...
+    int tail_rounds;     // TAIL launches: a wave enters its tail phase this many rounds after the queue ran dry ...
     int tail_lanes;      // ... once it holds at most this many rays
 };
 
@@ -194,11 +193,6 @@ struct Wf2Buffers {
     uint32_t* qcount;   // [max_bounces + 2][kSegments] queue sizes; row b = rays traced in bounce b (b >= 1)
     uint32_t* redo_count;  // [0]: paths set aside because the reference cannot reach their hit (wf2_finish) ...
     float4* redo_rec;      // ... two float4 each: the vertex's ray, origin.w = bounce bits, direction.w = path id bits
-    uint32_t* long_count;  // COOP launches: [max_bounces + 2] rays handed over to wf2_long by the launch of that bounce ...
-    uint2* long_list;      // ... each (path, segment) for the primary launch, (queue entry, 0) for a bounce launch; consumed by the
-    uint32_t long_cap;     //     wf2_long launch that follows, so one list serves all launches of a render
-    uint32_t* rg_cursor;   // regrouped tracing launches (wf2_trace_rg): [max_bounces + 2][kSegments] queue cursors, shared by the waves of a queue
-    int32_t* rg_spill;     // ... and the stack entries past the LDS part: [block][pool slot][entry]
     uint32_t redo_cap;     // records redo_rec holds (a few paths in 10^7 are set aside: not one record per path).  A hit
                            // that finds the buffer full is shaded as found -- the native tree's closest hit, without the
                            // reference's crack -- and counted in redo_count[1] (jpt_stats.set_aside_dropped)
@@ -281,22 +275,17 @@ __device__ __forceinline__ uint32_t lanes_below(unsigned long long mask, int lan
 //
 // A launch cannot end before its longest ray does, and a lone ray advances one dependent fetch at a time (~0.8 us a step on an
 // otherwise idle chip).  On the 1 M-triangle scene 40 of 16.6 M primary rays take 1 000 - 5 310 record steps (99.99 % take
-// fewer than 256): the primary launch spent 4.4 of its 7.6 ms waiting for them, one frame alone took 4.5 ms against 0.5 ms per
-// further frame (profiles/r04/r04g_tail_probe.txt, r04h_walk_hist.txt; round 3 had taken this launch for latency-bound as a
-// whole).  The COOP instantiations of the tracing kernels hand such a ray over: a ray that is still walking `coop_rounds`
-// rounds after its block's queue ran dry is dropped where it is and listed (a global list, one atomic per such ray), and the
-// small launch that follows, wf2_long, walks every listed ray AGAIN FROM THE ROOT with all 64 lanes of a wave: a lane walks
-// one subtree with its private stack, gives the entry on top of that stack to the wave's pool (LDS) whenever lanes are
-// idle, idle lanes take entries from the pool (an entry carries its level: TLAS, or the instance it belongs to), and after
-// every round all lanes adopt the closest distance any of them has found, so every lane culls with it.  The closest hit does
-// not depend on the order of the tests; two lanes that both keep a triangle at the final distance are an exact tie and
-// flagged as one (kHitTied), like two such triangles met by one walk.  5 310 dependent steps become ~150 rounds: S-unique's
-// primary launch 8.9 -> 4.2 ms, its bounce launches 3.4 -> 2.6 ms, a blocking render 20.1 -> 14.4 ms (profiles/r04/
-// r04l_coop_ab.txt).  Used for scenes of >= 200 000 triangles: on the small scenes no ray is long, the launches' tails are
-// the drain of ordinary rays, and the empty follow-up launches alone cost a blocking C3 render 15 % (r04m_coop_small_scenes.txt).
+// fewer than 256): the primary launch spent 4.4 of its 7.6 ms waiting for them (profiles/r04/r04g_tail_probe.txt,
+// r04h_walk_hist.txt).  coop_walk walks ONE ray with all 64 lanes of a wave, again from the root: a lane walks one subtree with
+// its private stack, gives the entry on top of that stack to the wave's pool (LDS) whenever lanes are idle, idle lanes take
+// entries from the pool (an entry carries its level: TLAS, or the instance it belongs to), and after every round all lanes adopt
+// the closest distance any of them has found, so every lane culls with it.  The closest hit does not depend on the order of the
+// tests; two lanes that both keep a triangle at the final distance are an exact tie and flagged as one (kHitTied), like two such
+// triangles met by one walk.  5 310 dependent steps become ~150 rounds: S-unique's primary launch 8.9 -> 4.2 ms (profiles/r04/
+// r04l_coop_ab.txt).  Used as the TAIL phase of the tracing launches on scenes of >= 200 000 triangles: on the small scenes no ray
+// is long and the launches' tails are the drain of ordinary rays.  (Round 4's other form -- the long rays listed and walked by a
+// follow-up launch, wf2_long -- cost small renders 15 % in empty launches and was removed in round 6: LAB_NOTEBOOK.md.)
 constexpr int kCoopPool = 64;      // pool entries per wave (two words each)
-constexpr uint32_t kLongGrid = 2048;       // blocks (= waves) of a wf2_long launch
-constexpr uint32_t kCoopListCap = 8192;   // rays one launch can hand over (the rest keep walking on their lanes)
 
 __device__ __forceinline__ float wave_min_f(float v)
 {
@@ -442,7 +431,7 @@ __device__ __forceinline__ TraceHit coop_walk(const WideSceneDev& sc, const type
     return out;
 }
 
-// The same walk as the TAIL of a tracing launch (COOP == 2), without a second launch: a wave whose block's queue has been dry for
+// The walk as the TAIL of a tracing launch: a wave whose block's queue has been dry for
 // `tail_rounds` rounds and that is down to `tail_lanes` rays stops walking them lane by lane -- a lone ray advances one dependent
 // step per microsecond, and a small render's launches each last as long as their longest walk (tools/step_latency.py: 64 x 64
 // pixels, longest walk 42 steps, launch 48 us; 1920 x 1080 x 1: 102 steps, 110 us) -- and walks them one after the other with
@@ -462,7 +451,7 @@ __device__ __attribute__((noinline)) void coop_walk_call(const WideSceneDev* __r
 
 // ---- bounce 0: generate + trace ------------------------------------------------------------------------
 
-template <bool COUNT, bool W4, int COOP = 0>   // COOP: 0 no, 1 long walks handed over to wf2_long, 2 finished by the wave itself (tail phase)
+template <bool COUNT, bool W4, bool TAIL = false>   // TAIL: the wave finishes its last, long walks itself, all lanes on one ray (coop_walk_call)
 __global__ __launch_bounds__(kBlock, JPT_PRIMARY_WAVES) void wf2_primary(WideSceneDev sc, Wf2Buffers wb, Wf2Dims dm, FrameParams fp, RefCamera cam,
                                                       WfTune tune, SkyCull cull, DevCounters* __restrict__ counters)
 {
@@ -483,8 +472,7 @@ __global__ __launch_bounds__(kBlock, JPT_PRIMARY_WAVES) void wf2_primary(WideSce
     int32_t spill[kStackSpill];
     const typename Traversal<COUNT, W4>::Stack my_stack{&stack[threadIdx.x], spill, kTraceBlock, kStackLds};
     const size_t seg_base = (size_t)seg * dm.seg_cap;
-    uint32_t dry_rounds = 0;   // (COOP: rounds of this wave since the block's queue ran dry; wave-uniform)
-    bool list_full = false;    // (COOP == 1: this lane's reservation in the hand-over list failed: not tried again)
+    uint32_t dry_rounds = 0;   // (TAIL: rounds of this wave since the block's queue ran dry; wave-uniform)
     DevCounters cnt = {};
     Traversal<COUNT, W4> tr;
     bool active = false, exhausted = false;
@@ -574,25 +562,12 @@ __global__ __launch_bounds__(kBlock, JPT_PRIMARY_WAVES) void wf2_primary(WideSce
                 unsaved = true;
                 if (COUNT) count_walk(cnt, walk_steps);
             }
-            if constexpr (COOP == 1 && W4) {
-                // the block's queue has been exhausted for kCoopRounds rounds and this ray is still walking: hand it over to
-                // wf2_long (see coop_walk).  (A wave-uniform count of rounds since the queue ran dry, not a per-lane one.)
-                if (exhausted && ++dry_rounds >= (uint32_t)tune.coop_rounds && active && !list_full) {
-                    const uint32_t k = atomicAdd(&wb.long_count[0], 1u);
-                    if (k < wb.long_cap) {
-                        wb.long_list[k] = make_uint2(path, seg);
-                        active = false;
-                    } else {
-                        list_full = true;   // (the ray keeps walking on its lane; one failed reservation, not one per round: ADVICE r04)
-                    }
-                }
-            }
-            if constexpr (COOP == 2 && W4) {
+            if constexpr (TAIL && W4) {
                 if (exhausted && ++dry_rounds >= (uint32_t)tune.tail_rounds && __popcll(__ballot(active)) <= tune.tail_lanes) break;
             }
         }
     }
-    if constexpr (COOP == 2 && W4) {
+    if constexpr (TAIL && W4) {
         // tail phase (coop_walk_call): the few rays this wave still holds, each walked by the whole wave
         unsigned long long left = __ballot(active);
         if (left) {
@@ -631,8 +606,8 @@ __global__ __launch_bounds__(kBlock, JPT_PRIMARY_WAVES) void wf2_primary(WideSce
 #endif
 constexpr int kMaxChain = JPT_MAX_CHAIN;
 // The walk of one block's ray queue -- `n` entries in the consecutive segments seg0, seg0 + 1, .. (end[k] = entries in the first k + 1
-// of them) -- with the block's stack columns and queue cursor in LDS: the body of wf2_trace, and the second phase of wf2_bounce.
-template <bool COUNT, bool W4, int COOP>
+// of them) -- with the block's stack columns and queue cursor in LDS: the body of wf2_trace.
+template <bool COUNT, bool W4, bool TAIL>
 __device__ __forceinline__ void trace_queue(const WideSceneDev& sc, const Wf2Buffers& wb, const Wf2Dims& dm, const int bounce, const WfTune& tune,
                                             const uint32_t seg0, const uint32_t (&end)[kMaxChain], const uint32_t n, int32_t* __restrict__ stack,
                                             uint32_t* __restrict__ s_cursor, DevCounters& cnt)
@@ -640,8 +615,7 @@ __device__ __forceinline__ void trace_queue(const WideSceneDev& sc, const Wf2Buf
     const int lane = threadIdx.x & 63;
     int32_t spill[kStackSpill];
     const typename Traversal<COUNT, W4>::Stack my_stack{&stack[threadIdx.x], spill, kTraceBlock, kStackLds};
-    uint32_t dry_rounds = 0;   // (COOP: rounds of this wave since the block's queue ran dry; wave-uniform)
-    bool list_full = false;    // (COOP == 1: this lane's reservation in the hand-over list failed: not tried again)
+    uint32_t dry_rounds = 0;   // (TAIL: rounds of this wave since the block's queue ran dry; wave-uniform)
     const float4* __restrict__ qo = wb.ray_o[bounce & 1];
     const float4* __restrict__ qd = wb.ray_d[bounce & 1];
     Traversal<COUNT, W4> tr;
@@ -702,23 +676,12 @@ __device__ __forceinline__ void trace_queue(const WideSceneDev& sc, const Wf2Buf
                 else save_hit();
                 if (COUNT) count_walk(cnt, walk_steps);
             }
-            if constexpr (COOP == 1 && W4) {
-                if (exhausted && ++dry_rounds >= (uint32_t)tune.coop_rounds && active && !list_full) {
-                    const uint32_t k = atomicAdd(&wb.long_count[bounce], 1u);
-                    if (k < wb.long_cap) {
-                        wb.long_list[k] = make_uint2((uint32_t)my_loc, 0u);
-                        active = false;
-                    } else {
-                        list_full = true;
-                    }
-                }
-            }
-            if constexpr (COOP == 2 && W4) {
+            if constexpr (TAIL && W4) {
                 if (exhausted && ++dry_rounds >= (uint32_t)tune.tail_rounds && __popcll(__ballot(active)) <= tune.tail_lanes) break;
             }
         }
     }
-    if constexpr (COOP == 2 && W4) {
+    if constexpr (TAIL && W4) {
         // tail phase (see wf2_primary)
         unsigned long long left = __ballot(active);
         if (left) {
@@ -746,7 +709,7 @@ __device__ __forceinline__ void trace_queue(const WideSceneDev& sc, const Wf2Buf
     if (JPT_LATE_HIT_STORE && unsaved) save_hit();
 }
 
-template <bool COUNT, bool W4, int COOP = 0>
+template <bool COUNT, bool W4, bool TAIL = false>
 __global__ __launch_bounds__(kBlock, JPT_WAVES_PER_SIMD) void wf2_trace(WideSceneDev sc, Wf2Buffers wb, Wf2Dims dm, int bounce, WfTune tune,
                                                     int chain, DevCounters* __restrict__ counters)
 {
@@ -764,63 +727,9 @@ __global__ __launch_bounds__(kBlock, JPT_WAVES_PER_SIMD) void wf2_trace(WideScen
     if (threadIdx.x == 0) s_cursor = 0;
     __syncthreads();
     DevCounters cnt = {};
-    trace_queue<COUNT, W4, COOP>(sc, wb, dm, bounce, tune, seg0, end, n, stack, &s_cursor, cnt);
+    trace_queue<COUNT, W4, TAIL>(sc, wb, dm, bounce, tune, seg0, end, n, stack, &s_cursor, cnt);
     if (COUNT) flush_counters(cnt, counters);
 }
-
-// the rays a COOP launch handed over, each walked by a whole wave (coop_walk); results stored the way the launch stores them
-template <bool COUNT, bool PRIMARY>
-__global__ __launch_bounds__(64) void wf2_long(WideSceneDev sc, Wf2Buffers wb, Wf2Dims dm, FrameParams fp, RefCamera cam, int bounce,
-                                               DevCounters* __restrict__ counters)
-{
-    const uint32_t n_all = wb.long_count[bounce];
-    const uint32_t n = n_all < wb.long_cap ? n_all : wb.long_cap;
-    if (blockIdx.x >= n) return;
-    __shared__ int32_t stack[kStackLds * 64];
-    __shared__ int32_t s_pool[2 * kCoopPool];
-    int32_t spill[kStackSpill];
-    const typename Traversal<COUNT, true>::Stack my_stack{&stack[threadIdx.x], spill, 64, kStackLds};
-    const int lane = threadIdx.x;
-    DevCounters cnt = {};
-    for (uint32_t k = blockIdx.x; k < n; k += gridDim.x) {
-        const uint2 rec = wb.long_list[k];
-        if (PRIMARY) {
-            const uint32_t path = rec.x, seg = rec.y;
-            uint32_t pslot, f;
-            path_slot_frame(path, dm, (uint32_t)fp.n_frames, pslot, f);
-            int px, ly;
-            slot_to_pixel(pslot, dm, px, ly);
-            uint32_t sx, sy;
-            const Ray ray = primary_ray(cam, fp.width, fp.height, px, local_to_global_row(ly, fp), fp.frame_index + f, sx, sy);
-            const TraceHit h = coop_walk<COUNT>(sc, my_stack, s_pool, ray.o, ray.d, cnt);
-            if (lane == 0) {
-                if (h.t < 1e9f) {   // into the segment's bounce-0 queue (wf2_primary has left its size in qcount)
-                    const size_t j = (size_t)seg * dm.seg_cap + atomicAdd(&wb.qcount[0 * kSegments + seg], 1u);
-                    wb.ray_o[0][j] = make_float4(ray.o.x, ray.o.y, ray.o.z, 0.0f);
-                    wb.ray_d[0][j] = make_float4(ray.d.x, ray.d.y, ray.d.z, __uint_as_float(path));
-                    wb.hit_a[j] = make_float4(h.t, h.u, h.v, __uint_as_float(h.tri));
-                    wb.hit_b[j] = h.inst | (h.front ? 0x80000000u : 0u);
-                } else {            // sky (main.glsl:380,395-397)
-                    const f3 sky = mk3(0.0f, 0.0f, 0.0f) + mk3(1.0f, 1.0f, 1.0f) * sample_sky(ray.d);
-                    store_final(wb, fp.accum_mode, path, sky);
-                    if ((int)f == fp.depth_frame) wb.first_depth[pslot] = cam.far_;
-                }
-            }
-        } else {
-            const size_t loc = rec.x;
-            const float4 ro = wb.ray_o[bounce & 1][loc], rd = wb.ray_d[bounce & 1][loc];
-            const TraceHit h = coop_walk<COUNT>(sc, my_stack, s_pool, mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), cnt);
-            if (lane == 0) {
-                wb.hit_a[loc] = make_float4(h.t, h.u, h.v, __uint_as_float(h.tri));
-                wb.hit_b[loc] = h.inst | (h.front ? 0x80000000u : 0u);
-            }
-        }
-    }
-    if (COUNT) flush_counters(cnt, counters);
-}
-
-#include "jpt_kernels_wf2_variants.h"   // wf2_trace_rg (JPT_TRACE_REGROUP=1: measured, not kept)
-#include "jpt_kernels_wf2_pool.h"       // wf2_trace_pool (JPT_TRACE_REGROUP=2)
 
 // ---- shading: one path vertex per queue entry (main.glsl:378-397) -------------------------------------------
 
@@ -994,69 +903,6 @@ __global__ __launch_bounds__(kBlock, LAST ? 8 : (TEX == 0 ? JPT_SHADE_NOTEX_WAVE
             stream_st4(&wb.ray_d[out][j], nd);
             stream_st4(&wb.thr_q[out][j], nt);
         }
-    }
-    if (COUNT) flush_counters(cnt, counters);
-}
-
-// ---- SMALL renders: one launch per bounce -- shade(b), then trace(b + 1), segment by segment (VERDICT r04 task 2) ----------
-//
-// A render is eleven dependent launches however little work it holds, each at least as long as its longest walk (DESIGN.md
-// section 4: a GPU's eighth of C3 is 0.31 ms of launches for 0.11 ms of work).  The hand-off from wf2_shade(b) to
-// wf2_trace(b + 1) never leaves a segment -- block s of the tracing launch reads what the blocks of the shading launch wrote
-// into segment s's queue -- so for small renders one block does both: it shades its segment's entries (grid-stride; the next
-// queue's size is counted in LDS instead of with global atomics), and after a block barrier (workgroup-scope release / acquire:
-// the queue entries went through this CU's L1) it walks the queue it has just written.  Six launches instead of eleven; same
-// operations on the same entries, so the same image.  Blocks now differ in what they are doing at any moment -- a shading
-// phase waits on gathers, a tracing phase issues VALU work -- which is what renders in flight otherwise provide.
-template <bool COUNT, int TEX>
-__global__ __launch_bounds__(kBlock, JPT_WAVES_PER_SIMD) void wf2_bounce(WideSceneDev sc, SceneShading sh, Wf2Buffers wb, Wf2Dims dm, FrameParams fp, float cam_far,
-                                                                         int bounce, WfTune tune, DevCounters* __restrict__ counters)
-{
-    __shared__ int32_t stack[kStackLds * kBlock];
-    __shared__ uint32_t s_cursor, s_next;
-    const int lane = threadIdx.x & 63;
-    const uint32_t seg = blockIdx.x;
-    const uint32_t n = wb.qcount[(size_t)bounce * kSegments + seg];
-    if (threadIdx.x == 0) {
-        s_cursor = 0;
-        s_next = 0;
-    }
-    __syncthreads();
-    DevCounters cnt = {};
-    const size_t seg_base = (size_t)seg * dm.seg_cap;
-    const int in = bounce & 1, out = (bounce + 1) & 1;
-    for (uint32_t base = 0; base < n; base += kBlock) {
-        const uint32_t i = base + threadIdx.x;
-        bool alive = false;
-        float4 no, nd, nt;
-        if (i < n) {
-            const float4 ro = stream_ld4(&wb.ray_o[in][seg_base + i]), rd = stream_ld4(&wb.ray_d[in][seg_base + i]);
-            const float4 tin = bounce > 0 ? stream_ld4(&wb.thr_q[in][seg_base + i]) : make_float4(1.0f, 1.0f, 1.0f, 0.0f);
-            const float4 ha = stream_ld4(&wb.hit_a[seg_base + i]);
-            const uint32_t hb = stream_ldu(&wb.hit_b[seg_base + i]);
-            bool unreachable;
-            alive = shade_entry<COUNT, false, TEX>(sh, wb, dm, fp, cam_far, bounce, ro, rd, tin, ha, hb, true, unreachable, no, nd, nt, cnt);
-        }
-        const unsigned long long m = __ballot(alive);
-        if (m) {
-            uint32_t wbase = 0;
-            if (lane == 0) wbase = atomicAdd(&s_next, (uint32_t)__popcll(m));
-            wbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)wbase);
-            if (alive) {
-                const size_t j = seg_base + wbase + lanes_below(m, lane);
-                stream_st4(&wb.ray_o[out][j], no);
-                stream_st4(&wb.ray_d[out][j], nd);
-                stream_st4(&wb.thr_q[out][j], nt);
-            }
-        }
-    }
-    __syncthreads();   // the segment's next queue is complete and visible to the whole block
-    const uint32_t n_next = s_next;
-    if (threadIdx.x == 0) wb.qcount[(size_t)(bounce + 1) * kSegments + seg] = n_next;   // (the host's ray count, the next launch's size)
-    if (n_next != 0u) {
-        uint32_t end[kMaxChain];
-        for (int k = 0; k < kMaxChain; k++) end[k] = n_next;
-        trace_queue<COUNT, true, 0>(sc, wb, dm, bounce + 1, tune, seg, end, n_next, stack, &s_cursor, cnt);
     }
     if (COUNT) flush_counters(cnt, counters);
 }
@@ -1503,7 +1349,6 @@ void launch_sky_tiles(hipStream_t stream, const FrameParams& fp, const RefCamera
 }
 uint32_t wf2_segments() { return kSegments; }
 uint32_t trace_stack_capacity() { return (uint32_t)(kStackLds + kStackSpill); }
-uint32_t wf2_rg_stack_capacity() { return (uint32_t)(kRgStack + kRgSpill); }
 
 // Frame groups.  Every launch of the pipeline ends with a tail: a few long rays in a few waves while the rest of the
 // chip has nothing left to do (a ray's latency under full load is ~20 us on average, ~100 us for the longest; C3's ten
@@ -1565,9 +1410,7 @@ size_t wf2_workspace_bytes(int width, int local_rows, int n_frames, int max_boun
             b += q * sizeof(float4) + 256;            // hit_a
             b += q * sizeof(uint32_t) + 256;          // hit_b
             b += paths * sizeof(float4) + 256;        // thr
-            b += ((size_t)(max_bounces + 2) * kSegments * 2 + 192) * sizeof(uint32_t) + 256;   // queue sizes + the set-aside count + the regrouped launches' cursors + the hand-over counts
-            b += (size_t)kCoopListCap * sizeof(uint2) + 256;                                     // rays handed over to wf2_long
-            if (tuning().trace_regroup) b += std::max(wf2_rg_spill_bytes(kRgMaxBlocks), wf2_pool_spill_bytes(kPoolMaxBlocks)) + 256;
+            b += ((size_t)(max_bounces + 2) * kSegments + 64) * sizeof(uint32_t) + 256;   // queue sizes + the set-aside counts
             b += (size_t)redo_capacity(paths) * 2 * sizeof(float4) + 256;    // set-aside records
         }
         const Wf2Dims all = make_dims(width, local_rows, n_frames, full_window(width, local_rows));
@@ -1608,13 +1451,8 @@ void launch_wf2_render(hipStream_t stream, const DeviceScene& ds, const FramePar
     Wf2Dims gdm[kMaxGroups];
     FrameParams gfp[kMaxGroups];
     for (int g = 0; g < groups; g++) {  // group 0 first: the host reads it
-        gb[g].qcount = (uint32_t*)carve(((size_t)nq * kSegments * 2 + 192) * sizeof(uint32_t));
+        gb[g].qcount = (uint32_t*)carve(((size_t)nq * kSegments + 64) * sizeof(uint32_t));
         gb[g].redo_count = gb[g].qcount + (size_t)nq * kSegments;
-        gb[g].rg_cursor = gb[g].redo_count + 64;
-        gb[g].long_count = gb[g].rg_cursor + (size_t)nq * kSegments;   // (128 words: one count per launch, max_bounces <= 64)
-        gb[g].long_list = (uint2*)carve((size_t)kCoopListCap * sizeof(uint2));
-        gb[g].long_cap = kCoopListCap;
-        gb[g].rg_spill = tuning().trace_regroup ? (int32_t*)carve(std::max(wf2_rg_spill_bytes(kRgMaxBlocks), wf2_pool_spill_bytes(kPoolMaxBlocks))) : nullptr;
     }
     float4* rad_all = (float4*)carve((size_t)dm_all.slots_per_frame * (size_t)fp.n_frames * sizeof(float4));
     uint32_t* fin8_all = (uint32_t*)carve((size_t)dm_all.slots_per_frame * (size_t)fp.n_frames * sizeof(uint32_t));
@@ -1660,7 +1498,7 @@ void launch_wf2_render(hipStream_t stream, const DeviceScene& ds, const FramePar
     SceneShading sh = ds.shading();
     if (tuning().reach == 0) sh.reach_tri = nullptr;
     const dim3 block(kBlock);
-    const WfTune tune{tuning().refill_idle, tuning().primary_refill_idle, tuning().node_min_lanes, tuning().leaf_min_lanes, tuning().inst_min_lanes, tuning().phase_frac16, tuning().coop_rounds, tuning().tail_rounds, tuning().tail_lanes};
+    const WfTune tune{tuning().refill_idle, tuning().primary_refill_idle, tuning().node_min_lanes, tuning().leaf_min_lanes, tuning().inst_min_lanes, tuning().phase_frac16, tuning().tail_rounds, tuning().tail_lanes};
 
     const int chain = [&] {  // JPT_TRACE_CHAIN overrides (tuning runs); two frame groups share the chip: half-width launches
         const int c = tuning().trace_chain > 0 ? tuning().trace_chain : (groups == 2 ? 2 : async.trace_chain);
@@ -1668,62 +1506,22 @@ void launch_wf2_render(hipStream_t stream, const DeviceScene& ds, const FramePar
     }();
     const dim3 tgrid((kSegments + (uint32_t)chain - 1u) / (uint32_t)chain);
     const dim3 pgrid(kSegments);
-    // JPT_TRACE_REGROUP=1: the bounce launches as wf2_trace_rg -- four-child records only, and only while the scene's worst-case
-    // stack fits the regrouped walk's 64 entries (else wf2_trace, whose stack holds trace_stack_capacity()).  A wave keeps
-    // kRgPool rays in 15 KB of LDS, so ten waves fit a CU: a launch that has the chip to itself wants ~2 560 waves, a queued
-    // render (four in flight) a quarter of that.
-    // long walks handed over to a whole wave (coop_walk): scenes large enough to have them (JPT_COOP overrides)
-    const bool coop_wanted = tuning().coop < 0 ? ds.n_tris >= 200000u : tuning().coop != 0;
-    // ... inside the launch, by the wave that holds them (the tail phase: COOP == 2; default where the rule above asks for the
-    // walk), or by the follow-up launch wf2_long (COOP == 1: JPT_TAIL=0, or a forced JPT_COOP=1)
-    const int tail_cfg = tuning().tail;
-    const bool tail = w4 && (tail_cfg == 2 || (tail_cfg == 1 && !coop_wanted) || (tail_cfg < 0 && tuning().coop < 0 && coop_wanted));
-    const bool coop = w4 && coop_wanted && !tail;
-    const bool regroup = tuning().trace_regroup == 1 && w4 && ds.stack_need4 <= wf2_rg_stack_capacity() && gb[0].rg_spill != nullptr;
-    // JPT_TRACE_REGROUP=2: the pooled launches (wf2_trace_pool): a wave per pool of kPoolRays rays, turns prepared one ahead.  The
-    // grid is generous -- a wave that finds its queue too short for it (1 024 rays per wave) exits at once -- and capped by the
-    // spill area; not with the cooperative tail (scenes of >= 200 000 triangles keep wf2_trace)
-    const bool pool = tuning().trace_regroup == 2 && w4 && !coop && !tail && ds.stack_need4 <= (uint32_t)(kPoolStack + kPoolSpill) && gb[0].rg_spill != nullptr;
-    const int pool_waves = [&] {
-        const uint32_t queues = tgrid.x;
-        const uint32_t target = tuning().rg_waves > 0 ? (uint32_t)tuning().rg_waves * queues : 3072u;
-        uint32_t wv = (target + queues - 1u) / queues;
-        if (wv < 1u) wv = 1u;
-        while (wv > 1u && wv * queues > kPoolMaxBlocks) wv--;
-        return (int)wv;
-    }();
-    const uint32_t pool_blocks = tgrid.x * (uint32_t)pool_waves;
-    // One launch per bounce (wf2_bounce) for renders of few paths: JPT_FUSE_BOUNCE=0 never, 1 whenever the launches allow it, -1
-    // (default) the library's rule: windows of at most `fuse_max_paths` paths.  Not with per-launch events (kernel timing wants the
-    // tracing launches on their own), nor with the cooperative or regrouped launches.
-    const size_t window_paths = (size_t)dm_all.slots_per_frame * (size_t)fp.n_frames;
-    const bool fuse = w4 && !coop && !tail && !regroup && !pool && trace_events == nullptr &&
-                      (tuning().fuse_bounce > 0 || (tuning().fuse_bounce < 0 && window_paths <= (size_t)tuning().fuse_max_paths));
-    const int rg_waves = [&] {
-        const uint32_t queues = tgrid.x;
-        const uint32_t target = async.trace_chain >= 4 ? 640u : (groups == 2 ? 1280u : 2560u);
-        uint32_t wv = tuning().rg_waves > 0 ? (uint32_t)tuning().rg_waves : (target + queues - 1u) / queues;
-        if (wv < 1u) wv = 1u;
-        while (wv > 1u && wv * queues > kRgMaxBlocks) wv--;
-        return (int)wv;
-    }();
-    const uint32_t rg_blocks = tgrid.x * (uint32_t)rg_waves;
+    // The waves of a tracing launch finish their last, very long walks themselves, all lanes on one ray (the TAIL instantiations,
+    // coop_walk_call): scenes large enough to have such walks (>= 200 000 triangles); JPT_TAIL=0 never, 1 on every scene.
+    const bool tail = w4 && (tuning().tail < 0 ? ds.n_tris >= 200000u : tuning().tail != 0);
     // the pipeline of one group on one stream
     auto run_group = [&](hipStream_t st, const Wf2Buffers& wb, const Wf2Dims& dm, const FrameParams& gp, hipEvent_t* ev) {
         // queue sizes of bounces >= 1 are accumulated with atomics by wf2_shade: start from zero
-        (void)hipMemsetAsync(wb.qcount + kSegments, 0, ((size_t)(nq - 1) * kSegments + 64 + (size_t)nq * kSegments + 128) * sizeof(uint32_t), st);  // (and the set-aside counts and the regrouped launches' cursors behind them)
+        (void)hipMemsetAsync(wb.qcount + kSegments, 0, ((size_t)(nq - 1) * kSegments + 64) * sizeof(uint32_t), st);  // (and the set-aside counts behind them)
         // Blocks go to the 8 XCDs round-robin by linear index (y * grid.x + x), and the chunks of a segment are far from
         // alike (the first ones are full, the last ones empty): with grid.x a multiple of 8 every XCD would always get
         // the same chunk position.  An odd grid.x deals every position to every XCD (capping C3's grid.x from 37 to 8
         // cost 9 %).
         const dim3 sgrid(((dm.seg_cap + kBlock - 1) / kBlock) | 1u, kSegments);
         if (ev) (void)hipEventRecord(ev[0], st);
-        if (coop) {
-            if (counters) hipLaunchKernelGGL((wf2_primary<true, true, 1>), pgrid, block, 0, st, sc, wb, dm, gp, cam, tune, async.cull, counters);
-            else hipLaunchKernelGGL((wf2_primary<false, true, 1>), pgrid, block, 0, st, sc, wb, dm, gp, cam, tune, async.cull, counters);
-        } else if (tail) {
-            if (counters) hipLaunchKernelGGL((wf2_primary<true, true, 2>), pgrid, block, 0, st, sc, wb, dm, gp, cam, tune, async.cull, counters);
-            else hipLaunchKernelGGL((wf2_primary<false, true, 2>), pgrid, block, 0, st, sc, wb, dm, gp, cam, tune, async.cull, counters);
+        if (tail) {
+            if (counters) hipLaunchKernelGGL((wf2_primary<true, true, true>), pgrid, block, 0, st, sc, wb, dm, gp, cam, tune, async.cull, counters);
+            else hipLaunchKernelGGL((wf2_primary<false, true, true>), pgrid, block, 0, st, sc, wb, dm, gp, cam, tune, async.cull, counters);
         } else if (counters) {
             if (w4) hipLaunchKernelGGL((wf2_primary<true, true>), pgrid, block, 0, st, sc, wb, dm, gp, cam, tune, async.cull, counters);
             else hipLaunchKernelGGL((wf2_primary<true, false>), pgrid, block, 0, st, sc, wb, dm, gp, cam, tune, async.cull, counters);
@@ -1731,21 +1529,8 @@ void launch_wf2_render(hipStream_t stream, const DeviceScene& ds, const FramePar
             if (w4) hipLaunchKernelGGL((wf2_primary<false, true>), pgrid, block, 0, st, sc, wb, dm, gp, cam, tune, async.cull, counters);
             else hipLaunchKernelGGL((wf2_primary<false, false>), pgrid, block, 0, st, sc, wb, dm, gp, cam, tune, async.cull, counters);
         }
-        if (coop) {   // the rays the launch handed over, each by a whole wave (blocks past their number exit at once)
-            if (counters) hipLaunchKernelGGL((wf2_long<true, true>), dim3(kLongGrid), dim3(64), 0, st, sc, wb, dm, gp, cam, 0, counters);
-            else hipLaunchKernelGGL((wf2_long<false, true>), dim3(kLongGrid), dim3(64), 0, st, sc, wb, dm, gp, cam, 0, counters);
-        }
         if (ev) (void)hipEventRecord(ev[1], st);
         for (int b = 0; b <= gp.max_bounces; b++) {
-            if (fuse && b < gp.max_bounces) {   // shade(b) + trace(b + 1) as one launch (small renders: wf2_bounce)
-                const bool tex = sh.tex != nullptr && sh.n_layers > 0 && sh.tex_res > 0;
-                const int texmode = !tex ? 0 : ((sh.sampler_mode & 2) ? 2 : 1);
-#define JPT_LAUNCH_BOUNCE(C, T) hipLaunchKernelGGL((wf2_bounce<C, T>), pgrid, block, 0, st, sc, sh, wb, dm, gp, cam.far_, b, tune, counters)
-                if (counters) { if (texmode == 0) JPT_LAUNCH_BOUNCE(true, 0); else if (texmode == 1) JPT_LAUNCH_BOUNCE(true, 1); else JPT_LAUNCH_BOUNCE(true, 2); }
-                else          { if (texmode == 0) JPT_LAUNCH_BOUNCE(false, 0); else if (texmode == 1) JPT_LAUNCH_BOUNCE(false, 1); else JPT_LAUNCH_BOUNCE(false, 2); }
-#undef JPT_LAUNCH_BOUNCE
-                continue;
-            }
             {
                 // instantiations: the paths' last vertices without the BRDF code, scenes without a texture array without
                 // the sampler code
@@ -1769,28 +1554,15 @@ void launch_wf2_render(hipStream_t stream, const DeviceScene& ds, const FramePar
             }
             if (b == gp.max_bounces) break;
             if (ev) (void)hipEventRecord(ev[2 * (b + 1)], st);
-            if (pool) {
-                if (counters) hipLaunchKernelGGL(wf2_trace_pool<true>, dim3(pool_blocks), dim3(64), 0, st, sc, wb, dm, b + 1, chain, pool_waves, tuning().pool_min_prefetch, counters);
-                else hipLaunchKernelGGL(wf2_trace_pool<false>, dim3(pool_blocks), dim3(64), 0, st, sc, wb, dm, b + 1, chain, pool_waves, tuning().pool_min_prefetch, counters);
-            } else if (regroup) {
-                if (counters) hipLaunchKernelGGL(wf2_trace_rg<true>, dim3(rg_blocks), dim3(64), 0, st, sc, wb, dm, b + 1, chain, rg_waves, counters);
-                else hipLaunchKernelGGL(wf2_trace_rg<false>, dim3(rg_blocks), dim3(64), 0, st, sc, wb, dm, b + 1, chain, rg_waves, counters);
-            } else if (coop) {
-                if (counters) hipLaunchKernelGGL((wf2_trace<true, true, 1>), tgrid, block, 0, st, sc, wb, dm, b + 1, tune, chain, counters);
-                else hipLaunchKernelGGL((wf2_trace<false, true, 1>), tgrid, block, 0, st, sc, wb, dm, b + 1, tune, chain, counters);
-            } else if (tail) {
-                if (counters) hipLaunchKernelGGL((wf2_trace<true, true, 2>), tgrid, block, 0, st, sc, wb, dm, b + 1, tune, chain, counters);
-                else hipLaunchKernelGGL((wf2_trace<false, true, 2>), tgrid, block, 0, st, sc, wb, dm, b + 1, tune, chain, counters);
+            if (tail) {
+                if (counters) hipLaunchKernelGGL((wf2_trace<true, true, true>), tgrid, block, 0, st, sc, wb, dm, b + 1, tune, chain, counters);
+                else hipLaunchKernelGGL((wf2_trace<false, true, true>), tgrid, block, 0, st, sc, wb, dm, b + 1, tune, chain, counters);
             } else if (counters) {
                 if (w4) hipLaunchKernelGGL((wf2_trace<true, true>), tgrid, block, 0, st, sc, wb, dm, b + 1, tune, chain, counters);
                 else hipLaunchKernelGGL((wf2_trace<true, false>), tgrid, block, 0, st, sc, wb, dm, b + 1, tune, chain, counters);
             } else {
                 if (w4) hipLaunchKernelGGL((wf2_trace<false, true>), tgrid, block, 0, st, sc, wb, dm, b + 1, tune, chain, counters);
                 else hipLaunchKernelGGL((wf2_trace<false, false>), tgrid, block, 0, st, sc, wb, dm, b + 1, tune, chain, counters);
-            }
-            if (coop && !regroup) {
-                if (counters) hipLaunchKernelGGL((wf2_long<true, false>), dim3(kLongGrid), dim3(64), 0, st, sc, wb, dm, gp, cam, b + 1, counters);
-                else hipLaunchKernelGGL((wf2_long<false, false>), dim3(kLongGrid), dim3(64), 0, st, sc, wb, dm, gp, cam, b + 1, counters);
             }
             if (ev) (void)hipEventRecord(ev[2 * (b + 1) + 1], st);
         }

@@ -33,26 +33,17 @@ struct Tuning {
     long set_aside_cap = -1;       // JPT_SET_ASIDE_CAP: records of the set-aside buffer (-1: the library's rule; tests force 0)
     int reach = 2;                 // JPT_REACH=0: ignore the reach records; 1: check but never redo (timing experiments only)
     bool shade_last = true;        // JPT_SHADE_LAST=0: the final shading launch uses the general kernel (A/B)
-    int coop = -1;                 // JPT_COOP=0/1: long walks handed over to a whole wave (coop_walk) never / always (-1: scenes of >= 200 000 triangles)
-    int coop_rounds = 128;         // JPT_COOP_ROUNDS: ... a ray still walking this many rounds after its block's queue ran dry
     int lone_async = 1;            // JPT_LONE_ASYNC=0: queued renders that find the pipeline empty are never launched like blocking ones
     int node_order = 0;            // JPT_NODE_ORDER=1: the four-child records of siblings next to each other (0: depth first)
     int primary_samples = -1;      // JPT_PRIMARY_SAMPLES=0/1: a wave of the primary launch takes one frame's sample of an 8 x 8 tile / every frame's
                                    // sample of 64 / n_frames pixels of a tile (-1: the library's rule)
     int tail = -1;                 // JPT_TAIL: the waves of a tracing launch walk their last, long rays themselves, all lanes on one ray
-                                   // (coop_walk_call), instead of handing them to wf2_long: -1 where JPT_COOP's own rule (not a forced
-                                   // JPT_COOP=1) asks for the cooperative walk, 0 never, 1 also on the scenes JPT_COOP leaves alone, 2 everywhere
+                                   // (coop_walk_call): -1 on scenes of >= 200 000 triangles, 0 never, 1 on every scene
     int tail_rounds = 128;         // JPT_TAIL_ROUNDS: ... from this many rounds after the block's queue ran dry
     int tail_lanes = 8;            // JPT_TAIL_LANES: ... once a wave is down to this many rays
-    int trace_regroup = 0;         // JPT_TRACE_REGROUP=1: bounce launches by wf2_trace_rg (ray state in LDS, compacted lists of rays per step kind: round 4,
-                                   // measured, not kept); 2: by wf2_trace_pool (the same with turns prepared one ahead and a lean state: round 5)
-    int pool_min_prefetch = 40;    // JPT_POOL_MIN_PREFETCH: wf2_trace_pool prepares its next turn ahead only when a list holds this many rays
-    int fuse_bounce = -1;          // JPT_FUSE_BOUNCE=0/1: wf2_shade(b) + wf2_trace(b + 1) as one launch per bounce (wf2_bounce) never / always (-1: small renders)
-    int fuse_max_paths = 0;        // JPT_FUSE_MAX_PATHS: ... the rule's bound on the render window's paths (0: the rule is off)
     int collapse = 3;              // JPT_COLLAPSE: two-child records merged into four-child ones by the least-area plan (jpt_builder.cpp, CollapsePlan) -- 0 greedily (the largest box first: rounds 1-4), 1 the TLAS, 2 the meshes' trees, 3 both
     int instance_boxes = 1024;     // JPT_INSTANCE_BOXES: a native scene's instance boxes bound up to this many boxes of the mesh's tree, transformed one by one
                                    // (1: the root box's corners, as the reference's rule and rounds 1-4)
-    int rg_waves = 0;              // JPT_RG_WAVES: waves (= blocks) per queue of the regrouped launches (0: the library's rule)
 };
 
 inline const Tuning& tuning()
@@ -85,22 +76,14 @@ inline const Tuning& tuning()
         v.max_leaf = geti("JPT_MAX_LEAF", 2);
         v.reach = geti("JPT_REACH", 2);
         v.shade_last = geti("JPT_SHADE_LAST", 1) != 0;
-        v.coop = geti("JPT_COOP", -1);
-        v.coop_rounds = geti("JPT_COOP_ROUNDS", 128);
-        if (v.coop_rounds < 1) v.coop_rounds = 1;
         v.lone_async = geti("JPT_LONE_ASYNC", 1);
         v.node_order = geti("JPT_NODE_ORDER", 0);
         v.primary_samples = geti("JPT_PRIMARY_SAMPLES", -1);
         v.tail = geti("JPT_TAIL", -1);
         v.tail_rounds = geti("JPT_TAIL_ROUNDS", 128);
         v.tail_lanes = geti("JPT_TAIL_LANES", 8);
-        v.trace_regroup = geti("JPT_TRACE_REGROUP", 0);
-        v.pool_min_prefetch = geti("JPT_POOL_MIN_PREFETCH", 40);
-        v.rg_waves = geti("JPT_RG_WAVES", 0);
         v.collapse = geti("JPT_COLLAPSE", 3);
         v.instance_boxes = geti("JPT_INSTANCE_BOXES", 1024);
-        v.fuse_bounce = geti("JPT_FUSE_BOUNCE", -1);
-        v.fuse_max_paths = geti("JPT_FUSE_MAX_PATHS", 0);
         v.exact_shadow = geti("JPT_EXACT_SHADOW", 1) != 0;
         if (const char* e = std::getenv("JPT_SET_ASIDE_CAP")) v.set_aside_cap = std::atol(e);
         if (const char* e = std::getenv("JPT_UPLOAD_WALK")) v.upload_as_given = e[0] == 'g' || e[0] == 'G';

@@ -932,17 +932,12 @@ def test_bench_self_launch_two_ranks_on_one_gpu(hiplib, launcher):
         assert d["multi_gpu"]["gather_plan"] == {"peer_copies": 1, "distinct_streams": 1, "own_piece_copies": 0}
 
 
-@pytest.mark.parametrize("switch", ["JPT_COOP=1 JPT_COOP_ROUNDS=2", "JPT_TAIL=2 JPT_TAIL_ROUNDS=2 JPT_TAIL_LANES=8", "JPT_TRACE_REGROUP=1",
-                                    "JPT_TRACE_REGROUP=2", "JPT_TRACE_REGROUP=2 JPT_POOL_MIN_PREFETCH=1", "JPT_FUSE_BOUNCE=1",
-                                    "JPT_TRACE_REGROUP=1 JPT_COOP=1 JPT_COOP_ROUNDS=2", "JPT_PRIMARY_SAMPLES=0",
+@pytest.mark.parametrize("switch", ["JPT_TAIL=1 JPT_TAIL_ROUNDS=2 JPT_TAIL_LANES=8", "JPT_PRIMARY_SAMPLES=0",
                                     "JPT_GROUPS=3", "JPT_GROUPS=2 JPT_PRIMARY_SAMPLES=0", "JPT_COLLAPSE=0 JPT_INSTANCE_BOXES=1"])
 def test_alternative_tracing_launches_are_bit_identical(hiplib, switch):
     """The tuning switches are read once per process, so the alternative launches run the parity tests in a child process:
-    JPT_COOP=1 with an eager hand-over (most tail rays of every launch are walked by wf2_long / coop_walk), JPT_TAIL=2 with eager
-    thresholds (the same walk inside the launch, by the wave that holds the ray: what large scenes get by default for their
-    few very long rays), JPT_TRACE_REGROUP=1 (wf2_trace_rg: ray state in LDS, compacted
-    lists per step kind), JPT_TRACE_REGROUP=2 (wf2_trace_pool) and JPT_FUSE_BOUNCE=1 (wf2_bounce) -- kept as measured, rejected
-    variants -- JPT_PRIMARY_SAMPLES=0 (a primary wave takes one frame's sample of a tile,
+    JPT_TAIL=1 with eager thresholds (a wave walks its last rays with all its lanes, coop_walk: what large scenes get by default
+    for their few very long rays), JPT_PRIMARY_SAMPLES=0 (a primary wave takes one frame's sample of a tile,
     as rounds 1-3 dealt them, instead of every frame's sample of a few pixels) and JPT_GROUPS=3 / 2 (blocking renders split
     into frame groups of unequal size: every group's paths live in a block of their own, which wf2_accumulate must find), and
     JPT_COLLAPSE=0 JPT_INSTANCE_BOXES=1 (the native trees as rounds 1-4 made them: four-child records collapsed greedily, an
@@ -957,9 +952,7 @@ def test_alternative_tracing_launches_are_bit_identical(hiplib, switch):
         env[k] = v
     p = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_parity.py"), os.path.join(root, "tests", "test_fuzz.py"),
                         os.path.abspath(__file__), "-m", "gpu", "-x", "-q", "-k",
-                        "c1_cornell or demo_scene_multi_frame or coincident or tie_between or duplicated or native_tree" +
-                        # (the walk-length counters with the cooperative walks in play; the regrouped launches keep none)
-                        ("" if "REGROUP" in switch else " or walk_length_statistics")],
+                        "c1_cornell or demo_scene_multi_frame or coincident or tie_between or duplicated or native_tree or walk_length_statistics"],
                        env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=1500)
     assert p.returncode == 0, p.stdout[-3000:]
     assert " passed" in p.stdout and "failed" not in p.stdout
