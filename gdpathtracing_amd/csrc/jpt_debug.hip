@@ -78,6 +78,7 @@ uint8_t node_step4_host(const WideNodeQ& q, const StepCase& c, int rcp_ulps)
     for (int k = 0; k < 3; k++) {
         float r = 1.0f / c.d[k];
         if (std::isfinite(r) && r != 0.0f) r = step_ulps(r, r > 0.0f ? rcp_ulps : -rcp_ulps);   // |r| larger for ulps > 0
+        r = r > kRcpClamp ? kRcpClamp : (r < -kRcpClamp ? -kRcpClamp : r);                         // (set_level keeps them finite)
         rD[k] = r;
         ood[k] = -(c.o[k] * rD[k]);
         a[k] = scale[k] * rD[k];

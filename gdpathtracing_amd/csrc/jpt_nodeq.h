@@ -48,6 +48,7 @@ constexpr float kPlaneSlack = 1.0f / 256.0f;
 // walk applies is 1/256 + 1/16384 of a step: the second part covers the rounding of scale * rD times a plane number.
 constexpr float kWalkEps = 1.0f / 1048576.0f;
 constexpr float kWalkSlackOverEps = 4160.0f;   // (1/256 + 1/16384) / kWalkEps, exactly
+constexpr float kRcpClamp = 1.2676506002282294e30f;   // 2^100: the walk's reciprocal directions are clamped to +-this (jpt_trace_core.h, set_level)
 
 // smallest power of two >= x (x > 0, finite); tiny or zero extents get the smallest normal number
 JPT_HD float pow2_at_least(float x)
