@@ -33,7 +33,7 @@ BUF_TRI_GEOMETRY, BUF_TRI_DATA, BUF_MATERIALS, BUF_BVH_NODES, BUF_INSTANCES, BUF
 # every symbol include/jpt.h declares
 SYMBOLS = [
     "jpt_abi_version", "jpt_create", "jpt_destroy", "jpt_last_error", "jpt_set_stream", "jpt_get_stream", "jpt_set_stream_priority", "jpt_renders_in_flight", "jpt_set_memory_policy", "jpt_get_workspace_bytes",
-    "jpt_scene_upload_reference_layout", "jpt_set_upload_mode", "jpt_scene_tree_kind", "jpt_scene_upload_note", "jpt_scene_ties_exact", "jpt_scene_levels", "jpt_scene_begin", "jpt_scene_add_mesh", "jpt_scene_add_instance",
+    "jpt_scene_upload_reference_layout", "jpt_set_upload_mode", "jpt_scene_tree_kind", "jpt_scene_upload_note", "jpt_scene_ties_exact", "jpt_scene_begin", "jpt_scene_add_mesh", "jpt_scene_add_instance",
     "jpt_scene_set_materials", "jpt_scene_set_textures", "jpt_scene_commit", "jpt_scene_get_reference_buffer",
     "jpt_scene_set_instance_transform", "jpt_scene_update_tlas", "jpt_scene_refit_tlas", "jpt_scene_update_reference_tlas",
     "jpt_set_params", "jpt_set_kernel", "jpt_set_debug_steps", "jpt_set_kernel_timing", "jpt_set_partition", "jpt_set_camera", "jpt_render", "jpt_render_counted", "jpt_render_async",
@@ -121,8 +121,6 @@ def lib():
     L.jpt_scene_upload_note.restype = C.c_char_p
     L.jpt_scene_ties_exact.argtypes = [vp, C.POINTER(C.c_char_p)]
     L.jpt_scene_ties_exact.restype = C.c_int
-    L.jpt_scene_levels.argtypes = [vp, C.POINTER(C.c_char_p)]
-    L.jpt_scene_levels.restype = C.c_int
     L.jpt_scene_begin.argtypes = [vp]
     L.jpt_scene_add_mesh.argtypes = [vp, C.POINTER(Surface), i32, C.POINTER(u32)]
     L.jpt_scene_add_instance.argtypes = [vp, u32, vp, vp, i32]

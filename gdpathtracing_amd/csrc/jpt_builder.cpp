@@ -6,7 +6,6 @@
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
-#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <future>
@@ -245,15 +244,13 @@ struct SahBlasBuilder {
     std::vector<float> centroid;     // 3 per triangle
     std::vector<uint32_t> order;     // permutation being built
     float pad = 0.0f;
-    int leaf_limit = 0;              // > 0: overrides tuning().max_leaf
 
 #ifndef JPT_SAH_BINS
 #define JPT_SAH_BINS 16
 #endif
     static constexpr int kBins = JPT_SAH_BINS;
-    // largest leaf the builder keeps without a split that pays (JPT_MAX_LEAF overrides, for tuning runs; leaf_limit: build_flat,
-    // whose primitives are whole leaves of the meshes' trees -- one per leaf)
-    int max_leaf() const { return leaf_limit > 0 ? leaf_limit : tuning().max_leaf; }
+    // largest leaf the builder keeps without a split that pays (JPT_MAX_LEAF overrides, for tuning runs)
+    static int max_leaf() { return tuning().max_leaf; }
 
     void prepare(int start, int end)
     {
@@ -2010,340 +2007,6 @@ bool reflatten_tlas(const RefScene& ref, WideScene& out, bool with4, std::string
     }
     compute_stack_need(out);
     return true;
-}
-
-// ---- one world-space level (round 6) -----------------------------------------------------------------------------------
-//
-// The reference walks two levels (main.glsl:305-350): a TLAS over the instances' world boxes, then the instance's own tree with
-// the ray taken into the instance's space.  An instance's box is a box whatever it holds: every ray that starts inside the open
-// Cornell cube enters the cube's instance first (entry distance 0), finds a far wall, and only then enters the character in
-// front of it -- C3 makes 1.27 instance entries per traced ray, a quarter of the records a ray steps through and a phase type of
-// the wave's round of its own.  For a STATIC scene whose instanced triangles fit the caches the native route therefore builds
-// one more tree: ONE level, in world space, over the leaves of all the instances' trees.  A primitive is (instance, leaf of its
-// mesh's tree) = one or two triangles; its box is the world box of those triangles' transformed vertices, padded (below).  Below
-// a cut the tree is each instance's own tree again, with world boxes (unions of the primitives' boxes); above it a binned-SAH
-// build over the cut's subtrees; then the least-area four-child collapse and 64-byte quantised records like the other trees'.
-// (Round 6's first form -- one SAH build over all primitives -- put walls and millimetre triangles under the same records, whose
-// 8-bit grids then gave the small ones boxes 1/254 of the WALL's extent: a few rays per million walked thousands of records.)  The walk tests boxes with the WORLD ray only; a leaf names its instance, and the instance's local ray -- the
-// expression of main.glsl:319-320, so Moller-Trumbore sees the operands the reference's sees and t, u, v are bit-identical --
-// is recomputed in the leaf step when the instance differs from the one the lane last used (Traversal<.., FLAT>, jpt_trace_core.h).
-// What the reference's own boxes let through stays with the reach records, which are per triangle and per instance, not per tree.
-//
-// PADDING.  The boxes must let the world ray in wherever the LOCAL ray's triangle test succeeds.  The local ray is o_l =
-// fl(inv * o), d_l = fl(inv3 * d) with the float matrices of the instance record; the point it hits, taken back to world space,
-// differs from the world ray's point at the same t by
-//     E1 o + e2 + M3 do + t (E1 d + M3 dd),   E1 = M3 inv3 - I,  e2 = M3 inv_t + T,  |do| <= 4u (|inv3||o| + |inv_t|),  |dd| <= 3u |inv3||d|
-// (u = 2^-24).  E1 and e2 are computed here, in double, from the very matrices the kernels use; with |o_k| <= R (the origin
-// bound, 8 x the scene's own bound + 1) and t |d_k| <= R + B (the hit lies inside the scene's bound B) the deviation on axis a
-// is at most  rowsum_a(|E1| + 6u |M3||inv3|) (2R + B) + |e2_a| + 6u (|M3||inv_t|)_a  -- 5e-5 B for a rotation, and a scene whose
-// transforms make it more than 1e-3 B is not taken.  Added to it: the mesh tree's own padding (what lets a triangle test that
-// succeeds a rounding error outside the triangle pass its box), mapped by |M3|, and 2e-6 of the box's largest coordinate like
-// every native box.  Rays from farther out than R (a camera far from a small scene: primary rays only -- later segments start on
-// surfaces) take the two-level walk, which stays on the device anyway: for wf2_finish's exact re-walks, and for scenes whose
-// instances move (jpt_scene_update_tlas / jpt_scene_refit_tlas drop the flat tree: the two levels are what a refit refits).
-void build_flat(const RefScene& ref, WideScene& out)
-{
-    out.flat_nodes4.clear();
-    out.flat_root4 = 0;
-    out.flat_ok = false;
-    out.flat_tri_bits = out.flat_cnt_bits = 0;
-    out.stack_need_flat = 0;
-    out.flat_origin_bound = 0.0f;
-    out.flat_note.clear();
-    auto refuse = [&](const std::string& why) { out.flat_note = why; };
-    if (tuning().flat == 0) return refuse("switched off (JPT_FLAT=0)");
-    const size_t ni = ref.instances.size();
-    if (ni == 0 || out.instances.size() != ni || out.tris.empty()) return refuse("no instances");
-    if (ni > 32767) return refuse("more than 32 767 instances");
-    // primitives: (instance, leaf of its mesh's tree)
-    struct Prim {
-        uint32_t inst, first, count;
-    };
-    std::vector<Prim> prims;
-    std::vector<std::vector<std::pair<uint32_t, uint32_t>>> leaves_of_root;   // per distinct BLAS root: its (first, count) leaves
-    std::vector<int32_t> roots;
-    auto leaves_of = [&](int32_t root) -> const std::vector<std::pair<uint32_t, uint32_t>>& {
-        for (size_t k = 0; k < roots.size(); k++)
-            if (roots[k] == root) return leaves_of_root[k];
-        std::vector<std::pair<uint32_t, uint32_t>> lv;
-        std::vector<int32_t> todo{root};
-        while (!todo.empty()) {
-            const int32_t r = todo.back();
-            todo.pop_back();
-            if (r < 0) {
-                const uint32_t bits = (uint32_t)~r;
-                lv.emplace_back(bits & kLeafFirstMask, (bits >> kLeafCountShift) + 1u);
-                continue;
-            }
-            if ((size_t)r >= out.blas_nodes.size()) continue;
-            const WideNode& w = out.blas_nodes[(size_t)r];
-            if (w.left == r && w.right == r) continue;   // empty-leaf record
-            todo.push_back(w.right);
-            todo.push_back(w.left);
-        }
-        roots.push_back(root);
-        leaves_of_root.push_back(std::move(lv));
-        return leaves_of_root.back();
-    };
-    size_t inst_tris = 0;
-    uint32_t max_count = 1;
-    for (size_t i = 0; i < ni; i++)
-        for (const auto& l : leaves_of(out.instances[i].root)) {
-            if ((size_t)l.first + l.second > ref.tri_geom.size()) return refuse("a leaf names triangles that do not exist");
-            prims.push_back(Prim{(uint32_t)i, l.first, l.second});
-            inst_tris += l.second;
-            max_count = std::max(max_count, l.second);
-        }
-    if (prims.empty()) return refuse("no triangles");
-    if (tuning().flat < 0 && inst_tris > (size_t)tuning().flat_max_tris)
-        return refuse("more instanced triangles (" + std::to_string(inst_tris) + ") than the one-level rule takes (JPT_FLAT_MAX_TRIS = " + std::to_string(tuning().flat_max_tris) + ")");
-    auto bit_width = [](uint32_t v) { uint32_t b = 0; while (v) { b++; v >>= 1; } return b; };
-    const uint32_t tri_bits = std::max(1u, bit_width((uint32_t)ref.tri_geom.size() - 1u)), cnt_bits = bit_width(max_count - 1u), inst_bits = bit_width((uint32_t)ni - 1u);
-    if (tri_bits + cnt_bits + inst_bits > 30u) return refuse("instance, triangle and count do not fit one 30-bit leaf reference");
-
-    // world boxes of the primitives' vertices, in double; the scene's bound B
-    const size_t np = prims.size();
-    std::vector<double> blo(np * 3), bhi(np * 3);
-    double B = 0.0;
-    for (size_t p = 0; p < np; p++) {
-        const float* m = ref.instances[prims[p].inst].transform;
-        double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
-        for (uint32_t k = 0; k < prims[p].count; k++)
-            for (int j = 0; j < 3; j++) {
-                const Vec4& v = ref.tri_geom[prims[p].first + k].vertices[j];
-                for (int r = 0; r < 3; r++) {
-                    const double w = (double)m[r] * v.x + (double)m[4 + r] * v.y + (double)m[8 + r] * v.z + (double)m[12 + r];
-                    lo[r] = std::min(lo[r], w);
-                    hi[r] = std::max(hi[r], w);
-                }
-            }
-        for (int r = 0; r < 3; r++) {
-            if (!std::isfinite(lo[r]) || !std::isfinite(hi[r]) || std::fabs(lo[r]) > 1e30 || std::fabs(hi[r]) > 1e30) return refuse("a triangle's world box is not finite");
-            blo[p * 3 + r] = lo[r];
-            bhi[p * 3 + r] = hi[r];
-            B = std::max(B, std::max(std::fabs(lo[r]), std::fabs(hi[r])));
-        }
-    }
-    const double R = 8.0 * B + 1.0;
-    // per instance: the padding its transform pair asks for (see above), plus the mesh tree's own padding mapped by |M3|
-    const double u = 1.0 / 16777216.0;
-    std::vector<double> ipad(ni * 3);
-    for (size_t i = 0; i < ni; i++) {
-        const RefInstance& in = ref.instances[i];
-        const float *m = in.transform, *v = in.inverse_transform;
-        if (!(m[3] == 0.0f && m[7] == 0.0f && m[11] == 0.0f && m[15] == 1.0f && v[3] == 0.0f && v[7] == 0.0f && v[11] == 0.0f && v[15] == 1.0f))
-            return refuse("an instance matrix is not affine");
-        // the mesh tree's padding: 2e-6 of the mesh's largest coordinate (SahBlasBuilder::prepare), from the (padded) root box
-        double mesh_m = 0.0;
-        if (in.blas_index < ref.bvh_nodes.size()) {
-            const RefBvhNode& rt = ref.bvh_nodes[in.blas_index];
-            const float c[6] = {rt.aabbMin.x, rt.aabbMin.y, rt.aabbMin.z, rt.aabbMax.x, rt.aabbMax.y, rt.aabbMax.z};
-            for (float x : c)
-                if (std::isfinite(x)) mesh_m = std::max(mesh_m, (double)std::fabs(x));
-        }
-        const double pad_local = 2.5e-6 * mesh_m + 1e-30;
-        for (int a = 0; a < 3; a++) {
-            double rs = 0.0, e2 = (double)m[12 + a], gt = 0.0, mp = 0.0;
-            for (int k = 0; k < 3; k++) {
-                double e1 = k == a ? -1.0 : 0.0, g = 0.0;
-                for (int j = 0; j < 3; j++) {   // (M3 inv3)[a][k] = sum_j M3[a][j] inv3[j][k];  M3[a][j] = m[j * 4 + a]
-                    e1 += (double)m[j * 4 + a] * (double)v[k * 4 + j];
-                    g += std::fabs((double)m[j * 4 + a]) * std::fabs((double)v[k * 4 + j]);
-                }
-                rs += std::fabs(e1) + 6.0 * u * g;
-                e2 += (double)m[k * 4 + a] * (double)v[12 + k];
-                gt += std::fabs((double)m[k * 4 + a]) * std::fabs((double)v[12 + k]);
-                mp += std::fabs((double)m[k * 4 + a]);
-            }
-            const double pad = rs * (2.0 * R + B) + std::fabs(e2) + 6.0 * u * gt + mp * pad_local;
-            if (!(pad <= 1e-3 * B + 1e-30)) return refuse("instance " + std::to_string(i) + ": transform and inverse_transform are too far from each other's inverse for world-space boxes");
-            ipad[i * 3 + a] = pad;
-        }
-    }
-
-    // the primitives' padded float boxes (in the order leaves_of lists them: instance by instance, depth first, left before right)
-    std::vector<Box3> pbox(np);
-    for (size_t p = 0; p < np; p++)
-        for (int r = 0; r < 3; r++) {
-            const double big = std::max(std::fabs(blo[p * 3 + r]), std::fabs(bhi[p * 3 + r]));
-            const double pad = ipad[(size_t)prims[p].inst * 3 + r] + 2e-6 * big;
-            pbox[p].lo[r] = std::nextafter((float)(blo[p * 3 + r] - pad), -FLT_MAX);   // (the conversion rounds to nearest: one step outwards)
-            pbox[p].hi[r] = std::nextafter((float)(bhi[p * 3 + r] + pad), FLT_MAX);
-        }
-    auto leaf_ref = [&](const Prim& p) -> int32_t { return ~(int32_t)(p.first | ((p.count - 1u) << tri_bits) | (p.inst << (tri_bits + cnt_bits))); };
-    // 1. Every instance's tree again, in world space: the topology of its mesh's tree (whose splits were chosen where the
-    //    triangles are), each record's boxes the unions of the primitives' world boxes below it -- tight, where the transformed
-    //    corners of the mesh-space boxes would be up to twice as large for a rotated instance.  `two`: two-child records with the
-    //    children's boxes, the form collapse4 reads; node_box[k]: the box of record k itself.
-    std::vector<WideNode> two;
-    std::vector<Box3> node_box;
-    constexpr int32_t kNothing = INT32_MIN;   // an empty mesh / an empty leaf: nothing to refer to
-    size_t next_prim = 0;
-    struct Frame { int32_t ref; int32_t self; int stage; int32_t child[2]; Box3 cbox[2]; };
-    auto copy_tree = [&](int32_t root, Box3& root_box) -> int32_t {
-        // (an explicit stack: the meshes' trees may be 512 levels deep)
-        std::vector<Frame> st;
-        int32_t result = kNothing;
-        Box3 result_box;
-        auto finish = [&](int32_t ref, const Box3& box) {   // hand a finished subtree to its parent
-            if (st.empty()) {
-                result = ref;
-                result_box = box;
-                return;
-            }
-            Frame& f = st.back();
-            f.child[f.stage] = ref;
-            f.cbox[f.stage] = box;
-            f.stage++;
-        };
-        auto enter = [&](int32_t ref) {
-            if (ref < 0) {
-                const size_t p = next_prim++;
-                finish(leaf_ref(prims[p]), pbox[p]);
-                return;
-            }
-            if ((size_t)ref >= out.blas_nodes.size() || (out.blas_nodes[(size_t)ref].left == ref && out.blas_nodes[(size_t)ref].right == ref)) {
-                finish(kNothing, Box3());
-                return;
-            }
-            Frame f;
-            f.ref = ref;
-            f.self = -1;
-            f.stage = 0;
-            f.child[0] = f.child[1] = kNothing;
-            st.push_back(f);
-        };
-        enter(root);
-        while (!st.empty()) {
-            Frame& f = st.back();
-            if (f.stage == 0) {
-                enter(out.blas_nodes[(size_t)f.ref].left);
-            } else if (f.stage == 1) {
-                enter(out.blas_nodes[(size_t)f.ref].right);
-            } else {
-                const Frame done = f;
-                st.pop_back();
-                if (done.child[0] == kNothing || done.child[1] == kNothing) {   // one side empty: the other stands for the record
-                    const int k = done.child[0] == kNothing ? 1 : 0;
-                    finish(done.child[k], done.cbox[k]);
-                    continue;
-                }
-                WideNode w;
-                std::memset(&w, 0, sizeof w);
-                for (int r = 0; r < 3; r++) {
-                    w.lmin[r] = done.cbox[0].lo[r]; w.lmax[r] = done.cbox[0].hi[r];
-                    w.rmin[r] = done.cbox[1].lo[r]; w.rmax[r] = done.cbox[1].hi[r];
-                }
-                w.left = done.child[0];
-                w.right = done.child[1];
-                Box3 box = done.cbox[0];
-                box.grow(done.cbox[1]);
-                two.push_back(w);
-                node_box.push_back(box);
-                finish((int32_t)two.size() - 1, box);
-            }
-        }
-        root_box = result_box;
-        return result;
-    };
-    // 2. The cut: what the top tree is built over.  An instance's box is a box whatever it holds -- the open Cornell cube's contains
-    //    every ray of the scene -- so the instances are opened, the largest box first, until the cut holds `want` subtrees: the cube
-    //    falls apart into its walls (whose flat boxes a ray meets where it meets the wall, not where it starts), a character into
-    //    a few dozen limbs.
-    struct CutItem { int32_t ref; Box3 box; };
-    std::vector<CutItem> cut;
-    {
-        std::vector<std::pair<float, size_t>> open;   // max-heap by area over `cand`
-        std::vector<CutItem> cand;
-        auto file = [&](int32_t ref, const Box3& box) {
-            if (ref == kNothing) return;
-            if (ref < 0) {
-                cut.push_back(CutItem{ref, box});
-                return;
-            }
-            cand.push_back(CutItem{ref, box});
-            open.emplace_back(box.half_area(), cand.size() - 1);
-            std::push_heap(open.begin(), open.end());
-        };
-        for (size_t i = 0; i < ni; i++) {
-            Box3 rb;
-            const int32_t r = copy_tree(out.instances[i].root, rb);
-            file(r, rb);
-        }
-        const size_t want = (size_t)std::min<long>(std::max<long>(tuning().flat_cut > 0 ? tuning().flat_cut : 64L * (long)ni, 4L), 16384L);
-        while (!open.empty() && cut.size() + open.size() < want) {
-            std::pop_heap(open.begin(), open.end());
-            const CutItem c = cand[open.back().second];
-            open.pop_back();
-            const WideNode& w = two[(size_t)c.ref];
-            Box3 lb, rb;
-            for (int r = 0; r < 3; r++) {
-                lb.lo[r] = w.lmin[r]; lb.hi[r] = w.lmax[r];
-                rb.lo[r] = w.rmin[r]; rb.hi[r] = w.rmax[r];
-            }
-            file(w.left, lb);
-            file(w.right, rb);
-        }
-        for (const auto& o : open) cut.push_back(cand[o.second]);
-    }
-    if (cut.empty()) return refuse("no triangles");
-    // 3. The top tree: binned SAH over the cut's boxes, one subtree per leaf.
-    std::vector<RefBvhNode> nodes;
-    std::vector<RefTriangle> no_tris;
-    SahBlasBuilder sb{nodes, no_tris};
-    sb.base = 0;
-    sb.pad = 0.0f;
-    sb.leaf_limit = 1;
-    const size_t nc = cut.size();
-    sb.tri_box.resize(nc);
-    sb.centroid.resize(nc * 3);
-    sb.order.resize(nc);
-    for (size_t k = 0; k < nc; k++) {
-        sb.tri_box[k] = cut[k].box;
-        for (int r = 0; r < 3; r++) sb.centroid[k * 3 + r] = 0.5f * (cut[k].box.lo[r] + cut[k].box.hi[r]);
-        sb.order[k] = (uint32_t)k;
-    }
-    (void)sb.build(0, (int)nc);
-    if (nodes.empty()) return refuse("no triangles");
-    std::vector<int32_t> made(nodes.size(), 0);
-    // (pre-order array, children after their parent: filled from the back so that a record's children exist when it is made)
-    for (size_t k = nodes.size(); k-- > 0;) {
-        const RefBvhNode& n = nodes[k];
-        if (n.tri_count > 0) {
-            made[k] = cut[sb.order[n.first_tri_index]].ref;
-            continue;
-        }
-        WideNode w;
-        std::memset(&w, 0, sizeof w);
-        const RefBvhNode &l = nodes[n.left_child], &r = nodes[n.right_child];
-        w.lmin[0] = l.aabbMin.x; w.lmin[1] = l.aabbMin.y; w.lmin[2] = l.aabbMin.z;
-        w.lmax[0] = l.aabbMax.x; w.lmax[1] = l.aabbMax.y; w.lmax[2] = l.aabbMax.z;
-        w.rmin[0] = r.aabbMin.x; w.rmin[1] = r.aabbMin.y; w.rmin[2] = r.aabbMin.z;
-        w.rmax[0] = r.aabbMax.x; w.rmax[1] = r.aabbMax.y; w.rmax[2] = r.aabbMax.z;
-        w.left = made[n.left_child];
-        w.right = made[n.right_child];
-        made[k] = (int32_t)two.size();
-        two.push_back(w);
-    }
-    const int32_t root2 = made[0];
-    {
-        std::vector<int32_t> memo(two.size(), -1);
-        CollapsePlan plan(two);
-        tl_plan = (tuning().collapse & 2) ? &plan : nullptr;
-        out.flat_root4 = collapse_root(two, out.flat_nodes4, root2, memo);
-        tl_plan = nullptr;
-    }
-    {
-        std::vector<int32_t> memo(out.flat_nodes4.size(), -1);
-        out.stack_need_flat = need4(out.flat_nodes4, out.flat_root4, memo);
-    }
-    out.flat_tri_bits = tri_bits;
-    out.flat_cnt_bits = cnt_bits;
-    out.flat_origin_bound = (float)R;
-    out.flat_ok = true;
-    if (std::getenv("JPT_FLAT_VERBOSE"))
-        std::fprintf(stderr, "build_flat: %zu primitives (%zu instanced triangles), cut of %zu subtrees, %zu two-child -> %zu four-child records, stack need %u (two levels: %u), B %.4g, bits %u+%u+%u\n",
-                     np, inst_tris, nc, two.size(), out.flat_nodes4.size(), out.stack_need_flat, out.stack_need4, B, tri_bits, cnt_bits, inst_bits);
 }
 
 void flatten4(WideScene& out)

@@ -104,15 +104,6 @@ struct WideScene {
     // worst-case number of live traversal-stack entries (TLAS pending + sentinel + BLAS pending) for the
     // two-child and the four-child records; the kernels' stack capacity must cover it
     uint32_t stack_need2 = 0, stack_need4 = 0;
-    // ONE world-space level over the same triangles (build_flat): four-child records whose boxes are world boxes and whose leaf
-    // references name an instance besides the triangles -- flat_ok false: not made (flat_note says why), the kernels walk two levels
-    std::vector<WideNode4> flat_nodes4;
-    int32_t flat_root4 = 0;
-    bool flat_ok = false;
-    uint32_t flat_tri_bits = 0, flat_cnt_bits = 0;   // leaf reference = ~(first triangle | (count - 1) << tri_bits | instance << (tri_bits + cnt_bits))
-    uint32_t stack_need_flat = 0;
-    float flat_origin_bound = 0.0f;                  // the boxes' padding covers rays whose origin has no coordinate beyond this
-    std::string flat_note;
 };
 
 enum class BuildMode {
@@ -185,9 +176,5 @@ void flatten4(WideScene& out);
 
 // fills WideScene::stack_need2 / stack_need4 (call after flatten / flatten4)
 void compute_stack_need(WideScene& out);
-
-// One world-space level for static native scenes (after flatten / flatten4): see jpt_builder.cpp.  Fills out.flat_* ; never fails
-// (a scene it does not take keeps flat_ok = false and the reason in flat_note).
-void build_flat(const RefScene& ref, WideScene& out);
 
 }  // namespace jpt

@@ -89,7 +89,6 @@ struct jpt_ctx {
     DevBuf<WideInstance> d_winst, d_winst4;
     DevBuf<WideNode4> d_nodes4;   // four-child records: BLAS part, then room for the TLAS part (one index space)
     DevBuf<WideNodeQ> d_nodesq;   // their quantised form (jpt_nodeq.h), same indices: what the kernels walk
-    DevBuf<WideNodeQ> d_flat_nodesq;   // the one-level tree of a static scene (WideScene::flat_nodes4, quantised)
     // the reference's own trees beside a native scene (ExactShadow): two-child records + the triangle map
     DevBuf<RefBvhNode> d_x_bvh;
     DevBuf<RefTriGeometry> d_x_tri_geom;
@@ -403,19 +402,6 @@ int upload_scene(jpt_ctx* c)
             return fail(c, JPT_E_LIMIT, "acceleration structure too deep: a traversal could need " + std::to_string(need) +
                                             " stack entries, the kernels hold " + std::to_string(trace_stack_capacity()));
     }
-    // static native scenes: one world-space level beside the two (jpt_builder.cpp, build_flat)
-    c->ds.flat_ok = false;
-    if (use4) {
-        build_flat(c->ref, c->wide);
-        if (c->wide.flat_ok && c->wide.stack_need_flat > trace_stack_capacity()) {
-            c->wide.flat_ok = false;
-            c->wide.flat_note = "the one-level tree is too deep for the kernels' stack";
-        }
-    } else {
-        c->wide.flat_ok = false;
-        c->wide.flat_nodes4.clear();
-        c->wide.flat_note = "reference trees are walked as they are";
-    }
     c->host_scene_ready = true;
     c->tlas_dirty = false;
     c->refit_active = false;
@@ -486,19 +472,6 @@ int upload_scene(jpt_ctx* c)
     d.use4 = use4;
     d.stack_need4 = c->wide.stack_need4;
     d.wide_instances4 = c->d_winst4.p;
-    if (c->wide.flat_ok) {
-        std::vector<WideNodeQ> q(c->wide.flat_nodes4.size());
-        for (size_t i = 0; i < q.size(); i++) quantize_node4(c->wide.flat_nodes4[i], q[i]);
-        HIP_TRY(c, c->d_flat_nodesq.upload(q, s));
-        HIP_TRY(c, hipStreamSynchronize(s));   // (`q` is pageable host memory)
-        d.flat_nodesq = c->d_flat_nodesq.p;
-        d.flat_root = c->wide.flat_root4;
-        d.flat_tri_bits = c->wide.flat_tri_bits;
-        d.flat_cnt_bits = c->wide.flat_cnt_bits;
-        d.stack_need_flat = c->wide.stack_need_flat;
-        d.flat_origin_bound = c->wide.flat_origin_bound;
-        d.flat_ok = true;
-    }
     {
         const int rcx = upload_shadow(c, false);
         if (rcx != JPT_OK) return rcx;
@@ -542,12 +515,8 @@ void compute_sky_cull(const jpt_ctx* c, SkyCull& out)
     const bool use4 = !c->ref_is_exact && c->native_tree;
     if (w.instances.empty()) return;
     if (use4) {
-        // (the root of the tree the primary launch walks: the one-level tree's where it does, do_render_batch)
-        const bool flat = c->async.flat_primary && c->ds.flat_ok && w.flat_ok;
-        const std::vector<WideNode4>& recs = flat ? w.flat_nodes4 : w.tlas_nodes4;
-        const int32_t root = flat ? w.flat_root4 : w.tlas_root4;
-        if (root < 0 || (size_t)root >= recs.size()) return;  // the root is a single instance (a single leaf)
-        const WideNode4& r = recs[(size_t)root];
+        if (w.tlas_root4 < 0 || (size_t)w.tlas_root4 >= w.tlas_nodes4.size()) return;  // the root is a single instance
+        const WideNode4& r = w.tlas_nodes4[(size_t)w.tlas_root4];
         for (int k = 0; k < 4; k++)
             if (r.child[k] != kEmptyChild) {
                 lo[n][0] = r.lo_x[k]; lo[n][1] = r.lo_y[k]; lo[n][2] = r.lo_z[k];
@@ -887,12 +856,6 @@ int do_render_batch(jpt_ctx* c, int32_t n_frames, uint32_t first_frame_index, bo
                 c->trace_events.push_back(e);
             }
             c->trace_events_used = (int32_t)need_ev;
-            // which launches walk the one-level tree: the bounce launches whenever the scene has it (their rays start on the scene's
-            // surfaces), the primary launch unless the camera lies farther out than the boxes' padding covers (build_flat)
-            const bool flat_usable = c->ds.flat_ok && !c->refit_active && tuning().flat != 0;
-            c->async.flat_bounce = flat_usable && (tuning().flat_launches & 2) != 0;
-            c->async.flat_primary = flat_usable && (tuning().flat_launches & 1) != 0 && std::fabs(c->camera.position.x) <= c->ds.flat_origin_bound &&
-                                    std::fabs(c->camera.position.y) <= c->ds.flat_origin_bound && std::fabs(c->camera.position.z) <= c->ds.flat_origin_bound;
             if (wf2) compute_sky_cull(c, c->async.cull);
             // the sky cells of whole tiles, for wf2_accumulate (REF_LDR8 sums of several frames): on the context's stream, which every
             // accumulation is ordered behind; again only when the camera (its frame index aside), the image size or the partition changed
@@ -1448,16 +1411,6 @@ int jpt_scene_ties_exact(jpt_ctx* c, const char** why_out)
     return c->ties_note.empty() ? 1 : 0;
 }
 
-int jpt_scene_levels(jpt_ctx* c, const char** why_out)
-{
-    if (why_out) *why_out = "";
-    if (!c) return JPT_E_INVALID;
-    if (!c->host_scene_ready) return fail(c, JPT_E_STATE, "no scene");
-    if (c->wide.flat_ok && !c->refit_active) return 1;
-    if (why_out) *why_out = c->wide.flat_note.c_str();
-    return 2;
-}
-
 int jpt_scene_begin(jpt_ctx* c)
 {
     if (!c) return JPT_E_INVALID;
@@ -1585,11 +1538,6 @@ int upload_tlas_update(jpt_ctx* c)
                                         std::to_string(need) + " stack entries, the kernels hold " + std::to_string(trace_stack_capacity()));
     }
     c->ds.stack_need4 = c->wide.stack_need4;
-    // the instances have moved: the one-level tree's boxes are those of the old transforms -- two levels from here on (until the next
-    // commit / upload builds it again)
-    c->ds.flat_ok = false;
-    c->wide.flat_ok = false;
-    c->wide.flat_note = "the instances have moved since the scene was committed (jpt_scene_update_tlas): two levels";
     if (c->device < 0) return JPT_OK;
     HIP_TRY(c, hipSetDevice(c->device));
     hipStream_t s = c->stream;
@@ -1780,9 +1728,6 @@ int jpt_scene_refit_tlas(jpt_ctx* c, const float* transforms12, uint32_t n_insta
         c->cull_boxes_current = false;
     }
     c->refit_active = true;
-    c->ds.flat_ok = false;   // the one-level tree holds the old transforms' boxes: two levels from here on (what the refit refits)
-    c->wide.flat_ok = false;
-    c->wide.flat_note = "the instances have moved since the scene was committed (jpt_scene_refit_tlas): two levels";
     c->ds.x.tlas_current = false;   // the copy of the reference's instance level is the last HOST update's: until the next one exact ties are decided inside one instance only (jpt_tie_walk.h)
     c->stats.last_build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return JPT_OK;

@@ -85,13 +85,6 @@ struct DeviceScene {
     const WideNodeQ* nodesq = nullptr;       // ... and their 64-byte quantised form, same indices: what the kernels walk
     const WideInstance* wide_instances4 = nullptr;
     int32_t tlas_root4 = 0;
-    // one world-space level over the same triangles (static native scenes: build_flat, jpt_builder.cpp); flat_ok false: the two
-    // levels above are all there is (or the instances have moved since)
-    bool flat_ok = false;
-    const WideNodeQ* flat_nodesq = nullptr;
-    int32_t flat_root = 0;
-    uint32_t flat_tri_bits = 0, flat_cnt_bits = 0, stack_need_flat = 0;
-    float flat_origin_bound = 0.0f;          // its boxes' padding covers rays that start no farther out than this (any coordinate)
     // reach records (jpt_types.h): null unless the scene was committed with JPT_BUILD_SAH
     const ReachTri* reach_tri = nullptr;
     const ReachInst* reach_inst = nullptr;
@@ -206,7 +199,6 @@ struct Wf2Async {
     SkyCull cull;          // for the primary launch of this render
     int trace_chain = 1;   // wf2_trace: consecutive segments per block (1: lowest latency; 4 when renders are queued)
     hipEvent_t before_acc = nullptr;  // the accumulation kernel waits for this event (whatever its stream)
-    bool flat_primary = false, flat_bounce = false;   // which launches of this render walk the scene's one-level tree (DeviceScene::flat_ok)
     const uint32_t* sky_tiles = nullptr;   // per 8 x 8 tile of the context's share of the image: its one rgba8 sky cell, if it has one
                                            // (launch_sky_tiles; null: wf2_accumulate decides every culled pixel by itself)
 };

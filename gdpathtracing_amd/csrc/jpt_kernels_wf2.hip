@@ -57,9 +57,9 @@ struct WfTune {
 // One round of the walk for every active lane of the wave, "while-while" style so that lanes in different
 // states do not serialise each other's code: (1) a tight loop of internal-record steps (lanes that reach a
 // leaf wait), (2) triangle leaves, (3) instance entries.  Returns true for lanes whose walk is complete.
-template <bool COUNT, bool W4, bool FLAT>
-__device__ __forceinline__ bool walk_round(Traversal<COUNT, W4, false, FLAT>& tr, bool active, const WideSceneDev& sc,
-                                           const typename Traversal<COUNT, W4, false, FLAT>::Stack& st, DevCounters& cnt, const WfTune& tune, uint32_t& steps)
+template <bool COUNT, bool W4>
+__device__ __forceinline__ bool walk_round(Traversal<COUNT, W4>& tr, bool active, const WideSceneDev& sc,
+                                           const typename Traversal<COUNT, W4>::Stack& st, DevCounters& cnt, const WfTune& tune, uint32_t& steps)
 {
     const int kNodeMinLanes = tune.node_min_lanes;
     const bool lane0 = (threadIdx.x & 63) == 0;
@@ -108,7 +108,7 @@ __device__ __forceinline__ bool walk_round(Traversal<COUNT, W4, false, FLAT>& tr
         }
     }
     if (wl) tr.leaf_step(sc, cnt);
-    if (!FLAT && wi) tr.instance_step(sc, st, cnt);
+    if (wi) tr.instance_step(sc, st, cnt);
     if (COUNT && (wl || wi)) steps++;
     return active && tr.finished();
 }
@@ -295,11 +295,11 @@ __device__ __forceinline__ float wave_min_f(float v)
 
 // (`pool`: 2 * kCoopPool words of LDS, word w at pool[(w >> 6) * pool_stride + (w & 63)] -- a flat array with pool_stride = 64,
 // or two rows of the block's stack array, see the tail phase of the tracing kernels)
-template <bool COUNT, bool FLAT>
-__device__ __forceinline__ TraceHit coop_walk(const WideSceneDev& sc, const typename Traversal<COUNT, true, false, FLAT>::Stack st, int32_t* __restrict__ pool,
+template <bool COUNT>
+__device__ __forceinline__ TraceHit coop_walk(const WideSceneDev& sc, const typename Traversal<COUNT, true>::Stack st, int32_t* __restrict__ pool,
                                            f3 ro, f3 rd, DevCounters& cnt, const uint32_t pool_stride = 64u)
 {
-    using Walk = Traversal<COUNT, true, false, FLAT>;
+    using Walk = Traversal<COUNT, true>;
     const int lane = threadIdx.x & 63;
     auto pw = [&](uint32_t w) -> int32_t& { return pool[(w >> 6) * pool_stride + (w & 63u)]; };
     constexpr uint32_t kNone = 0xffffffffu;   // hit.tri of a lane that holds no triangle of its own at hit.t
@@ -324,10 +324,9 @@ __device__ __forceinline__ TraceHit coop_walk(const WideSceneDev& sc, const type
                     tr.sp = 0;
                     tr.cur = ref;
                     tr.have = true;
-                    tr.in_blas = FLAT || (ctx & 1u) != 0u;
-                    tr.cur_inst = FLAT ? 0xffffffffu : ctx >> 1;   // (FLAT: the entry's first leaf makes its instance's local ray; the world ray's constants are begin()'s)
-                    if (FLAT) {
-                    } else if (tr.in_blas) {   // the instance's local ray (instance_step's arithmetic, main.glsl:319-320)
+                    tr.in_blas = (ctx & 1u) != 0u;
+                    tr.cur_inst = ctx >> 1;
+                    if (tr.in_blas) {   // the instance's local ray (instance_step's arithmetic, main.glsl:319-320)
                         const WideInstance* ip = sc.instances + tr.cur_inst;
                         const float4 m0 = ld4(&ip->inv[0]), m1 = ld4(&ip->inv[4]), m2 = ld4(&ip->inv[8]);
                         tr.o = mk3(m0.x * ro.x + m0.w * ro.y + m1.z * ro.z + m2.y, m0.y * ro.x + m1.x * ro.y + m1.w * ro.z + m2.z,
@@ -338,7 +337,7 @@ __device__ __forceinline__ TraceHit coop_walk(const WideSceneDev& sc, const type
                         tr.o = ro;
                         tr.d = rd;
                     }
-                    if (!FLAT) tr.set_level();
+                    tr.set_level();
                     active = true;
                 }
                 n_pool -= take;
@@ -439,20 +438,20 @@ __device__ __forceinline__ TraceHit coop_walk(const WideSceneDev& sc, const type
 // all its lanes, again from the root.  The call is OUT OF LINE so that the walk's registers are not the hot loop's (inlined
 // there it cost the loop spills and every launch 10-20 %, round 4); its pool is the top two rows of the wave's own columns of
 // the block's stack array, its private stacks the rows below.
-template <bool COUNT, bool FLAT>
+template <bool COUNT>
 __device__ __attribute__((noinline)) void coop_walk_call(const WideSceneDev* __restrict__ scp, int32_t* lds_col, int32_t* pool, float ox, float oy,
                                                          float oz, float dx, float dy, float dz, DevCounters* cntp, TraceHit* out)
 {
     int32_t spill[kStackSpill + 2];   // (the two LDS rows the pool takes are made up for here)
-    const typename Traversal<COUNT, true, false, FLAT>::Stack st{lds_col, spill, kTraceBlock, kStackLds - 2, kStackSpill + 2};
+    const typename Traversal<COUNT, true>::Stack st{lds_col, spill, kTraceBlock, kStackLds - 2, kStackSpill + 2};
     const WideSceneDev sc = *scp;
     DevCounters none = {};
-    *out = coop_walk<COUNT, FLAT>(sc, st, pool, mk3(ox, oy, oz), mk3(dx, dy, dz), COUNT ? *cntp : none, (uint32_t)kTraceBlock);
+    *out = coop_walk<COUNT>(sc, st, pool, mk3(ox, oy, oz), mk3(dx, dy, dz), COUNT ? *cntp : none, (uint32_t)kTraceBlock);
 }
 
 // ---- bounce 0: generate + trace ------------------------------------------------------------------------
 
-template <bool COUNT, bool W4, bool TAIL = false, bool FLAT = false>   // TAIL: the wave finishes its last, long walks itself, all lanes on one ray (coop_walk_call); FLAT: `sc` is the one-level tree
+template <bool COUNT, bool W4, bool TAIL = false>   // TAIL: the wave finishes its last, long walks itself, all lanes on one ray (coop_walk_call)
 __global__ __launch_bounds__(kBlock, JPT_PRIMARY_WAVES) void wf2_primary(WideSceneDev sc, Wf2Buffers wb, Wf2Dims dm, FrameParams fp, RefCamera cam,
                                                       WfTune tune, SkyCull cull, DevCounters* __restrict__ counters)
 {
@@ -471,11 +470,11 @@ __global__ __launch_bounds__(kBlock, JPT_PRIMARY_WAVES) void wf2_primary(WideSce
     }
     __syncthreads();
     int32_t spill[kStackSpill];
-    const typename Traversal<COUNT, W4, false, FLAT>::Stack my_stack{&stack[threadIdx.x], spill, kTraceBlock, kStackLds};
+    const typename Traversal<COUNT, W4>::Stack my_stack{&stack[threadIdx.x], spill, kTraceBlock, kStackLds};
     const size_t seg_base = (size_t)seg * dm.seg_cap;
     uint32_t dry_rounds = 0;   // (TAIL: rounds of this wave since the block's queue ran dry; wave-uniform)
     DevCounters cnt = {};
-    Traversal<COUNT, W4, false, FLAT> tr;
+    Traversal<COUNT, W4> tr;
     bool active = false, exhausted = false;
     bool unsaved = false;   // this lane's finished walk has not left its result yet (see wf2_trace: written when the wave refills)
     uint32_t path = 0;
@@ -558,13 +557,10 @@ __global__ __launch_bounds__(kBlock, JPT_PRIMARY_WAVES) void wf2_primary(WideSce
             continue;
         }
         {
-            if (walk_round<COUNT, W4, FLAT>(tr, active, sc, my_stack, cnt, tune, walk_steps)) {
+            if (walk_round<COUNT, W4>(tr, active, sc, my_stack, cnt, tune, walk_steps)) {
                 active = false;
                 unsaved = true;
                 if (COUNT) count_walk(cnt, walk_steps);
-#ifdef JPT_DEBUG_LONG
-                if (COUNT && walk_steps >= 400u) printf("LONG %u o %.9g %.9g %.9g d %.9g %.9g %.9g t %.9g tri %u\n", walk_steps, tr.wo.x, tr.wo.y, tr.wo.z, tr.wd.x, tr.wd.y, tr.wd.z, tr.hit.t, tr.hit.tri);
-#endif
             }
             if constexpr (TAIL && W4) {
                 if (exhausted && ++dry_rounds >= (uint32_t)tune.tail_rounds && __popcll(__ballot(active)) <= tune.tail_lanes) break;
@@ -582,7 +578,7 @@ __global__ __launch_bounds__(kBlock, JPT_PRIMARY_WAVES) void wf2_primary(WideSce
                 left &= left - 1ull;
                 TraceHit h;
                 const WideSceneDev sc_tail = sc;   // (a copy of its own: `sc` itself must not have its address taken, or the hot loop reads it from scratch)
-                coop_walk_call<COUNT, FLAT>(&sc_tail, &stack[threadIdx.x], &stack[(kStackLds - 2) * kTraceBlock + wave_col], __shfl(tr.wo.x, src),
+                coop_walk_call<COUNT>(&sc_tail, &stack[threadIdx.x], &stack[(kStackLds - 2) * kTraceBlock + wave_col], __shfl(tr.wo.x, src),
                                       __shfl(tr.wo.y, src), __shfl(tr.wo.z, src), __shfl(tr.wd.x, src), __shfl(tr.wd.y, src), __shfl(tr.wd.z, src),
                                       COUNT ? &cnt : nullptr, &h);
                 if (lane == src) {
@@ -611,18 +607,18 @@ __global__ __launch_bounds__(kBlock, JPT_PRIMARY_WAVES) void wf2_primary(WideSce
 constexpr int kMaxChain = JPT_MAX_CHAIN;
 // The walk of one block's ray queue -- `n` entries in the consecutive segments seg0, seg0 + 1, .. (end[k] = entries in the first k + 1
 // of them) -- with the block's stack columns and queue cursor in LDS: the body of wf2_trace.
-template <bool COUNT, bool W4, bool TAIL, bool FLAT>
+template <bool COUNT, bool W4, bool TAIL>
 __device__ __forceinline__ void trace_queue(const WideSceneDev& sc, const Wf2Buffers& wb, const Wf2Dims& dm, const int bounce, const WfTune& tune,
                                             const uint32_t seg0, const uint32_t (&end)[kMaxChain], const uint32_t n, int32_t* __restrict__ stack,
                                             uint32_t* __restrict__ s_cursor, DevCounters& cnt)
 {
     const int lane = threadIdx.x & 63;
     int32_t spill[kStackSpill];
-    const typename Traversal<COUNT, W4, false, FLAT>::Stack my_stack{&stack[threadIdx.x], spill, kTraceBlock, kStackLds};
+    const typename Traversal<COUNT, W4>::Stack my_stack{&stack[threadIdx.x], spill, kTraceBlock, kStackLds};
     uint32_t dry_rounds = 0;   // (TAIL: rounds of this wave since the block's queue ran dry; wave-uniform)
     const float4* __restrict__ qo = wb.ray_o[bounce & 1];
     const float4* __restrict__ qd = wb.ray_d[bounce & 1];
-    Traversal<COUNT, W4, false, FLAT> tr;
+    Traversal<COUNT, W4> tr;
     bool active = false, exhausted = false;
 #ifndef JPT_LATE_HIT_STORE
 #define JPT_LATE_HIT_STORE 1
@@ -674,14 +670,11 @@ __device__ __forceinline__ void trace_queue(const WideSceneDev& sc, const Wf2Buf
             continue;
         }
         {
-            if (walk_round<COUNT, W4, FLAT>(tr, active, sc, my_stack, cnt, tune, walk_steps)) {
+            if (walk_round<COUNT, W4>(tr, active, sc, my_stack, cnt, tune, walk_steps)) {
                 active = false;
                 if (JPT_LATE_HIT_STORE) unsaved = true;
                 else save_hit();
                 if (COUNT) count_walk(cnt, walk_steps);
-#ifdef JPT_DEBUG_LONG
-                if (COUNT && walk_steps >= 400u) printf("LONG %u o %.9g %.9g %.9g d %.9g %.9g %.9g t %.9g tri %u\n", walk_steps, tr.wo.x, tr.wo.y, tr.wo.z, tr.wd.x, tr.wd.y, tr.wd.z, tr.hit.t, tr.hit.tri);
-#endif
             }
             if constexpr (TAIL && W4) {
                 if (exhausted && ++dry_rounds >= (uint32_t)tune.tail_rounds && __popcll(__ballot(active)) <= tune.tail_lanes) break;
@@ -702,7 +695,7 @@ __device__ __forceinline__ void trace_queue(const WideSceneDev& sc, const Wf2Buf
                 left &= left - 1ull;
                 TraceHit h;
                 const WideSceneDev sc_tail = sc;   // (a copy of its own: `sc` itself must not have its address taken, or the hot loop reads it from scratch)
-                coop_walk_call<COUNT, FLAT>(&sc_tail, &stack[threadIdx.x], &stack[(kStackLds - 2) * kTraceBlock + wave_col], __shfl(tr.wo.x, src),
+                coop_walk_call<COUNT>(&sc_tail, &stack[threadIdx.x], &stack[(kStackLds - 2) * kTraceBlock + wave_col], __shfl(tr.wo.x, src),
                                       __shfl(tr.wo.y, src), __shfl(tr.wo.z, src), __shfl(tr.wd.x, src), __shfl(tr.wd.y, src), __shfl(tr.wd.z, src),
                                       COUNT ? &cnt : nullptr, &h);
                 if (lane == src) {
@@ -716,7 +709,7 @@ __device__ __forceinline__ void trace_queue(const WideSceneDev& sc, const Wf2Buf
     if (JPT_LATE_HIT_STORE && unsaved) save_hit();
 }
 
-template <bool COUNT, bool W4, bool TAIL = false, bool FLAT = false>
+template <bool COUNT, bool W4, bool TAIL = false>
 __global__ __launch_bounds__(kBlock, JPT_WAVES_PER_SIMD) void wf2_trace(WideSceneDev sc, Wf2Buffers wb, Wf2Dims dm, int bounce, WfTune tune,
                                                     int chain, DevCounters* __restrict__ counters)
 {
@@ -734,7 +727,7 @@ __global__ __launch_bounds__(kBlock, JPT_WAVES_PER_SIMD) void wf2_trace(WideScen
     if (threadIdx.x == 0) s_cursor = 0;
     __syncthreads();
     DevCounters cnt = {};
-    trace_queue<COUNT, W4, TAIL, FLAT>(sc, wb, dm, bounce, tune, seg0, end, n, stack, &s_cursor, cnt);
+    trace_queue<COUNT, W4, TAIL>(sc, wb, dm, bounce, tune, seg0, end, n, stack, &s_cursor, cnt);
     if (COUNT) flush_counters(cnt, counters);
 }
 
@@ -1502,13 +1495,6 @@ void launch_wf2_render(hipStream_t stream, const DeviceScene& ds, const FramePar
     sc.n_instances = ds.n_instances;
     sc.reach_tri = ds.reach_tri;
     sc.reach_inst = ds.reach_inst;
-    // the one-level tree of a static scene (build_flat): the same triangles and instance matrices under other records
-    const bool flat_ok = w4 && ds.flat_ok && ds.flat_nodesq != nullptr;
-    WideSceneDev sc_flat = sc;
-    sc_flat.nodesq = ds.flat_nodesq;
-    sc_flat.tlas_root = ds.flat_root;
-    sc_flat.flat_tri_bits = ds.flat_tri_bits;
-    sc_flat.flat_cnt_bits = ds.flat_cnt_bits;
     SceneShading sh = ds.shading();
     if (tuning().reach == 0) sh.reach_tri = nullptr;
     const dim3 block(kBlock);
@@ -1533,16 +1519,15 @@ void launch_wf2_render(hipStream_t stream, const DeviceScene& ds, const FramePar
         // cost 9 %).
         const dim3 sgrid(((dm.seg_cap + kBlock - 1) / kBlock) | 1u, kSegments);
         if (ev) (void)hipEventRecord(ev[0], st);
-        {
-            const bool flat = async.flat_primary && flat_ok;
-            const WideSceneDev& ps = flat ? sc_flat : sc;
-#define JPT_PRIMARY(C, W, T, F) hipLaunchKernelGGL((wf2_primary<C, W, T, F>), pgrid, block, 0, st, ps, wb, dm, gp, cam, tune, async.cull, counters)
-#define JPT_PRIMARY_C(W, T, F) do { if (counters) JPT_PRIMARY(true, W, T, F); else JPT_PRIMARY(false, W, T, F); } while (0)
-            if (!w4) JPT_PRIMARY_C(false, false, false);
-            else if (flat) { if (tail) JPT_PRIMARY_C(true, true, true); else JPT_PRIMARY_C(true, false, true); }
-            else { if (tail) JPT_PRIMARY_C(true, true, false); else JPT_PRIMARY_C(true, false, false); }
-#undef JPT_PRIMARY_C
-#undef JPT_PRIMARY
+        if (tail) {
+            if (counters) hipLaunchKernelGGL((wf2_primary<true, true, true>), pgrid, block, 0, st, sc, wb, dm, gp, cam, tune, async.cull, counters);
+            else hipLaunchKernelGGL((wf2_primary<false, true, true>), pgrid, block, 0, st, sc, wb, dm, gp, cam, tune, async.cull, counters);
+        } else if (counters) {
+            if (w4) hipLaunchKernelGGL((wf2_primary<true, true>), pgrid, block, 0, st, sc, wb, dm, gp, cam, tune, async.cull, counters);
+            else hipLaunchKernelGGL((wf2_primary<true, false>), pgrid, block, 0, st, sc, wb, dm, gp, cam, tune, async.cull, counters);
+        } else {
+            if (w4) hipLaunchKernelGGL((wf2_primary<false, true>), pgrid, block, 0, st, sc, wb, dm, gp, cam, tune, async.cull, counters);
+            else hipLaunchKernelGGL((wf2_primary<false, false>), pgrid, block, 0, st, sc, wb, dm, gp, cam, tune, async.cull, counters);
         }
         if (ev) (void)hipEventRecord(ev[1], st);
         for (int b = 0; b <= gp.max_bounces; b++) {
@@ -1569,16 +1554,15 @@ void launch_wf2_render(hipStream_t stream, const DeviceScene& ds, const FramePar
             }
             if (b == gp.max_bounces) break;
             if (ev) (void)hipEventRecord(ev[2 * (b + 1)], st);
-            {
-                const bool flat = async.flat_bounce && flat_ok;
-                const WideSceneDev& ts = flat ? sc_flat : sc;
-#define JPT_TRACE(C, W, T, F) hipLaunchKernelGGL((wf2_trace<C, W, T, F>), tgrid, block, 0, st, ts, wb, dm, b + 1, tune, chain, counters)
-#define JPT_TRACE_C(W, T, F) do { if (counters) JPT_TRACE(true, W, T, F); else JPT_TRACE(false, W, T, F); } while (0)
-                if (!w4) JPT_TRACE_C(false, false, false);
-                else if (flat) { if (tail) JPT_TRACE_C(true, true, true); else JPT_TRACE_C(true, false, true); }
-                else { if (tail) JPT_TRACE_C(true, true, false); else JPT_TRACE_C(true, false, false); }
-#undef JPT_TRACE_C
-#undef JPT_TRACE
+            if (tail) {
+                if (counters) hipLaunchKernelGGL((wf2_trace<true, true, true>), tgrid, block, 0, st, sc, wb, dm, b + 1, tune, chain, counters);
+                else hipLaunchKernelGGL((wf2_trace<false, true, true>), tgrid, block, 0, st, sc, wb, dm, b + 1, tune, chain, counters);
+            } else if (counters) {
+                if (w4) hipLaunchKernelGGL((wf2_trace<true, true>), tgrid, block, 0, st, sc, wb, dm, b + 1, tune, chain, counters);
+                else hipLaunchKernelGGL((wf2_trace<true, false>), tgrid, block, 0, st, sc, wb, dm, b + 1, tune, chain, counters);
+            } else {
+                if (w4) hipLaunchKernelGGL((wf2_trace<false, true>), tgrid, block, 0, st, sc, wb, dm, b + 1, tune, chain, counters);
+                else hipLaunchKernelGGL((wf2_trace<false, false>), tgrid, block, 0, st, sc, wb, dm, b + 1, tune, chain, counters);
             }
             if (ev) (void)hipEventRecord(ev[2 * (b + 1) + 1], st);
         }

@@ -37,9 +37,6 @@ struct WideSceneDev {
     uint32_t n_instances;
     const ReachTri* __restrict__ reach_tri;      // reach records (jpt_types.h); read by Traversal<.., REACH = true> only
     const ReachInst* __restrict__ reach_inst;
-    // FLAT walks (one world-space level, build_flat in jpt_builder.cpp): nodesq / tlas_root are that tree's records and root, and a
-    // leaf reference is ~(first triangle | (count - 1) << flat_tri_bits | instance << (flat_tri_bits + flat_cnt_bits))
-    uint32_t flat_tri_bits = 0, flat_cnt_bits = 0;
 };
 
 __device__ __forceinline__ float4 ld4(const void* p) { return *reinterpret_cast<const float4*>(p); }
@@ -78,13 +75,8 @@ struct TraceHit {
 // have reached (wf2_redo, jpt_kernels_wf2.hip): an instance is entered only if the world ray passes the world box the
 // reference gives it, and a triangle is accepted only if the local ray passes the box of its reference leaf -- the two
 // tests that decide reachability in main.glsl:270-350 (jpt_types.h, reach records).
-// FLAT = true walks the one-level world-space tree of a static scene: every record's boxes are tested with the WORLD ray (rD, ood
-// stay the world ray's for the whole walk), there is no instance entry and nothing to leave; a leaf names its instance, and the
-// instance's local ray (o, d: main.glsl:319-320's expression, instance_step's arithmetic) is made in the leaf step when the
-// instance is not the one the lane last made it for.
-template <bool COUNT, bool W4 = false, bool REACH = false, bool FLAT = false>
+template <bool COUNT, bool W4 = false, bool REACH = false>
 struct Traversal {
-    static_assert(!FLAT || (W4 && !REACH), "the one-level tree has four-child records; exact re-walks take the two levels");
     // The native route's four-child records are 64-byte quantised records (jpt_nodeq.h: four 16-byte loads instead of
     // seven and a third fewer VALU instructions -- the kernel sits at two thirds of its VALU issue capacity with the CU's
     // load-instruction rate next) walked with box tests that only have to be
@@ -149,8 +141,8 @@ struct Traversal {
         hit.tri = hit.inst = 0;
         hit.front = false;
         sp = 0;
-        in_blas = FLAT;                      // (FLAT: every negative reference is a triangle leaf)
-        cur_inst = FLAT ? 0xffffffffu : 0u;  // (FLAT: no instance's local ray made yet)
+        in_blas = false;
+        cur_inst = 0;
         cur = sc.tlas_root;
         have = sc.n_instances != 0;
     }
@@ -162,11 +154,10 @@ struct Traversal {
             // Reciprocals are kept FINITE (|rD| <= 2^100: kRcpClamp, jpt_nodeq.h).  With rD = inf for a direction component of exactly 0
             // the plane distances q * (scale * rD) + (origin * rD - o * rD) are inf - inf = NaN, the min / max drop them, and the axis
             // is not tested at all: still conservative, but a ray that lies IN a coordinate plane (a camera on an axis of the scene
-            // and the centre row or column of the image) then enters every box that lines up on the other two axes -- a few dozen
-            // records on a TLAS, up to 1 900 on the one-level tree of C3, where such a ray stays in world space for its whole walk
-            // (round 6: eight of 16.6 M primary rays held the primary launch for 1.7 ms instead of 0.2).  Clamped, the component
-            // counts as 2^-100 instead of 0: the ray leaves its plane by less than 1e-20 over any walk, and planes off the ray's
-            // own coordinate get +-huge distances of the right signs.
+            // and the centre row or column of the image) then enters every box that lines up on the other two axes -- up to 1 900
+            // records on a world-space tree of C3 (round 6, profiles/r06/r06f_*: eight of 16.6 M primary rays held a launch for 1.7 ms
+            // instead of 0.2).  Clamped, the component counts as 2^-100 instead of 0: the ray leaves its plane by less than 1e-20 over
+            // any walk, and planes off the ray's own coordinate get +-huge distances of the right signs.
             rD = mk3(__builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(d.x), -kRcpClamp, kRcpClamp), __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(d.y), -kRcpClamp, kRcpClamp),
                      __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(d.z), -kRcpClamp, kRcpClamp));
             ood = mk3(-(o.x * rD.x), -(o.y * rD.y), -(o.z * rD.z));
@@ -179,8 +170,8 @@ struct Traversal {
     // ---- the three kinds of records, as separate pieces so a kernel can run them in phases ----------------
 
     __device__ __forceinline__ bool wants_node() const { return have && cur >= 0; }
-    __device__ __forceinline__ bool wants_leaf() const { return have && cur < 0 && (FLAT || in_blas); }
-    __device__ __forceinline__ bool wants_instance() const { return !FLAT && have && cur < 0 && !in_blas; }
+    __device__ __forceinline__ bool wants_leaf() const { return have && cur < 0 && in_blas; }
+    __device__ __forceinline__ bool wants_instance() const { return have && cur < 0 && !in_blas; }
     __device__ __forceinline__ bool finished() const { return !have && sp == 0; }
 
     // four-child record: four box tests on the quantised planes, children visited nearest first.  The order among
@@ -200,7 +191,7 @@ struct Traversal {
     __device__ __forceinline__ void node_step4_rec(const float4 h0, const float4 h1, const float4 h2, const float4 cf, const Stack& st, DevCounters& cnt)
     {
         if (COUNT) {
-            if (FLAT || in_blas) cnt.blas_expand++;
+            if (in_blas) cnt.blas_expand++;
             else cnt.tlas_expand++;
         }
         // t = (origin + q * scale - o) * rD = q * (scale * rD) + (origin * rD + ood)
@@ -222,8 +213,7 @@ struct Traversal {
         const float nbz = __builtin_fmaf(-kPlaneSlack, __builtin_fabsf(az), bz), fbz = __builtin_fmaf(kPlaneSlack, __builtin_fabsf(az), bz);
 #endif
         // the plane words a ray meets first / last on each axis: lo / hi, swapped where the direction is negative
-        const f3& bd = FLAT ? wd : d;   // the direction the boxes are tested with (FLAT: d is a leaf's local direction)
-        const bool negx = __float_as_int(bd.x) < 0, negy = __float_as_int(bd.y) < 0, negz = __float_as_int(bd.z) < 0;
+        const bool negx = __float_as_int(d.x) < 0, negy = __float_as_int(d.y) < 0, negz = __float_as_int(d.z) < 0;
         const uint32_t lox = __float_as_uint(h1.z), loy = __float_as_uint(h1.w), loz = __float_as_uint(h2.x);
         const uint32_t hix = __float_as_uint(h2.y), hiy = __float_as_uint(h2.z), hiz = __float_as_uint(h2.w);
         const uint32_t nwx = negx ? hix : lox, fwx = negx ? lox : hix;
@@ -311,16 +301,8 @@ struct Traversal {
     __device__ __forceinline__ void leaf_step(const WideSceneDev& sc, DevCounters& cnt)
     {
         const uint32_t bits = (uint32_t)~cur;
-        uint32_t first = bits & kLeafFirstMask;
-        uint32_t count = (bits >> kLeafCountShift) + 1u;
-        bool enter = false;   // FLAT: this leaf belongs to another instance than the one o, d are the local ray of
-        uint32_t leaf_inst = 0u;
-        if (FLAT) {
-            first = bits & ((1u << sc.flat_tri_bits) - 1u);
-            count = ((bits >> sc.flat_tri_bits) & ((1u << sc.flat_cnt_bits) - 1u)) + 1u;
-            leaf_inst = bits >> (sc.flat_tri_bits + sc.flat_cnt_bits);
-            enter = leaf_inst != cur_inst;
-        }
+        const uint32_t first = bits & kLeafFirstMask;
+        const uint32_t count = (bits >> kLeafCountShift) + 1u;
         have = false;
         for (uint32_t i = 0; i < count; i++) {
             const uint32_t ti = first + i;
@@ -328,19 +310,6 @@ struct Traversal {
             const float4 q0 = ld4(&tp->v0[0]);
             const float4 q1 = ld4(&tp->e1[0]);
             const float4 q2 = ld4(&tp->e2[0]);
-            if (FLAT && enter) {   // (after the triangle's loads have been asked for: the matrix arrives with them)
-                enter = false;
-                cur_inst = leaf_inst;
-                const WideInstance* ip = sc.instances + leaf_inst;
-                const float4 m0 = ld4(&ip->inv[0]);
-                const float4 m1 = ld4(&ip->inv[4]);
-                const float4 m2 = ld4(&ip->inv[8]);
-                if (COUNT) cnt.inst_visits++;
-                o = mk3(m0.x * wo.x + m0.w * wo.y + m1.z * wo.z + m2.y, m0.y * wo.x + m1.x * wo.y + m1.w * wo.z + m2.z,
-                        m0.z * wo.x + m1.y * wo.y + m2.x * wo.z + m2.w);
-                d = mk3(m0.x * wd.x + m0.w * wd.y + m1.z * wd.z, m0.y * wd.x + m1.x * wd.y + m1.w * wd.z,
-                        m0.z * wd.x + m1.y * wd.y + m2.x * wd.z);
-            }
             if (COUNT) cnt.tri_tests++;
             const f3 v0 = mk3(q0.x, q0.y, q0.z), edge1 = mk3(q1.x, q1.y, q1.z), edge2 = mk3(q2.x, q2.y, q2.z);
             if (W4) {
@@ -451,7 +420,7 @@ struct Traversal {
     __device__ __forceinline__ void pop_next(const Stack& st)
     {
         cur = pop(st);
-        if (!FLAT && cur == kSentinel) {
+        if (cur == kSentinel) {
             in_blas = false;
             if (sp == 0) return;   // the instance was the last record of the walk: nobody needs the world ray's constants any more
             cur = pop(st);
@@ -477,7 +446,7 @@ struct Traversal {
             if (!have) return false;
         }
         if (cur >= 0) node_step(sc, st, cnt);
-        else if (FLAT || in_blas) leaf_step(sc, cnt);
+        else if (in_blas) leaf_step(sc, cnt);
         else instance_step(sc, st, cnt);
         return true;
     }

@@ -42,11 +42,6 @@ struct Tuning {
     int tail_rounds = 128;         // JPT_TAIL_ROUNDS: ... from this many rounds after the block's queue ran dry
     int tail_lanes = 8;            // JPT_TAIL_LANES: ... once a wave is down to this many rays
     int collapse = 3;              // JPT_COLLAPSE: two-child records merged into four-child ones by the least-area plan (jpt_builder.cpp, CollapsePlan) -- 0 greedily (the largest box first: rounds 1-4), 1 the TLAS, 2 the meshes' trees, 3 both
-    int flat = -1;                 // JPT_FLAT: one world-space level beside the two (build_flat, jpt_builder.cpp) -- -1 static native scenes of up to
-                                   // flat_max_tris instanced triangles, 0 never, 1 whatever the size
-    long flat_max_tris = 262144;   // JPT_FLAT_MAX_TRIS
-    int flat_launches = 3;         // JPT_FLAT_LAUNCHES: which launches walk it -- bit 0 the primary launch, bit 1 the bounce launches
-    long flat_cut = 0;             // JPT_FLAT_CUT: subtrees the one-level tree's top is built over (0: 64 per instance)
     int instance_boxes = 1024;     // JPT_INSTANCE_BOXES: a native scene's instance boxes bound up to this many boxes of the mesh's tree, transformed one by one
                                    // (1: the root box's corners, as the reference's rule and rounds 1-4)
 };
@@ -89,10 +84,6 @@ inline const Tuning& tuning()
         v.tail_lanes = geti("JPT_TAIL_LANES", 8);
         v.collapse = geti("JPT_COLLAPSE", 3);
         v.instance_boxes = geti("JPT_INSTANCE_BOXES", 1024);
-        v.flat = geti("JPT_FLAT", -1);
-        if (const char* e = std::getenv("JPT_FLAT_MAX_TRIS")) v.flat_max_tris = std::atol(e);
-        if (const char* e = std::getenv("JPT_FLAT_CUT")) v.flat_cut = std::atol(e);
-        v.flat_launches = geti("JPT_FLAT_LAUNCHES", 3);
         v.exact_shadow = geti("JPT_EXACT_SHADOW", 1) != 0;
         if (const char* e = std::getenv("JPT_SET_ASIDE_CAP")) v.set_aside_cap = std::atol(e);
         if (const char* e = std::getenv("JPT_UPLOAD_WALK")) v.upload_as_given = e[0] == 'g' || e[0] == 'G';

@@ -133,15 +133,6 @@ class Context:
             self._ck(rc, "jpt_scene_ties_exact")
         return bool(rc), (why.value.decode() if why.value else "")
 
-    def levels(self):
-        """(levels, why): 1 when the default kernels walk the one world-space level of a static native scene, else 2 and the reason
-        (jpt_scene_levels)."""
-        why = C.c_char_p()
-        rc = self._lib.jpt_scene_levels(self.h, C.byref(why))
-        if rc < 0:
-            self._ck(rc, "jpt_scene_levels")
-        return rc, (why.value.decode() if why.value else "")
-
     def upload_note(self) -> str:
         msg = self._lib.jpt_scene_upload_note(self.h)
         return msg.decode() if msg else ""

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define JPT_ABI_VERSION 7
+#define JPT_ABI_VERSION 6
 
 typedef struct jpt_ctx jpt_ctx;
 
@@ -255,17 +255,6 @@ const char *jpt_scene_upload_note(const jpt_ctx *ctx);
  * the restricted walk needs -- such an upload still renders on the native tree with reach records; only the winners of exact
  * ties may differ from the reference's.  jpt_stats.set_aside keeps counting the tied vertices either way.  Negative: JPT_E_*. */
 int jpt_scene_ties_exact(jpt_ctx *ctx, const char **why_out);
-/* ABI 7.  How many levels the default kernels walk for the scene this context holds.  The reference walks two (a TLAS over the
- * instances' boxes, then the instance's own tree: main.glsl:305-350), and so do the reference-layout trees here.  For a native
- * scene (JPT_BUILD_SAH / _WATERTIGHT, or a native upload) whose instanced triangles number at most 262 144 the library also
- * builds ONE world-space level over all of them -- each leaf names its instance, whose local ray (main.glsl:319-320's expression)
- * is made in the leaf, so the triangle tests and the image are the two-level walk's bit for bit -- and walks that instead: no
- * instance entries, a third fewer record steps on the demo scene.  Returns 1 then; 2 otherwise, with the
- * reason in *why_out (may be NULL; valid until the next scene call): a reference tree, a scene too large, transforms too far from
- * their stored inverses for world-space boxes -- or instances that have MOVED: jpt_scene_update_tlas, jpt_scene_refit_tlas and
- * jpt_scene_update_reference_tlas keep the two levels (which is what they update, in milliseconds) and drop the one-level tree
- * until the next jpt_scene_commit / upload.  JPT_FLAT=0 in the environment: never.  Negative: JPT_E_*.  No reference counterpart. */
-int jpt_scene_levels(jpt_ctx *ctx, const char **why_out);
 
 /* ---- scene ingest, route (ii): native build --------------------------------------------------- */
 

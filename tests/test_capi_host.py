@@ -20,7 +20,7 @@ def test_every_declared_symbol_is_exported(hiplib):
     for name in declared:
         assert hasattr(hiplib, name), "libjpt_hip.so does not export %s" % name
     assert sorted(capi.SYMBOLS) == declared
-    assert hiplib.jpt_abi_version() == 7
+    assert hiplib.jpt_abi_version() == 6
 
 
 def test_no_gpu_means_loud_failure_not_fallback(hiplib):

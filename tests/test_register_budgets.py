@@ -15,12 +15,10 @@ SRC = os.path.join(ROOT, "gdpathtracing_amd", "csrc", "jpt_kernels_wf2.hip")
 
 # kernel (mangled-name fragment) -> (most VGPRs, most bytes of scratch per lane, most scratch instructions in the body)
 BUDGETS = {
-    "9wf2_traceILb0ELb1ELb0ELb0E": (72, 320, 12),       # seven waves per SIMD; scratch = the stack entries past the LDS part, rarely touched
-    "9wf2_traceILb0ELb1ELb1ELb0E": (72, 1024, 80),      # ... with the tail phase's out-of-line call behind the loop
-    "9wf2_traceILb0ELb1ELb0ELb1E": (72, 320, 12),       # the one-level tree's walk (FLAT)
-    "11wf2_primaryILb0ELb1ELb0ELb0E": (72, 320, 14),    # (one spilled word in the refill path since round 5: stored at entry, read once per refill)
-    "11wf2_primaryILb0ELb1ELb1ELb0E": (72, 1100, 90),
-    "11wf2_primaryILb0ELb1ELb0ELb1E": (72, 320, 14),
+    "9wf2_traceILb0ELb1ELb0E": (72, 320, 12),       # seven waves per SIMD; scratch = the stack entries past the LDS part, rarely touched
+    "9wf2_traceILb0ELb1ELb1E": (72, 1024, 80),      # ... with the tail phase's out-of-line call behind the loop
+    "11wf2_primaryILb0ELb1ELb0E": (72, 320, 14),    # (one spilled word in the refill path since round 5: stored at entry, read once per refill)
+    "11wf2_primaryILb0ELb1ELb1E": (72, 1100, 90),
     "9wf2_shadeILb0ELb0ELi0E": (72, 0, 0),          # no texture array: 67
     "9wf2_shadeILb0ELb0ELi1E": (72, 0, 0),          # nearest filter
     "9wf2_shadeILb0ELb0ELi2E": (72, 0, 0),          # linear filter

@@ -1,4 +1,4 @@
-# one-level tree against two levels: per-launch times (serial launches), walk-length statistics, counters.  JPT_FLAT=0/1 python tools/flat_diag.py [closeup]
+# walk-length statistics of a counting C3 render, per-launch times with serial launches, blocking render time.   python tools/walk_diag.py [closeup]
 import os, sys; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from gdpathtracing_amd import capi, host, scenes
@@ -7,7 +7,6 @@ if len(sys.argv) > 1 and sys.argv[1] == "closeup":
     sc.camera = scenes.CameraDesc(scenes.transform12(None, (0.0, 0.0, 4.2)), fov_deg=75.0)
 W, H = 1920, 1080
 ctx = host.Context(0); ctx.build_scene(sc, capi.BUILD_SAH); ctx.set_params(W, H, 4, 0); ctx.set_camera(scenes.camera_block(sc.camera, W, H))
-print("levels", ctx.levels())
 ctx.render(8, 1, counted=True); st = ctx.stats()
 print("walk max", st["walk_steps_max"], "hist", st["walk_steps_hist"])
 ctx.set_kernel_timing(True)
