@@ -228,6 +228,11 @@ def main():
                          "on the ONE device, add the modelled link time of the gather (piece bytes / 153 GB/s per xGMI link, every peer "
                          "on its own link) and the measured assembly, and report it as `projected_scaling` (measured: false) -- what "
                          "the line can say about 2/4/8 GPUs without a multi-GPU node; 0 or 1: skip")
+    ap.add_argument("--preheat-ms", type=float, default=100.0,
+                    help="before the W warm-up steps: keep the device busy with the workload's own renders for this long (untimed, like the "
+                         "set-up).  The device drops its clocks within a fraction of a second of idling and takes tens of milliseconds of load "
+                         "to raise them again: a queue of 20 renders (16 ms) started from idle reads 8-15 %% below the steady rate whatever the "
+                         "library does (profiles/r06/r06l_driver_form.txt); 0: none")
     ap.add_argument("--depth", action="store_true", help="also produce the r32f depth image every render (only the temporal mode reads it)")
     ap.add_argument("--cpu-sample", default="auto")
     ap.add_argument("--pmc-json", default=os.path.join(ROOT, "profiles", "current_pmc.json"),
@@ -265,12 +270,35 @@ def main():
         local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    # JPT_BENCH_FORCE_DIST=1: the N > 1 flow -- process group, gather, assembly, per-rank phase times, the C5 leg -- with a world of ONE
+    # rank: what a box with one GPU can rehearse of the driver's 8-GPU launch with the real backend (RCCL loaded beside the library's
+    # six slot streams; tests/test_gpu_full.py).  Needs MASTER_ADDR / MASTER_PORT like any rank.
+    use_dist = world > 1 or os.environ.get("JPT_BENCH_FORCE_DIST") == "1"
+    if use_dist:
+        import datetime
+        import threading
         import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        # a rendezvous or a first collective that hangs must be a RECORD, not the driver's 1 800 s limit: two minutes for the process
+        # group, and a watchdog around everything up to the first completed gather that says what hung and exits non-zero
+        limit = datetime.timedelta(seconds=120)
         if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank), timeout=limit)
         else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+            dist.init_process_group(backend, rank=rank, world_size=world, timeout=limit)
+
+        def _hung():
+            sys.stderr.write("bench.py: rank %d of %d: no gather completed within 240 s of the process group coming up (backend %s, "
+                             "HSA_ENABLE_IPC_MODE_LEGACY=%s, GPU_MAX_HW_QUEUES=%s, device %d): a peer-to-peer set-up that hangs -- "
+                             "check dmabuf IPC and that every rank reached its first dist.gather\n"
+                             % (rank, world, backend, os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"), os.environ.get("GPU_MAX_HW_QUEUES"), local_rank))
+            sys.stderr.flush()
+            os._exit(5)
+
+        watchdog = threading.Timer(240.0, _hung)
+        watchdog.daemon = True
+        watchdog.start()
 
     if args.scene == "demo":
         sc = scenes.demo_scene(args.tris)
@@ -330,7 +358,7 @@ def main():
     gp = {"piece": None, "gathered": None}
 
     def setup_gather():
-        if world == 1:
+        if not use_dist:
             return
         ptr, nbytes = ctx.device_ldr() if args.gather == "ldr" else ctx.device_accum()
         typestr, tdtype = ("<i4", torch.int32) if args.gather == "ldr" else ("<f4", torch.float32)
@@ -367,7 +395,7 @@ def main():
     def step():
         ctx.accum_reset()
         ctx.render(cur["spp"], 1, asynchronous=True)
-        if world > 1:
+        if use_dist:
             gather()
             assemble()
 
@@ -400,7 +428,7 @@ def main():
         ctx.render(n_spp or spp, 1, counted=True)
         st = ctx.stats()
         t = torch.tensor([st[k] for k in COUNTER_KEYS], dtype=torch.int64, device="cuda" if backend == "nccl" else "cpu")
-        if world > 1:
+        if use_dist:
             dist.all_reduce(t)
         return dict(zip(COUNTER_KEYS, (int(x) for x in t.tolist())))
 
@@ -410,7 +438,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -421,7 +449,7 @@ def main():
         barrier()
         elapsed = time.perf_counter() - t0
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
-        if world > 1:
+        if use_dist:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
@@ -430,6 +458,20 @@ def main():
     # as "no warm-up steps", not as "time the resource creation").
     step()
     barrier()
+    if use_dist:
+        watchdog.cancel()   # the first gather (and the barrier behind it) completed on every rank
+    # ... and so are the device's clocks: everything up to here was blocking renders with host work in between, and the device clocks
+    # down when it idles.  The workload's own renders, queued, for --preheat-ms (reported in config.preheat_ms); then the W warm-up steps.
+    def preheat():
+        n, t_heat = 0, time.perf_counter()
+        while (time.perf_counter() - t_heat) * 1e3 < args.preheat_ms:
+            for _ in range(10):
+                step()
+            barrier()
+            n += 10
+        return n
+
+    preheat_steps = preheat()
     for _ in range(args.warmup):
         step()
     barrier()
@@ -442,14 +484,14 @@ def main():
     renders_in_flight = ctx.renders_in_flight()   # 6 where six of the library's streams run side by side, else 4
     gpu_image = ctx.read_accum() if (world == 1 and rank == 0) else None   # the image the timed region left behind (parity)
     verified = None
-    if (args.verify or world > 1) and rank == 0:   # N > 1: always -- the assembled image of the last timed step against one context's
-        got = ctx.read_ldr() if (world > 1 and args.gather == "ldr") else ctx.read_accum()
+    if (args.verify or use_dist) and rank == 0:   # N > 1: always -- the assembled image of the last timed step against one context's
+        got = ctx.read_ldr() if (use_dist and args.gather == "ldr") else ctx.read_accum()
         solo = host.Context(local_rank)
         solo.build_scene(sc, builder)
         solo.set_params(W, H, bounces, accum_mode)
         solo.set_camera(cam)
         solo.render(spp, 1)
-        verified = bool(np.array_equal(got, solo.read_ldr() if (world > 1 and args.gather == "ldr") else solo.read_accum()))
+        verified = bool(np.array_equal(got, solo.read_ldr() if (use_dist and args.gather == "ldr") else solo.read_accum()))
         solo.close()
 
     # Launch durations of the traversal kernels, measured live with HIP events on the stream they are launched on: the
@@ -483,8 +525,16 @@ def main():
     # N > 1: what the ranks spend where, and a second timed region at C5's size -- the configuration BASELINE.json tiles
     # over 8 GPUs (3840x2160, 16 spp, 6 bounces: 8 ms of work on one GPU, against C3's 1 ms and eleven dependent launches)
     multi = None
-    if world > 1:
+    if use_dist:
         multi = {"ranks_seen": dist.get_world_size(), "backend": backend}
+        # what every rank ran with (VERDICT r05 task 2d): the two variables a multi-process run depends on, and the renders the
+        # library kept in flight there
+        mine = {"rank": rank, "local_rank": local_rank, "device": torch.cuda.get_device_name(local_rank),
+                "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"), "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"),
+                "renders_in_flight": renders_in_flight}
+        every = [None] * world
+        dist.all_gather_object(every, mine)
+        multi["ranks"] = every
         try:
             multi["rccl_version"] = ".".join(str(x) for x in torch.cuda.nccl.version()) if backend == "nccl" else None
         except Exception:
@@ -522,7 +572,7 @@ def main():
 
     # ---- what 2 / 4 / 8 GPUs would do, projected from ONE: each rank's share timed here, the link modelled (VERDICT r04 task 2) ----
     projected = None
-    if world == 1 and args.project_ranks > 1 and args.kernel == "wavefront":
+    if world == 1 and not use_dist and args.project_ranks > 1 and args.kernel == "wavefront":
         XGMI_LINK_GBS = 153.0     # ~153 GB/s per xGMI link, one link per peer pair
         LINK_LATENCY_MS = 0.01    # one peer copy's fixed cost (order of magnitude of a hipMemcpyPeerAsync on an idle link)
 
@@ -615,12 +665,13 @@ def main():
 
     # the close-up camera on the same context: every pixel sees geometry, so rays/s here is the traversal rate proper
     closeup = None
-    if world == 1 and args.camera == "demo" and args.scene == "demo" and not args.no_closeup:
+    if world == 1 and not use_dist and args.camera == "demo" and args.scene == "demo" and not args.no_closeup:
         ctx.set_camera(scenes.camera_block(closeup_camera, W, H))
         ctx.accum_reset()
         ctx.render(spp, 1)
         c_rays = ctx.stats()["rays"]
         c_steps = max(10, args.steps)   # (as many as the headline: the timed region includes the pipeline's fill and drain)
+        preheat()
         for _ in range(2):
             step()
         barrier()
@@ -632,7 +683,7 @@ def main():
     # the drop-in route on the same workload: the reference-layout arrays of the same scene handed to
     # jpt_scene_upload_reference_layout (what the addon does when GeometryGroup3D::build() stays), on a second context
     dropin = None
-    if world == 1 and args.route == "commit" and args.kernel == "wavefront" and not args.no_dropin and gpu_image is not None:
+    if world == 1 and not use_dist and args.route == "commit" and args.kernel == "wavefront" and not args.no_dropin and gpu_image is not None:
         arrs = reference_layout_arrays()
         dctx = host.Context(local_rank)
         t0 = time.perf_counter()
@@ -650,6 +701,7 @@ def main():
             d_rays = dctx.stats()["rays"]
             step()
             barrier()
+            preheat()                      # (the upload above was host work: the device has idled and clocked down)
             for _ in range(2):
                 step()
             barrier()
@@ -823,6 +875,7 @@ def main():
                 "parallelism": "screen strips x%d" % world + ("" if world == 1 else ", gather of %s rows to rank 0" % ("rgba8 display" if args.gather == "ldr" else "float4 accumulation")),
                 "scene_build_s": round(build_s, 4),
                 "renders_in_flight": renders_in_flight, "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"),
+                "preheat_ms": args.preheat_ms, "preheat_steps": preheat_steps,
                 "outputs": "float4 accumulation + rgba8 display" + (" + r32f depth" if args.depth else " (depth image off: only temporal reprojection reads it)"),
             },
             "roofline": roofline,
@@ -907,7 +960,7 @@ def main():
                 status = 3
         print(json.dumps(out))
     ctx.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
     if status:
         sys.stderr.write("bench.py: parity above tolerance\n")

@@ -51,8 +51,9 @@ def gather_to_rank0(piece, dist, rank: int, world: int, gathered=None):
     fallback: a backend that cannot gather raises (an all_gather in its place would put 8x the bytes on every link
     without anybody noticing)."""
     import torch
-    if world == 1:
+    if world == 1 and (dist is None or not dist.is_initialized()):
         return piece.unsqueeze(0)
+    # (a process group of ONE rank still goes through the backend: that is how the GPU box's single device rehearses the RCCL call)
     if rank == 0 and gathered is None:
         gathered = torch.empty((world,) + tuple(piece.shape), dtype=piece.dtype, device=piece.device)
     dist.gather(piece, list(gathered.unbind(0)) if rank == 0 else None, dst=0)

@@ -932,6 +932,39 @@ def test_bench_self_launch_two_ranks_on_one_gpu(hiplib, launcher):
         assert d["multi_gpu"]["gather_plan"] == {"peer_copies": 1, "distinct_streams": 1, "own_piece_copies": 0}
 
 
+def test_bench_multi_gpu_flow_with_one_rank_of_rccl(hiplib):
+    """VERDICT r05 task 2b: the first time RCCL is loaded beside the library.  bench.py's N > 1 flow -- a torch.distributed process
+    group on the `nccl` backend (= RCCL), every step's dist.gather of the context's float4 rows through the ExternalStream the bench
+    orders its work on, jpt_assemble_from_ranks, the per-rank phase times (all_gather), the C5 leg -- with a world of ONE rank
+    (JPT_BENCH_FORCE_DIST=1), which is what a one-GPU box can run of it: RCCL's communicator and streams come up beside the six
+    high-priority slot streams and GPU_MAX_HW_QUEUES=6, and the assembled images are one context's, bit for bit."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "JPT_BENCH_BACKEND")}
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        env["MASTER_PORT"] = str(sk.getsockname()[1])
+    env["MASTER_ADDR"] = "127.0.0.1"
+    env["JPT_BENCH_FORCE_DIST"] = "1"
+    env.pop("GPU_MAX_HW_QUEUES", None)   # (bench.py's own default: six)
+    env.pop("HSA_ENABLE_IPC_MODE_LEGACY", None)   # (... and its own setdefault, as on the driver's torchrun form)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "6", "--warmup", "1", "--tris", "5000", "--no-cpu-baseline", "--preheat-ms", "0"]
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    m = d["multi_gpu"]
+    assert m["backend"] == "nccl" and m["ranks_seen"] == 1 and m["rccl_version"]
+    assert d["verified_bit_identical_to_one_context"] is True and m["c5"]["verified_bit_identical_to_one_context"] is True
+    r0 = m["ranks"][0]
+    assert r0["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" and r0["GPU_MAX_HW_QUEUES"] == "6" and r0["renders_in_flight"] in (4, 6)
+    assert len(m["c3_phase_ms_per_rank"]) == 1 and len(m["c3_phase_ms_per_rank"][0]) == 3
+
+
 @pytest.mark.parametrize("switch", ["JPT_TAIL=1 JPT_TAIL_ROUNDS=2 JPT_TAIL_LANES=8", "JPT_PRIMARY_SAMPLES=0",
                                     "JPT_GROUPS=3", "JPT_GROUPS=2 JPT_PRIMARY_SAMPLES=0", "JPT_COLLAPSE=0 JPT_INSTANCE_BOXES=1"])
 def test_alternative_tracing_launches_are_bit_identical(hiplib, switch):
