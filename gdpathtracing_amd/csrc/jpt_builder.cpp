@@ -249,8 +249,8 @@ struct SahBlasBuilder {
 #define JPT_SAH_BINS 16
 #endif
     static constexpr int kBins = JPT_SAH_BINS;
-    // largest leaf the builder keeps without a split that pays (JPT_MAX_LEAF overrides, for tuning runs)
-    static int max_leaf() { return tuning().max_leaf; }
+    // largest leaf the builder keeps without a split that pays
+    static int max_leaf() { return Tuning::max_leaf; }
 
     void prepare(int start, int end)
     {
@@ -774,11 +774,11 @@ struct InstanceCuts {
     int n_boxes;
     std::vector<std::pair<uint32_t, std::vector<Box>>> per_root;   // (a scene has few meshes; the boxes side by side, not scattered over the node array)
 
-    // JPT_INSTANCE_BOXES (1 024) boxes per instance while the scene's instances x boxes stay below 2^18 box transforms (a TLAS
+    // 1 024 boxes per instance while the scene's instances x boxes stay below 2^18 box transforms (a TLAS
     // update is meant to take milliseconds); never fewer than 16
     static int boxes_for(size_t n_instances)
     {
-        const int want = tuning().instance_boxes;
+        const int want = Tuning::instance_boxes;
         if (want <= 1) return want;
         const size_t share = ((size_t)1 << 18) / std::max<size_t>(n_instances, 1);
         return (int)std::max<size_t>(std::min<size_t>((size_t)want, share), std::min<size_t>((size_t)want, 16));
@@ -1345,7 +1345,7 @@ struct Flattener {
     // its size, not 2^depth), a node met again while its own subtree is still open is a cycle (kOpen: an error --
     // main.glsl:270-350 would never leave it), and no chain is followed deeper than kMaxDepth frames of the host
     // stack.  That loses nothing: the kernels' traversal stack holds fewer than 100 entries and a tree that could need
-    // more is refused after the flatten (compute_stack_need, jpt_capi.hip upload_scene), so a tree this deep was never
+    // more is refused after the flatten (compute_stack_need, jpt_capi.cpp upload_scene), so a tree this deep was never
     // going to be accepted; the bound only keeps collapse4 / need2 / need4, which recurse over what is made here, shallow.
     enum : uint8_t { kUnseen = 0, kOpen = 1, kDone = 2 };
     static constexpr uint32_t kMaxDepth = 512u;
@@ -1709,7 +1709,7 @@ struct Child4 {
     }
 };
 
-// JPT_COLLAPSE (bit 0: the TLAS, bit 1: the meshes' trees): WHICH two-child records become four-child records, chosen for the fewest expected record steps instead of
+// WHICH two-child records become four-child records (the TLAS and the meshes' trees alike), chosen for the fewest expected record steps instead of
 // greedily.  A ray that enters a kept record pays one step whatever the number of its slots, so the cost of a collapse is the sum
 // of the kept records' surface areas; the leaves are the same either way.  F(n, k) = least such sum below record n when n's
 // subtree may fill at most k slots of the kept record above it:
@@ -1775,20 +1775,15 @@ struct CollapsePlan {
 };
 thread_local CollapsePlan* tl_plan = nullptr;
 
-// collapse the subtree under two-child record `ni` of `src` into `dst`; returns the new record's index.
-// Order of the records in `dst` (JPT_NODE_ORDER, tuning().node_order): 0 = depth first (a record, then its first child's whole
-// subtree, ...), 1 = the up-to-four child records of a record next to each other (a 128-byte line holds two siblings), then
-// their subtrees.  `at` >= 0: the place the caller has already reserved for this record (memo[ni] == at).
-int32_t collapse4(const std::vector<WideNode>& src, std::vector<WideNode4>& dst, int32_t ni, std::vector<int32_t>& memo, int32_t at = -1)
+// collapse the subtree under two-child record `ni` of `src` into `dst` by the plan's cut; returns the new record's index.
+// Records are laid out depth first: a record, then its first child's whole subtree, ...  (Siblings side by side, two per
+// 128-byte line, measured no better: LAB_NOTEBOOK.md, round 5.)
+int32_t collapse4(const std::vector<WideNode>& src, std::vector<WideNode4>& dst, int32_t ni, std::vector<int32_t>& memo)
 {
-    if (at < 0 && memo[(size_t)ni] >= 0) return memo[(size_t)ni];
-    const bool siblings = tuning().node_order == 1;
-    int32_t self = at;
-    if (self < 0) {
-        self = (int32_t)dst.size();
-        memo[(size_t)ni] = self;
-        dst.emplace_back();
-    }
+    if (memo[(size_t)ni] >= 0) return memo[(size_t)ni];
+    const int32_t self = (int32_t)dst.size();
+    memo[(size_t)ni] = self;
+    dst.emplace_back();
     auto kids_of = [&](int32_t n, Child4* out) {
         const WideNode& w = src[(size_t)n];
         for (int k = 0; k < 3; k++) {
@@ -1801,7 +1796,7 @@ int32_t collapse4(const std::vector<WideNode>& src, std::vector<WideNode4>& dst,
     Child4 c[4];
     int n = 2;
     kids_of(ni, c);
-    if (tl_plan) {   // the plan's cut: slot budgets dealt down the two sides
+    {   // the plan's cut: slot budgets dealt down the two sides
         tl_plan->solve(ni);
         int budget[4] = {(int)tl_plan->pick[(size_t)ni * 3], 0, 0, 0};
         budget[1] = 4 - budget[0];
@@ -1822,38 +1817,8 @@ int32_t collapse4(const std::vector<WideNode>& src, std::vector<WideNode4>& dst,
             n++;   // (slot i is looked at again with its smaller budget)
         }
     }
-    while (!tl_plan && n < 4) {
-        int best = -1;
-        float best_area = -1.0f;
-        for (int i = 0; i < n; i++)
-            if (c[i].ref >= 0 && c[i].ref != ni) {  // internal (a self-reference marks an empty leaf record)
-                const WideNode& w = src[(size_t)c[i].ref];
-                if (w.left == c[i].ref && w.right == c[i].ref) continue;  // empty-leaf record: keep as is
-                const float a = c[i].area();
-                if (a > best_area) {
-                    best_area = a;
-                    best = i;
-                }
-            }
-        if (best < 0) break;
-        Child4 two[2];
-        kids_of(c[best].ref, two);
-        c[best] = two[0];
-        c[n++] = two[1];
-    }
     WideNode4 w;
     std::memset(&w, 0, sizeof w);
-    int32_t reserved[4] = {-1, -1, -1, -1};
-    if (siblings)   // places for the children first, side by side; their subtrees follow
-        for (int i = 0; i < n; i++) {
-            const int32_t r = c[i].ref;
-            if (r < 0) continue;
-            const WideNode& s2 = src[(size_t)r];
-            if ((s2.left == r && s2.right == r) || memo[(size_t)r] >= 0) continue;
-            reserved[i] = (int32_t)dst.size();
-            memo[(size_t)r] = reserved[i];
-            dst.emplace_back();
-        }
     for (int i = 0; i < 4; i++) {
         if (i < n) {
             w.lo_x[i] = c[i].lo[0]; w.lo_y[i] = c[i].lo[1]; w.lo_z[i] = c[i].lo[2];
@@ -1862,7 +1827,7 @@ int32_t collapse4(const std::vector<WideNode>& src, std::vector<WideNode4>& dst,
             if (r >= 0) {
                 const WideNode& s2 = src[(size_t)r];
                 if (s2.left == r && s2.right == r) r = kEmptyChild;  // empty-leaf record: nothing below
-                else r = collapse4(src, dst, r, memo, reserved[i]);
+                else r = collapse4(src, dst, r, memo);
             }
             w.child[i] = r;
         } else {
@@ -2001,7 +1966,7 @@ bool reflatten_tlas(const RefScene& ref, WideScene& out, bool with4, std::string
     if (with4) {
         std::vector<int32_t> memo_t(out.tlas_nodes.size(), -1);
         CollapsePlan plan_t(out.tlas_nodes);
-        tl_plan = (tuning().collapse & 1) ? &plan_t : nullptr;
+        tl_plan = &plan_t;
         out.tlas_root4 = collapse_root(out.tlas_nodes, out.tlas_nodes4, out.tlas_root, memo_t);
         tl_plan = nullptr;
     }
@@ -2017,14 +1982,14 @@ void flatten4(WideScene& out)
     out.instances4 = out.instances;
     {
         CollapsePlan plan(out.blas_nodes);
-        tl_plan = (tuning().collapse & 2) ? &plan : nullptr;
+        tl_plan = &plan;
         for (size_t i = 0; i < out.instances.size(); i++)
             out.instances4[i].root = collapse_root(out.blas_nodes, out.blas_nodes4, out.instances[i].root, memo);
         tl_plan = nullptr;
     }
     std::vector<int32_t> memo_t(out.tlas_nodes.size(), -1);
     CollapsePlan plan_t(out.tlas_nodes);
-    tl_plan = (tuning().collapse & 1) ? &plan_t : nullptr;
+    tl_plan = &plan_t;
     out.tlas_root4 = collapse_root(out.tlas_nodes, out.tlas_nodes4, out.tlas_root, memo_t);
     tl_plan = nullptr;
 }

@@ -1,4 +1,4 @@
-// jpt_capi.hip -- the C ABI of include/jpt.h over the HIP kernels and the host builder.
+// jpt_capi.cpp -- the C ABI of include/jpt.h over the HIP kernels and the host builder.
 #include "../../include/jpt.h"
 
 #include <hip/hip_runtime.h>
@@ -329,7 +329,6 @@ void note_ties(jpt_ctx* c)
     c->ties_note.clear();
     if (c->native_tree) {
         if (c->ref.reach_tri.empty()) c->ties_note = "the scene has no reach records (JPT_BUILD_SAH_WATERTIGHT): the native tree's order decides";
-        else if (!tuning().exact_shadow) c->ties_note = "switched off (JPT_EXACT_SHADOW=0)";
         else if (x.instances.empty()) c->ties_note.clear();   // nothing to hit
         else if (!x.valid) c->ties_note = "the reference's TLAS of this scene could not be built (TLAS::build, bvh.cpp:264-317)";
         else if (!x.resolvable)
@@ -348,7 +347,7 @@ int upload_shadow(jpt_ctx* c, bool instances_only)
     d.ok = false;
     const ExactShadow& x = c->ref.exact;
     note_ties(c);
-    if (!tuning().exact_shadow || !x.valid || !x.resolvable || !c->native_tree || c->ref.reach_tri.empty() || c->device < 0 || x.instances.empty())
+    if (!x.valid || !x.resolvable || !c->native_tree || c->ref.reach_tri.empty() || c->device < 0 || x.instances.empty())
         return JPT_OK;
     hipStream_t s = c->stream;
     if (!instances_only) {
@@ -690,7 +689,7 @@ bool ensure_group_streams(jpt_ctx* c, int groups)
             // one of the six queues the slots are measured to have to themselves (six_queues_probe).  A blocking render runs when
             // the renders queued before it have been ordered ahead of it on the context's stream; its groups queue behind whatever a
             // slot still holds.  (Normal / low slot priority chosen by the host: a stream of its own, as before.)
-            const bool borrow = c->slot_priority != JPT_STREAM_PRIORITY_NORMAL && c->slot_priority != JPT_STREAM_PRIORITY_LOW && tuning().slot_prio != 0;
+            const bool borrow = c->slot_priority != JPT_STREAM_PRIORITY_NORMAL && c->slot_priority != JPT_STREAM_PRIORITY_LOW;
             if (borrow) {
                 if (!ensure_pipe_slot(c, k)) return false;
                 c->async.aux_stream[k] = c->pipe_stream[k];
@@ -724,17 +723,12 @@ bool ensure_pipe_slot(jpt_ctx* c, int slot)
         // all slots normal 1.339 / 1.036 ms, all high 1.052 / 1.051, dealt over the three levels 1.230 / 1.212 (the normal-level
         // slot shares a queue with host streams), all low 1.137 / 1.135 (tools/prio_probe.sh, profiles/r02/prio_probe.txt).
         int least = 0, greatest = 0;
-        // (the embedding application decides per context with jpt_set_stream_priority; otherwise JPT_SLOT_PRIO / the default)
-        const int mode = c->slot_priority == JPT_STREAM_PRIORITY_NORMAL ? 0
-                         : c->slot_priority == JPT_STREAM_PRIORITY_HIGH ? 3
-                         : c->slot_priority == JPT_STREAM_PRIORITY_LOW ? 4 : tuning().slot_prio;
-        if (mode && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least > greatest) {
-            const int levels = least - greatest + 1;
-            const int prio = mode == 1 ? greatest + (slot % levels) : (mode == 2 ? (slot < 2 ? greatest : least) : (mode == 4 ? least : greatest));
-            ok = hipStreamCreateWithPriority(&c->pipe_stream[slot], hipStreamNonBlocking, prio) == hipSuccess;
-        } else {
+        // (the embedding application decides per context with jpt_set_stream_priority; the default is the highest level)
+        const bool normal = c->slot_priority == JPT_STREAM_PRIORITY_NORMAL, low = c->slot_priority == JPT_STREAM_PRIORITY_LOW;
+        if (!normal && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least > greatest)
+            ok = hipStreamCreateWithPriority(&c->pipe_stream[slot], hipStreamNonBlocking, low ? least : greatest) == hipSuccess;
+        else
             ok = hipStreamCreateWithFlags(&c->pipe_stream[slot], hipStreamNonBlocking) == hipSuccess;
-        }
     }
     if (ok && !c->ev_paths_done[slot]) ok = hipEventCreateWithFlags(&c->ev_paths_done[slot], hipEventDisableTiming) == hipSuccess;
     if (ok && !c->ev_acc_done[slot]) ok = hipEventCreateWithFlags(&c->ev_acc_done[slot], hipEventDisableTiming) == hipSuccess;
@@ -896,7 +890,7 @@ int do_render_batch(jpt_ctx* c, int32_t n_frames, uint32_t first_frame_index, bo
             const bool huge = one_workspace > ((size_t)24 << 30);  // 4 x 24 GiB of workspaces is where this stops
             // ... six where the slots' streams have six hardware queues to themselves (six_queues_probe), four otherwise
             const bool may_queue = wf2 && pipelining && !blocking && !counted;
-            const int pipe_slots = forced_slots ? forced_slots : (huge ? 2 : ((tuning().six_slots && may_queue && six_queues_probe(c)) ? 6 : 4));
+            const int pipe_slots = forced_slots ? forced_slots : (huge ? 2 : ((may_queue && six_queues_probe(c)) ? 6 : 4));
             const int slot = (int)(c->async_seq % (uint64_t)pipe_slots);
             if (may_queue) c->last_pipe_slots = pipe_slots;
             // A host that queues ONE render at a time (jpt_render_async, its own work, jpt_sync or the split read-back, again)
@@ -905,13 +899,13 @@ int do_render_batch(jpt_ctx* c, int32_t n_frames, uint32_t first_frame_index, bo
             // tools/lone_async_probe.py).  The third queued render in a row that finds nothing in flight -- the event every render
             // leaves on the context's stream has completed -- is launched like a blocking one instead (frame groups, full-width
             // launches; nobody waits for it here), and so on until a render finds work in flight.  A queue of renders is not
-            // affected: only its first render finds the pipeline empty.  (JPT_LONE_ASYNC=0: never.)
+            // affected: only its first render finds the pipeline empty.
             bool lone_async = false;
             if (wf2 && pipelining && !blocking && !counted && !need_ev) {
                 const bool idle = hipEventQuery(c->ev1) == hipSuccess;
                 (void)hipGetLastError();   // (hipErrorNotReady is an answer, not an error)
                 c->idle_streak = idle ? c->idle_streak + 1 : 0;
-                lone_async = tuning().lone_async && c->idle_streak >= 3;
+                lone_async = c->idle_streak >= 3;
             }
             if (wf2 && pipelining && !blocking && !counted && !need_ev && !lone_async && ensure_pipe_slot(c, slot)) {
                 // asynchronous render: path kernels on a helper stream + the other workspace; the accumulation on `s`
@@ -951,22 +945,14 @@ int do_render_batch(jpt_ctx* c, int32_t n_frames, uint32_t first_frame_index, bo
                 Wf2Async one_group = c->async;
                 one_group.aux_stream[0] = nullptr;
                 one_group.trace_chain = (huge || pipe_slots == 1) ? 1 : 4;   // (a single render in flight: full-width launches)
-                const bool acc_on_slot = tuning().acc_on_slot;
-                if (acc_on_slot) {
-                    // The accumulation runs on the slot's stream too, after whatever `s` holds now (the previous render's
-                    // accumulation, an upload, a read-back), and `s` then waits for it: the results are those of serial
-                    // execution, and `s` itself carries no kernels of a render -- the hardware runs four queues side by
-                    // side, and four slots plus a busy `s` were five (C3 1.287 -> 1.265 ms, a GPU's eighth of C3 329 -> 306 us)
-                    HIP_TRY(c, hipEventRecord(c->ev_paths_done[slot], s));
-                    one_group.before_acc = c->ev_paths_done[slot];
-                    launch_wf2_render(ps, c->ds, fp, c->camera, ws.p, c->d_accum.p, c->d_ldr.p, depth_img, nullptr, nullptr, one_group);
-                    HIP_TRY(c, hipEventRecord(c->ev_acc_done[slot], ps));
-                    HIP_TRY(c, hipStreamWaitEvent(s, c->ev_acc_done[slot], 0));
-                } else {
-                    launch_wf2_render(ps, c->ds, fp, c->camera, ws.p, c->d_accum.p, c->d_ldr.p, depth_img, nullptr, nullptr, one_group, s,
-                                      c->ev_paths_done[slot]);
-                    HIP_TRY(c, hipEventRecord(c->ev_acc_done[slot], s));
-                }
+                // The accumulation runs on the slot's stream too, after whatever `s` holds now (the previous render's accumulation, an
+                // upload, a read-back), and `s` then waits for it: the results are those of serial execution, and `s` itself carries no
+                // kernels of a render (the hardware runs a handful of queues side by side; a busy `s` would be one more)
+                HIP_TRY(c, hipEventRecord(c->ev_paths_done[slot], s));
+                one_group.before_acc = c->ev_paths_done[slot];
+                launch_wf2_render(ps, c->ds, fp, c->camera, ws.p, c->d_accum.p, c->d_ldr.p, depth_img, nullptr, nullptr, one_group);
+                HIP_TRY(c, hipEventRecord(c->ev_acc_done[slot], ps));
+                HIP_TRY(c, hipStreamWaitEvent(s, c->ev_acc_done[slot], 0));
                 c->acc_done_valid[slot] = true;
                 c->async_seq++;
                 pipelined = true;
@@ -1612,8 +1598,7 @@ int jpt_scene_refit_tlas(jpt_ctx* c, const float* transforms12, uint32_t n_insta
     // the host keeps the transforms (a later jpt_scene_update_tlas rebuilds from them); its arrays are stale from here on
     for (uint32_t i = 0; i < n_instances; i++) (void)c->builder.set_instance_transform(i, transforms12 + (size_t)i * 12);
     c->tlas_dirty = true;
-    const bool width2 = tuning().bvh_width == 2;
-    if (width2 || !c->ds.use4 || !c->scene_ready) return jpt_scene_update_tlas(c);  // no four-child records to refit
+    if (!c->ds.use4 || !c->scene_ready) return jpt_scene_update_tlas(c);  // no four-child records to refit
     if (n_instances == 0) return JPT_OK;
     const auto t0 = std::chrono::steady_clock::now();
     HIP_TRY(c, hipSetDevice(c->device));

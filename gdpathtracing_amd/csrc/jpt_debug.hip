@@ -83,14 +83,9 @@ uint8_t node_step4_host(const WideNodeQ& q, const StepCase& c, int rcp_ulps)
         ood[k] = -(c.o[k] * rD[k]);
         a[k] = scale[k] * rD[k];
         const float b = std::fmaf(origin[k], rD[k], ood[k]);
-#if JPT_WALK_WIDEN
         const float m = std::fmaf(kWalkSlackOverEps, std::fabs(a[k]), std::fabs(b)) + std::fabs(ood[k]);
         nb[k] = std::fmaf(-kWalkEps, m, b);
         fb[k] = std::fmaf(kWalkEps, m, b);
-#else
-        nb[k] = std::fmaf(-kPlaneSlack, std::fabs(a[k]), b);
-        fb[k] = std::fmaf(kPlaneSlack, std::fabs(a[k]), b);
-#endif
         uint32_t bits;
         std::memcpy(&bits, &c.d[k], 4);
         const bool neg = (int32_t)bits < 0;

@@ -1,4 +1,4 @@
-// jpt_kernels.h -- what the host layer (jpt_capi.hip) sees of the device code.
+// jpt_kernels.h -- what the host layer (jpt_capi.cpp) sees of the device code.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -186,7 +186,7 @@ uint32_t trace_stack_capacity();  // entries a lane's traversal stack can hold (
 size_t wf2_workspace_bytes(int width, int local_rows, int n_frames, int max_bounces);
 // Screen rectangles (pixels, inclusive) of the boxes the TLAS root offers a ray; a primary ray through a pixel
 // outside all of them is known to fail all of the root's box tests, i.e. to reach the sky after exactly one TLAS
-// expansion, without being traced.  n < 0: unknown, trace everything.  Filled on the host (jpt_capi.hip).
+// expansion, without being traced.  n < 0: unknown, trace everything.  Filled on the host (jpt_capi.cpp).
 struct SkyCull {
     int32_t n = -1;
     int32_t x0[4], y0[4], x1[4], y1[4];
@@ -204,7 +204,7 @@ struct Wf2Async {
 };
 void launch_wf2_render(hipStream_t stream, const DeviceScene& ds, const FrameParams& fp, const RefCamera& cam, void* workspace,
                        float4* accum, uint32_t* ldr, float* depth, DevCounters* counters, hipEvent_t* trace_events,
-                       const Wf2Async& async, hipStream_t acc_stream = nullptr, hipEvent_t paths_done = nullptr);
+                       const Wf2Async& async);
 
 // one wave busy for `ticks` of the device's wall clock (hipDeviceAttributeWallClockRate), to see which streams run side by side
 void launch_queue_spin(hipStream_t stream, long long ticks);

@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256) void temporal_kernel(RefTemporalParams tp, uin
     screen[i] = unorm8(col.x) | (unorm8(col.y) << 8) | (unorm8(col.z) << 16) | 0xFF000000u;
 }
 
-// ---- how many of the pipeline slots' streams run side by side (jpt_capi.hip, six_queues_probe) ---------------------------------
+// ---- how many of the pipeline slots' streams run side by side (jpt_capi.cpp, six_queues_probe) ---------------------------------
 
 // one wave that keeps its hardware queue busy for `ticks` of the constant-rate wall clock
 __global__ __launch_bounds__(64) void queue_spin_kernel(long long ticks)

@@ -273,7 +273,7 @@ void launch_ref_frame(hipStream_t stream, const DeviceScene& ds, const FramePara
     sc.reach_inst = ds.reach_inst;
     const SceneShading sh = ds.shading();
     dim3 grid((fp.width + 31) / 32, (fp.local_rows + 7) / 8), block(256);
-    const bool ties = ds.x.ok && ds.reach_tri != nullptr && !fp.debug_steps && tuning().exact_shadow;
+    const bool ties = ds.x.ok && ds.reach_tri != nullptr && !fp.debug_steps;
     if (ties) {
         if (counters) hipLaunchKernelGGL((ref_frame_kernel<true, true>), grid, block, 0, stream, sc, ds.x, sh, fp, cam, accum, ldr, depth, counters);
         else hipLaunchKernelGGL((ref_frame_kernel<false, true>), grid, block, 0, stream, sc, ds.x, sh, fp, cam, accum, ldr, depth, counters);

@@ -22,7 +22,7 @@
 // Per-lane traversal stacks live in LDS (20 entries x 256 lanes, deeper levels spill to scratch).
 //
 // launch_wf2_render runs one render: a blocking render of many paths splits its frames into two groups that run
-// this pipeline concurrently on two streams; asynchronous renders are pipelined one level up (jpt_capi.hip).
+// this pipeline concurrently on two streams; asynchronous renders are pipelined one level up (jpt_capi.cpp).
 #include <algorithm>
 #include <cstdlib>
 
@@ -114,66 +114,29 @@ __device__ __forceinline__ bool walk_round(Traversal<COUNT, W4>& tr, bool active
 }
 
 // What a render writes once and reads once -- ray and hit queues, finished paths' colours, the framebuffers -- goes past the caches
-// with the non-temporal hint (`nt` on the load / store), so that 200 MB of hand-offs per launch do not push the tree's records out of
-// the 4 MB L2s: C3 -2.5 %, close-up -1.4 %, the 4 M-triangle scene -3 % (round 5, profiles/r05/r05w_nt_streams_rates.txt).
-// -DJPT_NT_STREAMS=0: plain loads and stores; 1: the loads only; 2: the stores only (A/B builds).
-#ifndef JPT_NT_STREAMS
-#define JPT_NT_STREAMS 3
-#endif
+// with the non-temporal hint (`nt` on the load / store), so that 200 MB of hand-offs per launch do not push the tree's records out
+// of the 4 MB L2s (C3 -2.5 %, the 4 M-triangle scene -3 %: round 5).
 typedef float jpt_v4f __attribute__((ext_vector_type(4)));
+typedef uint32_t jpt_v4u __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float4 stream_ld4(const float4* p)
 {
-#if JPT_NT_STREAMS & 1
     const jpt_v4f v = __builtin_nontemporal_load(reinterpret_cast<const jpt_v4f*>(p));
     return make_float4(v.x, v.y, v.z, v.w);
-#else
-    return *p;
-#endif
 }
 __device__ __forceinline__ void stream_st4(float4* p, const float4 v)
 {
-#if JPT_NT_STREAMS & 2
     jpt_v4f w;
     w.x = v.x; w.y = v.y; w.z = v.z; w.w = v.w;
     __builtin_nontemporal_store(w, reinterpret_cast<jpt_v4f*>(p));
-#else
-    *p = v;
-#endif
 }
-typedef uint32_t jpt_v4u __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ uint4 stream_ldu4(const uint4* p)
 {
-#if JPT_NT_STREAMS & 1
     const jpt_v4u v = __builtin_nontemporal_load(reinterpret_cast<const jpt_v4u*>(p));
     return make_uint4(v.x, v.y, v.z, v.w);
-#else
-    return *p;
-#endif
 }
-__device__ __forceinline__ void stream_stf(float* p, const float v)
-{
-#if JPT_NT_STREAMS & 2
-    __builtin_nontemporal_store(v, p);
-#else
-    *p = v;
-#endif
-}
-__device__ __forceinline__ uint32_t stream_ldu(const uint32_t* p)
-{
-#if JPT_NT_STREAMS & 1
-    return __builtin_nontemporal_load(p);
-#else
-    return *p;
-#endif
-}
-__device__ __forceinline__ void stream_stu(uint32_t* p, const uint32_t v)
-{
-#if JPT_NT_STREAMS & 2
-    __builtin_nontemporal_store(v, p);
-#else
-    *p = v;
-#endif
-}
+__device__ __forceinline__ void stream_stf(float* p, const float v) { __builtin_nontemporal_store(v, p); }
+__device__ __forceinline__ uint32_t stream_ldu(const uint32_t* p) { return __builtin_nontemporal_load(p); }
+__device__ __forceinline__ void stream_stu(uint32_t* p, const uint32_t v) { __builtin_nontemporal_store(v, p); }
 
 constexpr uint32_t kHasRadiance = 0x80000000u;   // queue entry, direction.w: rad[path] holds the path's radiance (else it is 0)
 constexpr uint32_t kPathMask = 0x7fffffffu;
@@ -222,10 +185,9 @@ struct Wf2Dims {
     uint32_t n_chunks;         // tiles_per_frame * n_frames
     uint32_t seg_cap;          // entries per segment
     uint32_t run_shift;        // a segment is dealt runs of 2^run_shift consecutive chunks (neighbouring tiles of one frame)
-    FastDiv by_tiles_x, by_tiles_per_frame, by_full_tiles_x;
+    FastDiv by_tiles_x, by_full_tiles_x;
     FastDiv by_frames;         // path -> (slot, frame), path_slot_frame; wf2_accumulate: item -> (pixel, frame)
     int32_t acc_groups = 1;    // (wf2_accumulate: the frame groups whose blocks of rad / fin8 it reads, group_frames)
-    int32_t samples_together = 0;   // wf2_primary: a wave takes every frame's sample of 64 / n_frames pixels (consecutive path ids)
 };
 
 __device__ __forceinline__ void slot_to_pixel(uint32_t slot, const Wf2Dims& dm, int& px, int& ly)
@@ -519,14 +481,10 @@ __global__ __launch_bounds__(kBlock, JPT_PRIMARY_WAVES) void wf2_primary(WideSce
                 if (idx < n) {
                     const uint32_t j = idx >> 6;  // local chunk number: run j >> run_shift, position j & run_mask
                     const uint32_t chunk = ((seg + (j >> dm.run_shift) * kSegments) << dm.run_shift) + (j & run_mask);
-                    uint32_t f = fdiv(chunk, dm.by_tiles_per_frame);
-                    const uint32_t tile = chunk - f * dm.tiles_per_frame;
-                    uint32_t slot = tile * 64u + (idx & 63u);
-                    // samples_together: a wave takes 64 consecutive path ids: chunk c is (tile c / F, part c % F), its lanes the samples
-                    // part * 64 + lane of that tile, sample s being frame s % F of the tile's pixel s / F.  Otherwise one frame's sample of
-                    // all 64 pixels of a tile, as rounds 1-3 dealt them.
-                    if (dm.samples_together && chunk < dm.n_chunks)
-                        path_slot_frame(chunk * 64u + (idx & 63u), dm, (uint32_t)fp.n_frames, slot, f);
+                    // a wave takes 64 consecutive path ids: chunk c is (tile c / F, part c % F), its lanes the samples part * 64 + lane of that
+                    // tile, sample s being frame s % F of the tile's pixel s / F
+                    uint32_t slot = 0, f = 0;
+                    if (chunk < dm.n_chunks) path_slot_frame(chunk * 64u + (idx & 63u), dm, (uint32_t)fp.n_frames, slot, f);
                     int px, ly;
                     slot_to_pixel(slot, dm, px, ly);
                     if (chunk < dm.n_chunks && px < fp.width && ly < fp.local_rows) {
@@ -620,9 +578,6 @@ __device__ __forceinline__ void trace_queue(const WideSceneDev& sc, const Wf2Buf
     const float4* __restrict__ qd = wb.ray_d[bounce & 1];
     Traversal<COUNT, W4> tr;
     bool active = false, exhausted = false;
-#ifndef JPT_LATE_HIT_STORE
-#define JPT_LATE_HIT_STORE 1
-#endif
     bool unsaved = false;   // this lane's finished walk has not written its hit yet
     size_t my_loc = 0;
     uint32_t walk_steps = 0;   // (counting builds: record steps of this lane's ray)
@@ -638,7 +593,7 @@ __device__ __forceinline__ void trace_queue(const WideSceneDev& sc, const Wf2Buf
         const unsigned long long idle = __ballot(!active);
         const int n_idle = __popcll(idle);
         if (!exhausted && n_idle >= tune.refill_idle) {
-            if (JPT_LATE_HIT_STORE && unsaved) {
+            if (unsaved) {
                 save_hit();
                 unsaved = false;
             }
@@ -672,8 +627,7 @@ __device__ __forceinline__ void trace_queue(const WideSceneDev& sc, const Wf2Buf
         {
             if (walk_round<COUNT, W4>(tr, active, sc, my_stack, cnt, tune, walk_steps)) {
                 active = false;
-                if (JPT_LATE_HIT_STORE) unsaved = true;
-                else save_hit();
+                unsaved = true;
                 if (COUNT) count_walk(cnt, walk_steps);
             }
             if constexpr (TAIL && W4) {
@@ -685,7 +639,7 @@ __device__ __forceinline__ void trace_queue(const WideSceneDev& sc, const Wf2Buf
         // tail phase (see wf2_primary)
         unsigned long long left = __ballot(active);
         if (left) {
-            if (JPT_LATE_HIT_STORE && unsaved) {
+            if (unsaved) {
                 save_hit();
                 unsaved = false;
             }
@@ -706,7 +660,7 @@ __device__ __forceinline__ void trace_queue(const WideSceneDev& sc, const Wf2Buf
             }
         }
     }
-    if (JPT_LATE_HIT_STORE && unsaved) save_hit();
+    if (unsaved) save_hit();
 }
 
 template <bool COUNT, bool W4, bool TAIL = false>
@@ -989,9 +943,6 @@ __device__ __forceinline__ bool sky_cells_at(const RefCamera& cam, float two_ove
 // how far d.y can leave the range of the four corner values inside the quadrilateral, in cells; 1e30 when it is too wide to bound
 __device__ __forceinline__ float sky_interior_excess(const f3 c[4])
 {
-#ifdef JPT_SKY_CELL_NO_EXCESS   // (round 3's rule, for showing that test_sky_cells_of_culled_pixels_... catches it)
-    return 0.0f;
-#endif
     float chord2 = 0.0f, ay = 0.0f;
     for (int i = 0; i < 4; i++) {
         ay = fmax_(ay, __builtin_fabsf(c[i].y));
@@ -1010,7 +961,7 @@ __device__ __forceinline__ float sky_interior_excess(const f3 c[4])
 // corner rays of the tile agree on one rgba8 sky cell per channel, with the margins of the argument in wf2_accumulate?  Then every
 // culled pixel of the tile has that value for all its frames: tile_cell = 0x80000000 | r | g << 8 | b << 16; else 0 (the tile's
 // culled pixels are decided one by one, or take the exact route).  Depends on the camera, the image size and the partition only:
-// the host runs it when one of those changes (jpt_capi.hip), not per render -- 32 400 lanes once per camera instead of 32 400 waves
+// the host runs it when one of those changes (jpt_capi.cpp), not per render -- 32 400 lanes once per camera instead of 32 400 waves
 // x ~300 instructions in every accumulation.
 __global__ __launch_bounds__(kBlock) void wf2_sky_tiles(Wf2Dims dm, FrameParams fp, RefCamera cam, uint32_t* __restrict__ tile_cell)
 {
@@ -1310,30 +1261,15 @@ Wf2Dims make_dims(int width, int local_rows, int n_frames, const TileWindow& win
     dm.tiles_per_frame = (uint32_t)dm.tiles_x * (uint32_t)dm.tiles_y;
     dm.slots_per_frame = dm.tiles_per_frame * 64u;
     dm.n_chunks = dm.tiles_per_frame * (uint32_t)n_frames;
-    // Chunks are dealt to the segments in runs of 1, 2 or 4 neighbouring tiles of a frame: a wave refills its idle
-    // lanes from consecutive entries, and neighbouring tiles keep its rays alike for longer (record steps of the
-    // primary launch at 49 of 64 lanes instead of 37).  Longer runs start to unbalance the segments, and so do runs
-    // at all when a segment has few chunks (ms per queued render with runs of 1 / 2 / 4 / 8: C3 1.261 / 1.242 / 1.240 /
-    // 1.300, 1920x1080x16 2.417 / 2.374 / 2.358 / 2.369, 3840x2160x16 9.34 / 9.04 / 8.94 / 9.02, 1280x720x4 0.440 / 0.421 /
-    // 0.424 / 0.495; 1920x1080x2 0.431 / 0.444 / 0.452, one frame 0.331 / 0.367 / 0.376).  Those figures are from before
-    // the window: the chunks counted here are now the window's, i.e. nearly all of them are walked, and the thresholds
-    // are lower (C3's window: 24 chunks per segment, runs of 1 / 2 / 4 / 8: 1.125 / 1.120 / 1.114 / 1.116 ms; C2's: 5 per
-    // segment, 0.363 / 0.362 / 0.373).  JPT_RUN_SHIFT overrides.
-    dm.samples_together = tuning().primary_samples < 0 ? 1 : (tuning().primary_samples != 0);
-    const int forced_shift = tuning().run_shift;
+    // Chunks are dealt to the segments in runs of 2^run_shift consecutive chunks -- consecutive parts of one tile, whose rays stay
+    // alike for longer -- but runs also unbalance the segments: single chunks up to a few hundred per segment, runs of two / four
+    // only for the largest renders (3840 x 2160 x 16: 1 157 chunks per segment).  Swept in rounds 1-4: LAB_NOTEBOOK.md.
     const uint32_t per_segment = dm.n_chunks / kSegments;
-    // With samples_together (round 4) a run is consecutive PARTS of one tile, already more alike than neighbouring tiles were, and
-    // what runs add is imbalance: single chunks up to a few hundred per segment (C3, 24 per segment, runs of 1 / 2 / 4 chunks: 843 /
-    // 842 / 858 us queued; close-up and C4, 144: 4.34 / 4.33 / 4.44 and 2.76 / 2.77 / 2.78 ms), runs of four only for the largest
-    // renders (3840x2160x16, 1 157 per segment: 6.02 / 5.90 / 5.84 ms) -- profiles/r04/r04ag_samples_together.txt.
-    const uint32_t rule = dm.samples_together ? (per_segment >= 512u ? 2u : (per_segment >= 256u ? 1u : 0u))
-                                              : (n_frames < 4 || per_segment < 8u ? 0u : (per_segment < 16u ? 1u : 2u));
-    const uint32_t run_shift = forced_shift >= 0 ? (uint32_t)forced_shift : rule;
+    const uint32_t run_shift = per_segment >= 512u ? 2u : (per_segment >= 256u ? 1u : 0u);
     dm.run_shift = run_shift;
     const uint32_t n_runs = (dm.n_chunks + (1u << run_shift) - 1u) >> run_shift;
     dm.seg_cap = (((n_runs + kSegments - 1u) / kSegments) << run_shift) * 64u;
     dm.by_tiles_x = make_fastdiv((uint32_t)dm.tiles_x);
-    dm.by_tiles_per_frame = make_fastdiv(dm.tiles_per_frame);
     dm.by_frames = make_fastdiv((uint32_t)(n_frames > 0 ? n_frames : 1));
     return dm;
 }
@@ -1432,7 +1368,7 @@ __global__ void add_queue_counts(uint32_t* __restrict__ dst, const uint32_t* __r
 
 void launch_wf2_render(hipStream_t stream, const DeviceScene& ds, const FrameParams& fp, const RefCamera& cam, void* workspace,
                        float4* accum, uint32_t* ldr, float* depth, DevCounters* counters, hipEvent_t* trace_events,
-                       const Wf2Async& async, hipStream_t acc_stream, hipEvent_t paths_done)
+                       const Wf2Async& async)
 {
     const TileWindow window = cull_window(async.cull, fp);
     const Wf2Dims dm_all = make_dims(fp.width, fp.local_rows, fp.n_frames, window);
@@ -1484,7 +1420,7 @@ void launch_wf2_render(hipStream_t stream, const DeviceScene& ds, const FramePar
         gfp[g].depth_frame = (fp.depth_frame >= 0 && f0 + nf == fp.n_frames) ? nf - 1 : -1;  // the render's last frame writes the depth image (when there is one: jpt_set_outputs)
     }
 
-    const bool w4 = tuning().bvh_width == 4 && ds.use4;
+    const bool w4 = ds.use4;
     WideSceneDev sc;
     sc.blas_nodes = ds.blas_nodes;
     sc.tlas_nodes = ds.tlas_nodes;
@@ -1496,12 +1432,11 @@ void launch_wf2_render(hipStream_t stream, const DeviceScene& ds, const FramePar
     sc.reach_tri = ds.reach_tri;
     sc.reach_inst = ds.reach_inst;
     SceneShading sh = ds.shading();
-    if (tuning().reach == 0) sh.reach_tri = nullptr;
     const dim3 block(kBlock);
-    const WfTune tune{tuning().refill_idle, tuning().primary_refill_idle, tuning().node_min_lanes, tuning().leaf_min_lanes, tuning().inst_min_lanes, tuning().phase_frac16, tuning().tail_rounds, tuning().tail_lanes};
+    const WfTune tune{Tuning::refill_idle, Tuning::refill_idle, Tuning::node_min_lanes, Tuning::leaf_min_lanes, Tuning::inst_min_lanes, Tuning::phase_frac16, tuning().tail_rounds, tuning().tail_lanes};
 
-    const int chain = [&] {  // JPT_TRACE_CHAIN overrides (tuning runs); two frame groups share the chip: half-width launches
-        const int c = tuning().trace_chain > 0 ? tuning().trace_chain : (groups == 2 ? 2 : async.trace_chain);
+    const int chain = [&] {  // two frame groups share the chip: half-width launches
+        const int c = groups == 2 ? 2 : async.trace_chain;
         return c < 1 ? 1 : (c > kMaxChain ? kMaxChain : c);
     }();
     const dim3 tgrid((kSegments + (uint32_t)chain - 1u) / (uint32_t)chain);
@@ -1534,12 +1469,8 @@ void launch_wf2_render(hipStream_t stream, const DeviceScene& ds, const FramePar
             {
                 // instantiations: the paths' last vertices without the BRDF code, scenes without a texture array without
                 // the sampler code
-#ifdef JPT_SHADE_GENERAL_ONLY   // (A/B builds: no last-vertex instantiation, the sampler code always there)
-                const bool last = false, tex = true;
-#else
-                const bool last = b == gp.max_bounces && tuning().shade_last;
+                const bool last = b == gp.max_bounces;
                 const bool tex = sh.tex != nullptr && sh.n_layers > 0 && sh.tex_res > 0;
-#endif
                 // 0 no texture array, 1 nearest filter, 2 linear filter (jpt.h: bit 1 of the sampler mode)
                 const int texmode = !tex ? 0 : ((sh.sampler_mode & 2) ? 2 : 1);
 #define JPT_LAUNCH_SHADE(C, L, T) hipLaunchKernelGGL((wf2_shade<C, L, T>), sgrid, block, 0, st, sh, wb, dm, gp, cam.far_, b, counters)
@@ -1566,7 +1497,7 @@ void launch_wf2_render(hipStream_t stream, const DeviceScene& ds, const FramePar
             }
             if (ev) (void)hipEventRecord(ev[2 * (b + 1) + 1], st);
         }
-        if (sh.reach_tri && tuning().reach == 2) {  // the paths set aside because their hit is undecidable on the native tree: finished exactly
+        if (sh.reach_tri) {  // the paths set aside because their hit is undecidable on the native tree: finished exactly
             const dim3 rgrid(256), rblock(64);   // (blocks past the set-aside count exit at once; more records than threads: grid-stride)
             const TieShadowDev& sx = ds.x;
             if (sx.ok && w4) {
@@ -1606,14 +1537,8 @@ void launch_wf2_render(hipStream_t stream, const DeviceScene& ds, const FramePar
     wb_all.rad = rad_all;
     wb_all.fin8 = fin8_all;
     wb_all.first_depth = first_depth;
-    // the accumulation touches the framebuffers, so it runs where the context's renders are ordered: on acc_stream,
-    // which may differ from the stream the path kernels of this render ran on (render pipelining, jpt_capi.hip)
-    if (acc_stream && acc_stream != stream) {
-        (void)hipEventRecord(paths_done, stream);
-        (void)hipStreamWaitEvent(acc_stream, paths_done, 0);
-    } else {
-        acc_stream = stream;
-    }
+    // the accumulation touches the framebuffers: it waits for whatever ordered the context's renders before this one (before_acc)
+    hipStream_t acc_stream = stream;
     if (async.before_acc) (void)hipStreamWaitEvent(acc_stream, async.before_acc, 0);
     const uint32_t ablocks = ((uint32_t)dm_all.full_tiles_x * (uint32_t)dm_all.full_tiles_y * 64u + kBlock - 1) / kBlock;
     hipLaunchKernelGGL(wf2_accumulate, dim3(ablocks), block, 0, acc_stream, wb_all, dm_acc, fp, cam, async.cull, accum, ldr, depth, async.sky_tiles);

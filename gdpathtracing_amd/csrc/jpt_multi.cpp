@@ -1,4 +1,4 @@
-// jpt_multi.hip -- one image tiled across several GPUs of a node from ONE process (include/jpt.h, jpt_multi_*).
+// jpt_multi.cpp -- one image tiled across several GPUs of a node from ONE process (include/jpt.h, jpt_multi_*).
 //
 // The screen partition itself is in the single-context API (jpt_set_partition: 8-row strips dealt round-robin, every rank
 // renders all frames of its strips, per-pixel RNG streams make the assembled image bit-identical to one GPU's).  What a

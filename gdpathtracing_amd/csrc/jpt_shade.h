@@ -44,6 +44,8 @@ struct SceneShading {  // cold, once-per-hit data: kept in the reference layout
     int32_t sampler_mode;  // JPT_SAMPLER_*: bit 0 repeat, bit 1 linear
 };
 
+#if defined(__HIPCC__)   // (everything below is device code; the host layer -- jpt_capi.cpp, jpt_multi.cpp -- sees the structs above only)
+
 // ---- RNG (main.glsl:163-181) -----------------------------------------------------------------
 
 __device__ __forceinline__ void pcg2d(uint32_t& sx, uint32_t& sy, float& rx, float& ry)
@@ -384,5 +386,7 @@ __device__ __forceinline__ f3 aces_film(f3 x)  // progressive_rendering.glsl:19-
                clamp_((x.y * (a * x.y + b)) / (x.y * (c * x.y + d) + e), 0.0f, 1.0f),
                clamp_((x.z * (a * x.z + b)) / (x.z * (c * x.z + d) + e), 0.0f, 1.0f));
 }
+
+#endif  // __HIPCC__
 
 }  // namespace jpt

@@ -18,9 +18,6 @@ constexpr int kTraceBlock = 256;
 #ifndef JPT_WAVES_PER_SIMD
 #define JPT_WAVES_PER_SIMD 7
 #endif
-#ifndef JPT_WALK_WIDEN
-#define JPT_WALK_WIDEN 1
-#endif
 constexpr int kStackLds = JPT_STACK_LDS;              // per-lane entries kept in LDS ([entry][lane], conflict-free)
 constexpr int kStackSpill = 76;            // deeper entries go to scratch (rare)
 constexpr int32_t kSentinel = 0x7fffffff;  // "leave the instance" marker on the stack
@@ -198,20 +195,14 @@ struct Traversal {
         const float ax = h0.w * rD.x, ay = h1.x * rD.y, az = h1.y * rD.z;
         const float bx = __builtin_fmaf(h0.x, rD.x, ood.x), by = __builtin_fmaf(h0.y, rD.y, ood.y), bz = __builtin_fmaf(h0.z, rD.z, ood.z);
         // outwards, per axis: the planes' slack of 1/256 step and the evaluation's own error bound kWalkEps * (|b| + |o * rD|)
-        // (jpt_nodeq.h): entry planes earlier, exit planes later.  (-DJPT_WALK_WIDEN=0: the slack alone, round 2's step, for A/B
-        // timing only -- it can drop a far, small box whose corner the ray grazes: tests/test_quantized_walk.py.)
-#if JPT_WALK_WIDEN
+        // (jpt_nodeq.h): entry planes earlier, exit planes later.  (The slack alone can drop a far, small box whose corner the ray grazes:
+        // tests/test_quantized_walk.py.)
         const float mx = __builtin_fmaf(kWalkSlackOverEps, __builtin_fabsf(ax), __builtin_fabsf(bx)) + __builtin_fabsf(ood.x);
         const float my = __builtin_fmaf(kWalkSlackOverEps, __builtin_fabsf(ay), __builtin_fabsf(by)) + __builtin_fabsf(ood.y);
         const float mz = __builtin_fmaf(kWalkSlackOverEps, __builtin_fabsf(az), __builtin_fabsf(bz)) + __builtin_fabsf(ood.z);
         const float nbx = __builtin_fmaf(-kWalkEps, mx, bx), fbx = __builtin_fmaf(kWalkEps, mx, bx);
         const float nby = __builtin_fmaf(-kWalkEps, my, by), fby = __builtin_fmaf(kWalkEps, my, by);
         const float nbz = __builtin_fmaf(-kWalkEps, mz, bz), fbz = __builtin_fmaf(kWalkEps, mz, bz);
-#else
-        const float nbx = __builtin_fmaf(-kPlaneSlack, __builtin_fabsf(ax), bx), fbx = __builtin_fmaf(kPlaneSlack, __builtin_fabsf(ax), bx);
-        const float nby = __builtin_fmaf(-kPlaneSlack, __builtin_fabsf(ay), by), fby = __builtin_fmaf(kPlaneSlack, __builtin_fabsf(ay), by);
-        const float nbz = __builtin_fmaf(-kPlaneSlack, __builtin_fabsf(az), bz), fbz = __builtin_fmaf(kPlaneSlack, __builtin_fabsf(az), bz);
-#endif
         // the plane words a ray meets first / last on each axis: lo / hi, swapped where the direction is negative
         const bool negx = __float_as_int(d.x) < 0, negy = __float_as_int(d.y) < 0, negz = __float_as_int(d.z) < 0;
         const uint32_t lox = __float_as_uint(h1.z), loy = __float_as_uint(h1.w), loz = __float_as_uint(h2.x);

@@ -165,7 +165,7 @@ int jpt_get_stream(jpt_ctx *ctx, void **hip_stream);
  * section 4: C3 1.05 ms per queued render against 1.34 with everything at the normal level).  That choice also lets the
  * slots pre-empt the host's own compute work on a shared device.  An embedding application that wants otherwise says so
  * per context, before its first queued render or at any later time (existing slot streams are drained and re-made):
- *   DEFAULT  the library's rule (highest level; JPT_SLOT_PRIO in the environment overrides, for tuning runs)
+ *   DEFAULT  the library's rule (highest level)
  *   NORMAL   the level everything else uses: no pre-emption of host work; the queued rate then depends on which streams
  *            happen to share a hardware queue
  *   HIGH / LOW   the device's highest / lowest level
@@ -492,6 +492,30 @@ int jpt_debug_quantize_nodes4(const void *nodes4, uint32_t n_nodes, void *nodesq
 int jpt_debug_node_step4(int device_id, const void *nodes4, uint32_t n_nodes, const void *cases32, uint32_t n_cases,
                          int32_t host_rcp_ulps, uint8_t *taken_out);
 const char *jpt_debug_last_error(void);
+
+/* ---- environment ------------------------------------------------------------------------------------------------------
+ * The library READS these once per process (at the first jpt_create; gdpathtracing_amd/csrc/jpt_tuning.h) and never writes the
+ * environment.  They are for tests, audits and profiling runs; an embedding application needs none of them -- everything a
+ * host decides at run time has a call above (jpt_set_stream_priority, jpt_set_memory_policy, jpt_set_upload_mode, ...).
+ *
+ *   variable                  default   meaning
+ *   JPT_SKY_CULL              1         0: every primary ray is traced (audits; the image is the same)
+ *   JPT_WORKSPACE_BUDGET_MB   24576     most MiB one render's workspace may take before it is split into batches of frames
+ *                                       (jpt_set_memory_policy overrides per context)
+ *   JPT_PIPELINE              1         0: queued renders run one after another (per-kernel profiling: tools/pmc.sh, tools/diag.sh)
+ *   JPT_PIPE_SLOTS            0         2..8: renders in flight (0: the library's rule -- 4, or 6 where six slot streams run side by side)
+ *   JPT_GROUPS                0         1..4: frame groups of a blocking render (0: the library's rule; 1 for per-kernel profiling)
+ *   JPT_UPLOAD_WALK           --        "given": every reference-layout upload is walked node for node as uploaded (JPT_UPLOAD_WALK_AS_GIVEN)
+ *   JPT_SET_ASIDE_CAP         -1        records of the set-aside buffer (-1: 1/64 of the paths, at least 65 536; tests force 0)
+ *   JPT_TAIL                  -1        a wave walks its last, long rays with all its lanes: -1 on scenes of >= 200 000 triangles, 0 never, 1 always
+ *   JPT_TAIL_ROUNDS           128       ... from this many rounds after its block's queue ran dry
+ *   JPT_TAIL_LANES            8         ... once it is down to this many rays
+ *   JPT_LIB                   --        (Python binding only) path of the library to load instead of gdpathtracing_amd/libjpt_hip.so
+ *
+ * The HOST may want to export, before its first HIP call (see jpt_set_stream_priority above):
+ *   GPU_MAX_HW_QUEUES=6             six renders in flight instead of four for queued renders (the HIP runtime's variable)
+ *   HSA_ENABLE_IPC_MODE_LEGACY=0    multi-process runs (RCCL between ranks) on drivers that only support dmabuf IPC
+ */
 
 #ifdef __cplusplus
 }

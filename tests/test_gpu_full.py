@@ -738,7 +738,7 @@ def test_asynchronous_renders_pipeline_in_order(oracle, hiplib):
 
 def test_one_render_in_flight_at_a_time_then_a_burst(oracle, hiplib):
     """A host that queues one render, waits, queues the next: from the third such render on the library launches them like
-    blocking renders (frame groups, full-width launches: jpt_capi.hip, `lone_async`), and goes back to the pipelined form as soon
+    blocking renders (frame groups, full-width launches: jpt_capi.cpp, `lone_async`), and goes back to the pipelined form as soon
     as a render finds work in flight.  Eight renders continuing one accumulation -- five one at a time (sync, read-back or the
     split read-back in between), then a burst of three -- leave what the same frames leave through jpt_render, and that is the
     oracle's image."""
@@ -965,17 +965,13 @@ def test_bench_multi_gpu_flow_with_one_rank_of_rccl(hiplib):
     assert len(m["c3_phase_ms_per_rank"]) == 1 and len(m["c3_phase_ms_per_rank"][0]) == 3
 
 
-@pytest.mark.parametrize("switch", ["JPT_TAIL=1 JPT_TAIL_ROUNDS=2 JPT_TAIL_LANES=8", "JPT_PRIMARY_SAMPLES=0",
-                                    "JPT_GROUPS=3", "JPT_GROUPS=2 JPT_PRIMARY_SAMPLES=0", "JPT_COLLAPSE=0 JPT_INSTANCE_BOXES=1"])
+@pytest.mark.parametrize("switch", ["JPT_TAIL=1 JPT_TAIL_ROUNDS=2 JPT_TAIL_LANES=8", "JPT_GROUPS=3", "JPT_GROUPS=2 JPT_PIPE_SLOTS=2"])
 def test_alternative_tracing_launches_are_bit_identical(hiplib, switch):
-    """The tuning switches are read once per process, so the alternative launches run the parity tests in a child process:
-    JPT_TAIL=1 with eager thresholds (a wave walks its last rays with all its lanes, coop_walk: what large scenes get by default
-    for their few very long rays), JPT_PRIMARY_SAMPLES=0 (a primary wave takes one frame's sample of a tile,
-    as rounds 1-3 dealt them, instead of every frame's sample of a few pixels) and JPT_GROUPS=3 / 2 (blocking renders split
-    into frame groups of unequal size: every group's paths live in a block of their own, which wf2_accumulate must find), and
-    JPT_COLLAPSE=0 JPT_INSTANCE_BOXES=1 (the native trees as rounds 1-4 made them: four-child records collapsed greedily, an
-    instance's world box from its root box's corners).  Same images bit for bit as the default launches: a subset
-    of the parity suite, against the oracle."""
+    """The environment switches (include/jpt.h) are read once per process, so the alternative launches run the parity tests in a
+    child process: JPT_TAIL=1 with eager thresholds (a wave walks its last rays with all its lanes, coop_walk: what large scenes get
+    by default for their few very long rays), JPT_GROUPS=3 / 2 (blocking renders split into frame groups of unequal size: every
+    group's paths live in a block of their own, which wf2_accumulate must find) and two renders in flight instead of four or six.
+    Same images bit for bit as the default launches: a subset of the parity suite, against the oracle."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -1090,7 +1086,7 @@ def test_zero_throughput_vertices_are_counted(hiplib):
 def test_renders_in_flight_follow_the_hardware_queues(hiplib, queues, slots):
     """Six renders in flight where six of the library's streams get a hardware queue each (GPU_MAX_HW_QUEUES >= 6 at the process's
     first HIP call), four where they would have to share the default pool of four -- measured by the library before its first queued
-    render (jpt_capi.hip, six_queues_probe), reported by jpt_renders_in_flight.  Either way a queue of renders leaves the image of
+    render (jpt_capi.cpp, six_queues_probe), reported by jpt_renders_in_flight.  Either way a queue of renders leaves the image of
     the same renders made one at a time.  The variable is read once per process: a child process per setting."""
     import subprocess
     import sys
