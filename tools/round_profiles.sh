@@ -12,6 +12,7 @@ cp gpurun_out/diag/sq.json gpurun_out/round/${tag}_sq.json
 cp gpurun_out/round/${tag}_pmc.json profiles/current_pmc.json 2>/dev/null    # bench.py reads these two
 cp gpurun_out/round/${tag}_sq.json profiles/current_sq.json 2>/dev/null
 python bench.py > gpurun_out/round/${tag}_bench_default.json 2> gpurun_out/round/bench_default.err
+python bench.py --steps 20 --warmup 5 > gpurun_out/round/${tag}_bench_driver.json 2> gpurun_out/round/bench_driver.err   # (the driver's form)
 bash tools/configs.sh > gpurun_out/round/${tag}_configs.txt 2>&1
 mkdir -p gpurun_out/round/configs && cp gpurun_out/configs/*.json gpurun_out/round/configs/
 bash tools/counters.sh $tag:- 2>&1 | grep -v amdgpu.ids > gpurun_out/round/${tag}_counters.txt
