@@ -464,11 +464,17 @@ def main():
     # down when it idles.  The workload's own renders, queued, for --preheat-ms (reported in config.preheat_ms); then the W warm-up steps.
     def preheat():
         n, t_heat = 0, time.perf_counter()
-        while (time.perf_counter() - t_heat) * 1e3 < args.preheat_ms:
+        while args.preheat_ms > 0:
             for _ in range(10):
                 step()
             barrier()
             n += 10
+            # (every rank must leave the loop after the same batch -- the steps hold collectives: the ranks agree on the largest elapsed time)
+            t = torch.tensor([(time.perf_counter() - t_heat) * 1e3], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+            if use_dist:
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            if float(t.item()) >= args.preheat_ms or n >= 2000:
+                break
         return n
 
     preheat_steps = preheat()

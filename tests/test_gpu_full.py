@@ -932,6 +932,43 @@ def test_bench_self_launch_two_ranks_on_one_gpu(hiplib, launcher):
         assert d["multi_gpu"]["gather_plan"] == {"peer_copies": 1, "distinct_streams": 1, "own_piece_copies": 0}
 
 
+def test_bench_line_holds_the_contract_at_one_gpu(hiplib):
+    """The one JSON line of `python bench.py` at N = 1 (a small scene, few steps): the contract's fields, the `roofline` object with the
+    binding resource on top and the HBM pair beneath it (fractions are fractions or null -- the counter passes are committed for the
+    profiled workloads only), `cpu_baseline`, `parity` against the oracle on the image the timed region left behind, exit status 0."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "JPT_BENCH_BACKEND", "JPT_BENCH_FORCE_DIST")}
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--steps", "6", "--warmup", "2", "--tris", "5000", "--width", "640", "--height", "360", "--project-ranks", "2",
+           "--preheat-ms", "20"]
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert k in d, k
+    assert d["unit"] == "Mrays/s" and d["n_gpus"] == 1 and d["steps"] == 6 and d["warmup"] == 2 and d["higher_is_better"] is True
+    assert d["vs_baseline"] is None and d["dtype"] == "f32" and d["data"] == "synthetic" and "workload" in d["config"]
+    assert d["config"]["preheat_ms"] == 20.0 and d["config"]["preheat_steps"] >= 10
+    assert abs(d["value"] - d["config"]["rays_per_step"] / d["ms_per_step"] / 1e3) <= 1e-3 * d["value"]
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "lane_frac", "traffic", "kernel", "kernel_ms", "hbm", "binding"):
+        assert k in r, k
+    for k in ("achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes", "cache_served_achieved", "cache_served_frac"):
+        assert k in r["hbm"], k
+    for f in (r["frac"], r["lane_frac"], r["hbm"]["frac"]):
+        assert f is None or 0.0 <= f <= 1.0
+    assert r["kernel_ms"] > 0.0 and r["hbm"]["algorithmic_bytes"] > 0
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "Mrays/s" and "sample" in c
+    assert d["parity"]["ok"] is True and d["parity"]["differing_pixels"] == 0
+    assert d["dropin"]["differing_pixels_vs_commit_route"] == 0
+    assert d["projected_scaling"]["measured"] is False and d["projected_scaling"]["c3"]["ranks"]["2"]["rays_sum_equals_whole"] is True
+
+
 def test_bench_multi_gpu_flow_with_one_rank_of_rccl(hiplib):
     """VERDICT r05 task 2b: the first time RCCL is loaded beside the library.  bench.py's N > 1 flow -- a torch.distributed process
     group on the `nccl` backend (= RCCL), every step's dist.gather of the context's float4 rows through the ExternalStream the bench
