@@ -430,6 +430,11 @@ __global__ __launch_bounds__(kBlock, JPT_PRIMARY_WAVES) void wf2_primary(WideSce
         s_cursor = 0;
         s_out = 0;
     }
+    // The queue sizes of bounces >= 1 are accumulated with atomics by wf2_shade and must start from zero: block s clears segment s's
+    // word of every later row (and block 0 the set-aside counts behind them) -- this launch completes before the first wf2_shade
+    // starts, and one launch fewer per render is one link less in a chain of a dozen (a memset used to do this).
+    if ((int)threadIdx.x >= 1 && (int)threadIdx.x <= fp.max_bounces + 1) wb.qcount[(size_t)threadIdx.x * kSegments + seg] = 0u;
+    if (seg == 0 && threadIdx.x >= 192u) wb.redo_count[threadIdx.x - 192u] = 0u;
     __syncthreads();
     int32_t spill[kStackSpill];
     const typename Traversal<COUNT, W4>::Stack my_stack{&stack[threadIdx.x], spill, kTraceBlock, kStackLds};
@@ -1446,8 +1451,7 @@ void launch_wf2_render(hipStream_t stream, const DeviceScene& ds, const FramePar
     const bool tail = w4 && (tuning().tail < 0 ? ds.n_tris >= 200000u : tuning().tail != 0);
     // the pipeline of one group on one stream
     auto run_group = [&](hipStream_t st, const Wf2Buffers& wb, const Wf2Dims& dm, const FrameParams& gp, hipEvent_t* ev) {
-        // queue sizes of bounces >= 1 are accumulated with atomics by wf2_shade: start from zero
-        (void)hipMemsetAsync(wb.qcount + kSegments, 0, ((size_t)(nq - 1) * kSegments + 64) * sizeof(uint32_t), st);  // (and the set-aside counts behind them)
+        // (the queue sizes of bounces >= 1 and the set-aside counts start from zero: wf2_primary clears them)
         // Blocks go to the 8 XCDs round-robin by linear index (y * grid.x + x), and the chunks of a segment are far from
         // alike (the first ones are full, the last ones empty): with grid.x a multiple of 8 every XCD would always get
         // the same chunk position.  An odd grid.x deals every position to every XCD (capping C3's grid.x from 37 to 8
