@@ -784,6 +784,20 @@ def main():
                 valu = None
         hbm_frac = round(traffic / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if traffic else None
         valu_issue_frac = (valu or {}).get("valu_issue_frac")
+        # How full is the chip's VALU issue capacity at the QUEUED rate?  Every kernel of a render, its serial launch time x its share of
+        # the issue capacity (both from the committed passes) x its launches per render, over the measured time per queued render: the
+        # launches of the renders in flight fill each other's idle issue slots, and at ~1 the queued rate IS the instruction stream's
+        # roofline -- only fewer or cheaper instructions go faster (LAB_NOTEBOOK.md Part I section 5).
+        queued_issue = None
+        try:
+            if valu is not None and traffic is not None and args.kernel == "wavefront":
+                per_render = {"wf2_primary": 1, "wf2_trace": max(bounces, 0), "wf2_shade": bounces + 1, "wf2_finish": 1, "wf2_accumulate": 1}
+                busy_us = sum(n * pj[k]["time"]["avg_us"] * (sj[k].get("valu_issue_frac") or 0.0) for k, n in per_render.items() if k in pj and k in sj)
+                queued_issue = {"ratio": round(busy_us / (ms_per_step * 1e3), 4), "issue_us_per_render": round(busy_us, 1),
+                                "note": "sum over a render's kernels of serial launch time x valu_issue_frac x launches, / ms_per_step; ~1 (within the "
+                                        "instruction-pricing model's few per cent) = the queued rate is the instruction stream's VALU-issue roofline"}
+        except Exception:
+            queued_issue = None
         # what binds the dominant kernel: the largest of the utilisations this line can state (null when they are not known)
         # ... one of: "hbm" (counter traffic / duration >= 0.6 of the 8 TB/s peak: 6.3 TB/s is what the chip sustains), "valu_issue"
         # (>= 0.6 of the issue capacity), else "dependent_fetch_latency" -- neither the memory system nor the ALUs are busy, the
@@ -839,6 +853,7 @@ def main():
             # sources they ran on; null + `profiles_stale` when the sources have changed since)
             "valu_issue_frac": valu_issue_frac,
             "lane_utilisation": lane_util,
+            "queued_valu_issue": queued_issue,
             "valu": valu,
             "profiles_stale": stale,
             "kernels_sha": kernels_sha,
