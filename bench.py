@@ -897,6 +897,9 @@ def main():
                 "scene_build_s": round(build_s, 4),
                 "renders_in_flight": renders_in_flight, "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"),
                 "preheat_ms": args.preheat_ms, "preheat_steps": preheat_steps,
+                "preheat_note": "untimed renders of this workload before the W warm-up steps of every timed leg: the device clocks down within 50 ms of idling and "
+                                "needs ~12 ms of load to come back (tools/clock_ramp.py, profiles/r06/r06n); from idle a 20-step queue reads 5-15 % slower "
+                                "(profiles/r06/r06l, r06m); --preheat-ms 0 switches it off",
                 "outputs": "float4 accumulation + rgba8 display" + (" + r32f depth" if args.depth else " (depth image off: only temporal reprojection reads it)"),
             },
             "roofline": roofline,
